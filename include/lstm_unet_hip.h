@@ -1,0 +1,208 @@
+/*
+ * lstm_unet_hip.h -- C ABI of the MI355X (gfx950) ConvLSTM-UNet kernel library.
+ *
+ * The reference (arbellea/LSTM-UNet) has no FFI of its own: every op on the hot path is a
+ * TensorFlow/Keras layer call made from Networks.py / losses.py / train2D.py.  Each entry
+ * point below replaces one of those call sites (cited per function, file:line into the
+ * reference).  The Python host (lstm-unet_amd/lu_native/ops.py) binds them with ctypes;
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - all tensors fp32, channels-last: [frames, H, W, C]; "frame" = one (batch-slot, time) image
+ *   - raw device pointers, caller allocates everything (workspace size via *_workspace_bytes)
+ *   - functions only ENQUEUE on `stream` (a hipStream_t); they never synchronise, allocate or throw
+ *   - return 0 on success, non-zero on error; text via lu_last_error() (thread-local)
+ *   - weights use the Keras layout [kh][kw][Cin][Cout] (Cout fastest)
+ */
+#ifndef LSTM_UNET_HIP_H
+#define LSTM_UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lu_stream_t; /* hipStream_t */
+
+const char* lu_last_error(void);
+int lu_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   out[f, oy, ox, n] = bias[n] + sum_{s<n_src} sum_{kh,kw,c} in_s[f, vy, vx, c] * w_s[kh,kw,c,n]
+ *   vy = oy*stride + kh - pad_t (vx likewise); with dil == 2 the input is the zero-dilated
+ *   tensor (taps with odd vy/vx contribute 0, real row = vy/2) -- the dgrad of a stride-2 conv.
+ * Replaces: k.layers.Conv2D call (Networks.py:70,147), the 8 convs of the ConvLSTM2D cell
+ * (Networks.py:62-63; two sources = x_t and h_{t-1}), tf.concat + Conv2D in UpBlock2D
+ * (Networks.py:145-147; two sources = upsampled and skip), and their input-gradients.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lu_conv_src {
+    const float* x;         /* activations of this source */
+    const float* w;         /* weight row (tap, c) lives at w + tap*w_tap_stride + c*w_row_stride */
+    int64_t frame_stride;   /* elements between consecutive frames of x */
+    int64_t w_tap_stride;   /* elements between taps of w */
+    int32_t pix_stride;     /* elements between consecutive pixels of x (>= C) */
+    int32_t C;              /* channels read from this source */
+    int32_t w_row_stride;   /* elements between channel rows of w (>= N) */
+    int32_t _pad;
+} lu_conv_src;
+
+enum { LU_EPI_BIAS = 0, LU_EPI_LSTM = 1 };
+
+typedef struct lu_conv_desc {
+    lu_conv_src src[2];
+    int32_t n_src;
+    int32_t frames, Hin, Win;       /* real input extent (all sources share it) */
+    int32_t Hout, Wout;
+    int32_t k, stride, dil;         /* dil in {1,2}; stride in {1,2}; at most one of them is 2 */
+    int32_t pad_t, pad_l;
+    int32_t N;                      /* output channels */
+    int32_t out_pix_stride;
+    int32_t epilogue;               /* LU_EPI_* */
+    const float* bias;              /* [N] or NULL */
+    float* out;                     /* LU_EPI_BIAS: [frames,Hout,Wout,N] */
+    int64_t out_frame_stride;
+    /* LU_EPI_LSTM (N == 4F, F % 32 == 0): fused ConvLSTM gate block, see lu_lstm_gates_fwd */
+    const float* c_prev;            /* [frames,H,W,F] */
+    float* c_out;                   /* [frames,H,W,F] */
+    float* h_out;                   /* frame stride h_frame_stride, pixel stride F */
+    float* gates_out;               /* [frames,H,W,4F] post-activation i,f,g,o or NULL (inference) */
+    int64_t c_prev_frame_stride, c_out_frame_stride, h_frame_stride, gates_frame_stride;
+} lu_conv_desc;
+
+int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream);
+
+/* wt[kh'][kw'][co][ci] = w[k-1-kh'][k-1-kw'][c_off+ci][co]  for ci < C_sub -- the weight of the
+ * input-gradient convolution.  w is [k][k][C_tot][N]. */
+int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N, int c_off, int C_sub,
+                             lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient:  dw[kh,kw,c,n] (+)= sum_{f,oy,ox} x[f, oy*stride+kh-pad_t, ox*stride+kw-pad_l, c] * dy[f,oy,ox,n]
+ * (tape.gradient w.r.t. every conv kernel, train2D.py:92).  Split over pixels into `splits` slabs
+ * in `workspace`, then reduced deterministically into dw (dw = beta*dw + sum).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lu_wgrad_desc {
+    const float* x;  int64_t x_frame_stride;  int32_t x_pix_stride;  int32_t C;   /* input of the conv */
+    const float* dy; int64_t dy_frame_stride; int32_t dy_pix_stride; int32_t N;   /* grad of its output */
+    int32_t frames, Hin, Win, Hout, Wout;
+    int32_t k, stride, pad_t, pad_l;
+    float* dw;                /* row (tap,c) at dw + tap*dw_tap_stride + c*dw_row_stride */
+    int64_t dw_tap_stride; int32_t dw_row_stride;
+    int32_t splits;           /* >= 1 */
+    float beta;               /* 0: overwrite, 1: accumulate */
+    void* workspace;          /* lu_conv2d_wgrad_workspace_bytes(d) bytes */
+} lu_wgrad_desc;
+
+size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);
+int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ConvLSTM2D gate block (Keras cell maths, constructed Networks.py:48-50):
+ *   z = pre-activations [rows,4F], order i,f,g,o;  i,f,o = clip(0.2 z + 0.5, 0, 1), g = tanh
+ *   c = f*c_prev + i*g ;  h = o*tanh(c)
+ * rows = frames*H*W of one timestep; h is written with its own frame stride (h_seq[b,t]).
+ * ------------------------------------------------------------------------------------------- */
+int lu_lstm_gates_fwd(const float* z, const float* c_prev, float* c_out, float* h_out, float* gates_out,
+                      int32_t frames, int64_t pix_per_frame, int32_t F,
+                      int64_t h_frame_stride, lu_stream_t stream);
+
+/* backward of the gate block for one timestep:
+ *   dh = dh_a (+ dh_b if non-NULL); dc = dh*o*(1-tanh(c)^2) + dc_in(if non-NULL)
+ *   dz[rows,4F] (pre-activation grads), dc_prev_out = dc*f   */
+int lu_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c_cur,
+                      const float* dh_a, int64_t dh_a_frame_stride, const float* dh_b, const float* dc_in,
+                      float* dz, float* dc_prev_out,
+                      int32_t frames, int64_t pix_per_frame, int32_t F, lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Column reductions over rows of a [rows, C] matrix (row stride ld):  deterministic two-stage.
+ *   lu_colsum: out[c] = beta*out[c] + sum_r x[r,c]                       (bias gradients)
+ *   lu_bn_stats: sums[0:C] = sum x, sums[C:2C] = sum x^2   (double)      (BatchNormalization batch stats,
+ *                                                                          Networks.py:71,150)
+ * workspace: lu_colreduce_workspace_bytes(rows, C) bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t lu_colreduce_workspace_bytes(int64_t rows, int32_t C);
+int lu_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, float beta, void* workspace,
+              lu_stream_t stream);
+int lu_bn_stats(const float* x, int64_t rows, int32_t C, double* sums, void* workspace, lu_stream_t stream);
+
+/* from (possibly all-reduced) sums over `count` rows: mean/var -> scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale; saves mean and invstd for backward; moving stats <- momentum update
+ * with the UNBIASED variance (Keras fused BN).  moving_* may be NULL. */
+int lu_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* moving_mean, float* moving_var, float* scale, float* shift,
+                         float* save_mean, float* save_invstd, int32_t C, lu_stream_t stream);
+/* inference: scale/shift from the moving statistics */
+int lu_bn_finalize_infer(const float* gamma, const float* beta, const float* moving_mean,
+                         const float* moving_var, float eps, float* scale, float* shift, int32_t C,
+                         lu_stream_t stream);
+/* y = leaky_relu(x*scale[c] + shift[c], alpha)   (BN + LeakyReLU(0.3), Networks.py:71-72,150-151) */
+int lu_bn_lrelu_apply(const float* x, float* y, const float* scale, const float* shift, float alpha,
+                      int64_t rows, int32_t C, lu_stream_t stream);
+/* backward, stage 1: dz = dy * (z > 0 ? 1 : alpha), z recomputed from x; sums[0:C] = sum dz,
+ * sums[C:2C] = sum dz*xhat (double) */
+int lu_bn_lrelu_bwd_reduce(const float* x, const float* dy, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_invstd, float alpha, int64_t rows,
+                           int32_t C, double* sums, void* workspace, lu_stream_t stream);
+/* stage 2: dx = scale * (dz - sum_dz/count - xhat*sum_dz_xhat/count); dgamma = sum_dz_xhat, dbeta = sum_dz */
+int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_invstd, float alpha, const double* sums,
+                          double count, float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
+                          lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear x2 up-sampling, half-pixel centres, edge clamp (k.backend.resize_images, Networks.py:143)
+ * ------------------------------------------------------------------------------------------- */
+int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32_t H, int32_t W, int32_t C,
+                      lu_stream_t stream);
+/* dx[frames,H,W,C] = transpose of the above applied to dy (pixel stride dy_pix_stride, first C channels) */
+int lu_upsample2x_bwd(const float* dy, int32_t dy_pix_stride, float* dx, int32_t frames, int32_t H, int32_t W,
+                      int32_t C, lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spatial window copy with REFLECT or ZERO fill:
+ *   y[f, oy, ox, :] = x[f, map(oy - off_y), map(ox - off_x), :]
+ * mode 0 = zero outside, mode 1 = reflect (tf.pad "REFLECT", Networks.py:232).  Negative offsets crop
+ * (Networks.py:250).  x may have a pixel stride (channel slice of a wider tensor).
+ * ------------------------------------------------------------------------------------------- */
+int lu_window_copy(const float* x, int32_t x_pix_stride, float* y, int32_t frames, int32_t Hx, int32_t Wx,
+                   int32_t Hy, int32_t Wy, int32_t C, int32_t off_y, int32_t off_x, int32_t mode, float beta,
+                   lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3-class softmax + weighted, validity-masked cross entropy (losses.py:13-27) and its gradient.
+ *   stage 1: sums[0] = sum ce*w[gt]*valid, sums[1] = sum valid  (double), optional softmax output
+ *   stage 2: dlogits = grad_scale * w[gt]*valid*(softmax - onehot) / (sums[1] + 1e-5)
+ * logits [rows,3], gt [rows] float in {-1,0,1,2}.
+ * ------------------------------------------------------------------------------------------- */
+size_t lu_wce_workspace_bytes(int64_t rows);
+int lu_softmax_wce_fwd(const float* logits, const float* gt, const float* class_w, float* softmax_out,
+                       double* sums, int64_t rows, void* workspace, lu_stream_t stream);
+int lu_softmax_wce_bwd(const float* logits, const float* gt, const float* class_w, const double* sums,
+                       float grad_scale, float* dlogits, int64_t rows, lu_stream_t stream);
+/* loss[0] = sums[0] / (sums[1] + 1e-5) */
+int lu_wce_finalize(const double* sums, float* loss, lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * tf.keras Adam (train2D.py:61,93): m,v update, p -= alpha*m/(sqrt(v)+eps), alpha precomputed by the host
+ * as lr*sqrt(1-b2^t)/(1-b1^t); g is multiplied by grad_scale first (1/world for DP mean).
+ * ------------------------------------------------------------------------------------------- */
+int lu_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float alpha, float b1, float b2,
+                 float eps, float grad_scale, lu_stream_t stream);
+
+/* state mask (Networks.py:77-84): x[f, :] *= keep[f] */
+int lu_scale_frames(float* x, const float* keep, int32_t frames, int64_t per_frame, lu_stream_t stream);
+
+/* [n, a, b] -> [n, b, a]  (NCHW <-> NHWC at the public boundary, losses.py:17-18, train2D.py:98-100) */
+int lu_transpose_inner(const float* x, float* y, int64_t n, int32_t a, int32_t b, lu_stream_t stream);
+
+/* y = x + y on n elements (gradient fan-in of skip connections) */
+int lu_add_inplace(float* y, const float* x, int64_t n, lu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSTM_UNET_HIP_H */

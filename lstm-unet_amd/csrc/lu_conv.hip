@@ -1,0 +1,438 @@
+// lu_conv.hip -- implicit-GEMM convolution on the gfx950 fp32 matrix pipe.
+//
+// GEMM view: out[m, n] = sum_k A[m, k] * W[k, n],  m = (frame, oy, ox), n = output channel,
+// k = (source, kh, kw, c).  A is never materialised: every pipeline stage gathers a [256 px x 16 ch]
+// slab for ONE filter tap straight from the channels-last activation (64 B contiguous per pixel),
+// so consecutive taps of a channel chunk re-hit the same lines in L1/L2.
+//
+// Tile: 256 threads = 4 waves stacked along M; wave tile 64 x (32*NF) built from
+// v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles each -- MFMA-bound as long as it is fed).
+//   A in LDS: [256][16+4] floats, read with ONE ds_read_b128 per 4 MFMAs (lanes 0-31 take
+//             k = 8s..8s+3, lanes 32-63 take k = 8s+4..8s+7; the k pairing only has to agree with B).
+//             Row pitch 20 floats => the 16-lane ds_read_b128 groups hit 16 distinct 16-B slots.
+//   B in LDS: [16][BN] floats, ds_read_b32, 32 consecutive columns per half-wave.
+// Two LDS stages; global loads of stage i+1 are issued before the MFMAs of stage i.
+//
+// Up to two (activation, weight) sources accumulate into the same tile: ConvLSTM x_t and h_{t-1}
+// (Networks.py:62-63) or UpBlock's [upsampled, skip] concat (Networks.py:145-147) without ever
+// writing the concatenated tensor.  Sources whose channel count is not a multiple of 4 (the
+// 1-channel microscopy image) use a "thin" path where k enumerates flattened (tap, c).
+#include <stdarg.h>
+#include <string.h>
+#include <stdio.h>
+#include "lu_device.h"
+
+namespace {
+
+constexpr int CK = 16;
+constexpr int BM = 256;
+constexpr int A_LD = CK + 4;
+
+struct SrcInfo {
+    const float* x;
+    const float* w;
+    int64_t frame_stride;
+    int64_t w_tap_stride;
+    int32_t pix_stride, C, w_row_stride;
+    int32_t thin;     // 1: scalar gather over flattened (tap, c)
+    int32_t nchunk;   // vector: ceil(C/16); thin: ceil(k*k*C/16)
+};
+
+struct ConvArgs {
+    SrcInfo src[2];
+    int32_t n_src, n_it;
+    int64_t M;
+    int32_t HWo, Wout, Hin, Win;
+    int32_t k, kk, stride, dsh /* dil-1 */, pad_t, pad_l;
+    int32_t N, n_tiles;
+    int32_t out_pix_stride;
+    const float* bias;
+    float* out;
+    int64_t out_frame_stride;
+    // lstm epilogue
+    int32_t F;
+    const float* c_prev;
+    float* c_out;
+    float* h_out;
+    float* gates_out;
+    int64_t c_prev_fs, c_out_fs, h_fs, gates_fs;
+};
+
+struct IterState {
+    int s, chunk, tap, kh, kw;
+};
+
+__device__ __forceinline__ void iter_advance(IterState& st, const ConvArgs& a) {
+    const SrcInfo& si = a.src[st.s];
+    if (!si.thin) {
+        ++st.tap;
+        ++st.kw;
+        if (st.kw == a.k) {
+            st.kw = 0;
+            ++st.kh;
+        }
+        if (st.tap < a.kk) return;
+        st.tap = st.kh = st.kw = 0;
+    }
+    ++st.chunk;
+    if (st.chunk == si.nchunk) {
+        st.chunk = 0;
+        ++st.s;
+    }
+}
+
+__device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
+
+template <int NF, bool BVEC, int EPI>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int BN = 32 * NF;
+    constexpr int QPR = BN / 4;          // float4 per B row
+    constexpr int RPP = 256 / QPR;       // B rows per pass
+    constexpr int NPB = (CK + RPP - 1) / RPP;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int nt = bid % a.n_tiles;
+    const int64_t m0 = (int64_t)(bid / a.n_tiles) * BM;
+    const int n0 = nt * BN;
+
+    // ---- A gather bookkeeping: 4 pixel rows per thread, one 16-byte column group ----
+    const int q = tid & 3;
+    int fr[4], vy0[4], vx0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t m = m0 + (tid >> 2) + 64 * i;
+        if (m < a.M) {
+            int f = (int)(m / a.HWo);
+            int r = (int)(m - (int64_t)f * a.HWo);
+            int oy = r / a.Wout, ox = r - oy * a.Wout;
+            fr[i] = f;
+            vy0[i] = oy * a.stride - a.pad_t;
+            vx0[i] = ox * a.stride - a.pad_l;
+        } else {
+            fr[i] = 0;
+            vy0[i] = -(1 << 28);
+            vx0[i] = -(1 << 28);
+        }
+    }
+    // ---- B bookkeeping ----
+    const int bq = tid % QPR, brow0 = tid / QPR;
+    int bcol;  // first global column of this thread's float4
+    if (EPI == LU_EPI_LSTM) {
+        // tile columns = 4 gates x 32 channels: gate-major so a lane holds i,f,g,o of one channel
+        bcol = (bq >> 3) * a.F + nt * 32 + 4 * (bq & 7);
+    } else {
+        bcol = n0 + 4 * bq;
+    }
+
+    float4 ra[4];
+    float4 rb[NPB];
+
+    auto load_stage = [&](const IterState& st) {
+        const SrcInfo& si = a.src[st.s];
+        if (!si.thin) {
+            const int c = st.chunk * CK + 4 * q;
+            const bool cok = c < si.C;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
+                int iy = vy >> a.dsh, ix = vx >> a.dsh;
+                bool ok = cok && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win &&
+                          ((vy | vx) & a.dsh) == 0;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const float* p = si.x + (int64_t)fr[i] * si.frame_stride +
+                                     ((int64_t)iy * a.Win + ix) * si.pix_stride + c;
+                    v = *reinterpret_cast<const float4*>(p);
+                }
+                ra[i] = v;
+            }
+        } else {
+            const int kkC = a.kk * si.C;
+            int dy[4], dx[4], cc[4];
+            bool jok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int j = st.chunk * CK + 4 * q + e;
+                jok[e] = j < kkC;
+                int tap = j / si.C;
+                cc[e] = j - tap * si.C;
+                dy[e] = tap / a.k;
+                dx[e] = tap - dy[e] * a.k;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int vy = vy0[i] + dy[e], vx = vx0[i] + dx[e];
+                    int iy = vy >> a.dsh, ix = vx >> a.dsh;
+                    bool ok = jok[e] && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win &&
+                              ((vy | vx) & a.dsh) == 0;
+                    v[e] = ok ? si.x[(int64_t)fr[i] * si.frame_stride +
+                                     ((int64_t)iy * a.Win + ix) * si.pix_stride + cc[e]]
+                              : 0.f;
+                }
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        // weights
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            const int row = brow0 + RPP * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < CK) {
+                int tap, c;
+                bool rok;
+                if (!si.thin) {
+                    tap = st.tap;
+                    c = st.chunk * CK + row;
+                    rok = c < si.C;
+                } else {
+                    int j = st.chunk * CK + row;
+                    rok = j < a.kk * si.C;
+                    tap = j / si.C;
+                    c = j - tap * si.C;
+                }
+                if (rok) {
+                    const float* wp = si.w + (int64_t)tap * si.w_tap_stride + (int64_t)c * si.w_row_stride + bcol;
+                    if (BVEC) {
+                        if (EPI == LU_EPI_LSTM || bcol < a.N) v = *reinterpret_cast<const float4*>(wp);
+                    } else {
+                        if (bcol + 0 < a.N) v.x = wp[0];
+                        if (bcol + 1 < a.N) v.y = wp[1];
+                        if (bcol + 2 < a.N) v.z = wp[2];
+                        if (bcol + 3 < a.N) v.w = wp[3];
+                    }
+                }
+            }
+            rb[p] = v;
+        }
+    };
+
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + 64 * i) * A_LD + 4 * q]) = ra[i];
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            const int row = brow0 + RPP * p;
+            if (row < CK) *reinterpret_cast<float4*>(&Bs[buf][row * BN + 4 * bq]) = rb[p];
+        }
+    };
+
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+    IterState st{0, 0, 0, 0, 0};
+    load_stage(st);
+    store_stage(0);
+    __syncthreads();
+
+    const int arow = wave * 64 + (lane & 31);
+    const int khalf = 4 * (lane >> 5);
+    for (int it = 0; it < a.n_it; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < a.n_it;
+        if (more) {
+            iter_advance(st, a);
+            load_stage(st);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float af[2][4];
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                float4 t = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * mf) * A_LD + 8 * s + khalf]);
+                af[mf][0] = t.x;
+                af[mf][1] = t.y;
+                af[mf][2] = t.z;
+                af[mf][3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bv[NF];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(af[mf][j], bv[nf], acc[mf][nf]);
+            }
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const int ccol = lane & 31;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int64_t m = m0 + wave * 64 + mf * 32 + row;
+            if (m >= a.M) continue;
+            const int f = (int)(m / a.HWo);
+            const int64_t pix = m - (int64_t)f * a.HWo;
+            if (EPI == LU_EPI_LSTM) {
+                const int ch = nt * 32 + ccol;  // F % 32 == 0 is enforced by the host
+                const int F = a.F;
+                float zi = acc[mf][0][r], zf = acc[mf][NF > 1 ? 1 : 0][r], zg = acc[mf][NF > 2 ? 2 : 0][r],
+                      zo = acc[mf][NF > 3 ? 3 : 0][r];
+                if (a.bias) {
+                    zi += a.bias[ch];
+                    zf += a.bias[F + ch];
+                    zg += a.bias[2 * F + ch];
+                    zo += a.bias[3 * F + ch];
+                }
+                const float gi = hard_sigmoid(zi), gf = hard_sigmoid(zf), gg = tanhf(zg), go = hard_sigmoid(zo);
+                const float cp = a.c_prev[(int64_t)f * a.c_prev_fs + pix * F + ch];
+                const float cn = gf * cp + gi * gg;
+                const float hn = go * tanhf(cn);
+                a.c_out[(int64_t)f * a.c_out_fs + pix * F + ch] = cn;
+                a.h_out[(int64_t)f * a.h_fs + pix * F + ch] = hn;
+                if (a.gates_out) {
+                    float* gp = a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
+                    gp[0] = gi;
+                    gp[F] = gf;
+                    gp[2 * F] = gg;
+                    gp[3 * F] = go;
+                }
+            } else {
+                float* op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    const int col = n0 + 32 * nf + ccol;
+                    if (col < a.N) op[col] = acc[mf][nf][r] + (a.bias ? a.bias[col] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+// wt[kh'][kw'][co][ci] = w[k-1-kh'][k-1-kw'][c_off+ci][co]
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int C_tot, int N,
+                                      int c_off, int C_sub) {
+    // one block per (tap, 32x32 tile); LDS transpose for coalescing on both sides
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    const int src_tap = k * k - 1 - tap;
+    for (int r = ty; r < 32; r += 8) {
+        int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < C_sub && co < N) ? w[((int64_t)src_tap * C_tot + c_off + ci) * N + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int co = co0 + r, ci = ci0 + tx;
+        if (co < N && ci < C_sub) wt[((int64_t)tap * N + co) * C_sub + ci] = tile[tx][r];
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
+    LU_REQUIRE(d, "lu_conv2d_fwd: null descriptor");
+    LU_REQUIRE(d->n_src == 1 || d->n_src == 2, "lu_conv2d_fwd: n_src must be 1 or 2 (got %d)", d->n_src);
+    LU_REQUIRE(d->k >= 1 && d->k <= 7, "lu_conv2d_fwd: unsupported kernel size %d", d->k);
+    LU_REQUIRE((d->stride == 1 || d->stride == 2) && (d->dil == 1 || d->dil == 2) && !(d->stride == 2 && d->dil == 2),
+               "lu_conv2d_fwd: unsupported stride/dil %d/%d", d->stride, d->dil);
+    LU_REQUIRE(d->frames > 0 && d->Hout > 0 && d->Wout > 0 && d->N > 0, "lu_conv2d_fwd: empty problem");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_src = d->n_src;
+    a.k = d->k;
+    a.kk = d->k * d->k;
+    bool bvec = (d->N % 4 == 0);
+    a.n_it = 0;
+    for (int s = 0; s < d->n_src; ++s) {
+        const lu_conv_src& in = d->src[s];
+        LU_REQUIRE(in.x && in.w && in.C > 0, "lu_conv2d_fwd: source %d incomplete", s);
+        SrcInfo& si = a.src[s];
+        si.x = in.x;
+        si.w = in.w;
+        si.frame_stride = in.frame_stride;
+        si.w_tap_stride = in.w_tap_stride;
+        si.pix_stride = in.pix_stride;
+        si.C = in.C;
+        si.w_row_stride = in.w_row_stride;
+        bool vec = (in.C % 4 == 0) && (in.pix_stride % 4 == 0) && (in.frame_stride % 4 == 0) && aligned16(in.x);
+        si.thin = vec ? 0 : 1;
+        si.nchunk = vec ? (in.C + CK - 1) / CK : (a.kk * in.C + CK - 1) / CK;
+        a.n_it += vec ? si.nchunk * a.kk : si.nchunk;
+        bvec = bvec && (in.w_row_stride % 4 == 0) && (in.w_tap_stride % 4 == 0) && aligned16(in.w);
+    }
+    a.M = (int64_t)d->frames * d->Hout * d->Wout;
+    a.HWo = d->Hout * d->Wout;
+    a.Wout = d->Wout;
+    a.Hin = d->Hin;
+    a.Win = d->Win;
+    a.stride = d->stride;
+    a.dsh = d->dil - 1;
+    a.pad_t = d->pad_t;
+    a.pad_l = d->pad_l;
+    a.N = d->N;
+    a.out_pix_stride = d->out_pix_stride;
+    a.bias = d->bias;
+    a.out = d->out;
+    a.out_frame_stride = d->out_frame_stride;
+    const int64_t m_tiles = (a.M + BM - 1) / BM;
+    dim3 block(256);
+    if (d->epilogue == LU_EPI_LSTM) {
+        LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
+        LU_REQUIRE(bvec, "lu_conv2d_fwd: LSTM epilogue needs 16-byte aligned weights");
+        LU_REQUIRE(d->c_prev && d->c_out && d->h_out, "lu_conv2d_fwd: LSTM epilogue pointers missing");
+        a.F = d->N / 4;
+        a.c_prev = d->c_prev;
+        a.c_out = d->c_out;
+        a.h_out = d->h_out;
+        a.gates_out = d->gates_out;
+        a.c_prev_fs = d->c_prev_frame_stride;
+        a.c_out_fs = d->c_out_frame_stride;
+        a.h_fs = d->h_frame_stride;
+        a.gates_fs = d->gates_frame_stride;
+        a.n_tiles = a.F / 32;
+        dim3 grid((unsigned)(m_tiles * a.n_tiles));
+        LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM>), grid, block, stream, a);
+        return LU_CHECK_LAUNCH();
+    }
+    LU_REQUIRE(d->epilogue == LU_EPI_BIAS, "lu_conv2d_fwd: unknown epilogue %d", d->epilogue);
+    LU_REQUIRE(d->out, "lu_conv2d_fwd: out is null");
+    const int nf = d->N > 64 ? 4 : (d->N > 32 ? 2 : 1);
+    a.n_tiles = (d->N + 32 * nf - 1) / (32 * nf);
+    dim3 grid((unsigned)(m_tiles * a.n_tiles));
+#define LU_CONV_CASE(NF_, BV_)                                                                  \
+    if (nf == NF_ && bvec == BV_) {                                                             \
+        LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS>), grid, block, stream, a);            \
+        return LU_CHECK_LAUNCH();                                                               \
+    }
+    LU_CONV_CASE(4, true)
+    LU_CONV_CASE(2, true)
+    LU_CONV_CASE(1, true)
+    LU_CONV_CASE(4, false)
+    LU_CONV_CASE(2, false)
+    LU_CONV_CASE(1, false)
+#undef LU_CONV_CASE
+    lu_set_error("lu_conv2d_fwd: no kernel variant");
+    return 1;
+}
+
+extern "C" int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N, int c_off, int C_sub,
+                                        lu_stream_t stream) {
+    LU_REQUIRE(w && wt && k > 0 && C_sub > 0 && N > 0 && c_off >= 0 && c_off + C_sub <= C_tot,
+               "lu_weight_flip_transpose: bad arguments");
+    dim3 grid((N + 31) / 32, (C_sub + 31) / 32, k * k);
+    LU_LAUNCH(flip_transpose_kernel, grid, dim3(256), stream, w, wt, k, C_tot, N, c_off, C_sub);
+    return LU_CHECK_LAUNCH();
+}

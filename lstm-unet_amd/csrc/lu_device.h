@@ -1,0 +1,42 @@
+// lu_device.h -- device-side vocabulary of the gfx950 kernels.
+// The product build is HIP for gfx950 only.  The single abstraction point below (LU_EMU) exists so
+// that tests/emu can compile the SAME kernel sources for the host SIMT emulator in the GPU-less
+// build container; it is never defined in the product build.
+#pragma once
+#include <stdint.h>
+#include "../../include/lstm_unet_hip.h"
+
+#ifdef LU_EMU
+#include "emu_runtime.h"
+#define LU_LAUNCH(kernel, grid, block, stream, ...) \
+    lu_emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+static inline f32x16 lu_mfma(float a, float b, f32x16 c) { return lu_emu::mfma_32x32x2(a, b, c); }
+static inline float lu_shfl_xor(float v, int m) { return lu_emu::shfl_xor(v, m); }
+static inline float lu_shfl_down(float v, int d) { return lu_emu::shfl_down(v, d); }
+#define LU_CHECK_LAUNCH() 0
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LU_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+// v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain; 64 cycles / SIMD
+__device__ __forceinline__ f32x16 lu_mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float lu_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ float lu_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+#define LU_CHECK_LAUNCH() lu_check_launch()
+int lu_check_launch();
+#endif
+
+void lu_set_error(const char* fmt, ...);
+
+#define LU_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            lu_set_error(__VA_ARGS__); \
+            return 1;                  \
+        }                              \
+    } while (0)
+
+static inline int64_t lu_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

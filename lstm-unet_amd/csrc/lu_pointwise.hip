@@ -1,0 +1,684 @@
+// lu_pointwise.hip -- the HBM-bound kernels of the ConvLSTM-UNet step: ConvLSTM gate block,
+// BatchNorm(+LeakyReLU) statistics / apply / backward, bilinear x2 up-sampling, reflect-pad / crop
+// window copies, 3-class softmax + weighted cross-entropy, Adam, state mask, layout transposes.
+// All tensors are channels-last so consecutive lanes touch consecutive channels (coalesced);
+// reductions are two-stage and deterministic (per-block partials in a caller workspace, summed in a
+// fixed order in double) -- no float atomics anywhere.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "lu_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (shared by all translation units)
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_lu_err[512] = "";
+
+void lu_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_lu_err, sizeof(g_lu_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* lu_last_error(void) { return g_lu_err; }
+extern "C" int lu_abi_version(void) { return 1; }
+
+#ifndef LU_EMU
+int lu_check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        lu_set_error("HIP launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+#endif
+
+namespace {
+
+constexpr int NT = 256;
+
+inline unsigned grid_for(int64_t n, int per_thread = 1) {
+    int64_t b = (n + (int64_t)NT * per_thread - 1) / ((int64_t)NT * per_thread);
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (unsigned)b;
+}
+
+__device__ __forceinline__ float hsig(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float hsig_grad_from_out(float o) { return (o > 0.f && o < 1.f) ? 0.2f : 0.f; }
+
+// ---------------------------------------------------------------------------------------------
+// ConvLSTM gate block
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_gates_fwd_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+                                      float* __restrict__ c_out, float* __restrict__ h_out,
+                                      float* __restrict__ gates_out, int64_t total, int64_t ppf, int F, int64_t h_fs) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t row = i / F;
+        const int ch = (int)(i - row * F);
+        const float* zp = z + row * 4 * F + ch;
+        const float gi = hsig(zp[0]), gf = hsig(zp[F]), gg = tanhf(zp[2 * F]), go = hsig(zp[3 * F]);
+        const float cn = gf * c_prev[i] + gi * gg;
+        c_out[i] = cn;
+        const int64_t f = row / ppf;
+        h_out[f * h_fs + (row - f * ppf) * F + ch] = go * tanhf(cn);
+        if (gates_out) {
+            float* gp = gates_out + row * 4 * F + ch;
+            gp[0] = gi;
+            gp[F] = gf;
+            gp[2 * F] = gg;
+            gp[3 * F] = go;
+        }
+    }
+}
+
+__global__ void lstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                      const float* __restrict__ c_cur, const float* __restrict__ dh_a, int64_t dha_fs,
+                                      const float* __restrict__ dh_b, const float* __restrict__ dc_in,
+                                      float* __restrict__ dz, float* __restrict__ dc_prev_out, int64_t total,
+                                      int64_t ppf, int F) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t row = i / F;
+        const int ch = (int)(i - row * F);
+        const int64_t f = row / ppf;
+        float dh = dh_a[f * dha_fs + (row - f * ppf) * F + ch];
+        if (dh_b) dh += dh_b[i];
+        const float* gp = gates + row * 4 * F + ch;
+        const float gi = gp[0], gf = gp[F], gg = gp[2 * F], go = gp[3 * F];
+        const float tc = tanhf(c_cur[i]);
+        float dc = dh * go * (1.f - tc * tc);
+        if (dc_in) dc += dc_in[i];
+        float* dp = dz + row * 4 * F + ch;
+        dp[0] = dc * gg * hsig_grad_from_out(gi);
+        dp[F] = dc * c_prev[i] * hsig_grad_from_out(gf);
+        dp[2 * F] = dc * gi * (1.f - gg * gg);
+        dp[3 * F] = dh * tc * hsig_grad_from_out(go);
+        dc_prev_out[i] = dc * gf;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// two-stage column reduction:  partial[blk][q][c] (double), q < 2
+// block = 64 channels x 4 row lanes
+// ---------------------------------------------------------------------------------------------
+struct ColPlan {
+    int64_t rows_per_blk;
+    int nblk, ctiles;
+};
+inline ColPlan col_plan(int64_t rows, int C) {
+    ColPlan p;
+    p.ctiles = (C + 63) / 64;
+    int64_t target = 2048 / p.ctiles;
+    if (target < 1) target = 1;
+    p.rows_per_blk = (rows + target - 1) / target;
+    if (p.rows_per_blk < 64) p.rows_per_blk = 64;
+    p.rows_per_blk = (p.rows_per_blk + 3) / 4 * 4;
+    p.nblk = (int)((rows + p.rows_per_blk - 1) / p.rows_per_blk);
+    if (p.nblk < 1) p.nblk = 1;
+    return p;
+}
+
+struct FnSum {
+    const float* x;
+    int ld;
+    __device__ void operator()(int64_t r, int c, float& v0, float& v1) const {
+        v0 = x[r * ld + c];
+        v1 = 0.f;
+    }
+};
+struct FnStats {
+    const float* x;
+    int ld;
+    __device__ void operator()(int64_t r, int c, float& v0, float& v1) const {
+        float v = x[r * ld + c];
+        v0 = v;
+        v1 = v * v;
+    }
+};
+struct FnBnBwd {
+    const float *x, *dy, *scale, *shift, *mean, *invstd;
+    float alpha;
+    int ld;
+    __device__ void operator()(int64_t r, int c, float& v0, float& v1) const {
+        float xv = x[r * ld + c];
+        float zz = xv * scale[c] + shift[c];
+        float dz = dy[r * ld + c] * (zz > 0.f ? 1.f : alpha);
+        v0 = dz;
+        v1 = dz * (xv - mean[c]) * invstd[c];
+    }
+};
+
+template <class Fn>
+__global__ void colreduce_kernel(Fn fn, int64_t rows, int C, int64_t rows_per_blk, double* __restrict__ partial) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > rows) r1 = rows;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            float v0, v1;
+            fn(r, c, v0, v1);
+            s0 += v0;
+            s1 += v1;
+        }
+    }
+    red[0][rl][cl] = s0;
+    red[1][rl][cl] = s1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t0 = (double)red[0][0][cl] + (double)red[0][1][cl] + (double)red[0][2][cl] + (double)red[0][3][cl];
+        double t1 = (double)red[1][0][cl] + (double)red[1][1][cl] + (double)red[1][2][cl] + (double)red[1][3][cl];
+        partial[((int64_t)blockIdx.x * 2 + 0) * C + c] = t0;
+        partial[((int64_t)blockIdx.x * 2 + 1) * C + c] = t1;
+    }
+}
+
+// mode 0: out_d[q*C + c] = sum ; mode 1: out_f[c] = beta*out_f[c] + sum(q=0)
+__global__ void colreduce_final_kernel(const double* __restrict__ partial, int nblk, int C, double* out_d, float* out_f,
+                                       float beta, int mode) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int nq = mode == 0 ? 2 : 1;
+    if (i >= nq * C) return;
+    const int q = i / C, c = i - q * C;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[((int64_t)b * 2 + q) * C + c];
+    if (mode == 0) out_d[i] = s;
+    else out_f[c] = (beta != 0.f ? beta * out_f[c] : 0.f) + (float)s;
+}
+
+template <class Fn>
+int run_colreduce(Fn fn, int64_t rows, int C, void* ws, double* out_d, float* out_f, float beta, int mode,
+                  lu_stream_t stream) {
+    ColPlan p = col_plan(rows, C);
+    LU_LAUNCH((colreduce_kernel<Fn>), dim3(p.nblk, p.ctiles), dim3(NT), stream, fn, rows, C, p.rows_per_blk,
+              (double*)ws);
+    int rc = LU_CHECK_LAUNCH();
+    if (rc) return rc;
+    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + NT - 1) / NT), dim3(NT), stream, (const double*)ws, p.nblk, C,
+              out_d, out_f, beta, mode);
+    return LU_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm finalize / apply / backward-apply
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double count, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* moving_mean,
+                                         float* moving_var, float* scale, float* shift, float* save_mean,
+                                         float* save_invstd, int C) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (moving_mean) {
+        const double unb = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+        moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+        moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
+    }
+}
+
+__global__ void bn_finalize_infer_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                         float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(mv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mm[c] * sc;
+}
+
+template <bool VEC>
+__global__ void bn_lrelu_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, float alpha, int64_t total, int C) {
+    if (VEC) {
+        const int64_t n4 = total >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+            const int c = (int)((i * 4) % C);
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            float4 o;
+            float t;
+            t = v.x * scale[c] + shift[c];
+            o.x = t > 0.f ? t : alpha * t;
+            t = v.y * scale[c + 1] + shift[c + 1];
+            o.y = t > 0.f ? t : alpha * t;
+            t = v.z * scale[c + 2] + shift[c + 2];
+            o.z = t > 0.f ? t : alpha * t;
+            t = v.w * scale[c + 3] + shift[c + 3];
+            o.w = t > 0.f ? t : alpha * t;
+            reinterpret_cast<float4*>(y)[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+            const int c = (int)(i % C);
+            const float t = x[i] * scale[c] + shift[c];
+            y[i] = t > 0.f ? t : alpha * t;
+        }
+    }
+}
+
+__global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                          float alpha, const double* __restrict__ sums, double count,
+                                          float* __restrict__ dx, float* dgamma, float* dbeta, int64_t total, int C) {
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += NT) {
+            dbeta[c] = (float)sums[c];
+            dgamma[c] = (float)sums[C + c];
+        }
+    }
+    const float inv_n = (float)(1.0 / count);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const float xv = x[i];
+        const float zz = xv * scale[c] + shift[c];
+        const float dz = dy[i] * (zz > 0.f ? 1.f : alpha);
+        const float xhat = (xv - mean[c]) * invstd[c];
+        dx[i] = scale[c] * (dz - (float)sums[c] * inv_n - xhat * (float)sums[C + c] * inv_n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear x2 (half-pixel centres, edge clamp)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up2_taps(int o, int n_in, int& lo, int& hi, float& frac) {
+    const float src = (o + 0.5f) * 0.5f - 0.5f;
+    const float fl = floorf(src);
+    frac = src - fl;
+    const int i0 = (int)fl;
+    lo = i0 < 0 ? 0 : (i0 > n_in - 1 ? n_in - 1 : i0);
+    hi = i0 + 1 < 0 ? 0 : (i0 + 1 > n_in - 1 ? n_in - 1 : i0 + 1);
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int frames, int H, int W,
+                                      int C) {
+    const int64_t total = (int64_t)frames * 4 * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oy = (int)(t % (2 * H));
+        const int64_t f = t / (2 * H);
+        int ylo, yhi, xlo, xhi;
+        float fy, fx;
+        up2_taps(oy, H, ylo, yhi, fy);
+        up2_taps(ox, W, xlo, xhi, fx);
+        const float* xf = x + f * (int64_t)H * W * C + c;
+        const float v00 = xf[((int64_t)ylo * W + xlo) * C], v01 = xf[((int64_t)ylo * W + xhi) * C];
+        const float v10 = xf[((int64_t)yhi * W + xlo) * C], v11 = xf[((int64_t)yhi * W + xhi) * C];
+        const float top = v00 * (1.f - fx) + v01 * fx, bot = v10 * (1.f - fx) + v11 * fx;
+        y[i] = top * (1.f - fy) + bot * fy;
+    }
+}
+
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, int dy_ps, float* __restrict__ dx, int frames,
+                                      int H, int W, int C) {
+    const int64_t total = (int64_t)frames * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int64_t f = t / H;
+        const float* df = dy + f * (int64_t)4 * H * W * dy_ps + c;
+        float acc = 0.f;
+        for (int oy = 2 * iy - 1; oy <= 2 * iy + 2; ++oy) {
+            if (oy < 0 || oy >= 2 * H) continue;
+            int ylo, yhi;
+            float fy;
+            up2_taps(oy, H, ylo, yhi, fy);
+            const float wy = (ylo == iy ? 1.f - fy : 0.f) + (yhi == iy ? fy : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
+                if (ox < 0 || ox >= 2 * W) continue;
+                int xlo, xhi;
+                float fx;
+                up2_taps(ox, W, xlo, xhi, fx);
+                const float wx = (xlo == ix ? 1.f - fx : 0.f) + (xhi == ix ? fx : 0.f);
+                if (wx == 0.f) continue;
+                acc += wy * wx * df[((int64_t)oy * 2 * W + ox) * dy_ps];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// window copy (reflect pad / zero embed / crop)
+// ---------------------------------------------------------------------------------------------
+__global__ void window_copy_kernel(const float* __restrict__ x, int x_ps, float* __restrict__ y, int frames, int Hx,
+                                   int Wx, int Hy, int Wy, int C, int off_y, int off_x, int mode, float beta) {
+    const int64_t total = (int64_t)frames * Hy * Wy * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % Wy);
+        t /= Wy;
+        const int oy = (int)(t % Hy);
+        const int64_t f = t / Hy;
+        int sy = oy - off_y, sx = ox - off_x;
+        bool ok = true;
+        if (mode == 1) {
+            if (sy < 0) sy = -sy;
+            if (sy >= Hx) sy = 2 * (Hx - 1) - sy;
+            if (sx < 0) sx = -sx;
+            if (sx >= Wx) sx = 2 * (Wx - 1) - sx;
+        } else {
+            ok = sy >= 0 && sy < Hx && sx >= 0 && sx < Wx;
+        }
+        const float v = ok ? x[((f * Hx + sy) * Wx + sx) * x_ps + c] : 0.f;
+        y[i] = (beta != 0.f ? beta * y[i] : 0.f) + v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax + weighted CE
+// ---------------------------------------------------------------------------------------------
+__global__ void wce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ gt, const float* cw,
+                               float* __restrict__ sm_out, int64_t rows, double* __restrict__ partial) {
+    __shared__ float red[2][NT];
+    float s_loss = 0.f, s_valid = 0.f;
+    const float w0 = cw[0], w1 = cw[1], w2 = cw[2];
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+        const float l0 = logits[r * 3], l1 = logits[r * 3 + 1], l2 = logits[r * 3 + 2];
+        const float m = fmaxf(l0, fmaxf(l1, l2));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+        const float se = e0 + e1 + e2;
+        if (sm_out) {
+            const float inv = 1.f / se;
+            sm_out[r * 3] = e0 * inv;
+            sm_out[r * 3 + 1] = e1 * inv;
+            sm_out[r * 3 + 2] = e2 * inv;
+        }
+        const float g = gt[r];
+        if (g > -1.f) {
+            const int gi = (int)g;
+            const float w = gi == 0 ? w0 : (gi == 1 ? w1 : (gi == 2 ? w2 : 0.f));
+            const float picked = gi <= 0 ? l0 : (gi == 1 ? l1 : l2);
+            s_loss += (logf(se) + m - picked) * w;
+            s_valid += 1.f;
+        }
+    }
+    red[0][threadIdx.x] = s_loss;
+    red[1][threadIdx.x] = s_valid;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int i = 0; i < NT; ++i) t += (double)red[threadIdx.x][i];
+        partial[(int64_t)blockIdx.x * 2 + threadIdx.x] = t;
+    }
+}
+
+__global__ void wce_final_kernel(const double* __restrict__ partial, int nblk, double* sums) {
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * 2 + threadIdx.x];
+        sums[threadIdx.x] = t;
+    }
+}
+
+__global__ void wce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ gt, const float* cw,
+                               const double* __restrict__ sums, float grad_scale, float* __restrict__ dl,
+                               int64_t rows) {
+    const float inv = grad_scale / (float)(sums[1] + 0.00001);
+    const float w0 = cw[0], w1 = cw[1], w2 = cw[2];
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+        const float g = gt[r];
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if (g > -1.f) {
+            const int gi = (int)g;
+            const float w = (gi == 0 ? w0 : (gi == 1 ? w1 : (gi == 2 ? w2 : 0.f))) * inv;
+            const float l0 = logits[r * 3], l1 = logits[r * 3 + 1], l2 = logits[r * 3 + 2];
+            const float m = fmaxf(l0, fmaxf(l1, l2));
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+            const float is = 1.f / (e0 + e1 + e2);
+            d0 = w * (e0 * is - (gi <= 0 ? 1.f : 0.f));
+            d1 = w * (e1 * is - (gi == 1 ? 1.f : 0.f));
+            d2 = w * (e2 * is - (gi >= 2 ? 1.f : 0.f));
+        }
+        dl[r * 3] = d0;
+        dl[r * 3 + 1] = d1;
+        dl[r * 3 + 2] = d2;
+    }
+}
+
+__global__ void wce_loss_kernel(const double* sums, float* loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = (float)(sums[0] / (sums[1] + 0.00001));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam, state mask, transposes, add
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float gv = g[i] * gs;
+        const float mn = b1 * m[i] + (1.f - b1) * gv;
+        const float vn = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mn;
+        v[i] = vn;
+        p[i] = p[i] - alpha * mn / (sqrtf(vn) + eps);
+    }
+}
+
+__global__ void scale_frames_kernel(float* __restrict__ x, const float* __restrict__ keep, int64_t per_frame,
+                                    int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT)
+        x[i] *= keep[i / per_frame];
+}
+
+__global__ void transpose_inner_kernel(const float* __restrict__ x, float* __restrict__ y, int a, int b) {
+    __shared__ float tile[32][33];
+    const int64_t n = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xn = x + n * (int64_t)a * b;
+    float* yn = y + n * (int64_t)a * b;
+    for (int r = ty; r < 32; r += 8)
+        if (a0 + r < a && b0 + tx < b) tile[r][tx] = xn[(int64_t)(a0 + r) * b + b0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (b0 + r < b && a0 + tx < a) yn[(int64_t)(b0 + r) * a + a0 + tx] = tile[tx][r];
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] += x[i];
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" int lu_lstm_gates_fwd(const float* z, const float* c_prev, float* c_out, float* h_out, float* gates_out,
+                                 int32_t frames, int64_t ppf, int32_t F, int64_t h_fs, lu_stream_t stream) {
+    LU_REQUIRE(z && c_prev && c_out && h_out && frames > 0 && ppf > 0 && F > 0, "lu_lstm_gates_fwd: bad arguments");
+    const int64_t total = (int64_t)frames * ppf * F;
+    LU_LAUNCH(lstm_gates_fwd_kernel, dim3(grid_for(total)), dim3(NT), stream, z, c_prev, c_out, h_out, gates_out,
+              total, ppf, (int)F, h_fs);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c_cur, const float* dh_a,
+                                 int64_t dh_a_fs, const float* dh_b, const float* dc_in, float* dz,
+                                 float* dc_prev_out, int32_t frames, int64_t ppf, int32_t F, lu_stream_t stream) {
+    LU_REQUIRE(gates && c_prev && c_cur && dh_a && dz && dc_prev_out && frames > 0 && ppf > 0 && F > 0,
+               "lu_lstm_gates_bwd: bad arguments");
+    const int64_t total = (int64_t)frames * ppf * F;
+    LU_LAUNCH(lstm_gates_bwd_kernel, dim3(grid_for(total)), dim3(NT), stream, gates, c_prev, c_cur, dh_a, dh_a_fs,
+              dh_b, dc_in, dz, dc_prev_out, total, ppf, (int)F);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" size_t lu_colreduce_workspace_bytes(int64_t rows, int32_t C) {
+    ColPlan p = col_plan(rows, C);
+    return (size_t)p.nblk * 2 * C * sizeof(double);
+}
+
+extern "C" int lu_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, float beta, void* ws,
+                         lu_stream_t stream) {
+    LU_REQUIRE(x && out && ws && rows > 0 && C > 0 && ld >= C, "lu_colsum: bad arguments");
+    FnSum fn{x, ld};
+    return run_colreduce(fn, rows, C, ws, nullptr, out, beta, 1, stream);
+}
+
+extern "C" int lu_bn_stats(const float* x, int64_t rows, int32_t C, double* sums, void* ws, lu_stream_t stream) {
+    LU_REQUIRE(x && sums && ws && rows > 0 && C > 0, "lu_bn_stats: bad arguments");
+    FnStats fn{x, C};
+    return run_colreduce(fn, rows, C, ws, sums, nullptr, 0.f, 0, stream);
+}
+
+extern "C" int lu_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
+                                    float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
+                                    float* shift, float* save_mean, float* save_invstd, int32_t C,
+                                    lu_stream_t stream) {
+    LU_REQUIRE(sums && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 0,
+               "lu_bn_finalize_train: bad arguments");
+    LU_LAUNCH(bn_finalize_train_kernel, dim3((C + NT - 1) / NT), dim3(NT), stream, sums, count, gamma, beta, eps,
+              momentum, moving_mean, moving_var, scale, shift, save_mean, save_invstd, (int)C);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_bn_finalize_infer(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
+                                    float* scale, float* shift, int32_t C, lu_stream_t stream) {
+    LU_REQUIRE(gamma && beta && mm && mv && scale && shift && C > 0, "lu_bn_finalize_infer: bad arguments");
+    LU_LAUNCH(bn_finalize_infer_kernel, dim3((C + NT - 1) / NT), dim3(NT), stream, gamma, beta, mm, mv, eps, scale,
+              shift, (int)C);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_bn_lrelu_apply(const float* x, float* y, const float* scale, const float* shift, float alpha,
+                                 int64_t rows, int32_t C, lu_stream_t stream) {
+    LU_REQUIRE(x && y && scale && shift && rows > 0 && C > 0, "lu_bn_lrelu_apply: bad arguments");
+    const int64_t total = rows * C;
+    const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (vec)
+        LU_LAUNCH((bn_lrelu_apply_kernel<true>), dim3(grid_for(total / 4)), dim3(NT), stream, x, y, scale, shift,
+                  alpha, total, (int)C);
+    else
+        LU_LAUNCH((bn_lrelu_apply_kernel<false>), dim3(grid_for(total)), dim3(NT), stream, x, y, scale, shift, alpha,
+                  total, (int)C);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_bn_lrelu_bwd_reduce(const float* x, const float* dy, const float* scale, const float* shift,
+                                      const float* save_mean, const float* save_invstd, float alpha, int64_t rows,
+                                      int32_t C, double* sums, void* ws, lu_stream_t stream) {
+    LU_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums && ws && rows > 0 && C > 0,
+               "lu_bn_lrelu_bwd_reduce: bad arguments");
+    FnBnBwd fn{x, dy, scale, shift, save_mean, save_invstd, alpha, C};
+    return run_colreduce(fn, rows, C, ws, sums, nullptr, 0.f, 0, stream);
+}
+
+extern "C" int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const float* scale, const float* shift,
+                                     const float* save_mean, const float* save_invstd, float alpha,
+                                     const double* sums, double count, float* dx, float* dgamma, float* dbeta,
+                                     int64_t rows, int32_t C, lu_stream_t stream) {
+    LU_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums && dx && rows > 0 && C > 0 && count > 0,
+               "lu_bn_lrelu_bwd_apply: bad arguments");
+    const int64_t total = rows * C;
+    LU_LAUNCH(bn_lrelu_bwd_apply_kernel, dim3(grid_for(total)), dim3(NT), stream, x, dy, scale, shift, save_mean,
+              save_invstd, alpha, sums, count, dx, dgamma, dbeta, total, (int)C);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32_t H, int32_t W, int32_t C,
+                                 lu_stream_t stream) {
+    LU_REQUIRE(x && y && frames > 0 && H > 0 && W > 0 && C > 0, "lu_upsample2x_fwd: bad arguments");
+    LU_LAUNCH(upsample2x_fwd_kernel, dim3(grid_for((int64_t)frames * 4 * H * W * C)), dim3(NT), stream, x, y,
+              (int)frames, (int)H, (int)W, (int)C);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_upsample2x_bwd(const float* dy, int32_t dy_ps, float* dx, int32_t frames, int32_t H, int32_t W,
+                                 int32_t C, lu_stream_t stream) {
+    LU_REQUIRE(dy && dx && frames > 0 && H > 0 && W > 0 && C > 0 && dy_ps >= C, "lu_upsample2x_bwd: bad arguments");
+    LU_LAUNCH(upsample2x_bwd_kernel, dim3(grid_for((int64_t)frames * H * W * C)), dim3(NT), stream, dy, (int)dy_ps,
+              dx, (int)frames, (int)H, (int)W, (int)C);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_window_copy(const float* x, int32_t x_ps, float* y, int32_t frames, int32_t Hx, int32_t Wx,
+                              int32_t Hy, int32_t Wy, int32_t C, int32_t off_y, int32_t off_x, int32_t mode,
+                              float beta, lu_stream_t stream) {
+    LU_REQUIRE(x && y && frames > 0 && Hx > 0 && Wx > 0 && Hy > 0 && Wy > 0 && C > 0 && x_ps >= C,
+               "lu_window_copy: bad arguments");
+    if (mode == 1)
+        LU_REQUIRE(off_y < Hx && off_x < Wx && Hy - off_y - Hx < Hx && Wy - off_x - Wx < Wx,
+                   "lu_window_copy: reflect pad must be smaller than the image");
+    LU_LAUNCH(window_copy_kernel, dim3(grid_for((int64_t)frames * Hy * Wy * C)), dim3(NT), stream, x, (int)x_ps, y,
+              (int)frames, (int)Hx, (int)Wx, (int)Hy, (int)Wy, (int)C, (int)off_y, (int)off_x, (int)mode, beta);
+    return LU_CHECK_LAUNCH();
+}
+
+static int wce_blocks(int64_t rows) {
+    int64_t b = (rows + NT - 1) / NT;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+extern "C" size_t lu_wce_workspace_bytes(int64_t rows) { return (size_t)wce_blocks(rows) * 2 * sizeof(double); }
+
+extern "C" int lu_softmax_wce_fwd(const float* logits, const float* gt, const float* class_w, float* softmax_out,
+                                  double* sums, int64_t rows, void* ws, lu_stream_t stream) {
+    LU_REQUIRE(logits && gt && class_w && sums && ws && rows > 0, "lu_softmax_wce_fwd: bad arguments");
+    const int nb = wce_blocks(rows);
+    LU_LAUNCH(wce_fwd_kernel, dim3(nb), dim3(NT), stream, logits, gt, class_w, softmax_out, rows, (double*)ws);
+    int rc = LU_CHECK_LAUNCH();
+    if (rc) return rc;
+    LU_LAUNCH(wce_final_kernel, dim3(1), dim3(64), stream, (const double*)ws, nb, sums);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_softmax_wce_bwd(const float* logits, const float* gt, const float* class_w, const double* sums,
+                                  float grad_scale, float* dlogits, int64_t rows, lu_stream_t stream) {
+    LU_REQUIRE(logits && gt && class_w && sums && dlogits && rows > 0, "lu_softmax_wce_bwd: bad arguments");
+    LU_LAUNCH(wce_bwd_kernel, dim3(grid_for(rows)), dim3(NT), stream, logits, gt, class_w, sums, grad_scale, dlogits,
+              rows);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_wce_finalize(const double* sums, float* loss, lu_stream_t stream) {
+    LU_REQUIRE(sums && loss, "lu_wce_finalize: bad arguments");
+    LU_LAUNCH(wce_loss_kernel, dim3(1), dim3(64), stream, sums, loss);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float alpha, float b1, float b2,
+                            float eps, float grad_scale, lu_stream_t stream) {
+    LU_REQUIRE(p && g && m && v && n > 0, "lu_adam_step: bad arguments");
+    LU_LAUNCH(adam_kernel, dim3(grid_for(n, 4)), dim3(NT), stream, p, g, m, v, n, alpha, b1, b2, eps, grad_scale);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_scale_frames(float* x, const float* keep, int32_t frames, int64_t per_frame, lu_stream_t stream) {
+    LU_REQUIRE(x && keep && frames > 0 && per_frame > 0, "lu_scale_frames: bad arguments");
+    const int64_t total = (int64_t)frames * per_frame;
+    LU_LAUNCH(scale_frames_kernel, dim3(grid_for(total)), dim3(NT), stream, x, keep, per_frame, total);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_transpose_inner(const float* x, float* y, int64_t n, int32_t a, int32_t b, lu_stream_t stream) {
+    LU_REQUIRE(x && y && n > 0 && a > 0 && b > 0 && n < 65536, "lu_transpose_inner: bad arguments");
+    LU_LAUNCH(transpose_inner_kernel, dim3((b + 31) / 32, (a + 31) / 32, (unsigned)n), dim3(NT), stream, x, y, (int)a,
+              (int)b);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_add_inplace(float* y, const float* x, int64_t n, lu_stream_t stream) {
+    LU_REQUIRE(x && y && n > 0, "lu_add_inplace: bad arguments");
+    LU_LAUNCH(add_inplace_kernel, dim3(grid_for(n, 4)), dim3(NT), stream, y, x, n);
+    return LU_CHECK_LAUNCH();
+}

@@ -1,0 +1,75 @@
+"""ctypes view of include/lstm_unet_hip.h: struct layouts and prototypes.  Pure declarations --
+no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
+import ctypes as C
+
+c_f32p = C.c_void_p      # raw device pointers travel as integers
+i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
+
+LU_EPI_BIAS, LU_EPI_LSTM = 0, 1
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [('x', c_f32p), ('w', c_f32p), ('frame_stride', i64), ('w_tap_stride', i64),
+                ('pix_stride', i32), ('C', i32), ('w_row_stride', i32), ('_pad', i32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('src', ConvSrc * 2), ('n_src', i32), ('frames', i32), ('Hin', i32), ('Win', i32),
+                ('Hout', i32), ('Wout', i32), ('k', i32), ('stride', i32), ('dil', i32),
+                ('pad_t', i32), ('pad_l', i32), ('N', i32), ('out_pix_stride', i32), ('epilogue', i32),
+                ('bias', c_f32p), ('out', c_f32p), ('out_frame_stride', i64),
+                ('c_prev', c_f32p), ('c_out', c_f32p), ('h_out', c_f32p), ('gates_out', c_f32p),
+                ('c_prev_frame_stride', i64), ('c_out_frame_stride', i64), ('h_frame_stride', i64),
+                ('gates_frame_stride', i64)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x', c_f32p), ('x_frame_stride', i64), ('x_pix_stride', i32), ('C', i32),
+                ('dy', c_f32p), ('dy_frame_stride', i64), ('dy_pix_stride', i32), ('N', i32),
+                ('frames', i32), ('Hin', i32), ('Win', i32), ('Hout', i32), ('Wout', i32),
+                ('k', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
+                ('dw', c_f32p), ('dw_tap_stride', i64), ('dw_row_stride', i32), ('splits', i32),
+                ('beta', f32), ('workspace', C.c_void_p)]
+
+
+P = C.c_void_p
+S = C.c_void_p  # stream
+PROTOTYPES = {
+    'lu_last_error': (C.c_char_p, []),
+    'lu_abi_version': (C.c_int, []),
+    'lu_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), S]),
+    'lu_weight_flip_transpose': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, S]),
+    'lu_conv2d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(WgradDesc)]),
+    'lu_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), S]),
+    'lu_lstm_gates_fwd': (C.c_int, [P, P, P, P, P, i32, i64, i32, i64, S]),
+    'lu_lstm_gates_bwd': (C.c_int, [P, P, P, P, i64, P, P, P, P, i32, i64, i32, S]),
+    'lu_colreduce_workspace_bytes': (C.c_size_t, [i64, i32]),
+    'lu_colsum': (C.c_int, [P, i64, i32, i32, P, f32, P, S]),
+    'lu_bn_stats': (C.c_int, [P, i64, i32, P, P, S]),
+    'lu_bn_finalize_train': (C.c_int, [P, f64, P, P, f32, f32, P, P, P, P, P, P, i32, S]),
+    'lu_bn_finalize_infer': (C.c_int, [P, P, P, P, f32, P, P, i32, S]),
+    'lu_bn_lrelu_apply': (C.c_int, [P, P, P, P, f32, i64, i32, S]),
+    'lu_bn_lrelu_bwd_reduce': (C.c_int, [P, P, P, P, P, P, f32, i64, i32, P, P, S]),
+    'lu_bn_lrelu_bwd_apply': (C.c_int, [P, P, P, P, P, P, f32, P, f64, P, P, P, i64, i32, S]),
+    'lu_upsample2x_fwd': (C.c_int, [P, P, i32, i32, i32, i32, S]),
+    'lu_upsample2x_bwd': (C.c_int, [P, i32, P, i32, i32, i32, i32, S]),
+    'lu_window_copy': (C.c_int, [P, i32, P, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, S]),
+    'lu_wce_workspace_bytes': (C.c_size_t, [i64]),
+    'lu_softmax_wce_fwd': (C.c_int, [P, P, P, P, P, i64, P, S]),
+    'lu_softmax_wce_bwd': (C.c_int, [P, P, P, P, f32, P, i64, S]),
+    'lu_wce_finalize': (C.c_int, [P, P, S]),
+    'lu_adam_step': (C.c_int, [P, P, P, P, i64, f32, f32, f32, f32, f32, S]),
+    'lu_scale_frames': (C.c_int, [P, P, i32, i64, S]),
+    'lu_transpose_inner': (C.c_int, [P, P, i64, i32, i32, S]),
+    'lu_add_inplace': (C.c_int, [P, P, i64, S]),
+}
+
+
+def bind(path):
+    """dlopen `path` and attach every prototype; raises if a declared symbol is missing."""
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib

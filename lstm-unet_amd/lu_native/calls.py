@@ -1,0 +1,67 @@
+"""Thin, pointer-level call helpers over the C ABI (descriptor packing + error checks).
+Everything here works on raw addresses; ops.py feeds it torch device pointers."""
+import ctypes as C
+
+from . import cabi
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(lib, rc, what):
+    if rc != 0:
+        msg = lib.lu_last_error()
+        raise NativeError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def same_pad(n_in, k, s):
+    """TF 'SAME' geometry (Conv2D padding='same', reference Networks.py:55-56)."""
+    n_out = -(-n_in // s)
+    total = max((n_out - 1) * s + k - n_in, 0)
+    return n_out, total // 2, total - total // 2
+
+
+def conv_src(x, frame_stride, pix_stride, Cin, w, w_tap_stride, w_row_stride):
+    s = cabi.ConvSrc()
+    s.x, s.w = x, w
+    s.frame_stride, s.w_tap_stride = frame_stride, w_tap_stride
+    s.pix_stride, s.C, s.w_row_stride = pix_stride, Cin, w_row_stride
+    return s
+
+
+def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,
+           out_frame_stride, out_pix_stride, lstm=None):
+    d = cabi.ConvDesc()
+    d.n_src = len(srcs)
+    for i, s in enumerate(srcs):
+        d.src[i] = s
+    d.frames, d.Hin, d.Win, d.Hout, d.Wout = frames, Hin, Win, Hout, Wout
+    d.k, d.stride, d.dil, d.pad_t, d.pad_l, d.N = k, stride, dil, pad_t, pad_l, N
+    d.bias, d.out, d.out_frame_stride, d.out_pix_stride = bias, out, out_frame_stride, out_pix_stride
+    d.epilogue = cabi.LU_EPI_BIAS
+    if lstm is not None:
+        d.epilogue = cabi.LU_EPI_LSTM
+        (d.c_prev, d.c_prev_frame_stride, d.c_out, d.c_out_frame_stride, d.h_out, d.h_frame_stride,
+         d.gates_out, d.gates_frame_stride) = lstm
+    check(lib, lib.lu_conv2d_fwd(C.byref(d), stream), 'lu_conv2d_fwd')
+
+
+def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, Wout, k, stride, pad_t, pad_l,
+               dw, dw_tap_stride, dw_row_stride, splits, beta):
+    d = cabi.WgradDesc()
+    d.x, d.x_frame_stride, d.x_pix_stride, d.C = x, x_fs, x_ps, Cin
+    d.dy, d.dy_frame_stride, d.dy_pix_stride, d.N = dy, dy_fs, dy_ps, N
+    d.frames, d.Hin, d.Win, d.Hout, d.Wout = frames, Hin, Win, Hout, Wout
+    d.k, d.stride, d.pad_t, d.pad_l = k, stride, pad_t, pad_l
+    d.dw, d.dw_tap_stride, d.dw_row_stride, d.splits, d.beta = dw, dw_tap_stride, dw_row_stride, splits, beta
+    return d
+
+
+def wgrad_splits(pixels, k, Cin, N, target_blocks=1024):
+    """Pixel-axis split so that (taps x c-tiles x n-tiles x splits) fills the 256 CUs a few times over."""
+    ct = max(1, -(-Cin // 128)) if Cin % 4 == 0 else -(-(k * k * Cin) // 32)
+    taps = k * k if Cin % 4 == 0 else 1
+    tiles = taps * ct * max(1, -(-N // 128))
+    s = max(1, min(target_blocks // max(tiles, 1), pixels // 512))
+    return max(1, min(s, 256))

@@ -1,0 +1,198 @@
+// emu_runtime.h -- TEST INFRASTRUCTURE ONLY.
+// A tiny single-OS-thread SIMT emulator so that the *unmodified* kernel sources under
+// lstm-unet_amd/csrc can be compiled for the host (clang++ -DLU_EMU) and checked against the
+// oracle in the GPU-less build container.  Each GPU thread is a ucontext fiber; a block's 256
+// fibers run round-robin between barriers; one block runs at a time.  MFMA and wave shuffles are
+// emulated through a per-wave exchange buffer with the exact gfx950 lane->element maps.
+// It is never built into, loaded by, or reachable from the product library.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace lu_emu {
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    dim3 tid;
+    int lin = 0;
+    int state = 0;  // 0 runnable, 1 blocked, 2 done
+};
+
+struct Runtime {
+    ucontext_t main_ctx;
+    std::vector<Fiber> fibers;
+    Fiber* cur = nullptr;
+    dim3 blockIdx_, blockDim_, gridDim_;
+    int nthreads = 0;
+    int block_arrived = 0;
+    int wave_arrived[16] = {0};
+    float xa[16][64];
+    float xb[16][64];
+    std::function<void()> body;
+};
+inline Runtime g_rt;
+
+inline void yield_to_main() { swapcontext(&g_rt.cur->ctx, &g_rt.main_ctx); }
+
+inline void block_barrier() {
+    Runtime& r = g_rt;
+    int alive = 0;
+    for (int i = 0; i < r.nthreads; ++i) alive += (r.fibers[i].state != 2);
+    if (++r.block_arrived == alive) {
+        r.block_arrived = 0;
+        for (int i = 0; i < r.nthreads; ++i)
+            if (r.fibers[i].state == 1) r.fibers[i].state = 0;
+        return;
+    }
+    r.cur->state = 1;
+    yield_to_main();
+}
+
+inline void wave_barrier() {
+    Runtime& r = g_rt;
+    int w = r.cur->lin >> 6;
+    int lo = w * 64, hi = lo + 64 < r.nthreads ? lo + 64 : r.nthreads;
+    int alive = 0;
+    for (int i = lo; i < hi; ++i) alive += (r.fibers[i].state != 2);
+    if (++r.wave_arrived[w] == alive) {
+        r.wave_arrived[w] = 0;
+        for (int i = lo; i < hi; ++i)
+            if (r.fibers[i].state == 3) r.fibers[i].state = 0;
+        return;
+    }
+    r.cur->state = 3;  // blocked on wave barrier (distinct from block barrier)
+    yield_to_main();
+}
+
+inline void fiber_entry() {
+    g_rt.body();
+    g_rt.cur->state = 2;
+    // a finished thread no longer participates in barriers: re-evaluate pending ones
+    swapcontext(&g_rt.cur->ctx, &g_rt.main_ctx);
+}
+
+inline void run_block() {
+    Runtime& r = g_rt;
+    const size_t STK = 256 * 1024;
+    r.block_arrived = 0;
+    memset(r.wave_arrived, 0, sizeof(r.wave_arrived));
+    for (int i = 0; i < r.nthreads; ++i) {
+        Fiber& f = r.fibers[i];
+        if (!f.stack) f.stack = (char*)malloc(STK);
+        f.state = 0;
+        f.lin = i;
+        f.tid = dim3(i % r.blockDim_.x, (i / r.blockDim_.x) % r.blockDim_.y, i / (r.blockDim_.x * r.blockDim_.y));
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STK;
+        f.ctx.uc_link = &r.main_ctx;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    int done = 0;
+    long spins = 0;
+    while (done < r.nthreads) {
+        bool progressed = false;
+        for (int i = 0; i < r.nthreads; ++i) {
+            Fiber& f = r.fibers[i];
+            if (f.state != 0) continue;
+            r.cur = &f;
+            swapcontext(&r.main_ctx, &f.ctx);
+            progressed = true;
+            if (f.state == 2) ++done;
+        }
+        if (!progressed) {
+            fprintf(stderr, "lu_emu: deadlock (divergent barrier?) block (%u,%u,%u)\n", r.blockIdx_.x, r.blockIdx_.y,
+                    r.blockIdx_.z);
+            abort();
+        }
+        if (++spins > 100000000L) abort();
+    }
+}
+
+template <class F>
+inline void launch(dim3 grid, dim3 block, F body) {
+    Runtime& r = g_rt;
+    r.gridDim_ = grid;
+    r.blockDim_ = block;
+    r.nthreads = block.x * block.y * block.z;
+    if ((int)r.fibers.size() < r.nthreads) r.fibers.resize(r.nthreads);
+    r.body = body;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                r.blockIdx_ = dim3(bx, by, bz);
+                run_block();
+            }
+}
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
+// Result is a k-ordered fmaf chain (guide: bitwise equal to the hardware).
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    Runtime& r = g_rt;
+    int lane = r.cur->lin & 63, w = r.cur->lin >> 6;
+    r.xa[w][lane] = a;
+    r.xb[w][lane] = b;
+    wave_barrier();
+    int col = lane & 31;
+    for (int reg = 0; reg < 16; ++reg) {
+        int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float acc = c[reg];
+        for (int k = 0; k < 2; ++k) acc = fmaf(r.xa[w][row + 32 * k], r.xb[w][col + 32 * k], acc);
+        c[reg] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+
+inline float shfl_xor(float v, int mask) {
+    Runtime& r = g_rt;
+    int lane = r.cur->lin & 63, w = r.cur->lin >> 6;
+    r.xa[w][lane] = v;
+    wave_barrier();
+    float o = r.xa[w][lane ^ mask];
+    wave_barrier();
+    return o;
+}
+inline float shfl_down(float v, int d) {
+    Runtime& r = g_rt;
+    int lane = r.cur->lin & 63, w = r.cur->lin >> 6;
+    r.xa[w][lane] = v;
+    wave_barrier();
+    float o = lane + d < 64 ? r.xa[w][lane + d] : v;
+    wave_barrier();
+    return o;
+}
+
+}  // namespace lu_emu
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define threadIdx (lu_emu::g_rt.cur->tid)
+#define blockIdx (lu_emu::g_rt.blockIdx_)
+#define blockDim (lu_emu::g_rt.blockDim_)
+#define gridDim (lu_emu::g_rt.gridDim_)
+#define __syncthreads() lu_emu::block_barrier()
+
+typedef void* hipStream_t;
