@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Headline benchmark: ConvLSTM-UNet training frames/s (seq_len*batch per optimiser step) on
+synthetic 256x256 clips, BASELINE.json config-2 per GPU (T=8, B=4 slots/GPU, Params.py widths:
+5x5 ConvLSTM @128/256/256/512, 3x3 encoder/decoder, fp32), weak-scaled data-parallel over N GPUs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward(training) + weighted CE + backward (BPTT inside the window) + Adam + recurrent
+state mask [+ bucketed RCCL gradient all-reduce].  Inputs are resident in HBM before the timed
+region.  Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel:
+the fused ConvLSTM step, fp32 MFMA bound, timed live with HIP events on the launch stream) and
+`cpu_baseline` (the torch-CPU oracle of the same network on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'lstm-unet_amd'))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def conv_flops(k, cin, cout, h, w):
+    return 2.0 * k * k * cin * cout * h * w
+
+
+def step_flops(net, H, W, B, T, cin=1):
+    """Algorithmic FLOPs of one training step: 3x forward, minus the data-image dgrad,
+    minus the t=0 recurrent dgrad of every ConvLSTM (no gradient into the carried state)."""
+    from lu_native.plan import make_plan
+    plan = make_plan(net, cin)
+    fwd = skip_first = rec = 0.0
+    h, w, first = H, W, True
+    for blk in plan['down']:
+        for l in blk['lstm']:
+            fx = conv_flops(l['k'], l['cin'], 4 * l['f'], h, w)
+            fh = conv_flops(l['k'], l['f'], 4 * l['f'], h, w)
+            fwd += fx + fh
+            rec += fh
+            if first:
+                skip_first = fx
+                first = False
+        for l in blk['conv']:
+            if l['stride'] == 2:
+                h, w = -(-h // 2), -(-w // 2)
+            fwd += conv_flops(l['k'], l['cin'], l['cout'], h, w)
+    for blk in plan['up']:
+        if blk['up_factor'] == 2:
+            h, w = 2 * h, 2 * w
+        for l in blk['conv']:
+            fwd += conv_flops(l['k'], l['cin'], l['cout'], h, w)
+    per_frame = 3 * fwd - skip_first - rec / T
+    return per_frame * B * T, fwd
+
+
+def lstm_step_flops(net, H, W, B, cin=1):
+    """[(level, flops of ONE fused ConvLSTM step launch)]"""
+    from lu_native.plan import make_plan
+    plan = make_plan(net, cin)
+    out, h, w = [], H, W
+    for blk in plan['down']:
+        for l in blk['lstm']:
+            out.append(B * (conv_flops(l['k'], l['cin'], 4 * l['f'], h, w) + conv_flops(l['k'], l['f'], 4 * l['f'], h, w)))
+        if blk['stride'] == 2:
+            h, w = -(-h // 2), -(-w // 2)
+    return out
+
+
+def synthetic_batches(n, B, T, H, W, rank, device):
+    from DataHandeling import SyntheticSequence2D
+    prov = SyntheticSequence2D(image_crop_size=(H, W), unroll_len=T, batch_size=B, data_format='NCHW',
+                               seed=1234, rank=rank)
+    out = []
+    for i in range(n):
+        img, seg, _, keep = prov.get_batch()
+        keep[:] = 1.0
+        if i % 4 == 3:
+            keep[i % B] = 0.0     # one slot's clip ends every 4th step
+        out.append((torch.from_numpy(img).to(device), torch.from_numpy(seg).to(device), torch.from_numpy(keep).to(device)))
+    return out
+
+
+def cpu_baseline(net, budget_s=40.0):
+    """The torch-CPU restatement (oracle/torch_oracle.py, fp32, all host threads) on a bounded sample."""
+    from oracle import np_oracle as npo
+    from oracle import torch_oracle as tho
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    H = W = 64
+    B, T = 1, 2
+    p = npo.init_params(net, 1, seed=0)
+    m = tho.TorchULSTM(net, 1, p, dtype=torch.float32)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B, T, H, W, 1)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+    t0 = time.time()
+    m.train_step(x, gt, [0.15, 0.25, 0.6])
+    warm = time.time() - t0
+    n, elapsed = 0, 0.0
+    while elapsed < budget_s / 2 and n < 5 and warm < budget_s:
+        t0 = time.time()
+        m.train_step(x, gt, [0.15, 0.25, 0.6])
+        m.reset_states_per_batch(np.ones(B))
+        elapsed += time.time() - t0
+        n += 1
+    per = elapsed / n if n else warm
+    return {'value': round(B * T / per, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'same net (Params.py widths), %dx%d crop, B=%d T=%d, %d step(s) after 1 warm-up, torch CPU fp32 '
+                      'restatement of the TF2 path (TF not installed)' % (H, W, B, T, max(n, 1))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=4, help='clip slots per GPU')
+    ap.add_argument('--unroll', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sync-bn', action='store_true')
+    args = ap.parse_args()
+
+    import Params
+    from lu_native import ops
+    from lu_native.dp import DataParallel
+    import train2D
+
+    dp = DataParallel()
+    if dp.world_size != args.gpus:
+        print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size), file=sys.stderr)
+    torch.cuda.set_device(dp.local_rank)
+    dev = torch.device('cuda', dp.local_rank)
+    net = Params.CTCParams.net_kernel_params
+    H = W = args.size
+    B, T = args.batch, args.unroll
+    trainer = train2D.Trainer(Params.CTCParams.net_model, net, 'NCHW', Params.CTCParams.class_weights,
+                              Params.CTCParams.learning_rate, dp=dp, sync_bn=args.sync_bn, seed=0)
+    batches = synthetic_batches(4, B, T, H, W, dp.rank, dev)
+
+    def one_step(i):
+        img, seg, keep = batches[i % len(batches)]
+        trainer.train_step(img, seg, want_outputs=False)
+        trainer.model.reset_states_per_batch(keep)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    dp.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if dp.world_size > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    frames_per_s = dp.world_size * B * T * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: fused ConvLSTM step (conv_fwd_kernel<4,true,LSTM>) ----
+    roofline = None
+    if dp.rank == 0:
+        ops.EVENT_LOG = []
+        one_step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        ev, ops.EVENT_LOG = ops.EVENT_LOG, None
+        per_launch = lstm_step_flops(net, H, W, B)
+        tot_ms = sum(a.elapsed_time(b) for a, b in ev)
+        n_launch = len(ev)
+        flops = sum(per_launch) * T          # every level runs T fused steps per training step
+        if n_launch and tot_ms > 0:
+            achieved = flops / (tot_ms * 1e-3) / 1e12
+            roofline = {'kernel': 'conv_fwd_kernel<4,true,LU_EPI_LSTM> (fused ConvLSTM step: two-source 5x5 implicit '
+                                  'GEMM + gate epilogue)', 'bound': 'mfma', 'achieved': round(achieved, 2),
+                        'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                        'traffic': None, 'launches_per_step': n_launch,
+                        'avg_launch_ms': round(tot_ms / n_launch, 4),
+                        'flops_per_launch_avg': flops / n_launch}
+    total_flops, _ = step_flops(net, H, W, B, T)
+    cpu = None
+    if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(net)
+        except Exception as exc:  # the baseline is informational; never lose the GPU line over it
+            cpu = {'value': None, 'unit': 'frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+    if dp.rank == 0:
+        line = {
+            'metric': 'training frames/sec (seq_len*batch) at 256x256',
+            'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config-2 per GPU: %dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet '
+                                   'Params.py widths (5x5 ConvLSTM 128/256/256/512, 3x3 convs), fp32, random-init' %
+                                   (H, W, T, B), 'global_batch': B * dp.world_size, 'seq_len': T,
+                       'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
+            'step_tflop_per_gpu': round(total_flops / 1e12, 2),
+            'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dp.world_size > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

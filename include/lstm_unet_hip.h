@@ -183,6 +183,8 @@ int lu_softmax_wce_fwd(const float* logits, const float* gt, const float* class_
                        double* sums, int64_t rows, void* workspace, lu_stream_t stream);
 int lu_softmax_wce_bwd(const float* logits, const float* gt, const float* class_w, const double* sums,
                        float grad_scale, float* dlogits, int64_t rows, lu_stream_t stream);
+/* k.layers.Softmax over the 3 classes (Networks.py:206,252): out[r,:] = softmax(logits[r,:]) */
+int lu_softmax3(const float* logits, float* out, int64_t rows, lu_stream_t stream);
 /* loss[0] = sums[0] / (sums[1] + 1e-5) */
 int lu_wce_finalize(const double* sums, float* loss, lu_stream_t stream);
 

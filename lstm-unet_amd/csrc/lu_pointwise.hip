@@ -454,6 +454,18 @@ __global__ void wce_bwd_kernel(const float* __restrict__ logits, const float* __
     }
 }
 
+__global__ void softmax3_kernel(const float* __restrict__ logits, float* __restrict__ out, int64_t rows) {
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+        const float l0 = logits[r * 3], l1 = logits[r * 3 + 1], l2 = logits[r * 3 + 2];
+        const float m = fmaxf(l0, fmaxf(l1, l2));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+        const float inv = 1.f / (e0 + e1 + e2);
+        out[r * 3] = e0 * inv;
+        out[r * 3 + 1] = e1 * inv;
+        out[r * 3 + 2] = e2 * inv;
+    }
+}
+
 __global__ void wce_loss_kernel(const double* sums, float* loss) {
     if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = (float)(sums[0] / (sums[1] + 0.00001));
 }
@@ -647,6 +659,12 @@ extern "C" int lu_softmax_wce_bwd(const float* logits, const float* gt, const fl
     LU_REQUIRE(logits && gt && class_w && sums && dlogits && rows > 0, "lu_softmax_wce_bwd: bad arguments");
     LU_LAUNCH(wce_bwd_kernel, dim3(grid_for(rows)), dim3(NT), stream, logits, gt, class_w, sums, grad_scale, dlogits,
               rows);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_softmax3(const float* logits, float* out, int64_t rows, lu_stream_t stream) {
+    LU_REQUIRE(logits && out && rows > 0, "lu_softmax3: bad arguments");
+    LU_LAUNCH(softmax3_kernel, dim3(grid_for(rows)), dim3(NT), stream, logits, out, rows);
     return LU_CHECK_LAUNCH();
 }
 

@@ -58,6 +58,7 @@ PROTOTYPES = {
     'lu_softmax_wce_fwd': (C.c_int, [P, P, P, P, P, i64, P, S]),
     'lu_softmax_wce_bwd': (C.c_int, [P, P, P, P, f32, P, i64, S]),
     'lu_wce_finalize': (C.c_int, [P, P, S]),
+    'lu_softmax3': (C.c_int, [P, P, i64, S]),
     'lu_adam_step': (C.c_int, [P, P, P, P, i64, f32, f32, f32, f32, f32, S]),
     'lu_scale_frames': (C.c_int, [P, P, i32, i64, S]),
     'lu_transpose_inner': (C.c_int, [P, P, i64, i32, i32, S]),

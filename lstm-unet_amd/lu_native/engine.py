@@ -1,0 +1,407 @@
+"""ConvLSTM-UNet execution engine: explicit forward tape + hand-written backward over the HIP ops.
+
+Internal conventions
+  * activations are channels-last fp32 [frames, H, W, C]
+  * frames are TIME-MAJOR: frame index = t*B + b.  Every per-timestep tensor of the recurrence
+    (x_t, h_{t-1}, gates_t, dz_t ...) is then one contiguous slab, h_all[0:T] / h_all[1:T+1] are the
+    "previous" / "output" hidden sequences without copies, and the hoisted weight-gradient GEMMs see
+    dense [T*B] frame ranges.
+  * parameters / gradients / Adam moments live in flat buffers ordered by backward completion
+    (plan.param_specs) so DP gradient buckets can be all-reduced while backward continues.
+
+Reference behaviour reproduced (file:line into arbellea/LSTM-UNet):
+  ULSTMnet2D.call   Networks.py:208-254     DownBlock2D.call Networks.py:60-75
+  UpBlock2D.call    Networks.py:141-153     state API        Networks.py:77-98,279-291
+  truncated BPTT: carried (h, c) are constants of the next window (stateful=True, Networks.py:48-50)
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .plan import make_plan, param_specs, bn_stat_specs, init_tensor
+
+LRELU_ALPHA = 0.3   # k.layers.LeakyReLU() default
+BN_EPS = 1e-3       # k.layers.BatchNormalization defaults
+BN_MOMENTUM = 0.99
+
+
+def model_pads(h, w, total_stride, pad_image):
+    """Networks.py:210-228."""
+    mp = total_stride if pad_image else 0
+    return ((mp, mp + (total_stride - h % total_stride) % total_stride),
+            (mp, mp + (total_stride - w % total_stride) % total_stride))
+
+
+class Engine:
+    def __init__(self, net_params, pad_image=True, seed=0, dp=None, sync_bn=False, plan_fn=None):
+        self.net_params = net_params
+        self._plan_fn = plan_fn if plan_fn is not None else (lambda cin: make_plan(net_params, cin))
+        self.pad_image = bool(pad_image)
+        self.seed = seed
+        self.dp = dp
+        self.sync_bn = bool(sync_bn) and dp is not None and dp.world_size > 1
+        self.plan = None
+        self.device = None
+        self.P = {}       # name -> view into flat_params
+        self.G = {}       # name -> view into flat_grads
+        self.S = {}       # BN moving statistics
+        self.states = None   # [block][layer] -> [h, c] device tensors or None
+        self.batch = None
+        self.tape = None
+        self.segments = []   # [(name, start, end)] gradient buckets in backward-completion order
+        self.on_bucket_ready = None  # callback(start, end) fired as each bucket's gradient completes
+
+    # ------------------------------------------------------------------ build
+    def build(self, in_channels, device):
+        if self.plan is not None:
+            if in_channels != self.plan['in_channels']:
+                raise ValueError('model was built for %d input channels' % self.plan['in_channels'])
+            return
+        self.plan = self._plan_fn(in_channels)
+        self.device = device
+        specs = param_specs(self.plan)
+        offs, total = [], 0
+        for name, shape, kind in specs:
+            n = int(np.prod(shape))
+            offs.append((name, shape, kind, total, n))
+            total += (n + 3) // 4 * 4     # keep every tensor 16-byte aligned inside the flat buffer
+        self.n_flat = total
+        self.flat_params = torch.zeros(total, device=device, dtype=torch.float32)
+        self.flat_grads = torch.zeros(total, device=device, dtype=torch.float32)
+        gen = torch.Generator().manual_seed(self.seed)
+        host = torch.zeros(total, dtype=torch.float32)
+        for name, shape, kind, o, n in offs:
+            host[o:o + n] = init_tensor(shape, kind, gen).reshape(-1)
+            self.P[name] = self.flat_params[o:o + n].view(shape)
+            self.G[name] = self.flat_grads[o:o + n].view(shape)
+        self.flat_params.copy_(host)
+        self._offsets = {name: (o, n) for name, shape, kind, o, n in offs}
+        # buckets: one per block, in the order backward finishes them
+        self.segments = []
+        order = [f'up.{i}' for i in reversed(range(len(self.plan['up'])))] + \
+                [f'down.{i}' for i in reversed(range(len(self.plan['down'])))]
+        for blk in order:
+            members = [(o, n) for name, _, _, o, n in offs if name.startswith(blk + '.')]
+            self.segments.append((blk, min(o for o, _ in members), max((o + n + 3) // 4 * 4 for o, n in members)))
+        for name, shape, kind in bn_stat_specs(self.plan):
+            self.S[name] = init_tensor(shape, kind, None).to(device)
+        self.states = [[None for _ in blk['lstm']] for blk in self.plan['down']]
+        pending = getattr(self, '_pending_states', None)
+        if pending is not None:
+            self._pending_states = None
+            self.set_states(pending)
+
+    def trainable_names(self):
+        return list(self.P.keys())
+
+    def num_trainable(self):
+        return sum(int(v.numel()) for v in self.P.values())
+
+    def load_params(self, params):
+        """name -> array; used by tests (oracle-initialised weights) and checkpoint restore."""
+        for k, v in params.items():
+            t = torch.as_tensor(np.asarray(v), dtype=torch.float32)
+            dst = self.P.get(k, self.S.get(k))
+            if dst is None:
+                raise KeyError(k)
+            dst.copy_(t.reshape(dst.shape))
+
+    def export_params(self):
+        out = {k: v.detach().cpu().numpy().copy() for k, v in self.P.items()}
+        out.update({k: v.detach().cpu().numpy().copy() for k, v in self.S.items()})
+        return out
+
+    # ------------------------------------------------------------------ helpers
+    def _bn_forward(self, prefix, y, training, rec):
+        gamma, beta = self.P[prefix + '.gamma'], self.P[prefix + '.beta']
+        mm, mv = self.S[prefix + '.moving_mean'], self.S[prefix + '.moving_var']
+        if training:
+            sums = ops.bn_stats(y)
+            count = y.numel() // y.shape[-1]
+            if self.sync_bn:
+                self.dp.all_reduce_(sums)
+                count *= self.dp.world_size
+            scale, shift, mean, invstd = ops.bn_finalize_train(sums, count, gamma, beta, BN_EPS, BN_MOMENTUM, mm, mv)
+            if rec is not None:
+                rec.update(scale=scale, shift=shift, mean=mean, invstd=invstd, count=count)
+        else:
+            scale, shift = ops.bn_finalize_infer(gamma, beta, mm, mv, BN_EPS)
+        return ops.bn_lrelu_apply(y, scale, shift, LRELU_ALPHA)
+
+    def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape):
+        """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151)."""
+        w = self.P[f'{prefix}.conv.{ci}.kernel']
+        pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
+        y = ops.conv2d(pairs, self.P[f'{prefix}.conv.{ci}.bias'], spec['stride'])
+        rec = None
+        if tape is not None:
+            rec = {'kind': 'conv', 'prefix': prefix, 'ci': ci, 'spec': spec, 'srcs': srcs, 'bn': with_bn}
+            tape.append(rec)
+        if not with_bn:
+            return y
+        if rec is not None:
+            rec['y'] = y
+        return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec)
+
+    def _conv_unit_backward(self, rec, dz, need_dx):
+        """-> list of input gradients (one per source, None where not needed)."""
+        prefix, ci, spec = rec['prefix'], rec['ci'], rec['spec']
+        w = self.P[f'{prefix}.conv.{ci}.kernel']
+        gw = self.G[f'{prefix}.conv.{ci}.kernel']
+        if rec['bn']:
+            bn = f'{prefix}.bn.{ci}'
+            y = rec['y']
+            sums = ops.bn_lrelu_bwd_reduce(y, dz, rec['scale'], rec['shift'], rec['mean'], rec['invstd'], LRELU_ALPHA)
+            if self.sync_bn:
+                Cc = y.shape[-1]
+                self.G[bn + '.beta'].copy_(sums[:Cc])        # local sums: the gradient all-reduce adds ranks
+                self.G[bn + '.gamma'].copy_(sums[Cc:])
+                self.dp.all_reduce_(sums)
+                dy = ops.bn_lrelu_bwd_apply(y, dz, rec['scale'], rec['shift'], rec['mean'], rec['invstd'],
+                                            LRELU_ALPHA, sums, rec['count'], None, None, out=dz)
+            else:
+                dy = ops.bn_lrelu_bwd_apply(y, dz, rec['scale'], rec['shift'], rec['mean'], rec['invstd'],
+                                            LRELU_ALPHA, sums, rec['count'], self.G[bn + '.gamma'],
+                                            self.G[bn + '.beta'], out=dz)
+            rec['y'] = None
+        else:
+            dy = dz
+        ops.bias_grad(dy, self.G[f'{prefix}.conv.{ci}.bias'])
+        dxs = []
+        for (x, co, cs), need in zip(rec['srcs'], need_dx):
+            ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'])
+            dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs) if need else None)
+        rec['srcs'] = None
+        return dxs
+
+    # ------------------------------------------------------------------ ConvLSTM layer
+    def _lstm_forward(self, bi, li, spec, x_seq, T, B, tape):
+        """x_seq [T*B,H,W,C] time-major -> h sequence [T*B,H,W,F]; updates the carried state."""
+        _, H, W, _ = x_seq.shape
+        F = spec['f']
+        dev = x_seq.device
+        pre = f'down.{bi}.lstm.{li}'
+        kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
+        h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
+        c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
+        st = self.states[bi][li]
+        if st is None:
+            h_all[0].zero_()
+            c_all[0].zero_()
+        else:
+            if tuple(st[0].shape) != (B, H, W, F):
+                raise ValueError('stateful ConvLSTM: batch/shape changed from %s to %s' %
+                                 (tuple(st[0].shape), (B, H, W, F)))
+            h_all[0].copy_(st[0])
+            c_all[0].copy_(st[1])
+        gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32) if tape is not None else None
+        x5 = x_seq.view(T, B, H, W, -1)
+        for t in range(T):
+            ops.convlstm_step(x5[t], h_all[t], c_all[t], kernel, rec_k, bias, h_all[t + 1], c_all[t + 1],
+                              gates[t] if gates is not None else None)
+        if st is None:
+            self.states[bi][li] = [h_all[T].clone(), c_all[T].clone()]
+        else:
+            st[0].copy_(h_all[T])
+            st[1].copy_(c_all[T])
+        if tape is not None:
+            tape.append({'kind': 'lstm', 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'h_all': h_all, 'c_all': c_all,
+                         'gates': gates, 'T': T, 'B': B})
+        return h_all[1:].view(T * B, H, W, F)
+
+    def _lstm_backward(self, rec, dh_seq, need_dx):
+        """BPTT inside the window; gradients do not flow into the carried state."""
+        bi, li, spec, T, B = rec['bi'], rec['li'], rec['spec'], rec['T'], rec['B']
+        pre = f'down.{bi}.lstm.{li}'
+        kernel, rec_k = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel']
+        h_all, c_all, gates, x_seq = rec['h_all'], rec['c_all'], rec['gates'], rec['x']
+        _, _, H, W, F = h_all.shape
+        dev = h_all.device
+        dz = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32)
+        dh5 = dh_seq.view(T, B, H, W, F)
+        dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
+        dh_rec = None
+        rec_kt = ops.flip_transpose(rec_k) if T > 1 else None
+        p = (spec['k'] - 1) // 2
+        for t in reversed(range(T)):
+            ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc[(t + 1) & 1] if t < T - 1 else None,
+                               dz[t], dc[t & 1])
+            if t > 0:
+                if dh_rec is None:
+                    dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
+                ops.calls.conv2d(ops.lib(), ops._stream(), [ops._src(dz[t], rec_kt)], B, H, W, H, W, spec['k'], 1, 1,
+                                 p, p, F, None, dh_rec.data_ptr(), dh_rec.stride(0), dh_rec.stride(2))
+        rec['gates'] = None
+        dz_seq = dz.view(T * B, H, W, 4 * F)
+        # hoisted over all T: one big reduction per weight
+        ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1)
+        ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
+        ops.bias_grad(dz_seq, self.G[pre + '.bias'])
+        dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1) if need_dx else None
+        rec['h_all'] = rec['c_all'] = rec['x'] = None
+        return dx
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, x_tb, T, B, training):
+        """x_tb [T*B,H,W,C] time-major -> logits [T*B,H,W,last_depth]; records a tape when training."""
+        self.build(x_tb.shape[-1], x_tb.device)
+        if self.batch is None:
+            self.batch = B
+        elif self.batch != B:
+            raise ValueError('stateful model: batch size is fixed at first call (%d), got %d' % (self.batch, B))
+        plan = self.plan
+        tape = [] if training else None
+        _, H, W, _ = x_tb.shape
+        py, px = model_pads(H, W, plan['total_stride'], self.pad_image)
+        if any(py) or any(px):
+            x_in = ops.window_copy(x_tb, (H + sum(py), W + sum(px)), (py[0], px[0]), 1)
+        else:
+            x_in = x_tb
+        skips = []
+        act = x_in
+        for bi, blk in enumerate(plan['down']):
+            skips.append(act)
+            seq = act
+            for li, l in enumerate(blk['lstm']):
+                seq = self._lstm_forward(bi, li, l, seq, T, B, tape)
+            for ci, l in enumerate(blk['conv']):
+                seq = self._conv_unit(f'down.{bi}', ci, l, [(seq, 0, l['cin'])], True, training, tape)
+            act = seq
+        up_in = act
+        for bi, (blk, skip) in enumerate(zip(plan['up'], skips[::-1])):
+            if blk['up_factor'] == 2:
+                u = ops.upsample2x(up_in)
+                if tape is not None:
+                    tape.append({'kind': 'up', 'in_hw': (up_in.shape[1], up_in.shape[2])})
+            else:
+                u = up_in
+            n = len(blk['conv'])
+            a = None
+            for ci, l in enumerate(blk['conv']):
+                last = blk['return_logits'] and ci == n - 1
+                srcs = [(u, 0, blk['c_up']), (skip, blk['c_up'], blk['c_skip'])] if ci == 0 else [(a, 0, l['cin'])]
+                a = self._conv_unit(f'up.{bi}', ci, l, srcs, not last, training, tape)
+            up_in = a
+        logits = up_in
+        if any(py) or any(px):
+            logits = ops.window_copy(logits, (H, W), (-py[0], -px[0]), 0)
+        if training:
+            self.tape = {'ops': tape, 'pads': (py, px), 'hw': (H, W), 'T': T, 'B': B}
+        return logits
+
+    def backward(self, dlogits):
+        """dlogits [T*B,H,W,last_depth] -> fills flat_grads (all trainable tensors)."""
+        if self.tape is None:
+            raise RuntimeError('backward() needs a training forward first')
+        tp, self.tape = self.tape, None
+        tape = tp['ops']
+        py, px = tp['pads']
+        H, W = tp['hw']
+        plan = self.plan
+        d = dlogits
+        if any(py) or any(px):
+            d = ops.window_copy(dlogits, (H + sum(py), W + sum(px)), (py[0], px[0]), 0)
+        nd = len(plan['down'])
+        g_down = [None] * nd    # gradient w.r.t. the output of each down block
+        seg = 0
+        # ---- decoder ----
+        for bi in reversed(range(len(plan['up']))):
+            blk = plan['up'][bi]
+            for ci in reversed(range(len(blk['conv']))):
+                rec = tape.pop()
+                assert rec['kind'] == 'conv' and rec['prefix'] == f'up.{bi}' and rec['ci'] == ci
+                if ci > 0:
+                    (d,) = self._conv_unit_backward(rec, d, [True])
+                else:
+                    skip_level = nd - 2 - bi       # up0 <- D2 ... up(nd-1) <- image (level -1: no grad)
+                    d_u, d_skip = self._conv_unit_backward(rec, d, [True, skip_level >= 0])
+                    if skip_level >= 0:
+                        g_down[skip_level] = d_skip
+                    if blk['up_factor'] == 2:
+                        urec = tape.pop()
+                        assert urec['kind'] == 'up'
+                        d = ops.upsample2x_bwd(d_u, urec['in_hw'])
+                    else:
+                        d = d_u
+            self._bucket_done(seg)
+            seg += 1
+        g_down[nd - 1] = d
+        # ---- encoder ----
+        for bi in reversed(range(nd)):
+            blk = plan['down'][bi]
+            d = g_down[bi]
+            g_down[bi] = None
+            for ci in reversed(range(len(blk['conv']))):
+                rec = tape.pop()
+                assert rec['kind'] == 'conv' and rec['prefix'] == f'down.{bi}' and rec['ci'] == ci
+                (d,) = self._conv_unit_backward(rec, d, [True])
+            for li in reversed(range(len(blk['lstm']))):
+                rec = tape.pop()
+                assert rec['kind'] == 'lstm' and rec['bi'] == bi and rec['li'] == li
+                d = self._lstm_backward(rec, d, need_dx=(bi > 0 or li > 0))
+            if bi > 0:
+                ops.add_(g_down[bi - 1], d)
+            self._bucket_done(seg)
+            seg += 1
+        assert not tape
+
+    def _bucket_done(self, seg):
+        if self.on_bucket_ready is not None:
+            _, s, e = self.segments[seg]
+            self.on_bucket_ready(s, e)
+
+    # ------------------------------------------------------------------ recurrent state API
+    def reset_states_per_batch(self, keep):
+        """h, c *= keep[b]  (1 = clip continues, 0 = clip ended; Networks.py:77-84)."""
+        if self.states is None:
+            return
+        keep = torch.as_tensor(keep, dtype=torch.float32).reshape(-1).to(self.device)
+        for blk in self.states:
+            for st in blk:
+                if st is not None:
+                    ops.scale_frames(st[0], keep)
+                    ops.scale_frames(st[1], keep)
+
+    def get_states(self):
+        if self.states is None:
+            return None
+        out = []
+        for blk in self.states:
+            out.append([[None, None] if st is None else [st[0].cpu().numpy(), st[1].cpu().numpy()] for st in blk])
+        return out
+
+    def set_states(self, states):
+        if self.states is None:     # not built yet: apply at first call
+            self._pending_states = states
+            return
+        for bi, blk in enumerate(states):
+            for li, st in enumerate(blk):
+                if st is None or st[0] is None:
+                    self.states[bi][li] = None      # reset_states(None) -> zeros
+                else:
+                    h = torch.as_tensor(np.asarray(st[0]), dtype=torch.float32).to(self.device).contiguous()
+                    c = torch.as_tensor(np.asarray(st[1]), dtype=torch.float32).to(self.device).contiguous()
+                    self.states[bi][li] = [h, c]
+
+
+class Adam:
+    """tf.keras Adam over the engine's flat buffers (train2D.py:61: lr from params, beta .9/.999, eps 1e-7)."""
+
+    def __init__(self, engine, lr=1e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.engine = engine
+        self.lr, self.b1, self.b2, self.eps = lr, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self.m = None
+        self.v = None
+
+    def apply_gradients(self, grad_scale=1.0):
+        e = self.engine
+        if self.m is None:
+            self.m = torch.zeros_like(e.flat_params)
+            self.v = torch.zeros_like(e.flat_params)
+        self.iterations += 1
+        t = self.iterations
+        alpha = self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        ops.adam_step(e.flat_params, e.flat_grads, self.m, self.v, alpha, self.b1, self.b2, self.eps, grad_scale)

@@ -1,0 +1,339 @@
+"""Tensor-level wrappers over the gfx950 kernel library (C ABI in include/lstm_unet_hip.h).
+
+torch is used for device memory, streams and torch.distributed only.  Every function here takes
+CUDA(HIP) float32 tensors, hands raw pointers to the C ABI and enqueues on torch's current stream.
+There is NO CPU / eager fallback: a missing library or a non-device tensor raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import cabi, calls
+from .calls import NativeError, same_pad
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblstmunet_hip.so')
+_lib = None
+EVENT_LOG = None   # bench.py: list collecting (start, end) torch.cuda.Event pairs around fused ConvLSTM steps
+
+
+def lib():
+    """The HIP kernel library; loud failure if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError('HIP kernel library missing: %s -- build it with `python -m lu_native.build` '
+                              '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+        _lib = cabi.bind(LIB_PATH)
+        if _lib.lu_abi_version() != 1:
+            raise NativeError('ABI version mismatch in %s' % LIB_PATH)
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeError('lu_native ops need device tensors (got %s); no CPU fallback exists' % t.device)
+        if t.dtype != torch.float32 and t.dtype != torch.float64:
+            raise NativeError('unexpected dtype %s' % t.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _src(x, w):
+    """x: [frames,H,W,C] (channel-slice views allowed), w: [k,k,C,N] (channel-slice views allowed)."""
+    assert x.dim() == 4 and w.dim() == 4 and x.stride(3) == 1 and w.stride(3) == 1, (x.shape, x.stride(), w.shape)
+    assert x.stride(1) == x.shape[2] * x.stride(2), 'rows of x must be dense'
+    assert w.shape[2] == x.shape[3] and w.stride(0) == w.shape[1] * w.stride(1)
+    return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data_ptr(), w.stride(1), w.stride(2))
+
+
+def conv2d(pairs, bias, stride=1, out=None):
+    """SAME convolution summed over (activation, weight) pairs -> [frames,Ho,Wo,N]."""
+    x0, w0 = pairs[0]
+    _chk(bias, out, *[t for p in pairs for t in p])
+    frames, Hin, Win = x0.shape[:3]
+    k, N = w0.shape[0], w0.shape[3]
+    Hout, pt, _ = same_pad(Hin, k, stride)
+    Wout, pl, _ = same_pad(Win, k, stride)
+    if out is None:
+        out = torch.empty((frames, Hout, Wout, N), device=x0.device, dtype=torch.float32)
+    calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, 1, pt, pl,
+                 N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2))
+    return out
+
+
+def flip_transpose(w, c_off=0, c_sub=None):
+    """dense [k,k,C,N] kernel, channels [c_off, c_off+c_sub) -> dense [k,k,N,c_sub] kernel of the
+    input-gradient convolution (spatially flipped, channel-transposed)."""
+    _chk(w)
+    assert w.is_contiguous()
+    k, _, Ctot, N = w.shape
+    c_sub = Ctot - c_off if c_sub is None else c_sub
+    wt = torch.empty((k, k, N, c_sub), device=w.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_weight_flip_transpose(w.data_ptr(), wt.data_ptr(), k, Ctot, N, c_off, c_sub,
+                                                      _stream()), 'lu_weight_flip_transpose')
+    return wt
+
+
+def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None):
+    """Gradient w.r.t. (channels [c_off, c_off+c_sub) of) the input of conv2d(x, w, stride): a
+    convolution of the (zero-dilated when stride == 2) dy with the flipped / transposed kernel."""
+    _chk(dy, w)
+    k = w.shape[0]
+    Hin, Win = in_hw
+    _, pt, _ = same_pad(Hin, k, stride)
+    _, pl, _ = same_pad(Win, k, stride)
+    wt = flip_transpose(w, c_off, c_sub)
+    frames, Hd, Wd, N = dy.shape
+    Cs = wt.shape[3]
+    if out is None:
+        out = torch.empty((frames, Hin, Win, Cs), device=dy.device, dtype=torch.float32)
+    calls.conv2d(lib(), _stream(), [_src(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs,
+                 None, out.data_ptr(), out.stride(0), out.stride(2))
+    return out
+
+
+def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
+    """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy."""
+    _chk(x, dy, dw)
+    frames, Hin, Win, Cin = x.shape
+    _, Hout, Wout, N = dy.shape
+    k = dw.shape[0]
+    _, pt, _ = same_pad(Hin, k, stride)
+    _, pl, _ = same_pad(Win, k, stride)
+    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N)
+    d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
+                         frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
+                         splits, beta)
+    nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    d.workspace = ws.data_ptr()
+    calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
+    return dw
+
+
+def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out):
+    """One ConvLSTM2D cell step (reference Networks.py:48-50,62-63).  Fused two-source conv + gate
+    epilogue when F % 32 == 0, otherwise conv -> pre-activations -> gate kernel."""
+    _chk(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out)
+    frames, H, W, _ = x_t.shape
+    F = rec.shape[2]
+    k = kernel.shape[0]
+    p = (k - 1) // 2
+    if F % 32 == 0:
+        ev = None
+        if EVENT_LOG is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
+                     4 * F, _p(bias), None, 0, 0,
+                     lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
+                           h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0))
+        if ev is not None:
+            ev[1].record()
+            EVENT_LOG.append(ev)
+    else:
+        z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
+        assert c_prev.is_contiguous() and c_out.is_contiguous()
+        calls.check(lib(), lib().lu_lstm_gates_fwd(z.data_ptr(), c_prev.data_ptr(), c_out.data_ptr(), h_out.data_ptr(),
+                                                   _p(gates_out), frames, H * W, F, h_out.stride(0), _stream()),
+                    'lu_lstm_gates_fwd')
+
+
+def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc_in, dz, dc_prev_out):
+    _chk(gates, c_prev, c_cur, dh_a, dh_b, dc_in, dz, dc_prev_out)
+    frames, H, W, F = c_cur.shape
+    for t in (gates, c_prev, c_cur, dz, dc_prev_out):
+        assert t.is_contiguous()
+    calls.check(lib(), lib().lu_lstm_gates_bwd(gates.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(), dh_a.data_ptr(),
+                                               dh_a.stride(0), _p(dh_b), _p(dc_in), dz.data_ptr(),
+                                               dc_prev_out.data_ptr(), frames, H * W, F, _stream()),
+                'lu_lstm_gates_bwd')
+
+
+def _colws(rows, Cc, device):
+    n = lib().lu_colreduce_workspace_bytes(rows, Cc)
+    return torch.empty((n + 7) // 8, device=device, dtype=torch.float64)
+
+
+def colsum(x2d_rows, Cc, ld, ptr, out, beta, device):
+    ws = _colws(x2d_rows, Cc, device)
+    calls.check(lib(), lib().lu_colsum(ptr, x2d_rows, Cc, ld, out.data_ptr(), beta, ws.data_ptr(), _stream()),
+                'lu_colsum')
+
+
+def bias_grad(dy, out, beta=0.0):
+    """out[N] = sum over all pixels of dy[..., N]."""
+    _chk(dy, out)
+    assert dy.is_contiguous()
+    Cc = dy.shape[-1]
+    colsum(dy.numel() // Cc, Cc, Cc, dy.data_ptr(), out, beta, dy.device)
+
+
+def bn_stats(y):
+    _chk(y)
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    sums = torch.empty(2 * Cc, device=y.device, dtype=torch.float64)
+    ws = _colws(rows, Cc, y.device)
+    calls.check(lib(), lib().lu_bn_stats(y.data_ptr(), rows, Cc, sums.data_ptr(), ws.data_ptr(), _stream()),
+                'lu_bn_stats')
+    return sums
+
+
+def bn_finalize_train(sums, count, gamma, beta, eps, momentum, mm, mv):
+    Cc = gamma.numel()
+    dev = gamma.device
+    scale, shift, mean, invstd = (torch.empty(Cc, device=dev, dtype=torch.float32) for _ in range(4))
+    calls.check(lib(), lib().lu_bn_finalize_train(sums.data_ptr(), float(count), gamma.data_ptr(), beta.data_ptr(),
+                                                  eps, momentum, _p(mm), _p(mv), scale.data_ptr(), shift.data_ptr(),
+                                                  mean.data_ptr(), invstd.data_ptr(), Cc, _stream()),
+                'lu_bn_finalize_train')
+    return scale, shift, mean, invstd
+
+
+def bn_finalize_infer(gamma, beta, mm, mv, eps):
+    Cc = gamma.numel()
+    scale, shift = (torch.empty(Cc, device=gamma.device, dtype=torch.float32) for _ in range(2))
+    calls.check(lib(), lib().lu_bn_finalize_infer(gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(), eps,
+                                                  scale.data_ptr(), shift.data_ptr(), Cc, _stream()),
+                'lu_bn_finalize_infer')
+    return scale, shift
+
+
+def bn_lrelu_apply(y, scale, shift, alpha, out=None):
+    _chk(y, scale, shift)
+    Cc = y.shape[-1]
+    if out is None:
+        out = torch.empty_like(y)
+    calls.check(lib(), lib().lu_bn_lrelu_apply(y.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), alpha,
+                                               y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_apply')
+    return out
+
+
+def bn_lrelu_bwd_reduce(y, dz, scale, shift, mean, invstd, alpha):
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    sums = torch.empty(2 * Cc, device=y.device, dtype=torch.float64)
+    ws = _colws(rows, Cc, y.device)
+    calls.check(lib(), lib().lu_bn_lrelu_bwd_reduce(y.data_ptr(), dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                    mean.data_ptr(), invstd.data_ptr(), alpha, rows, Cc,
+                                                    sums.data_ptr(), ws.data_ptr(), _stream()),
+                'lu_bn_lrelu_bwd_reduce')
+    return sums
+
+
+def bn_lrelu_bwd_apply(y, dz, scale, shift, mean, invstd, alpha, sums, count, dgamma, dbeta, out=None):
+    Cc = y.shape[-1]
+    if out is None:
+        out = torch.empty_like(y)
+    calls.check(lib(), lib().lu_bn_lrelu_bwd_apply(y.data_ptr(), dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   mean.data_ptr(), invstd.data_ptr(), alpha, sums.data_ptr(),
+                                                   float(count), out.data_ptr(), _p(dgamma), _p(dbeta),
+                                                   y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_bwd_apply')
+    return out
+
+
+def upsample2x(x):
+    _chk(x)
+    frames, H, W, Cc = x.shape
+    y = torch.empty((frames, 2 * H, 2 * W, Cc), device=x.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_upsample2x_fwd(x.data_ptr(), y.data_ptr(), frames, H, W, Cc, _stream()),
+                'lu_upsample2x_fwd')
+    return y
+
+
+def upsample2x_bwd(dy, in_hw):
+    """dy: [frames,2H,2W,C] (channel-slice view allowed) -> [frames,H,W,C]."""
+    _chk(dy)
+    frames, _, _, Cc = dy.shape
+    H, W = in_hw
+    dx = torch.empty((frames, H, W, Cc), device=dy.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_upsample2x_bwd(dy.data_ptr(), dy.stride(2), dx.data_ptr(), frames, H, W, Cc, _stream()),
+                'lu_upsample2x_bwd')
+    return dx
+
+
+def window_copy(x, out_hw, off, mode, out=None, beta=0.0):
+    """mode 1: REFLECT pad (reference Networks.py:232); mode 0: zero outside (crop / zero-embed)."""
+    _chk(x, out)
+    frames, Hx, Wx, Cc = x.shape
+    Hy, Wy = out_hw
+    if out is None:
+        out = torch.empty((frames, Hy, Wy, Cc), device=x.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_window_copy(x.data_ptr(), x.stride(2), out.data_ptr(), frames, Hx, Wx, Hy, Wy, Cc,
+                                            off[0], off[1], mode, beta, _stream()), 'lu_window_copy')
+    return out
+
+
+def wce_forward(logits2d, gt1d, class_w, want_softmax):
+    """-> (sums[2] double: [sum ce*w*valid, sum valid], softmax or None)."""
+    _chk(logits2d, gt1d, class_w)
+    rows = gt1d.numel()
+    sums = torch.empty(2, device=logits2d.device, dtype=torch.float64)
+    ws = torch.empty(lib().lu_wce_workspace_bytes(rows) // 8 + 1, device=logits2d.device, dtype=torch.float64)
+    sm = torch.empty_like(logits2d) if want_softmax else None
+    calls.check(lib(), lib().lu_softmax_wce_fwd(logits2d.data_ptr(), gt1d.data_ptr(), class_w.data_ptr(), _p(sm),
+                                                sums.data_ptr(), rows, ws.data_ptr(), _stream()), 'lu_softmax_wce_fwd')
+    return sums, sm
+
+
+def wce_backward(logits2d, gt1d, class_w, sums, grad_scale=1.0):
+    dl = torch.empty_like(logits2d)
+    calls.check(lib(), lib().lu_softmax_wce_bwd(logits2d.data_ptr(), gt1d.data_ptr(), class_w.data_ptr(),
+                                                sums.data_ptr(), grad_scale, dl.data_ptr(), gt1d.numel(), _stream()),
+                'lu_softmax_wce_bwd')
+    return dl
+
+
+def softmax3(logits):
+    _chk(logits)
+    assert logits.is_contiguous() and logits.shape[-1] == 3
+    out = torch.empty_like(logits)
+    calls.check(lib(), lib().lu_softmax3(logits.data_ptr(), out.data_ptr(), logits.numel() // 3, _stream()),
+                'lu_softmax3')
+    return out
+
+
+def wce_loss(sums):
+    loss = torch.empty(1, device=sums.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_wce_finalize(sums.data_ptr(), loss.data_ptr(), _stream()), 'lu_wce_finalize')
+    return loss
+
+
+def adam_step(p, g, m, v, alpha, b1, b2, eps, grad_scale=1.0):
+    _chk(p, g, m, v)
+    calls.check(lib(), lib().lu_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), alpha, b1,
+                                          b2, eps, grad_scale, _stream()), 'lu_adam_step')
+
+
+def scale_frames(x, keep):
+    _chk(x, keep)
+    assert x.is_contiguous()
+    calls.check(lib(), lib().lu_scale_frames(x.data_ptr(), keep.data_ptr(), x.shape[0], x.numel() // x.shape[0],
+                                             _stream()), 'lu_scale_frames')
+
+
+def transpose_inner(x, n, a, b):
+    """[n,a,b] -> [n,b,a] on a contiguous tensor (NCHW <-> NHWC per frame)."""
+    _chk(x)
+    y = torch.empty(x.numel(), device=x.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_transpose_inner(x.data_ptr(), y.data_ptr(), n, a, b, _stream()), 'lu_transpose_inner')
+    return y
+
+
+def add_(y, x):
+    _chk(x, y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    calls.check(lib(), lib().lu_add_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), 'lu_add_inplace')
+    return y

@@ -1,0 +1,320 @@
+"""Training driver with the command line of the reference's train2D.py (flags :288-352) and its
+step contract (train_step/val_step :87-117, loop :145-220):
+
+  one step = forward(training=True) -> WeightedCELoss on the logits -> gradients of every trainable
+  tensor -> Adam(lr, .9, .999, 1e-7) -> step counter += 1; the recurrent-state keep-mask of THAT
+  batch is applied after the step; validation runs with training=False on its own swapped-in
+  recurrent state; both steps return (softmax, logits channels-last, loss).
+
+Multi-GPU: launched as one process per GPU (torchrun); batch slots shard across ranks and gradient
+buckets are all-reduced by RCCL while backward runs (lu_native.dp).  The reference is single-device
+(--net_gpus is parsed and unused there, train2D.py:305); the flag is kept and ignored here too.
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+import torch
+
+import Networks as Nets
+import losses
+from lu_native import ops
+from lu_native.dp import DataParallel
+from lu_native.engine import Adam
+from utils import log_print
+
+
+class AWSError(Exception):
+    pass
+
+
+class Trainer(object):
+    """Owns model + optimiser + DP plumbing; exposes train_step / val_step."""
+
+    def __init__(self, net_model, net_kernel_params, data_format='NCHW', class_weights=(0.15, 0.25, 0.6),
+                 learning_rate=1e-5, dp=None, sync_bn=False, seed=0):
+        self.dp = dp if dp is not None else DataParallel()
+        self.data_format = data_format
+        self.model = net_model(net_kernel_params, data_format, False, seed=seed, dp=self.dp, sync_bn=sync_bn)
+        self.engine = self.model.engine
+        self.optimizer = Adam(self.engine, lr=learning_rate)
+        self.class_weights = list(class_weights)
+        self._cw = None
+        self._nchw = data_format[1] == 'C'
+        self.step = 0
+        self.engine.on_bucket_ready = self.dp.bucket_ready
+
+    def _prep(self, image, label):
+        dev = Nets._device()
+        x_tb, T, B = Nets._to_internal(image, self._nchw, dev)
+        g_tb, _, _ = Nets._to_internal(label, self._nchw, dev)
+        if self._cw is None:
+            self._cw = torch.tensor(self.class_weights, dtype=torch.float32, device=dev)
+        return x_tb, g_tb.view(-1), T, B
+
+    def _outputs(self, logits_tb, sm_tb, T, B):
+        softmax = Nets._from_internal(sm_tb.view(logits_tb.shape), T, B, self._nchw)
+        predictions = Nets._from_internal(logits_tb, T, B, False)      # channels-last, as train2D.py:98-100
+        return softmax, predictions
+
+    def train_step(self, image, label, want_outputs=True):
+        x_tb, g, T, B = self._prep(image, label)
+        e = self.engine
+        logits = e.forward(x_tb, T, B, True)
+        if self.dp.flat is None:
+            self.dp.attach(e.flat_grads)
+        lg = logits.view(-1, logits.shape[-1])
+        sums, sm = ops.wce_forward(lg, g, self._cw, want_outputs)
+        self.dp.all_reduce_(sums)            # global valid-pixel normalisation (losses.py:26)
+        dl = ops.wce_backward(lg, g, self._cw, sums, 1.0)
+        e.backward(dl.view(logits.shape))
+        self.dp.finish()
+        self.optimizer.apply_gradients(1.0)  # gradients were SUMMED over ranks of a globally normalised loss
+        self.step += 1
+        loss = ops.wce_loss(sums)
+        if not want_outputs:
+            return None, None, loss
+        softmax, predictions = self._outputs(logits, sm, T, B)
+        return softmax, predictions, loss
+
+    def val_step(self, image, label):
+        x_tb, g, T, B = self._prep(image, label)
+        logits = self.engine.forward(x_tb, T, B, False)
+        lg = logits.view(-1, logits.shape[-1])
+        sums, sm = ops.wce_forward(lg, g, self._cw, True)
+        self.dp.all_reduce_(sums)
+        softmax, predictions = self._outputs(logits, sm, T, B)
+        return softmax, predictions, ops.wce_loss(sums)
+
+    # -- checkpoints (own format) --
+    def state_dict(self):
+        e = self.engine
+        return {'step': self.step, 'params': e.flat_params.cpu(), 'bn': {k: v.cpu() for k, v in e.S.items()},
+                'adam_m': None if self.optimizer.m is None else self.optimizer.m.cpu(),
+                'adam_v': None if self.optimizer.v is None else self.optimizer.v.cpu(),
+                'adam_iterations': self.optimizer.iterations, 'states': self.model.get_states()}
+
+    def load_state_dict(self, sd, in_channels=1):
+        e = self.engine
+        e.build(in_channels, Nets._device())
+        e.flat_params.copy_(sd['params'])
+        for k, v in sd['bn'].items():
+            e.S[k].copy_(v)
+        if sd['adam_m'] is not None:
+            self.optimizer.m = sd['adam_m'].to(e.device)
+            self.optimizer.v = sd['adam_v'].to(e.device)
+        self.optimizer.iterations = sd['adam_iterations']
+        self.step = sd['step']
+        if sd.get('states') is not None:
+            self.model.set_states(sd['states'])
+
+
+class _RunningMean(object):
+    """k.metrics.Mean: never reset in the reference (train2D.py:52-58) -> running mean over the run."""
+
+    def __init__(self):
+        self.total, self.count = 0.0, 0
+
+    def __call__(self, v):
+        v = float(v)
+        if not np.isnan(v):
+            self.total += v
+            self.count += 1
+
+    def result(self):
+        return self.total / max(self.count, 1)
+
+
+def train(params):
+    dp = DataParallel()
+    is_main = dp.rank == 0
+    trainer = Trainer(params.net_model, params.net_kernel_params, params.data_format, params.class_weights,
+                      params.learning_rate, dp=dp, sync_bn=getattr(params, 'sync_bn', False))
+    model = trainer.model
+    train_data_provider, val_data_provider = params.train_data_provider, params.val_data_provider
+    train_data_provider.start_queues(None)
+    val_data_provider.start_queues(None)
+    seg_measure = losses.seg_measure(params.channel_axis + 1, three_d=False)
+    train_loss, train_seg, train_acc = _RunningMean(), _RunningMean(), _RunningMean()
+    val_loss, val_seg, val_acc = _RunningMean(), _RunningMean(), _RunningMean()
+    ckpt_dir = os.path.join(params.experiment_save_dir, 'tf_ckpts')
+    saved = []
+
+    def save_ckpt():
+        if params.dry_run or not is_main:
+            return None
+        os.makedirs(ckpt_dir, exist_ok=True)
+        path = os.path.join(ckpt_dir, 'ckpt-%d.pt' % trainer.step)
+        torch.save(trainer.state_dict(), path)
+        saved.append(path)
+        while len(saved) > params.save_checkpoint_max_to_keep:
+            old = saved.pop(0)
+            if os.path.exists(old):
+                os.remove(old)
+        return path
+
+    if params.load_checkpoint:
+        path = params.load_checkpoint_path
+        if os.path.isdir(path):
+            cands = sorted((f for f in os.listdir(path) if f.startswith('ckpt-')),
+                           key=lambda f: int(f.split('-')[1].split('.')[0]))
+            path = os.path.join(path, cands[-1]) if cands else ''
+        if path:
+            try:
+                trainer.load_state_dict(torch.load(path, map_location='cpu'))
+                log_print('Restored from {}'.format(path))
+            except FileNotFoundError:
+                raise ValueError('Could not load checkpoint: {}'.format(path))
+        else:
+            log_print('Initializing from scratch.')
+    else:
+        log_print('Initializing from scratch.')
+
+    def accuracy(label, predictions):
+        lab = torch.as_tensor(label).squeeze(params.channel_axis + 1)
+        pred = predictions.argmax(-1).cpu()
+        return float((pred == lab.long()).float().mean())
+
+    template = '{}: Step {}, Loss: {}, Accuracy: {}'
+    val_states = model.get_states()
+    try:
+        for _ in range(trainer.step, params.num_iterations + 1):
+            if params.aws:
+                import requests
+                r = requests.get('http://169.254.169.254/latest/meta-data/spot/instance-action')
+                if not r.status_code == 404:
+                    raise AWSError('Quitting Spot Instance Gracefully')
+            image_sequence, seg_sequence, _, is_last_batch = train_data_provider.get_batch()
+            softmax, predictions, loss_value = trainer.train_step(image_sequence, seg_sequence)
+            model.reset_states_per_batch(is_last_batch)
+            train_loss(loss_value)
+            pred_pub = predictions.permute(0, 1, 4, 2, 3) if params.channel_axis == 1 else predictions
+            train_seg(seg_measure(seg_sequence, pred_pub))
+            train_acc(accuracy(seg_sequence, predictions))
+            step = trainer.step
+            if step % params.save_checkpoint_iteration == 0 or step == params.num_iterations:
+                p = save_ckpt()
+                if p:
+                    log_print('Saved checkpoint for step {}: {}'.format(step, p))
+            if not step % params.print_to_console_interval and is_main:
+                log_print(template.format('Training', step, train_loss.result(), train_acc.result() * 100))
+            if not step % params.validation_interval:
+                train_states = model.get_states()
+                model.set_states(val_states)
+                v_img, v_seg, _, v_last = val_data_provider.get_batch()
+                _, v_pred, v_loss = trainer.val_step(v_img, v_seg)
+                model.reset_states_per_batch(v_last)
+                val_loss(v_loss)
+                v_pub = v_pred.permute(0, 1, 4, 2, 3) if params.channel_axis == 1 else v_pred
+                val_seg(seg_measure(v_seg, v_pub))
+                val_acc(accuracy(v_seg, v_pred))
+                if is_main:
+                    log_print(template.format('Validation', step, val_loss.result(), val_acc.result() * 100))
+                val_states = model.get_states()
+                model.set_states(train_states)
+    except (KeyboardInterrupt, ValueError, AWSError) as err:
+        if not params.dry_run:
+            log_print('Saving Model Before closing due to error: {}'.format(str(err)))
+            save_ckpt()
+    finally:
+        if not params.dry_run and is_main and trainer.engine.plan is not None:
+            model_fname = os.path.join(params.experiment_save_dir, 'model.ckpt')
+            model.save_weights(model_fname)
+            with open(os.path.join(params.experiment_save_dir, 'model_params.pickle'), 'wb') as fobj:
+                pickle.dump({'name': model.__class__.__name__, 'params': (params.net_kernel_params,)}, fobj,
+                            protocol=pickle.HIGHEST_PROTOCOL)
+            log_print('Saved Model to file: {}'.format(model_fname))
+        elif params.dry_run:
+            log_print('WARNING: dry_run flag is ON! Not Saving Model')
+        log_print('Done')
+    return trainer
+
+
+# ------------------------------------------------------------------------------------------------
+# command line: same 32 flags / dests as the reference (train2D.py:288-352)
+# ------------------------------------------------------------------------------------------------
+class _AddNets(argparse.Action):
+    def __call__(self, parser, namespace, values, option_string=None):
+        setattr(namespace, self.dest, [getattr(Nets, v) for v in values])
+
+
+class _AddReader(argparse.Action):
+    def __call__(self, parser, namespace, values, option_string=None):
+        import DataHandeling
+        setattr(namespace, self.dest, getattr(DataHandeling, values))
+
+
+class _AddDatasets(argparse.Action):
+    def __call__(self, parser, namespace, values, option_string=None):
+        if len(values) % 2:
+            raise ValueError('dataset values should be of length 2*N where N is the number of datasets')
+        setattr(namespace, self.dest, [(values[i], values[i + 1]) for i in range(0, len(values), 2)])
+
+
+_FLAG = dict  # readability
+FLAGS = [
+    (('-n', '--experiment_name'), _FLAG(dest='experiment_name', type=str, help='Name of experiment')),
+    (('--gpu_id',), _FLAG(dest='gpu_id', type=str, help="Visible GPUs: example, '0,2,3'")),
+    (('--dry_run',), _FLAG(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
+    (('--profile',), _FLAG(dest='profile', type=bool, help='Write profiling data (use rocprofv3 around the run)')),
+    (('--root_data_dir',), _FLAG(dest='root_data_dir', type=str, help='Root folder containing training data')),
+    (('--data_provider_class',), _FLAG(dest='data_provider_class', type=str, action=_AddReader,
+                                       help='Type of data provider')),
+    (('--dataset',), _FLAG(dest='train_sequence_list', type=str, action=_AddDatasets, nargs='+',
+                           help='Datasets to run. string of pairs: DatasetName, SequenceNumber')),
+    (('--val_dataset',), _FLAG(dest='val_sequence_list', type=str, action=_AddDatasets, nargs='+',
+                               help='Datasets to run. string of pairs DatasetName, SequenceNumber')),
+    (('--net_gpus',), _FLAG(dest='net_gpus', type=int, nargs='+', help='gpus for each net (unused, as upstream)')),
+    (('--net_types',), _FLAG(dest='net_types', type=int, nargs='+', action=_AddNets, help='Type of nets')),
+    (('--crop_size',), _FLAG(dest='crop_size', type=int, nargs=2, help='crop size for y and x dimensions')),
+    (('--train_q_capacity',), _FLAG(dest='train_q_capacity', type=int, help='Capacity of training queue')),
+    (('--val_q_capacity',), _FLAG(dest='val_q_capacity', type=int, help='Capacity of validation queue')),
+    (('--num_train_threads',), _FLAG(dest='num_train_threads', type=int, help='Number of train data threads')),
+    (('--num_val_threads',), _FLAG(dest='num_val_threads', type=int, help='Number of validation data threads')),
+    (('--data_format',), _FLAG(dest='data_format', type=str, choices=['NCHW', 'NWHC', 'NHWC'],
+                               help="Data format NCHW or NHWC ('NWHC' accepted: upstream typo)")),
+    (('--batch_size',), _FLAG(dest='batch_size', type=int, help='Batch size')),
+    (('--unroll_len',), _FLAG(dest='unroll_len', type=int, help='LSTM unroll length')),
+    (('--num_iterations',), _FLAG(dest='num_iterations', type=int, help='Maximum number of training iterations')),
+    (('--validation_interval',), _FLAG(dest='validation_interval', type=int,
+                                       help='Number of iterations between validation iteration')),
+    (('--load_checkpoint',), _FLAG(dest='load_checkpoint', action='store_const', const=True,
+                                   help='Load from checkpoint')),
+    (('--load_checkpoint_path',), _FLAG(dest='load_checkpoint_path', type=str,
+                                        help='path to checkpoint, used only with --load_checkpoint')),
+    (('--continue_run',), _FLAG(dest='continue_run', action='store_const', const=True,
+                                help='Continue run in existing directory')),
+    (('--learning_rate',), _FLAG(dest='learning_rate', type=float, help='Learning rate')),
+    (('--class_weights',), _FLAG(dest='class_weights', type=float, nargs=3,
+                                 help='class weights for background, foreground and edge classes')),
+    (('--save_checkpoint_dir',), _FLAG(dest='save_checkpoint_dir', type=str, help='root directory to save checkpoints')),
+    (('--save_log_dir',), _FLAG(dest='save_log_dir', type=str, help='root directory to save logs')),
+    (('--tb_sub_folder',), _FLAG(dest='tb_sub_folder', type=str, help='sub-folder to save outputs')),
+    (('--save_checkpoint_iteration',), _FLAG(dest='save_checkpoint_iteration', type=int,
+                                             help='number of iterations between save checkpoint')),
+    (('--save_checkpoint_max_to_keep',), _FLAG(dest='save_checkpoint_max_to_keep', type=int,
+                                               help='max recent checkpoints to keep')),
+    (('--save_checkpoint_every_N_hours',), _FLAG(dest='save_checkpoint_every_N_hours', type=int,
+                                                 help='keep checkpoint every N hours')),
+    (('--write_to_tb_interval',), _FLAG(dest='write_to_tb_interval', type=int, help='Interval between log writes')),
+]
+
+
+def build_arg_parser():
+    parser = argparse.ArgumentParser(description='Run Train LSTMUnet Segmentation (MI355X-native)')
+    for names, kw in FLAGS:
+        parser.add_argument(*names, **kw)
+    parser.add_argument('--sync_bn', dest='sync_bn', action='store_const', const=True,
+                        help='[MI355X] pool BatchNorm statistics over all DP ranks')
+    return parser
+
+
+if __name__ == '__main__':
+    import Params
+    args = build_arg_parser().parse_args()
+    args_dict = {key: val for key, val in vars(args).items() if val is not None}
+    print(args_dict)
+    train(Params.CTCParams(args_dict))

@@ -1,0 +1,147 @@
+"""TEST INFRASTRUCTURE: backend-neutral wrappers over the C ABI.
+  * backend 'emu': kernel sources compiled for the host SIMT emulator (tests/emu), numpy buffers
+  * backend 'hip': the real gfx950 library, torch device buffers (needs a GPU; `-m gpu`)
+Mirrors what lu_native/ops.py does; every call goes through include/lstm_unet_hip.h's C ABI."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'lstm-unet_amd'))
+from lu_native import cabi, calls  # noqa: E402
+
+
+class EmuBackend(object):
+    name = 'emu'
+
+    def __init__(self):
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+        import build_emu
+        self.lib = cabi.bind(build_emu.build())
+        self.stream = None
+
+    def dev(self, a, dtype=np.float32):
+        return np.array(a, dtype=dtype, order="C", copy=True)
+
+    def empty(self, shape, dtype=np.float32):
+        return np.full(shape, np.nan, dtype)
+
+    def ptr(self, d, offset_elems=0):
+        return None if d is None else d.ctypes.data + offset_elems * d.itemsize
+
+    def host(self, d):
+        return d
+
+
+class HipBackend(object):
+    name = 'hip'
+
+    def __init__(self):
+        import torch
+        from lu_native import ops
+        self.torch = torch
+        self.lib = ops.lib()
+        self.stream = None   # default stream
+
+    def dev(self, a, dtype=np.float32):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+    def empty(self, shape, dtype=np.float32):
+        t = self.torch.empty(shape, dtype=self.torch.float32 if dtype == np.float32 else self.torch.float64,
+                             device='cuda')
+        return t.fill_(float('nan'))
+
+    def ptr(self, d, offset_elems=0):
+        return None if d is None else d.data_ptr() + offset_elems * d.element_size()
+
+    def host(self, d):
+        self.torch.cuda.synchronize()
+        return d.cpu().numpy()
+
+
+_BACKENDS = {}
+
+
+def backend(name):
+    if name not in _BACKENDS:
+        _BACKENDS[name] = EmuBackend() if name == 'emu' else HipBackend()
+    return _BACKENDS[name]
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None):
+    """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy."""
+    frames, Hin, Win = srcs[0].shape[:3]
+    if N is None:
+        N = ws[0].shape[-1]
+    if pad is None:
+        Hout, pt, _ = calls.same_pad(Hin, k, stride)
+        Wout, pl, _ = calls.same_pad(Win, k, stride)
+    else:
+        pt, pl = pad
+        Hout, Wout = out_hw
+    out = be.empty((frames, Hout, Wout, N))
+    keep, cs = [], []
+    for x, w in zip(srcs, ws):
+        Cin = x.shape[3]
+        xd, wd = be.dev(x), be.dev(w)
+        keep += [xd, wd]
+        cs.append(calls.conv_src(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(wd), Cin * N, N))
+    bd = None if bias is None else be.dev(bias)
+    calls.conv2d(be.lib, be.stream, cs, frames, Hin, Win, Hout, Wout, k, stride, dil, pt, pl, N, be.ptr(bd),
+                 be.ptr(out), Hout * Wout * N, N)
+    return be.host(out)
+
+
+def flip_transpose(be, w, c_off=0, C_sub=None):
+    k, _, Ct, N = w.shape
+    C_sub = Ct - c_off if C_sub is None else C_sub
+    wt = be.empty((k, k, N, C_sub))
+    wd = be.dev(w)
+    calls.check(be.lib, be.lib.lu_weight_flip_transpose(be.ptr(wd), be.ptr(wt), k, Ct, N, c_off, C_sub, be.stream),
+                'flip')
+    return be.host(wt)
+
+
+def conv2d_dgrad(be, dy, w, in_hw, stride):
+    k = w.shape[0]
+    Hin, Win = in_hw
+    _, pt, _ = calls.same_pad(Hin, k, stride)
+    _, pl, _ = calls.same_pad(Win, k, stride)
+    wt = flip_transpose(be, w)
+    return conv2d(be, [dy], [wt], None, k, 1, stride, pad=(k - 1 - pt, k - 1 - pl), out_hw=(Hin, Win))
+
+
+def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0):
+    frames, Hin, Win, Cin = x.shape
+    _, Hout, Wout, N = dy.shape
+    _, pt, _ = calls.same_pad(Hin, k, stride)
+    _, pl, _ = calls.same_pad(Win, k, stride)
+    dw = be.empty((k, k, Cin, N)) if dw0 is None else be.dev(dw0)
+    xd, dyd = be.dev(x), be.dev(dy)
+    d = calls.wgrad_desc(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(dyd), Hout * Wout * N, N, N, frames, Hin, Win,
+                         Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta)
+    ws = be.empty((be.lib.lu_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4 + 4,))
+    d.workspace = be.ptr(ws)
+    calls.check(be.lib, be.lib.lu_conv2d_wgrad(C.byref(d), be.stream), 'wgrad')
+    return be.host(dw)
+
+
+def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias):
+    frames, H, W, Cin = x_t.shape
+    F = rec.shape[2]
+    k = kernel.shape[0]
+    c_out, h_out, gates = be.empty((frames, H, W, F)), be.empty((frames, H, W, F)), be.empty((frames, H, W, 4 * F))
+    xd, hd, cd, kd, rd, bd = [be.dev(a) for a in (x_t, h, c, kernel, rec, bias)]
+    srcs = [calls.conv_src(be.ptr(xd), H * W * Cin, Cin, Cin, be.ptr(kd), Cin * 4 * F, 4 * F),
+            calls.conv_src(be.ptr(hd), H * W * F, F, F, be.ptr(rd), F * 4 * F, 4 * F)]
+    p = (k - 1) // 2
+    calls.conv2d(be.lib, be.stream, srcs, frames, H, W, H, W, k, 1, 1, p, p, 4 * F, be.ptr(bd), None, 0, 0,
+                 lstm=(be.ptr(cd), H * W * F, be.ptr(c_out), H * W * F, be.ptr(h_out), H * W * F, be.ptr(gates),
+                       H * W * 4 * F))
+    return be.host(h_out), be.host(c_out), be.host(gates)

@@ -1,0 +1,200 @@
+"""Whole-path parity: the product's engine / public API vs the oracle (numpy fp64 forward, torch fp64
+autograd for gradients and the Adam update).  'hip' = real gfx950 library (`-m gpu`); 'emu' = same
+host code on the host-emulated kernels (CPU, small shapes) to validate tape/backward plumbing.
+
+Stated tolerances: logits |d| <= 1e-3*max(1,|ref|) after T steps; gradients compared
+relative to the largest reference gradient of that tensor; argmax maps bit-exact outside a top-2-gap
+< 2e-3 tie band; SEG within 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as npo
+from oracle import torch_oracle as tho
+from conftest import tiny_net, c1_net
+from engine_backend import engine_backend
+
+BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def dev(request):
+    with engine_backend(request.param) as d:
+        yield d
+
+
+def perturbed_params(net, cin, seed):
+    rng = np.random.default_rng(seed)
+    p = npo.init_params(net, cin, seed=seed, dtype=np.float32)
+    for k in p:
+        if k.endswith(('gamma', 'moving_var')):
+            p[k] = (p[k] + 0.2 * rng.random(p[k].shape)).astype(np.float32)
+        elif k.endswith(('beta', 'bias', 'moving_mean')):
+            p[k] = (p[k] + 0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    return p
+
+
+def make_engine(net, p, cin, dev, pad_image=False):
+    from lu_native.engine import Engine
+    e = Engine(net, pad_image=pad_image)
+    e.build(cin, dev)
+    e.load_params(p)
+    return e
+
+
+def to_tb(x):   # [B,T,H,W,C] -> time-major frames
+    B, T = x.shape[:2]
+    return np.ascontiguousarray(np.swapaxes(x, 0, 1)).reshape((T * B,) + x.shape[2:])
+
+
+def from_tb(y, B, T):
+    return np.swapaxes(y.reshape((T, B) + y.shape[1:]), 0, 1)
+
+
+def rel_err(a, b, floor=0.0):
+    """max|a-b| relative to max|b|; `floor` keeps tensors whose true gradient is ~0 (conv biases in
+    front of BatchNorm: the mean subtraction cancels them exactly) from dividing by rounding noise."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max(), floor))
+
+
+def grad_floor(grads):
+    return 1e-3 * max(float(np.abs(np.asarray(g)).max()) for g in grads.values())
+
+
+CASES = [  # name, net, cin, B, T, H, W, pad_image
+    ('unfused-k3', tiny_net(3), 1, 2, 2, 16, 16, False),
+    ('fused-k3-pad', tiny_net(3, (32, 8, 8, 32), (8, 8, 8, 8)), 1, 1, 2, 18, 21, True),
+]
+GPU_CASES = [
+    ('c1', c1_net(), 1, 1, 4, 128, 128, False),
+    ('k5-odd', tiny_net(5, (32, 64, 32, 64), (32, 16, 16, 8)), 3, 2, 3, 35, 35, True),
+]
+
+
+def _all_cases(request_dev):
+    return CASES + (GPU_CASES if request_dev.type == 'cuda' else [])
+
+
+def test_forward_and_inference_parity(dev):
+    for name, net, cin, B, T, H, W, pad in _all_cases(dev):
+        rng = np.random.default_rng(1)
+        x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+        p = perturbed_params(net, cin, 3)
+        for training in (True, False):
+            e = make_engine(net, p, cin, dev, pad)
+            ref = npo.model_forward(net, p, x, training=training, pad_image=pad, update_moving=True)
+            lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, training)
+            got = from_tb(lg.cpu().numpy(), B, T)
+            tol = 1e-3 * max(1.0, float(np.abs(ref['logits']).max()))
+            assert np.abs(got - ref['logits']).max() <= tol, (name, training)
+            # carried state after the window
+            for bi, blk in enumerate(ref['states']):
+                for li, (h, c) in enumerate(blk):
+                    assert np.abs(e.states[bi][li][0].cpu().numpy() - h).max() <= 1e-3, (name, 'h', bi)
+                    assert np.abs(e.states[bi][li][1].cpu().numpy() - c).max() <= 1e-3, (name, 'c', bi)
+            if training:
+                for k, v in ref['moving'].items():
+                    assert np.abs(e.S[k].cpu().numpy() - v).max() <= 1e-4, (name, k)
+            # second window continues from the carried state, after a keep-mask
+            keep = np.array([1.0, 0.0][:B], np.float32)
+            e.tape = None
+            e.reset_states_per_batch(keep)
+            st2 = npo.reset_states_per_batch(ref['states'], keep)
+            ref2 = npo.model_forward(net, p if not training else {**p, **ref['moving']}, x[:, ::-1], states=st2,
+                                     training=training, pad_image=pad)
+            lg2 = e.forward(torch.from_numpy(to_tb(x[:, ::-1])).to(dev), T, B, training)
+            assert np.abs(from_tb(lg2.cpu().numpy(), B, T) - ref2['logits']).max() <= tol, (name, 'window2')
+            # argmax label maps: bit-exact outside the tie band
+            top2 = np.sort(ref2['logits'], -1)
+            band = (top2[..., -1] - top2[..., -2]) < 2e-3
+            agree = from_tb(lg2.cpu().numpy(), B, T).argmax(-1) == ref2['logits'].argmax(-1)
+            assert np.all(agree | band), name
+
+
+def test_train_step_parity(dev):
+    """loss, every gradient tensor, Adam-updated weights and carried state of one optimiser step
+    (train2D.py:87-95), then a second step from the carried state."""
+    from lu_native.engine import Adam
+    from lu_native import ops
+    cw = [0.15, 0.25, 0.6]
+    for name, net, cin, B, T, H, W, pad in _all_cases(dev):
+        if pad:
+            continue    # training uses pad_image=False (train2D.py:46)
+        rng = np.random.default_rng(5)
+        p = perturbed_params(net, cin, 7)
+        e = make_engine(net, p, cin, dev, False)
+        opt = Adam(e, lr=1e-3)
+        tm = tho.TorchULSTM(net, cin, p, dtype=torch.float64)
+        cwt = torch.tensor(cw, dtype=torch.float32, device=dev)
+        for step in range(2):
+            x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+            gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+            loss_ref, logits_ref, grads_ref = tm.train_step(x, gt, cw, lr=1e-3)
+            lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+            g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+            sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+            dl = ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0)
+            e.backward(dl.view(lg.shape))
+            loss = float(ops.wce_loss(sums).cpu()[0])
+            assert abs(loss - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref))), (name, step)
+            fl = grad_floor({k: v.numpy() for k, v in grads_ref.items()})
+            worst = max((rel_err(e.G[k].cpu().numpy(), grads_ref[k].numpy(), fl), k) for k in grads_ref)
+            assert worst[0] <= 2e-3, (name, step, worst)
+            opt.apply_gradients()
+            perr = max(float(np.abs(e.P[k].cpu().numpy() - tm.P[k].numpy()).max()) for k in grads_ref)
+            # Adam's first steps move every weight by ~lr; sign flips of tiny gradients can cost up to 2*lr
+            n_bad = sum(int((np.abs(e.P[k].cpu().numpy() - tm.P[k].numpy()) > 2e-4).sum()) for k in grads_ref)
+            n_all = sum(int(np.prod(tm.P[k].shape)) for k in grads_ref)
+            assert perr <= 2.5e-3 and n_bad <= 1e-3 * n_all, (name, step, perr, n_bad, n_all)
+            keep = np.ones(B, np.float32)
+            keep[-1] = 0.0
+            e.reset_states_per_batch(keep)
+            tm.reset_states_per_batch(keep)
+            # keep the two trajectories glued: continue the oracle from the product's weights
+            for k in grads_ref:
+                tm.P[k] = torch.tensor(e.P[k].cpu().numpy(), dtype=torch.float64)
+
+
+def test_public_api_and_autograd_path(dev):
+    import Networks
+    import losses
+    net = tiny_net(3)
+    p = perturbed_params(net, 1, 2)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 2, 16, 16, 1)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(2, 2, 16, 16, 1)).astype(np.float32)
+    ref = npo.model_forward(net, p, x, training=True, pad_image=False)
+    out = {}
+    for fmt in ('NCHW', 'NHWC'):
+        m = Networks.ULSTMnet2D(net, fmt, False)
+        assert m.get_states()[0][0] == [None, None]
+        m.engine.build(1, dev)
+        m.engine.load_params(p)
+        xin = np.transpose(x, (0, 1, 4, 2, 3)) if fmt == 'NCHW' else x
+        gin = np.transpose(gt, (0, 1, 4, 2, 3)) if fmt == 'NCHW' else gt
+        logits, sm = m(xin, True)
+        assert tuple(logits.shape) == ((2, 2, 3, 16, 16) if fmt == 'NCHW' else (2, 2, 16, 16, 3))
+        lcl = logits.detach().cpu().numpy()
+        lcl = np.transpose(lcl, (0, 1, 3, 4, 2)) if fmt == 'NCHW' else lcl
+        assert np.abs(lcl - ref['logits']).max() <= 1e-3
+        smc = sm.cpu().numpy()
+        smc = np.transpose(smc, (0, 1, 3, 4, 2)) if fmt == 'NCHW' else smc
+        assert np.abs(smc - ref['softmax']).max() <= 1e-4
+        ce = losses.WeightedCELoss(2 if fmt == 'NCHW' else 4, [0.15, 0.25, 0.6])
+        loss = ce(gin, logits)
+        assert abs(float(loss) - npo.weighted_ce(gt[..., 0], ref['logits'], [0.15, 0.25, 0.6])) <= 1e-4
+        loss.backward()
+        out[fmt] = m.parameters()[0].grad.cpu().numpy().copy()
+        st = m.get_states()
+        assert st[0][0][0].shape == (2, 16, 16, 8)
+        m.set_states(st)
+        m.reset_states_per_batch(np.array([0.0, 1.0], np.float32))
+        assert float(np.abs(m.get_states()[0][0][0][0]).max()) == 0.0
+    assert np.abs(out['NCHW'] - out['NHWC']).max() <= 1e-6
+    tm = tho.TorchULSTM(net, 1, p, dtype=torch.float64)
+    _, _, grads = tm.train_step(x, gt[..., 0], [0.15, 0.25, 0.6], apply=False)
+    eng = m.engine
+    fl = grad_floor({k: v.numpy() for k, v in grads.items()})
+    worst = max(rel_err(eng.G[k].cpu().numpy(), grads[k].numpy(), fl) for k in grads)
+    assert worst <= 2e-3

@@ -1,0 +1,297 @@
+"""Kernel-level parity against the oracle, through the C ABI of include/lstm_unet_hip.h.
+
+Two backends run the SAME assertions:
+  * 'emu' (CPU, not gpu): lstm-unet_amd/csrc/*.hip compiled for the host SIMT emulator in tests/emu
+    (test infrastructure) -- catches index / fragment-layout / masking mistakes without a GPU;
+  * 'hip' (`-m gpu`): the real gfx950 library on the MI355X.
+Tolerances (fp32 kernels vs fp64 oracle): 5e-5 absolute for convolutions with |values| ~ O(1..10)
+and K up to ~1200, 1e-4..2e-4 for weight gradients (long pixel reductions), ~1e-5 pointwise.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as npo
+from oracle import torch_oracle as tho
+import kernel_harness as KH
+from kernel_harness import f32
+from lu_native import calls
+
+BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(scope='module', params=BACKENDS)
+def be(request):
+    return KH.backend(request.param)
+
+
+RNG = np.random.default_rng(11)
+
+
+def rnd(*shape, scale=1.0):
+    return f32(RNG.standard_normal(shape) * scale)
+
+
+def close(a, b, tol):
+    err = float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+    assert np.isfinite(err) and err <= tol, err
+
+
+def ck(be, rc, what):
+    calls.check(be.lib, rc, what)
+
+
+CONV_CASES = [  # frames, H, W, C, N, k, stride
+    (1, 8, 8, 16, 32, 3, 1), (2, 9, 7, 8, 12, 3, 1), (1, 10, 12, 20, 40, 5, 1), (2, 8, 10, 1, 8, 5, 1),
+    (1, 9, 9, 3, 70, 3, 2), (1, 8, 8, 24, 130, 3, 2), (1, 6, 6, 8, 3, 1, 1), (3, 5, 5, 4, 33, 5, 2),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd(be, case):
+    fr, H, W, Cc, N, k, s = case
+    x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+    close(KH.conv2d(be, [x], [w], b, k, s), npo.conv2d_same(x, w, b, s), 5e-5)
+
+
+def test_conv_two_sources_and_strided_views(be):
+    """UpBlock2D concat([up, skip]) (Networks.py:145) as two sources reading channel slices."""
+    xa, xb = rnd(2, 6, 7, 12), rnd(2, 6, 7, 1)
+    w = rnd(3, 3, 13, 20, scale=0.2)
+    b = rnd(20)
+    ref = npo.conv2d_same(np.concatenate([xa, xb], -1), w, b, 1)
+    xad, xbd, wd, bd = be.dev(xa), be.dev(xb), be.dev(w), be.dev(b)
+    srcs = [calls.conv_src(be.ptr(xad), 6 * 7 * 12, 12, 12, be.ptr(wd), 13 * 20, 20),
+            calls.conv_src(be.ptr(xbd), 6 * 7, 1, 1, be.ptr(wd, 12 * 20), 13 * 20, 20)]
+    out = be.empty((2, 6, 7, 20))
+    calls.conv2d(be.lib, be.stream, srcs, 2, 6, 7, 6, 7, 3, 1, 1, 1, 1, 20, be.ptr(bd), be.ptr(out), 6 * 7 * 20, 20)
+    close(be.host(out), ref, 5e-5)
+    # a source that is a channel slice of a wider activation tensor (pix_stride > C)
+    wide = rnd(2, 6, 7, 24)
+    w2 = rnd(3, 3, 8, 16, scale=0.2)
+    wided, w2d = be.dev(wide), be.dev(w2)
+    srcs = [calls.conv_src(be.ptr(wided, 8), 6 * 7 * 24, 24, 8, be.ptr(w2d), 8 * 16, 16)]
+    out = be.empty((2, 6, 7, 16))
+    calls.conv2d(be.lib, be.stream, srcs, 2, 6, 7, 6, 7, 3, 1, 1, 1, 1, 16, None, be.ptr(out), 6 * 7 * 16, 16)
+    close(be.host(out), npo.conv2d_same(wide[..., 8:16], w2, None, 1), 5e-5)
+
+
+def _torch_conv_grads(x, w, dy, stride):
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    y = tho.conv2d_same(xt, wt, None, stride)
+    gx, gw = torch.autograd.grad(y, [xt, wt], torch.tensor(dy, dtype=torch.float64))
+    return gx.numpy(), gw.numpy()
+
+
+@pytest.mark.parametrize('case', [(2, 8, 9, 8, 12, 3, 1), (1, 7, 7, 4, 8, 5, 1), (2, 8, 8, 8, 16, 3, 2),
+                                  (1, 9, 7, 12, 8, 3, 2), (1, 8, 8, 4, 4, 5, 2), (1, 6, 6, 3, 5, 3, 1),
+                                  (1, 6, 5, 8, 3, 1, 1)])
+def test_conv_dgrad_wgrad(be, case):
+    fr, H, W, Cc, N, k, s = case
+    x, w = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.3)
+    Ho, Wo = calls.same_pad(H, k, s)[0], calls.same_pad(W, k, s)[0]
+    dy = rnd(fr, Ho, Wo, N)
+    gx, gw = _torch_conv_grads(x, w, dy, s)
+    close(KH.conv2d_dgrad(be, dy, w, (H, W), s), gx, 5e-5)
+    close(KH.conv2d_wgrad(be, x, dy, k, s, splits=1), gw, 1e-4)
+    close(KH.conv2d_wgrad(be, x, dy, k, s, splits=3), gw, 1e-4)
+
+
+def test_wgrad_wide_channels_and_beta(be):
+    x, dy = rnd(1, 6, 6, 132), rnd(1, 6, 6, 136)
+    _, gw = _torch_conv_grads(x, rnd(3, 3, 132, 136), dy, 1)
+    dw0 = rnd(3, 3, 132, 136)
+    close(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=2, dw0=dw0, beta=1.0), gw + dw0, 2e-4)
+    x, dy = rnd(1, 6, 6, 40), rnd(1, 6, 6, 8)
+    _, gw = _torch_conv_grads(x, rnd(3, 3, 40, 8), dy, 1)
+    close(KH.conv2d_wgrad(be, x, dy, 3, 1), gw, 1e-4)
+
+
+@pytest.mark.parametrize('k,cin', [(3, 8), (5, 1)])
+def test_convlstm_fused_step(be, k, cin):
+    """Fused two-source conv + gate epilogue == Keras ConvLSTM2D cell step."""
+    F = 32
+    x, h, c = rnd(2, 6, 7, cin), rnd(2, 6, 7, F, scale=0.5), rnd(2, 6, 7, F)
+    ker, rec, b = rnd(k, k, cin, 4 * F, scale=0.3), rnd(k, k, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    h1, c1 = npo.convlstm_step(x, h, c, ker, rec, b)
+    hg, cg, gates = KH.convlstm_step_fused(be, x, h, c, ker, rec, b)
+    close(hg, h1, 2e-5)
+    close(cg, c1, 2e-5)
+    z = npo.conv2d_same(x, ker, b) + npo.conv2d_same(h, rec)
+    close(gates[..., :F], npo.hard_sigmoid(z[..., :F]), 2e-5)
+    close(gates[..., 2 * F:3 * F], np.tanh(z[..., 2 * F:3 * F]), 2e-5)
+
+
+def test_lstm_gates_pointwise_fwd_bwd(be):
+    fr, H, W, F = 2, 4, 5, 6
+    z, c0 = rnd(fr, H, W, 4 * F, scale=2.0), rnd(fr, H, W, F)
+    zd, c0d = be.dev(z), be.dev(c0)
+    c1 = be.empty(c0.shape)
+    hseq = be.empty((fr, 3, H, W, F))   # h written into slot t=1 of a [B,T,...] buffer
+    gates = be.empty(z.shape)
+    ck(be, be.lib.lu_lstm_gates_fwd(be.ptr(zd), be.ptr(c0d), be.ptr(c1), be.ptr(hseq, H * W * F), be.ptr(gates), fr,
+                                    H * W, F, 3 * H * W * F, be.stream), 'gates_fwd')
+    zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    ct = torch.tensor(c0, dtype=torch.float64, requires_grad=True)
+    i, f, g, o = [zt[..., j * F:(j + 1) * F] for j in range(4)]
+    cn = tho.hard_sigmoid(f) * ct + tho.hard_sigmoid(i) * torch.tanh(g)
+    hn = tho.hard_sigmoid(o) * torch.tanh(cn)
+    close(be.host(c1), cn.detach().numpy(), 1e-5)
+    close(be.host(hseq)[:, 1], hn.detach().numpy(), 1e-5)
+    dh, dh2, dc = rnd(fr, H, W, F), rnd(fr, H, W, F), rnd(fr, H, W, F)
+    gz, gc = torch.autograd.grad([hn, cn], [zt, ct], [torch.tensor(dh + dh2, dtype=torch.float64),
+                                                      torch.tensor(dc, dtype=torch.float64)])
+    dz, dcp = be.empty(z.shape), be.empty(c0.shape)
+    dhd, dh2d, dcd = be.dev(dh), be.dev(dh2), be.dev(dc)
+    ck(be, be.lib.lu_lstm_gates_bwd(be.ptr(gates), be.ptr(c0d), be.ptr(c1), be.ptr(dhd), H * W * F, be.ptr(dh2d),
+                                    be.ptr(dcd), be.ptr(dz), be.ptr(dcp), fr, H * W, F, be.stream), 'gates_bwd')
+    close(be.host(dz), gz.numpy(), 1e-5)
+    close(be.host(dcp), gc.numpy(), 1e-5)
+
+
+def test_bn_lrelu_fwd_bwd(be):
+    rows, Cc = 300, 20
+    x = rnd(rows, Cc, scale=2.0) + 0.5
+    gamma, beta = f32(1 + 0.2 * RNG.random(Cc)), rnd(Cc, scale=0.3)
+    mm, mv = rnd(Cc, scale=0.1), f32(1 + RNG.random(Cc))
+    xd, gd, bd = be.dev(x), be.dev(gamma), be.dev(beta)
+    ws = be.empty((be.lib.lu_colreduce_workspace_bytes(rows, Cc) // 8 + 1,), np.float64)
+    sums = be.empty((2 * Cc,), np.float64)
+    ck(be, be.lib.lu_bn_stats(be.ptr(xd), rows, Cc, be.ptr(sums), be.ptr(ws), be.stream), 'stats')
+    close(be.host(sums)[:Cc], x.astype(np.float64).sum(0), 1e-3)
+    scale, shift, smean, sinv = [be.empty((Cc,)) for _ in range(4)]
+    mm2, mv2 = be.dev(mm), be.dev(mv)
+    ck(be, be.lib.lu_bn_finalize_train(be.ptr(sums), float(rows), be.ptr(gd), be.ptr(bd), 1e-3, 0.99, be.ptr(mm2),
+                                       be.ptr(mv2), be.ptr(scale), be.ptr(shift), be.ptr(smean), be.ptr(sinv), Cc,
+                                       be.stream), 'fin')
+    y = be.empty(x.shape)
+    ck(be, be.lib.lu_bn_lrelu_apply(be.ptr(xd), be.ptr(y), be.ptr(scale), be.ptr(shift), 0.3, rows, Cc, be.stream),
+       'apply')
+    yr, mean, var = npo.batchnorm_train(x.reshape(1, 1, rows, Cc), gamma, beta)
+    close(be.host(y), npo.leaky_relu(yr).reshape(rows, Cc), 2e-5)
+    emm, emv = npo.batchnorm_moving_update(mm, mv, mean, var, rows)
+    close(be.host(mm2), emm, 1e-6)
+    close(be.host(mv2), emv, 1e-5)
+    # backward vs torch autograd
+    dy = rnd(rows, Cc)
+    dyd = be.dev(dy)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt_, bt_ = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (gamma, beta)]
+    z, _, _ = tho.bn_train(xt.reshape(1, 1, rows, Cc), gt_, bt_)
+    out = torch.nn.functional.leaky_relu(z, 0.3).reshape(rows, Cc)
+    gx, gg, gb = torch.autograd.grad(out, [xt, gt_, bt_], torch.tensor(dy, dtype=torch.float64))
+    bs = be.empty((2 * Cc,), np.float64)
+    ck(be, be.lib.lu_bn_lrelu_bwd_reduce(be.ptr(xd), be.ptr(dyd), be.ptr(scale), be.ptr(shift), be.ptr(smean),
+                                         be.ptr(sinv), 0.3, rows, Cc, be.ptr(bs), be.ptr(ws), be.stream), 'bwd_reduce')
+    dx, dg, db = be.empty(x.shape), be.empty((Cc,)), be.empty((Cc,))
+    ck(be, be.lib.lu_bn_lrelu_bwd_apply(be.ptr(xd), be.ptr(dyd), be.ptr(scale), be.ptr(shift), be.ptr(smean),
+                                        be.ptr(sinv), 0.3, be.ptr(bs), float(rows), be.ptr(dx), be.ptr(dg), be.ptr(db),
+                                        rows, Cc, be.stream), 'bwd')
+    close(be.host(dx), gx.numpy(), 2e-5)
+    close(be.host(dg), gg.numpy(), 2e-4)
+    close(be.host(db), gb.numpy(), 2e-4)
+    # inference path
+    mmd, mvd = be.dev(mm), be.dev(mv)
+    ck(be, be.lib.lu_bn_finalize_infer(be.ptr(gd), be.ptr(bd), be.ptr(mmd), be.ptr(mvd), 1e-3, be.ptr(scale),
+                                       be.ptr(shift), Cc, be.stream), 'fin_inf')
+    ck(be, be.lib.lu_bn_lrelu_apply(be.ptr(xd), be.ptr(y), be.ptr(scale), be.ptr(shift), 0.3, rows, Cc, be.stream),
+       'apply')
+    close(be.host(y), npo.leaky_relu(npo.batchnorm_infer(x, gamma, beta, mm, mv)), 2e-5)
+
+
+def test_colsum(be):
+    x = rnd(777, 10)
+    xd = be.dev(x)
+    ws = be.empty((be.lib.lu_colreduce_workspace_bytes(777, 6) // 8 + 1,), np.float64)
+    out = be.dev(np.ones(6))
+    ck(be, be.lib.lu_colsum(be.ptr(xd, 2), 777, 6, 10, be.ptr(out), 1.0, be.ptr(ws), be.stream), 'colsum')
+    close(be.host(out), 1 + x[:, 2:8].astype(np.float64).sum(0), 1e-4)
+
+
+def test_upsample_fwd_bwd(be):
+    fr, H, W, Cc = 2, 5, 4, 3
+    x = rnd(fr, H, W, Cc)
+    xd = be.dev(x)
+    y = be.empty((fr, 2 * H, 2 * W, Cc))
+    ck(be, be.lib.lu_upsample2x_fwd(be.ptr(xd), be.ptr(y), fr, H, W, Cc, be.stream), 'up')
+    close(be.host(y), npo.resize_bilinear(x, 2), 1e-6)
+    dyw = rnd(fr, 2 * H, 2 * W, Cc + 2)    # gradient arrives as a channel slice of a wider tensor
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    (gx,) = torch.autograd.grad(tho.resize_bilinear(xt, 2), [xt], torch.tensor(dyw[..., :Cc], dtype=torch.float64))
+    dx = be.empty(x.shape)
+    dywd = be.dev(dyw)
+    ck(be, be.lib.lu_upsample2x_bwd(be.ptr(dywd), Cc + 2, be.ptr(dx), fr, H, W, Cc, be.stream), 'upb')
+    close(be.host(dx), gx.numpy(), 1e-5)
+
+
+def test_window_copy_reflect_crop_embed(be):
+    x = rnd(2, 5, 6, 2)
+    xd = be.dev(x)
+    y = be.empty((2, 10, 11, 2))
+    ck(be, be.lib.lu_window_copy(be.ptr(xd), 2, be.ptr(y), 2, 5, 6, 10, 11, 2, 2, 1, 1, 0.0, be.stream), 'reflect')
+    assert np.array_equal(be.host(y), npo.reflect_pad_hw(x, (2, 3), (1, 4)).astype(np.float32))
+    crop = be.empty((2, 5, 6, 2))
+    ck(be, be.lib.lu_window_copy(be.ptr(y), 2, be.ptr(crop), 2, 10, 11, 5, 6, 2, -2, -1, 0, 0.0, be.stream), 'crop')
+    assert np.array_equal(be.host(crop), x)
+    emb = be.dev(np.ones((2, 10, 11, 2)))
+    ck(be, be.lib.lu_window_copy(be.ptr(xd), 2, be.ptr(emb), 2, 5, 6, 10, 11, 2, 2, 1, 0, 1.0, be.stream), 'embed')
+    exp = np.ones((2, 10, 11, 2), np.float32)
+    exp[:, 2:7, 1:7] += x
+    assert np.array_equal(be.host(emb), exp)
+
+
+def test_softmax_wce(be):
+    rows = 1000
+    lg = rnd(rows, 3, scale=2.0)
+    gt = f32(RNG.integers(-1, 3, rows))
+    cw = f32([0.15, 0.25, 0.6])
+    lgd, gtd, cwd = be.dev(lg), be.dev(gt), be.dev(cw)
+    ws = be.empty((be.lib.lu_wce_workspace_bytes(rows) // 8 + 1,), np.float64)
+    sums, sm, loss = be.empty((2,), np.float64), be.empty(lg.shape), be.empty((1,))
+    ck(be, be.lib.lu_softmax_wce_fwd(be.ptr(lgd), be.ptr(gtd), be.ptr(cwd), be.ptr(sm), be.ptr(sums), rows, be.ptr(ws),
+                                     be.stream), 'f')
+    ck(be, be.lib.lu_wce_finalize(be.ptr(sums), be.ptr(loss), be.stream), 'fin')
+    assert abs(be.host(loss)[0] - npo.weighted_ce(gt, lg, cw)) < 1e-5
+    close(be.host(sm), npo.softmax(lg.astype(np.float64)), 1e-6)
+    sm2 = be.empty(lg.shape)
+    ck(be, be.lib.lu_softmax3(be.ptr(lgd), be.ptr(sm2), rows, be.stream), 'softmax3')
+    close(be.host(sm2), npo.softmax(lg.astype(np.float64)), 1e-6)
+    lt = torch.tensor(lg, dtype=torch.float64, requires_grad=True)
+    (gl,) = torch.autograd.grad(tho.weighted_ce(torch.tensor(gt, dtype=torch.float64), lt, cw.tolist()), [lt])
+    dl = be.empty(lg.shape)
+    ck(be, be.lib.lu_softmax_wce_bwd(be.ptr(lgd), be.ptr(gtd), be.ptr(cwd), be.ptr(sums), 1.0, be.ptr(dl), rows,
+                                     be.stream), 'b')
+    close(be.host(dl), gl.numpy(), 1e-7)
+
+
+def test_adam_scale_transpose_add(be):
+    n = 1003
+    p, g = rnd(n), rnd(n)
+    m, v = rnd(n, scale=0.1), f32(RNG.random(n) * 0.01)
+    step, lr = 3, 1e-3
+    alpha = lr * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+    ep, em, ev = npo.adam_step(p.astype(np.float64), 0.5 * g.astype(np.float64), m.astype(np.float64),
+                               v.astype(np.float64), step, lr=lr)
+    pd, gd, md, vd = be.dev(p), be.dev(g), be.dev(m), be.dev(v)
+    ck(be, be.lib.lu_adam_step(be.ptr(pd), be.ptr(gd), be.ptr(md), be.ptr(vd), n, alpha, 0.9, 0.999, 1e-7, 0.5,
+                               be.stream), 'adam')
+    close(be.host(pd), ep, 1e-6)
+    close(be.host(md), em, 1e-6)
+    close(be.host(vd), ev, 1e-6)
+    st = rnd(3, 40)
+    keep = f32([1, 0, 1])
+    std, kd = be.dev(st), be.dev(keep)
+    ck(be, be.lib.lu_scale_frames(be.ptr(std), be.ptr(kd), 3, 40, be.stream), 'mask')
+    assert np.array_equal(be.host(std), st * keep[:, None])
+    a = rnd(2, 35, 3)
+    ad = be.dev(a)
+    b = be.empty((2, 3, 35))
+    ck(be, be.lib.lu_transpose_inner(be.ptr(ad), be.ptr(b), 2, 35, 3, be.stream), 'tr')
+    assert np.array_equal(be.host(b), a.transpose(0, 2, 1))
+    y0, x0 = rnd(100), rnd(100)
+    yd, x0d = be.dev(y0), be.dev(x0)
+    ck(be, be.lib.lu_add_inplace(be.ptr(yd), be.ptr(x0d), 100, be.stream), 'add')
+    assert np.array_equal(be.host(yd), y0 + x0)
