@@ -88,12 +88,11 @@ def synthetic_batches(n, B, T, H, W, rank, device):
     return out
 
 
-def cpu_baseline(net, budget_s=40.0):
+def cpu_baseline(net, budget_s=45.0):
     """The torch-CPU restatement (oracle/torch_oracle.py, fp32, all host threads) on a bounded sample."""
     from oracle import np_oracle as npo
     from oracle import torch_oracle as tho
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     H = W = 64
     B, T = 1, 2
     p = npo.init_params(net, 1, seed=0)
@@ -101,16 +100,32 @@ def cpu_baseline(net, budget_s=40.0):
     rng = np.random.default_rng(0)
     x = rng.standard_normal((B, T, H, W, 1)).astype(np.float32)
     gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
-    t0 = time.time()
-    m.train_step(x, gt, [0.15, 0.25, 0.6])
-    warm = time.time() - t0
-    n, elapsed = 0, 0.0
-    while elapsed < budget_s / 2 and n < 5 and warm < budget_s:
+
+    def timed_step():
         t0 = time.time()
         m.train_step(x, gt, [0.15, 0.25, 0.6])
         m.reset_states_per_batch(np.ones(B))
-        elapsed += time.time() - t0
+        return time.time() - t0
+
+    # torch's CPU convolutions collapse when oversubscribed (256 threads: >100 s/step on the GPU box),
+    # so walk the thread count up from 8 and keep the fastest; `cores` reports the threads actually used.
+    t_start = time.time()
+    best = (float('inf'), 1)
+    for nt in [c for c in (8, 16, 32, 64, 128) if c <= cores] or [cores]:
+        torch.set_num_threads(nt)
+        timed_step()                      # warm-up at this thread count
+        dt = timed_step()
+        if dt < best[0]:
+            best = (dt, nt)
+        elif dt > 1.5 * best[0] or time.time() - t_start > budget_s / 2:
+            break
+    cores = best[1]
+    torch.set_num_threads(cores)
+    n, elapsed = 0, 0.0
+    while n < 3 and (n == 0 or time.time() - t_start < budget_s):
+        elapsed += timed_step()
         n += 1
+    warm = best[0]
     per = elapsed / n if n else warm
     return {'value': round(B * T / per, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'sample': 'same net (Params.py widths), %dx%d crop, B=%d T=%d, %d step(s) after 1 warm-up, torch CPU fp32 '

@@ -39,8 +39,9 @@ struct SrcInfo {
 };
 
 struct ConvArgs {
-    SrcInfo src[2];
-    int32_t n_src, n_it;
+    SrcInfo src[2];    // vector sources (C % 4 == 0, 16-byte aligned): the pipelined hot loop
+    SrcInfo tsrc[2];   // thin sources (e.g. the 1-channel image): short synchronous prologue
+    int32_t n_src, n_thin, n_it;
     int64_t M;
     int32_t HWo, Wout, Hin, Win;
     int32_t k, kk, stride, dsh /* dil-1 */, pad_t, pad_l;
@@ -63,19 +64,16 @@ struct IterState {
 };
 
 __device__ __forceinline__ void iter_advance(IterState& st, const ConvArgs& a) {
-    const SrcInfo& si = a.src[st.s];
-    if (!si.thin) {
-        ++st.tap;
-        ++st.kw;
-        if (st.kw == a.k) {
-            st.kw = 0;
-            ++st.kh;
-        }
-        if (st.tap < a.kk) return;
-        st.tap = st.kh = st.kw = 0;
+    ++st.tap;
+    ++st.kw;
+    if (st.kw == a.k) {
+        st.kw = 0;
+        ++st.kh;
     }
+    if (st.tap < a.kk) return;
+    st.tap = st.kh = st.kw = 0;
     ++st.chunk;
-    if (st.chunk == si.nchunk) {
+    if (st.chunk == a.src[st.s].nchunk) {
         st.chunk = 0;
         ++st.s;
     }
@@ -84,7 +82,7 @@ __device__ __forceinline__ void iter_advance(IterState& st, const ConvArgs& a) {
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 
 template <int NF, bool BVEC, int EPI>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     constexpr int BN = 32 * NF;
     constexpr int QPR = BN / 4;          // float4 per B row
     constexpr int RPP = 256 / QPR;       // B rows per pass
@@ -128,99 +126,94 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     }
 
     float4 ra[4];
-    float4 rb[NPB];
+    float4 rb0, rb1;   // (scalars, not an array: hipcc promoted `float4 rb[NPB]` to an LDS-backed alloca)
+    rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // NOTE: every global load below is UNCONDITIONAL: masked lanes read lu_zero16 (16 B of device zeros).
+    // Guarding the load (`if (ok) v = *p`) makes hipcc branch around each load with `s_waitcnt vmcnt(0)`
+    // in between -- six serialized memory round trips per stage; zeroing AFTER the load drags the wait
+    // up to the issue point.  Selecting the POINTER keeps all loads of a stage in flight across the MFMAs.
+    const float* const zp = lu_zero16;
+    auto load_w = [&](const SrcInfo& si, bool thin, int tap_v, int chunk, int p) -> float4 {
+        const int row = brow0 + RPP * p;
+        int tap, c;
+        bool rok;
+        if (!thin) {
+            tap = tap_v;
+            c = chunk * CK + row;
+            rok = row < CK && c < si.C;
+        } else {
+            int j = chunk * CK + row;
+            rok = row < CK && j < a.kk * si.C;
+            tap = j / si.C;
+            c = j - tap * si.C;
+        }
+        const float* wp = si.w + (int64_t)tap * si.w_tap_stride + (int64_t)c * si.w_row_stride + bcol;
+        if (BVEC) {
+            const bool ok = rok && ((EPI == LU_EPI_LSTM) || bcol < a.N);
+            return *reinterpret_cast<const float4*>(ok ? wp : zp);
+        } else {
+            const float t0 = *((rok && bcol + 0 < a.N) ? wp + 0 : zp), t1 = *((rok && bcol + 1 < a.N) ? wp + 1 : zp),
+                        t2 = *((rok && bcol + 2 < a.N) ? wp + 2 : zp), t3 = *((rok && bcol + 3 < a.N) ? wp + 3 : zp);
+            return make_float4(t0, t1, t2, t3);
+        }
+    };
+    auto load_weights = [&](const SrcInfo& si, bool thin, int tap_v, int chunk) {
+        rb0 = load_w(si, thin, tap_v, chunk, 0);
+        if (NPB > 1) rb1 = load_w(si, thin, tap_v, chunk, 1);
+    };
     auto load_stage = [&](const IterState& st) {
         const SrcInfo& si = a.src[st.s];
-        if (!si.thin) {
-            const int c = st.chunk * CK + 4 * q;
-            const bool cok = c < si.C;
+        const int c = st.chunk * CK + 4 * q;
+        const bool cok = c < si.C;
+        const float* pv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
-                int iy = vy >> a.dsh, ix = vx >> a.dsh;
-                bool ok = cok && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win &&
-                          ((vy | vx) & a.dsh) == 0;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const float* p = si.x + (int64_t)fr[i] * si.frame_stride +
-                                     ((int64_t)iy * a.Win + ix) * si.pix_stride + c;
-                    v = *reinterpret_cast<const float4*>(p);
-                }
-                ra[i] = v;
-            }
-        } else {
-            const int kkC = a.kk * si.C;
-            int dy[4], dx[4], cc[4];
-            bool jok[4];
+        for (int i = 0; i < 4; ++i) {
+            const int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
+            const int iy = vy >> a.dsh, ix = vx >> a.dsh;
+            const bool ok = cok && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win && ((vy | vx) & a.dsh) == 0;
+            const float* p = si.x + (int64_t)fr[i] * si.frame_stride + ((int64_t)iy * a.Win + ix) * si.pix_stride + c;
+            pv[i] = ok ? p : zp;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pv[i]);
+        load_weights(si, false, st.tap, st.chunk);
+    };
+    auto load_thin = [&](const SrcInfo& si, int chunk) {
+        const int kkC = a.kk * si.C;
+        int dy[4], dx[4], cc[4];
+        bool jok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int j = chunk * CK + 4 * q + e;
+            jok[e] = j < kkC;
+            int tap = j / si.C;
+            cc[e] = j - tap * si.C;
+            dy[e] = tap / a.k;
+            dx[e] = tap - dy[e] * a.k;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int j = st.chunk * CK + 4 * q + e;
-                jok[e] = j < kkC;
-                int tap = j / si.C;
-                cc[e] = j - tap * si.C;
-                dy[e] = tap / a.k;
-                dx[e] = tap - dy[e] * a.k;
+                const int vy = vy0[i] + dy[e], vx = vx0[i] + dx[e];
+                const int iy = vy >> a.dsh, ix = vx >> a.dsh;
+                const bool ok = jok[e] && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win && ((vy | vx) & a.dsh) == 0;
+                const float* p = si.x + (int64_t)fr[i] * si.frame_stride + ((int64_t)iy * a.Win + ix) * si.pix_stride + cc[e];
+                v[e] = *(ok ? p : zp);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int vy = vy0[i] + dy[e], vx = vx0[i] + dx[e];
-                    int iy = vy >> a.dsh, ix = vx >> a.dsh;
-                    bool ok = jok[e] && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win &&
-                              ((vy | vx) & a.dsh) == 0;
-                    v[e] = ok ? si.x[(int64_t)fr[i] * si.frame_stride +
-                                     ((int64_t)iy * a.Win + ix) * si.pix_stride + cc[e]]
-                              : 0.f;
-                }
-                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            ra[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        // weights
-#pragma unroll
-        for (int p = 0; p < NPB; ++p) {
-            const int row = brow0 + RPP * p;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < CK) {
-                int tap, c;
-                bool rok;
-                if (!si.thin) {
-                    tap = st.tap;
-                    c = st.chunk * CK + row;
-                    rok = c < si.C;
-                } else {
-                    int j = st.chunk * CK + row;
-                    rok = j < a.kk * si.C;
-                    tap = j / si.C;
-                    c = j - tap * si.C;
-                }
-                if (rok) {
-                    const float* wp = si.w + (int64_t)tap * si.w_tap_stride + (int64_t)c * si.w_row_stride + bcol;
-                    if (BVEC) {
-                        if (EPI == LU_EPI_LSTM || bcol < a.N) v = *reinterpret_cast<const float4*>(wp);
-                    } else {
-                        if (bcol + 0 < a.N) v.x = wp[0];
-                        if (bcol + 1 < a.N) v.y = wp[1];
-                        if (bcol + 2 < a.N) v.z = wp[2];
-                        if (bcol + 3 < a.N) v.w = wp[3];
-                    }
-                }
-            }
-            rb[p] = v;
-        }
+        load_weights(si, true, 0, chunk);
     };
 
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + 64 * i) * A_LD + 4 * q]) = ra[i];
-#pragma unroll
-        for (int p = 0; p < NPB; ++p) {
-            const int row = brow0 + RPP * p;
-            if (row < CK) *reinterpret_cast<float4*>(&Bs[buf][row * BN + 4 * bq]) = rb[p];
-        }
+        if (RPP <= CK || brow0 < CK) *reinterpret_cast<float4*>(&Bs[buf][brow0 * BN + 4 * bq]) = rb0;
+        if (NPB > 1) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + RPP) * BN + 4 * bq]) = rb1;
     };
 
     f32x16 acc[2][NF];
@@ -231,20 +224,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
-    IterState st{0, 0, 0, 0, 0};
-    load_stage(st);
-    store_stage(0);
-    __syncthreads();
-
     const int arow = wave * 64 + (lane & 31);
     const int khalf = 4 * (lane >> 5);
-    for (int it = 0; it < a.n_it; ++it) {
-        const int buf = it & 1;
-        const bool more = it + 1 < a.n_it;
-        if (more) {
-            iter_advance(st, a);
-            load_stage(st);
-        }
+    auto mma_stage = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float af[2][4];
@@ -267,8 +249,39 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(af[mf][j], bv[nf], acc[mf][nf]);
             }
         }
-        if (more) store_stage(buf ^ 1);
+    };
+
+    // ---- thin sources: a few synchronous stages (K = k*k*C is tiny), kept out of the hot loop ----
+    for (int ts = 0; ts < a.n_thin; ++ts) {
+        const SrcInfo& si = a.tsrc[ts];
+        for (int ch = 0; ch < si.nchunk; ++ch) {
+            load_thin(si, ch);
+            store_stage(0);
+            __syncthreads();
+            mma_stage(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- vector sources: two-stage software pipeline, one (tap, 16-channel chunk) per stage ----
+    if (a.n_it > 0) {
+        IterState st{0, 0, 0, 0, 0};
+        load_stage(st);
+        store_stage(0);
         __syncthreads();
+        for (int it = 0; it < a.n_it; ++it) {
+            const int buf = it & 1;
+            // No `if (more)` around the prefetch / LDS store: hipcc merges the two equally-guarded blocks and
+            // drags the weight-tile ds_writes (and their vmcnt wait) in front of the MFMAs.  The last
+            // iteration simply re-fetches its own stage into the idle buffer (1/n_it extra traffic).
+            if (it + 1 < a.n_it) iter_advance(st, a);
+            load_stage(st);
+            LU_SCHED_FENCE();
+            mma_stage(buf);
+            LU_SCHED_FENCE();
+            store_stage(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ----
@@ -351,15 +364,17 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     LU_REQUIRE(d->frames > 0 && d->Hout > 0 && d->Wout > 0 && d->N > 0, "lu_conv2d_fwd: empty problem");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.n_src = d->n_src;
     a.k = d->k;
     a.kk = d->k * d->k;
     bool bvec = (d->N % 4 == 0);
     a.n_it = 0;
+    a.n_src = 0;
+    a.n_thin = 0;
     for (int s = 0; s < d->n_src; ++s) {
         const lu_conv_src& in = d->src[s];
         LU_REQUIRE(in.x && in.w && in.C > 0, "lu_conv2d_fwd: source %d incomplete", s);
-        SrcInfo& si = a.src[s];
+        const bool vec = (in.C % 4 == 0) && (in.pix_stride % 4 == 0) && (in.frame_stride % 4 == 0) && aligned16(in.x);
+        SrcInfo& si = vec ? a.src[a.n_src++] : a.tsrc[a.n_thin++];
         si.x = in.x;
         si.w = in.w;
         si.frame_stride = in.frame_stride;
@@ -367,10 +382,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         si.pix_stride = in.pix_stride;
         si.C = in.C;
         si.w_row_stride = in.w_row_stride;
-        bool vec = (in.C % 4 == 0) && (in.pix_stride % 4 == 0) && (in.frame_stride % 4 == 0) && aligned16(in.x);
         si.thin = vec ? 0 : 1;
         si.nchunk = vec ? (in.C + CK - 1) / CK : (a.kk * in.C + CK - 1) / CK;
-        a.n_it += vec ? si.nchunk * a.kk : si.nchunk;
+        if (vec) a.n_it += si.nchunk * a.kk;
         bvec = bvec && (in.w_row_stride % 4 == 0) && (in.w_tap_stride % 4 == 0) && aligned16(in.w);
     }
     a.M = (int64_t)d->frames * d->Hout * d->Wout;

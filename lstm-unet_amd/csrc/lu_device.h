@@ -14,6 +14,7 @@ static inline f32x16 lu_mfma(float a, float b, f32x16 c) { return lu_emu::mfma_3
 static inline float lu_shfl_xor(float v, int m) { return lu_emu::shfl_xor(v, m); }
 static inline float lu_shfl_down(float v, int d) { return lu_emu::shfl_down(v, d); }
 #define LU_CHECK_LAUNCH() 0
+#define LU_SCHED_FENCE() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,8 +27,23 @@ __device__ __forceinline__ f32x16 lu_mfma(float a, float b, f32x16 c) {
 __device__ __forceinline__ float lu_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float lu_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 #define LU_CHECK_LAUNCH() lu_check_launch()
+// pins instruction order across this point: sched_barrier stops the machine scheduler, the empty asm with a
+// memory clobber stops the IR optimiser (which otherwise hoists the next stage's LDS stores -- and the vmcnt
+// wait they need -- above the MFMA block, destroying the load/compute overlap).  Emits no instruction.
+#define LU_SCHED_FENCE()                      \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
 int lu_check_launch();
 #endif
+
+// 16 bytes of zeros in device memory: masked-out lanes of the tile loaders read THIS instead of branching
+// around the load or zeroing afterwards (either makes hipcc wait for the load right where it was issued).
+// (deliberately NOT const: a const would live in the constant address space and turn the selected pointer
+// into a flat pointer -> flat_load instead of global_load.)
+__device__ __attribute__((aligned(16))) static float lu_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 void lu_set_error(const char* fmt, ...);
 

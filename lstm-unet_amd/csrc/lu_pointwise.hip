@@ -109,7 +109,7 @@ struct ColPlan {
 inline ColPlan col_plan(int64_t rows, int C) {
     ColPlan p;
     p.ctiles = (C + 63) / 64;
-    int64_t target = 2048 / p.ctiles;
+    int64_t target = 768 / p.ctiles;
     if (target < 1) target = 1;
     p.rows_per_blk = (rows + target - 1) / target;
     if (p.rows_per_blk < 64) p.rows_per_blk = 64;
@@ -178,16 +178,25 @@ __global__ void colreduce_kernel(Fn fn, int64_t rows, int C, int64_t rows_per_bl
 }
 
 // mode 0: out_d[q*C + c] = sum ; mode 1: out_f[c] = beta*out_f[c] + sum(q=0)
+// block = 64 columns x 4 partial-block lanes (coalesced over columns, fixed summation order)
 __global__ void colreduce_final_kernel(const double* __restrict__ partial, int nblk, int C, double* out_d, float* out_f,
                                        float beta, int mode) {
-    const int i = blockIdx.x * NT + threadIdx.x;
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int nq = mode == 0 ? 2 : 1;
-    if (i >= nq * C) return;
-    const int q = i / C, c = i - q * C;
+    const int i = blockIdx.x * 64 + cl;          // flattened (q, c)
+    const bool ok = i < nq * C;
+    const int q = ok ? i / C : 0, c = ok ? i - q * C : 0;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[((int64_t)b * 2 + q) * C + c];
-    if (mode == 0) out_d[i] = s;
-    else out_f[c] = (beta != 0.f ? beta * out_f[c] : 0.f) + (float)s;
+    if (ok)
+        for (int b = rl; b < nblk; b += 4) s += partial[((int64_t)b * 2 + q) * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        const double t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (mode == 0) out_d[i] = t;
+        else out_f[c] = (beta != 0.f ? beta * out_f[c] : 0.f) + (float)t;
+    }
 }
 
 template <class Fn>
@@ -198,7 +207,7 @@ int run_colreduce(Fn fn, int64_t rows, int C, void* ws, double* out_d, float* ou
               (double*)ws);
     int rc = LU_CHECK_LAUNCH();
     if (rc) return rc;
-    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + NT - 1) / NT), dim3(NT), stream, (const double*)ws, p.nblk, C,
+    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + 63) / 64), dim3(NT), stream, (const double*)ws, p.nblk, C,
               out_d, out_f, beta, mode);
     return LU_CHECK_LAUNCH();
 }

@@ -70,85 +70,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const int aq = tid % QPA, arow0 = tid / QPA;
     const int bq = tid % QPB, brow0 = tid / QPB;
 
-    float4 ra[THIN ? 1 : NPA];
-    float rat[2];
-    float4 rb[NPB];
+    // scalars, not arrays: hipcc promoted the small float4 staging arrays to LDS-backed allocas
+    float4 ra0, ra1, rb0, rb1;
+    ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rat0 = 0.f, rat1 = 0.f;
 
+    // All global loads are unconditional; masked lanes read lu_zero16 (see lu_conv.hip for why).
+    const float* const zp = lu_zero16;
+    auto load_a = [&](int64_t pb, int ps) -> float4 {
+        const int row = arow0 + RPA * ps;
+        const int64_t p = pb + row;
+        const int c = c0 + 4 * aq;
+        bool ok = row < KP && p < p_end && c < a.C;
+        const int64_t pc = ok ? p : 0;
+        const int f = (int)(pc / a.HWo);
+        const int r = (int)(pc - (int64_t)f * a.HWo);
+        const int oy = r / a.Wout, ox = r - oy * a.Wout;
+        const int iy = oy * a.stride + kh - a.pad_t, ix = ox * a.stride + kw - a.pad_l;
+        ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const float* src = a.x + (int64_t)f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
+        return *reinterpret_cast<const float4*>(ok ? src : zp);
+    };
+    auto load_a_thin = [&](int64_t pb, int ps) -> float {
+        const int row = (tid >> 5) + 8 * ps;
+        const int64_t p = pb + row;
+        bool ok = t_ok && p < p_end;
+        const int64_t pc = ok ? p : 0;
+        const int f = (int)(pc / a.HWo);
+        const int r = (int)(pc - (int64_t)f * a.HWo);
+        const int oy = r / a.Wout, ox = r - oy * a.Wout;
+        const int iy = oy * a.stride + t_kh - a.pad_t, ix = ox * a.stride + t_kw - a.pad_l;
+        ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const float* src = a.x + (int64_t)f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + t_c;
+        return *(ok ? src : zp);
+    };
+    auto load_b = [&](int64_t pb, int ps) -> float4 {
+        const int row = brow0 + RPB * ps;
+        const int64_t p = pb + row;
+        const int n = n0 + 4 * bq;
+        const bool rok = row < KP && p < p_end;
+        const int64_t pc = rok ? p : 0;
+        const int f = (int)(pc / a.HWo);
+        const int64_t r = pc - (int64_t)f * a.HWo;
+        const float* yrow = a.dy + (int64_t)f * a.dy_fs + r * a.dy_ps + n;
+        if (YVEC) {
+            return *reinterpret_cast<const float4*>((rok && n < a.N) ? yrow : zp);
+        } else {
+            const float t0 = *((rok && n + 0 < a.N) ? yrow + 0 : zp), t1 = *((rok && n + 1 < a.N) ? yrow + 1 : zp),
+                        t2 = *((rok && n + 2 < a.N) ? yrow + 2 : zp), t3 = *((rok && n + 3 < a.N) ? yrow + 3 : zp);
+            return make_float4(t0, t1, t2, t3);
+        }
+    };
     auto load_stage = [&](int it) {
         const int64_t pb = p_begin + (int64_t)it * KP;
         if (!THIN) {
-#pragma unroll
-            for (int ps = 0; ps < NPA; ++ps) {
-                const int row = arow0 + RPA * ps;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int64_t p = pb + row;
-                const int c = c0 + 4 * aq;
-                if (row < KP && p < p_end && c < a.C) {
-                    int f = (int)(p / a.HWo);
-                    int r = (int)(p - (int64_t)f * a.HWo);
-                    int oy = r / a.Wout, ox = r - oy * a.Wout;
-                    int iy = oy * a.stride + kh - a.pad_t, ix = ox * a.stride + kw - a.pad_l;
-                    if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-                        v = *reinterpret_cast<const float4*>(a.x + (int64_t)f * a.x_fs +
-                                                             ((int64_t)iy * a.Win + ix) * a.x_ps + c);
-                }
-                ra[ps] = v;
-            }
+            ra0 = load_a(pb, 0);
+            if (NPA > 1) ra1 = load_a(pb, 1);
         } else {
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int row = (tid >> 5) + 8 * ps;
-                const int64_t p = pb + row;
-                float v = 0.f;
-                if (t_ok && p < p_end) {
-                    int f = (int)(p / a.HWo);
-                    int r = (int)(p - (int64_t)f * a.HWo);
-                    int oy = r / a.Wout, ox = r - oy * a.Wout;
-                    int iy = oy * a.stride + t_kh - a.pad_t, ix = ox * a.stride + t_kw - a.pad_l;
-                    if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-                        v = a.x[(int64_t)f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + t_c];
-                }
-                rat[ps] = v;
-            }
+            rat0 = load_a_thin(pb, 0);
+            rat1 = load_a_thin(pb, 1);
         }
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) {
-            const int row = brow0 + RPB * ps;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int64_t p = pb + row;
-            const int n = n0 + 4 * bq;
-            if (row < KP && p < p_end) {
-                int f = (int)(p / a.HWo);
-                int64_t r = p - (int64_t)f * a.HWo;
-                const float* yp = a.dy + (int64_t)f * a.dy_fs + r * a.dy_ps + n;
-                if (YVEC) {
-                    if (n < a.N) v = *reinterpret_cast<const float4*>(yp);
-                } else {
-                    if (n + 0 < a.N) v.x = yp[0];
-                    if (n + 1 < a.N) v.y = yp[1];
-                    if (n + 2 < a.N) v.z = yp[2];
-                    if (n + 3 < a.N) v.w = yp[3];
-                }
-            }
-            rb[ps] = v;
-        }
+        rb0 = load_b(pb, 0);
+        if (NPB > 1) rb1 = load_b(pb, 1);
     };
     auto store_stage = [&](int buf) {
         if (!THIN) {
-#pragma unroll
-            for (int ps = 0; ps < NPA; ++ps) {
-                const int row = arow0 + RPA * ps;
-                if (row < KP) *reinterpret_cast<float4*>(&As[buf][row * BMw + 4 * aq]) = ra[ps];
-            }
+            if (RPA <= KP || arow0 < KP) *reinterpret_cast<float4*>(&As[buf][arow0 * BMw + 4 * aq]) = ra0;
+            if (NPA > 1) *reinterpret_cast<float4*>(&As[buf][(arow0 + RPA) * BMw + 4 * aq]) = ra1;
         } else {
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) As[buf][((tid >> 5) + 8 * ps) * BMw + tcol] = rat[ps];
+            As[buf][(tid >> 5) * BMw + tcol] = rat0;
+            As[buf][((tid >> 5) + 8) * BMw + tcol] = rat1;
         }
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) {
-            const int row = brow0 + RPB * ps;
-            if (row < KP) *reinterpret_cast<float4*>(&Bs[buf][row * BNw + 4 * bq]) = rb[ps];
-        }
+        if (RPB <= KP || brow0 < KP) *reinterpret_cast<float4*>(&Bs[buf][brow0 * BNw + 4 * bq]) = rb0;
+        if (NPB > 1) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + RPB) * BNw + 4 * bq]) = rb1;
     };
 
     f32x16 acc[MF][NF];
@@ -167,8 +161,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const int khalf = lane >> 5, l31 = lane & 31;
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
-        const bool more = it + 1 < n_it;
-        if (more) load_stage(it + 1);
+        // unguarded prefetch/store (see lu_conv.hip): the last iteration re-fetches its own stage
+        load_stage(it + 1 < n_it ? it + 1 : it);
+        LU_SCHED_FENCE();
 #pragma unroll
         for (int kk2 = 0; kk2 < KP; kk2 += 2) {
             float av[MF], bv[NF];
@@ -181,7 +176,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(av[mf], bv[nf], acc[mf][nf]);
         }
-        if (more) store_stage(buf ^ 1);
+        LU_SCHED_FENCE();
+        store_stage(buf ^ 1);
         __syncthreads();
     }
 

@@ -52,6 +52,7 @@ class Engine:
         self.tape = None
         self.segments = []   # [(name, start, end)] gradient buckets in backward-completion order
         self.on_bucket_ready = None  # callback(start, end) fired as each bucket's gradient completes
+        self.debug = None            # tools/diag_gpu.py: dict collecting clones of intermediate gradients
 
     # ------------------------------------------------------------------ build
     def build(self, in_channels, device):
@@ -333,6 +334,8 @@ class Engine:
             blk = plan['down'][bi]
             d = g_down[bi]
             g_down[bi] = None
+            if self.debug is not None:
+                self.debug[f'g_down.{bi}'] = d.clone()
             for ci in reversed(range(len(blk['conv']))):
                 rec = tape.pop()
                 assert rec['kind'] == 'conv' and rec['prefix'] == f'down.{bi}' and rec['ci'] == ci
@@ -340,7 +343,11 @@ class Engine:
             for li in reversed(range(len(blk['lstm']))):
                 rec = tape.pop()
                 assert rec['kind'] == 'lstm' and rec['bi'] == bi and rec['li'] == li
+                if self.debug is not None:
+                    self.debug[f'dh_seq.{bi}.{li}'] = d.clone()
                 d = self._lstm_backward(rec, d, need_dx=(bi > 0 or li > 0))
+                if self.debug is not None and d is not None:
+                    self.debug[f'lstm_dx.{bi}.{li}'] = d.clone()
             if bi > 0:
                 ops.add_(g_down[bi - 1], d)
             self._bucket_done(seg)

@@ -106,6 +106,7 @@ class TorchULSTM:
         self.adam_m = {k: torch.zeros_like(self.P[k]) for k in self.trainable}
         self.adam_v = {k: torch.zeros_like(self.P[k]) for k in self.trainable}
         self.step = 0
+        self.capture = None   # diagnostics: dict name -> activation tensors with retain_grad()
 
     # ---- forward ----------------------------------------------------------------
     def forward(self, x, training=True, update_moving=True):
@@ -156,8 +157,14 @@ class TorchULSTM:
                 blk_states.append((hT.detach(), cT.detach()))
             new_states.append(blk_states)
             act = seq.reshape((b * t,) + tuple(seq.shape[2:]))
+            if self.capture is not None and act.requires_grad:
+                act.retain_grad()
+                self.capture[f'lstm_out.{bi}'] = act
             for ci, l in enumerate(blk['conv']):
                 act = cbl(f'down.{bi}', ci, l, act)
+            if self.capture is not None and act.requires_grad:
+                act.retain_grad()
+                self.capture[f'down_out.{bi}'] = act
             out_skip = act
             out_down = act.reshape((b, t) + tuple(act.shape[1:]))
         up_in = out_skip

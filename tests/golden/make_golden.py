@@ -182,6 +182,18 @@ def main():
             'gpu_id', 'filename_format', 'data_format', 'FOV', 'min_cell_size', 'max_cell_size', 'edge_dist',
             'pre_sequence_frames', 'dry_run', 'save_intermediate')},
     }
+    # ---- CLI flag surface (option strings + dest), extracted from the reference's argparse calls ----
+    import re
+    flag_re = re.compile(r"add_argument\(([^)]*?)dest='(\w+)'", re.S)
+    cli = {}
+    for fname in ('train2D.py', 'Inference2D.py'):
+        text = open(os.path.join(REF, fname)).read()
+        flags = []
+        for m in flag_re.finditer(text):
+            opts = re.findall(r"'(--?[\w]+)'", m.group(1))
+            flags.append({'options': opts, 'dest': m.group(2)})
+        cli[fname] = flags
+    dump['cli_flags'] = cli
     with open(os.path.join(OUT, 'default_params.json'), 'w') as f:
         json.dump(dump, f, indent=1, sort_keys=True)
     print('wrote goldens to', OUT)

@@ -1,0 +1,95 @@
+"""GPU diagnostic: per-tensor gradient errors of the C1 train step vs the fp64 oracle, determinism,
+and per-shape conv fwd/dgrad/wgrad checks at the C1 layer shapes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from oracle import np_oracle as npo, torch_oracle as tho
+from conftest import c1_net
+from test_engine import perturbed_params, rel_err, grad_floor, make_engine, to_tb
+from lu_native import ops, calls
+import kernel_harness as KH
+
+dev = torch.device('cuda', 0)
+net = c1_net(); cin = 1; B, T, H, W = 1, 4, 128, 128
+rng = np.random.default_rng(5)
+p = perturbed_params(net, cin, 7)
+x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+cw = [0.15, 0.25, 0.6]
+tm = tho.TorchULSTM(net, cin, p, dtype=torch.float64)
+loss_ref, _, gref = tm.train_step(x, gt, cw, apply=False)
+cwt = torch.tensor(cw, dtype=torch.float32, device=dev)
+
+def run():
+    e = make_engine(net, p, cin, dev, False)
+    lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+    g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+    sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+    dl = ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0)
+    e.backward(dl.view(lg.shape))
+    torch.cuda.synchronize()
+    return {k: e.G[k].cpu().numpy().copy() for k in e.G}, float(ops.wce_loss(sums).cpu()[0])
+
+g1, l1 = run()
+g2, l2 = run()
+print('loss', l1, l2, float(loss_ref))
+print('deterministic:', all(np.array_equal(g1[k], g2[k]) for k in g1))
+fl = grad_floor({k: v.numpy() for k, v in gref.items()})
+errs = sorted(((rel_err(g1[k], gref[k].numpy(), fl), k) for k in gref), reverse=True)
+for e_, k in errs[:40]:
+    print('%.3e %s  max|ref| %.3e' % (e_, k, float(gref[k].abs().max())))
+
+# ---- intermediate gradients: engine (GPU) vs oracle (fp64) ----
+tm2 = tho.TorchULSTM(net, cin, p, dtype=torch.float64)
+tm2.capture = {}
+for k in tm2.trainable:
+    tm2.P[k] = tm2.P[k].detach().requires_grad_(True)
+lgt = tm2.forward(torch.tensor(x, dtype=torch.float64), training=True)
+tho.weighted_ce(torch.tensor(gt, dtype=torch.float64), lgt, cw).backward()
+e = make_engine(net, p, cin, dev, False)
+e.debug = {}
+lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+e.backward(ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0).view(lg.shape))
+torch.cuda.synchronize()
+def bt_to_tb(a):   # oracle frames are (b,t)-ordered, engine frames (t,b)
+    a = a.reshape((B, T) + a.shape[1:])
+    return np.ascontiguousarray(np.swapaxes(a, 0, 1)).reshape((T * B,) + a.shape[2:])
+for bi in range(4):
+    ref = bt_to_tb(tm2.capture[f'down_out.{bi}'].grad.numpy())
+    got = e.debug[f'g_down.{bi}'].cpu().numpy()
+    print('g_down.%d rel err %.3e (max|ref| %.3e)' % (bi, np.abs(got - ref).max() / np.abs(ref).max(), np.abs(ref).max()))
+    ref = bt_to_tb(tm2.capture[f'lstm_out.{bi}'].grad.numpy())
+    got = e.debug[f'dh_seq.{bi}.0'].cpu().numpy()
+    print('dh_seq.%d rel err %.3e (max|ref| %.3e)' % (bi, np.abs(got - ref).max() / np.abs(ref).max(), np.abs(ref).max()))
+    if bi > 0:
+        # lstm dx of block bi == oracle grad of down_out[bi-1] minus the skip-path part; report its magnitude only
+        got = e.debug[f'lstm_dx.{bi}.0'].cpu().numpy()
+        print('   lstm_dx.%d max %.3e' % (bi, np.abs(got).max()))
+
+# per-shape kernel checks at C1 shapes
+be = KH.backend('hip')
+r = np.random.default_rng(3)
+def rn(*s, scale=1.0): return (r.standard_normal(s) * scale).astype(np.float32)
+def tgrads(xx, ww, dy, s):
+    xt = torch.tensor(xx, dtype=torch.float64, requires_grad=True); wt = torch.tensor(ww, dtype=torch.float64, requires_grad=True)
+    y = tho.conv2d_same(xt, wt, None, s)
+    gx, gw = torch.autograd.grad(y, [xt, wt], torch.tensor(dy, dtype=torch.float64))
+    return y.detach().numpy(), gx.numpy(), gw.numpy()
+for (fr, Hh, Ww, C, N, k, s) in [(4, 32, 32, 32, 32, 3, 1), (4, 32, 32, 32, 32, 3, 2), (4, 16, 16, 32, 32, 3, 1), (4, 64, 64, 32, 32, 3, 2),
+                                 (4, 128, 128, 32, 32, 3, 2), (4, 16, 16, 64, 32, 3, 1), (1, 32, 32, 32, 128, 3, 1), (4, 128, 128, 33, 32, 3, 1),
+                                 (1, 64, 64, 32, 128, 3, 1), (4, 128, 128, 32, 3, 1, 1)]:
+    xx, ww = rn(fr, Hh, Ww, C), rn(k, k, C, N, scale=0.2)
+    Ho, Wo = calls.same_pad(Hh, k, s)[0], calls.same_pad(Ww, k, s)[0]
+    dy = rn(fr, Ho, Wo, N)
+    y, gx, gw = tgrads(xx, ww, dy, s)
+    ef = np.abs(KH.conv2d(be, [xx], [ww], None, k, s) - y).max() / np.abs(y).max()
+    ed = np.abs(KH.conv2d_dgrad(be, dy, ww, (Hh, Ww), s) - gx).max() / np.abs(gx).max()
+    from lu_native.calls import wgrad_splits
+    sp = wgrad_splits(fr * Ho * Wo, k, C, N)
+    ew = np.abs(KH.conv2d_wgrad(be, xx, dy, k, s, splits=sp) - gw).max() / np.abs(gw).max()
+    ew1 = np.abs(KH.conv2d_wgrad(be, xx, dy, k, s, splits=1) - gw).max() / np.abs(gw).max()
+    print('shape', (fr, Hh, Ww, C, N, k, s), 'fwd %.2e dgrad %.2e wgrad(splits=%d) %.2e wgrad(1) %.2e' % (ef, ed, sp, ew, ew1))
