@@ -70,8 +70,15 @@ typedef struct lu_conv_desc {
     float* h_out;                   /* frame stride h_frame_stride, pixel stride F */
     float* gates_out;               /* [frames,H,W,4F] post-activation i,f,g,o or NULL (inference) */
     int64_t c_prev_frame_stride, c_out_frame_stride, h_frame_stride, gates_frame_stride;
+    /* optional split of the K axis (taps x channel chunks) for problems with too few output tiles to fill
+     * 256 CUs (coarse-level recurrent dgrads): partial tiles go to `workspace`
+     * (lu_conv2d_workspace_bytes) and are summed in a fixed order.  LU_EPI_BIAS only; 0/1 = off. */
+    int32_t splits;
+    int32_t _pad2;
+    void* workspace;
 } lu_conv_desc;
 
+size_t lu_conv2d_workspace_bytes(const lu_conv_desc* d);
 int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream);
 
 /* wt[kh'][kw'][co][ci] = w[k-1-kh'][k-1-kw'][c_off+ci][co]  for ci < C_sub -- the weight of the

@@ -45,7 +45,9 @@ struct ConvArgs {
     int64_t M;
     int32_t HWo, Wout, Hin, Win;
     int32_t k, kk, stride, dsh /* dil-1 */, pad_t, pad_l;
-    int32_t N, n_tiles;
+    int32_t N, n_tiles, m_tiles;
+    int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
+    float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
     int32_t out_pix_stride;
     const float* bias;
     float* out;
@@ -91,10 +93,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).  All n-tiles of
+    // one m-tile get consecutive slots of the SAME XCD so the activation slab they share is fetched into one L2.
     const int bid = blockIdx.x;
-    const int nt = bid % a.n_tiles;
-    const int64_t m0 = (int64_t)(bid / a.n_tiles) * BM;
+    const int slot = bid >> 3;
+    const int nt = slot % a.n_tiles;
+    const int mt = (slot / a.n_tiles) * 8 + (bid & 7);
+    if (mt >= a.m_tiles) return;     // grid is padded to a multiple of 8 m-tiles; uniform per block, before any barrier
+    const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
+    const int ks = blockIdx.y;
 
     // ---- A gather bookkeeping: 4 pixel rows per thread, one 16-byte column group ----
     const int q = tid & 3;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     };
 
     // ---- thin sources: a few synchronous stages (K = k*k*C is tiny), kept out of the hot loop ----
-    for (int ts = 0; ts < a.n_thin; ++ts) {
+    for (int ts = 0; ts < (ks == 0 ? a.n_thin : 0); ++ts) {
         const SrcInfo& si = a.tsrc[ts];
         for (int ch = 0; ch < si.nchunk; ++ch) {
             load_thin(si, ch);
@@ -264,17 +272,34 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     }
 
     // ---- vector sources: two-stage software pipeline, one (tap, 16-channel chunk) per stage ----
-    if (a.n_it > 0) {
+    int it0 = 0, it1 = a.n_it;
+    if (a.ksplit > 1) {
+        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per;
+        it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
+    }
+    if (it1 > it0) {
         IterState st{0, 0, 0, 0, 0};
+        {   // decode the first stage of this K-range
+            int r = it0;
+            while (r >= a.src[st.s].nchunk * a.kk) {
+                r -= a.src[st.s].nchunk * a.kk;
+                ++st.s;
+            }
+            st.chunk = r / a.kk;
+            st.tap = r - st.chunk * a.kk;
+            st.kh = st.tap / a.k;
+            st.kw = st.tap - st.kh * a.k;
+        }
         load_stage(st);
         store_stage(0);
         __syncthreads();
-        for (int it = 0; it < a.n_it; ++it) {
-            const int buf = it & 1;
+        for (int it = it0; it < it1; ++it) {
+            const int buf = (it - it0) & 1;
             // No `if (more)` around the prefetch / LDS store: hipcc merges the two equally-guarded blocks and
             // drags the weight-tile ds_writes (and their vmcnt wait) in front of the MFMAs.  The last
             // iteration simply re-fetches its own stage into the idle buffer (1/n_it extra traffic).
-            if (it + 1 < a.n_it) iter_advance(st, a);
+            if (it + 1 < it1) iter_advance(st, a);
             load_stage(st);
             LU_SCHED_FENCE();
             mma_stage(buf);
@@ -319,6 +344,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
                     gp[2 * F] = gg;
                     gp[3 * F] = go;
                 }
+            } else if (a.ksplit > 1) {
+                float* op = a.ws + ((int64_t)ks * a.M + m) * a.N;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    const int col = n0 + 32 * nf + ccol;
+                    if (col < a.N) op[col] = acc[mf][nf][r];
+                }
             } else {
                 float* op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride;
 #pragma unroll
@@ -328,6 +360,21 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
                 }
             }
         }
+    }
+}
+
+// out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic)
+__global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t M, int N, int HWo,
+                                     const float* __restrict__ bias, float* __restrict__ out, int64_t out_fs,
+                                     int out_ps) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / N;
+        const int n = (int)(i - m * N);
+        float s = bias ? bias[n] : 0.f;
+        for (int k = 0; k < ksplit; ++k) s += ws[(int64_t)k * total + i];
+        const int64_t f = m / HWo;
+        out[f * out_fs + (m - f * HWo) * out_ps + n] = s;
     }
 }
 
@@ -402,6 +449,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.out = d->out;
     a.out_frame_stride = d->out_frame_stride;
     const int64_t m_tiles = (a.M + BM - 1) / BM;
+    a.m_tiles = (int32_t)m_tiles;
+    const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
+    a.ksplit = 1;
     dim3 block(256);
     if (d->epilogue == LU_EPI_LSTM) {
         LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
@@ -417,7 +467,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.h_fs = d->h_frame_stride;
         a.gates_fs = d->gates_frame_stride;
         a.n_tiles = a.F / 32;
-        dim3 grid((unsigned)(m_tiles * a.n_tiles));
+        dim3 grid((unsigned)(m_tiles8 * a.n_tiles));
         LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM>), grid, block, stream, a);
         return LU_CHECK_LAUNCH();
     }
@@ -425,10 +475,21 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     LU_REQUIRE(d->out, "lu_conv2d_fwd: out is null");
     const int nf = d->N > 64 ? 4 : (d->N > 32 ? 2 : 1);
     a.n_tiles = (d->N + 32 * nf - 1) / (32 * nf);
-    dim3 grid((unsigned)(m_tiles * a.n_tiles));
+    if (d->splits > 1 && a.n_it >= 2 * d->splits) {
+        LU_REQUIRE(d->workspace, "lu_conv2d_fwd: splits > 1 needs a workspace");
+        a.ksplit = d->splits;
+        a.ws = (float*)d->workspace;
+    }
+    dim3 grid((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
         LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS>), grid, block, stream, a);            \
+        int rc_ = LU_CHECK_LAUNCH();                                                            \
+        if (rc_ || a.ksplit == 1) return rc_;                                                   \
+        const int64_t tot_ = a.M * a.N;                                                         \
+        const unsigned rg_ = (unsigned)((tot_ + 255) / 256 < 8192 ? (tot_ + 255) / 256 : 8192); \
+        LU_LAUNCH(ksplit_reduce_kernel, dim3(rg_), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N,   \
+                  a.HWo, a.bias, a.out, a.out_frame_stride, a.out_pix_stride);                  \
         return LU_CHECK_LAUNCH();                                                               \
     }
     LU_CONV_CASE(4, true)
@@ -440,6 +501,11 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
 #undef LU_CONV_CASE
     lu_set_error("lu_conv2d_fwd: no kernel variant");
     return 1;
+}
+
+extern "C" size_t lu_conv2d_workspace_bytes(const lu_conv_desc* d) {
+    if (!d || d->splits <= 1) return 0;
+    return (size_t)d->splits * d->frames * d->Hout * d->Wout * (size_t)d->N * sizeof(float);
 }
 
 extern "C" int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N, int c_off, int C_sub,

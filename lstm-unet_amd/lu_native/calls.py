@@ -30,8 +30,17 @@ def conv_src(x, frame_stride, pix_stride, Cin, w, w_tap_stride, w_row_stride):
     return s
 
 
+def conv_splits(frames, Hout, Wout, N, k, channels):
+    """K-axis split for problems with too few 256x128 output tiles to occupy 256 CUs twice over."""
+    tiles = -(-(frames * Hout * Wout) // 256) * -(-N // 128)
+    n_it = k * k * -(-channels // 16)
+    if tiles >= 384 or n_it < 64:
+        return 1
+    return int(max(1, min(512 // tiles, n_it // 32, 16)))
+
+
 def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,
-           out_frame_stride, out_pix_stride, lstm=None):
+           out_frame_stride, out_pix_stride, lstm=None, splits=1, workspace=None):
     d = cabi.ConvDesc()
     d.n_src = len(srcs)
     for i, s in enumerate(srcs):
@@ -40,6 +49,7 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
     d.k, d.stride, d.dil, d.pad_t, d.pad_l, d.N = k, stride, dil, pad_t, pad_l, N
     d.bias, d.out, d.out_frame_stride, d.out_pix_stride = bias, out, out_frame_stride, out_pix_stride
     d.epilogue = cabi.LU_EPI_BIAS
+    d.splits, d.workspace = splits, workspace
     if lstm is not None:
         d.epilogue = cabi.LU_EPI_LSTM
         (d.c_prev, d.c_prev_frame_stride, d.c_out, d.c_out_frame_stride, d.h_out, d.h_frame_stride,

@@ -232,8 +232,7 @@ class Engine:
             if t > 0:
                 if dh_rec is None:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
-                ops.calls.conv2d(ops.lib(), ops._stream(), [ops._src(dz[t], rec_kt)], B, H, W, H, W, spec['k'], 1, 1,
-                                 p, p, F, None, dh_rec.data_ptr(), dh_rec.stride(0), dh_rec.stride(2))
+                ops.conv_raw([(dz[t], rec_kt)], B, H, W, H, W, spec['k'], 1, 1, p, p, F, None, dh_rec)
         rec['gates'] = None
         dz_seq = dz.view(T * B, H, W, 4 * F)
         # hoisted over all T: one big reduction per weight

@@ -57,6 +57,18 @@ def _src(x, w):
     return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data_ptr(), w.stride(1), w.stride(2))
 
 
+def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out):
+    """One lu_conv2d_fwd launch (bias epilogue); picks a K-split + workspace for tile-starved problems."""
+    channels = sum(x.shape[3] for x, _ in pairs)
+    splits = calls.conv_splits(frames, Hout, Wout, N, k, channels)
+    ws = None
+    if splits > 1:
+        ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
+    calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t,
+                 pad_l, N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2), splits=splits, workspace=_p(ws))
+    return out
+
+
 def conv2d(pairs, bias, stride=1, out=None):
     """SAME convolution summed over (activation, weight) pairs -> [frames,Ho,Wo,N]."""
     x0, w0 = pairs[0]
@@ -67,9 +79,7 @@ def conv2d(pairs, bias, stride=1, out=None):
     Wout, pl, _ = same_pad(Win, k, stride)
     if out is None:
         out = torch.empty((frames, Hout, Wout, N), device=x0.device, dtype=torch.float32)
-    calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, 1, pt, pl,
-                 N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2))
-    return out
+    return conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, 1, pt, pl, N, bias, out)
 
 
 def flip_transpose(w, c_off=0, c_sub=None):
@@ -98,9 +108,7 @@ def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None):
     Cs = wt.shape[3]
     if out is None:
         out = torch.empty((frames, Hin, Win, Cs), device=dy.device, dtype=torch.float32)
-    calls.conv2d(lib(), _stream(), [_src(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs,
-                 None, out.data_ptr(), out.stride(0), out.stride(2))
-    return out
+    return conv_raw([(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs, None, out)
 
 
 def conv2d_wgrad(x, dy, dw, stride, beta=0.0):

@@ -74,7 +74,7 @@ def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None):
+def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1):
     """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy."""
     frames, Hin, Win = srcs[0].shape[:3]
     if N is None:
@@ -93,8 +93,9 @@ def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None
         keep += [xd, wd]
         cs.append(calls.conv_src(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(wd), Cin * N, N))
     bd = None if bias is None else be.dev(bias)
+    wsb = be.empty((splits * frames * Hout * Wout * N,)) if splits > 1 else None
     calls.conv2d(be.lib, be.stream, cs, frames, Hin, Win, Hout, Wout, k, stride, dil, pt, pl, N, be.ptr(bd),
-                 be.ptr(out), Hout * Wout * N, N)
+                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb))
     return be.host(out)
 
 

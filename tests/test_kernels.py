@@ -56,6 +56,20 @@ def test_conv_fwd(be, case):
     close(KH.conv2d(be, [x], [w], b, k, s), npo.conv2d_same(x, w, b, s), 5e-5)
 
 
+def test_conv_ksplit_and_many_mtiles(be):
+    """K-axis split (tile-starved coarse levels) and the XCD-aware tile order with > 8 m-tiles."""
+    x, w, b = rnd(1, 16, 16, 48), rnd(3, 3, 48, 40, scale=0.2), rnd(40)
+    ref = npo.conv2d_same(x, w, b, 1)
+    for sp in (2, 3, 5):
+        close(KH.conv2d(be, [x], [w], b, 3, 1, splits=sp), ref, 5e-5)
+    x, w = rnd(3, 30, 31, 8), rnd(3, 3, 8, 8, scale=0.3)          # 2790 px -> 11 m-tiles (padded to 16)
+    close(KH.conv2d(be, [x], [w], None, 3, 1), npo.conv2d_same(x, w, None, 1), 5e-5)
+    xi, xh = rnd(2, 6, 6, 1), rnd(2, 6, 6, 32)                     # thin + vector source with a K split
+    wi, wh = rnd(5, 5, 1, 24, scale=0.3), rnd(5, 5, 32, 24, scale=0.1)
+    ref = npo.conv2d_same(xi, wi) + npo.conv2d_same(xh, wh)
+    close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, splits=4), ref, 5e-5)
+
+
 def test_conv_two_sources_and_strided_views(be):
     """UpBlock2D concat([up, skip]) (Networks.py:145) as two sources reading channel slices."""
     xa, xb = rnd(2, 6, 7, 12), rnd(2, 6, 7, 1)
