@@ -152,8 +152,9 @@ def main():
     dp = DataParallel()
     if dp.world_size != args.gpus:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size), file=sys.stderr)
-    torch.cuda.set_device(dp.local_rank)
-    dev = torch.device('cuda', dp.local_rank)
+    dev_index = dp.local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     net = Params.CTCParams.net_kernel_params
     H = W = args.size
     B, T = args.batch, args.unroll
@@ -186,8 +187,9 @@ def main():
     roofline = None
     if dp.rank == 0:
         ops.EVENT_LOG = []
-        one_step(args.warmup + args.steps)
-        torch.cuda.synchronize()
+    one_step(args.warmup + args.steps)      # every rank takes part (the step contains collectives)
+    torch.cuda.synchronize()
+    if dp.rank == 0:
         ev, ops.EVENT_LOG = ops.EVENT_LOG, None
         per_launch = lstm_step_flops(net, H, W, B)
         tot_ms = sum(a.elapsed_time(b) for a, b in ev)

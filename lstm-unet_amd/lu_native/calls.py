@@ -1,6 +1,7 @@
 """Thin, pointer-level call helpers over the C ABI (descriptor packing + error checks).
 Everything here works on raw addresses; ops.py feeds it torch device pointers."""
 import ctypes as C
+import os
 
 from . import cabi
 
@@ -68,10 +69,13 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     return d
 
 
-def wgrad_splits(pixels, k, Cin, N, target_blocks=1024):
-    """Pixel-axis split so that (taps x c-tiles x n-tiles x splits) fills the 256 CUs a few times over."""
+def wgrad_splits(pixels, k, Cin, N, target_blocks=6144):
+    """Pixel-axis split.  The wgrad kernel holds 4 workgroups per CU (1024 slots on 256 CUs); with only ~1000
+    long-running blocks the slowest CU (4 blocks vs 3) sets the time, so aim for several thousand shorter
+    blocks (>= 2048 pixels = 128 pipeline stages each) and let the dispatcher balance them."""
+    target_blocks = int(os.environ.get('LU_WGRAD_BLOCKS', target_blocks))     # tuning knob (bench A/B)
     ct = max(1, -(-Cin // 128)) if Cin % 4 == 0 else -(-(k * k * Cin) // 32)
     taps = k * k if Cin % 4 == 0 else 1
     tiles = taps * ct * max(1, -(-N // 128))
-    s = max(1, min(target_blocks // max(tiles, 1), pixels // 512))
+    s = max(1, min(target_blocks // max(tiles, 1), pixels // 2048))
     return max(1, min(s, 256))

@@ -23,11 +23,12 @@ class DataParallel(object):
         self.flat = None
         if self.world_size > 1 and not dist.is_initialized():
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+                # LU_DP_BACKEND=gloo lets several ranks share ONE GPU (control-flow checks on a 1-GPU box)
+                backend = os.environ.get('LU_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
-            if backend == 'nccl':
-                torch.cuda.set_device(self.local_rank)
+            if torch.cuda.is_available():
+                torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
 
     # -- small synchronous-on-stream reductions ------------------------------------------
