@@ -24,7 +24,7 @@ struct WgradArgs {
     int32_t x_ps, dy_ps, C, N;
     int64_t M;          // frames*Hout*Wout
     int64_t chunk;      // pixels per split (multiple of KP)
-    int32_t HWo, Wout, Hin, Win;
+    int32_t HWo, Wout, Hout, Hin, Win;
     int32_t k, kk, stride, pad_t, pad_l;
     int32_t c_tiles;
     float* ws;          // [splits][kk*C*N]
@@ -77,42 +77,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
     // All global loads are unconditional; masked lanes read lu_zero16 (see lu_conv.hip for why).
     const float* const zp = lu_zero16;
-    auto load_a = [&](int64_t pb, int ps) -> float4 {
-        const int row = arow0 + RPA * ps;
-        const int64_t p = pb + row;
-        const int c = c0 + 4 * aq;
-        bool ok = row < KP && p < p_end && c < a.C;
-        const int64_t pc = ok ? p : 0;
-        const int f = (int)(pc / a.HWo);
-        const int r = (int)(pc - (int64_t)f * a.HWo);
-        const int oy = r / a.Wout, ox = r - oy * a.Wout;
-        const int iy = oy * a.stride + kh - a.pad_t, ix = ox * a.stride + kw - a.pad_l;
-        ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const float* src = a.x + (int64_t)f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
+    // Per-row pixel cursors (frame, oy, ox), advanced by KP pixels per stage with adds/compares only: the
+    // per-stage integer divisions of a naive decode cost more VALU issue slots than the stage's MFMAs leave free.
+    struct Pix {
+        int64_t p;
+        int f, oy, ox;
+    };
+    auto pix_init = [&](int row) {
+        Pix c;
+        c.p = p_begin + row;
+        const int64_t pc = c.p < a.M ? c.p : 0;
+        c.f = (int)(pc / a.HWo);
+        const int r = (int)(pc - (int64_t)c.f * a.HWo);
+        c.oy = r / a.Wout;
+        c.ox = r - c.oy * a.Wout;
+        return c;
+    };
+    auto pix_advance = [&](Pix& c) {
+        c.p += KP;
+        c.ox += KP;
+        while (c.ox >= a.Wout) {
+            c.ox -= a.Wout;
+            if (++c.oy == a.Hout) {
+                c.oy = 0;
+                ++c.f;
+            }
+        }
+    };
+    Pix pa0 = pix_init(THIN ? (tid >> 5) : arow0), pa1 = pix_init(THIN ? (tid >> 5) + 8 : arow0 + RPA);
+    Pix pb0 = pix_init(brow0), pb1 = pix_init(brow0 + RPB);
+
+    auto load_a = [&](const Pix& c, int row) -> float4 {
+        const int ch = c0 + 4 * aq;
+        const int iy = c.oy * a.stride + kh - a.pad_t, ix = c.ox * a.stride + kw - a.pad_l;
+        const bool ok = row < KP && c.p < p_end && ch < a.C && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const float* src = a.x + (int64_t)c.f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + ch;
         return *reinterpret_cast<const float4*>(ok ? src : zp);
     };
-    auto load_a_thin = [&](int64_t pb, int ps) -> float {
-        const int row = (tid >> 5) + 8 * ps;
-        const int64_t p = pb + row;
-        bool ok = t_ok && p < p_end;
-        const int64_t pc = ok ? p : 0;
-        const int f = (int)(pc / a.HWo);
-        const int r = (int)(pc - (int64_t)f * a.HWo);
-        const int oy = r / a.Wout, ox = r - oy * a.Wout;
-        const int iy = oy * a.stride + t_kh - a.pad_t, ix = ox * a.stride + t_kw - a.pad_l;
-        ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const float* src = a.x + (int64_t)f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + t_c;
+    auto load_a_thin = [&](const Pix& c) -> float {
+        const int iy = c.oy * a.stride + t_kh - a.pad_t, ix = c.ox * a.stride + t_kw - a.pad_l;
+        const bool ok = t_ok && c.p < p_end && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const float* src = a.x + (int64_t)c.f * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + t_c;
         return *(ok ? src : zp);
     };
-    auto load_b = [&](int64_t pb, int ps) -> float4 {
-        const int row = brow0 + RPB * ps;
-        const int64_t p = pb + row;
+    auto load_b = [&](const Pix& c, int row) -> float4 {
         const int n = n0 + 4 * bq;
-        const bool rok = row < KP && p < p_end;
-        const int64_t pc = rok ? p : 0;
-        const int f = (int)(pc / a.HWo);
-        const int64_t r = pc - (int64_t)f * a.HWo;
-        const float* yrow = a.dy + (int64_t)f * a.dy_fs + r * a.dy_ps + n;
+        const bool rok = row < KP && c.p < p_end;
+        const float* yrow = a.dy + (int64_t)c.f * a.dy_fs + ((int64_t)c.oy * a.Wout + c.ox) * a.dy_ps + n;
         if (YVEC) {
             return *reinterpret_cast<const float4*>((rok && n < a.N) ? yrow : zp);
         } else {
@@ -121,17 +132,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             return make_float4(t0, t1, t2, t3);
         }
     };
-    auto load_stage = [&](int it) {
-        const int64_t pb = p_begin + (int64_t)it * KP;
+    auto load_stage = [&]() {
         if (!THIN) {
-            ra0 = load_a(pb, 0);
-            if (NPA > 1) ra1 = load_a(pb, 1);
+            ra0 = load_a(pa0, arow0);
+            if (NPA > 1) ra1 = load_a(pa1, arow0 + RPA);
         } else {
-            rat0 = load_a_thin(pb, 0);
-            rat1 = load_a_thin(pb, 1);
+            rat0 = load_a_thin(pa0);
+            rat1 = load_a_thin(pa1);
         }
-        rb0 = load_b(pb, 0);
-        if (NPB > 1) rb1 = load_b(pb, 1);
+        rb0 = load_b(pb0, brow0);
+        if (NPB > 1) rb1 = load_b(pb1, brow0 + RPB);
+    };
+    auto advance_stage = [&]() {
+        pix_advance(pa0);
+        if (THIN || NPA > 1) pix_advance(pa1);
+        pix_advance(pb0);
+        if (NPB > 1) pix_advance(pb1);
     };
     auto store_stage = [&](int buf) {
         if (!THIN) {
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
     if (n_it > 0) {
-        load_stage(0);
+        load_stage();
         store_stage(0);
     }
     __syncthreads();
@@ -162,7 +178,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
         // unguarded prefetch/store (see lu_conv.hip): the last iteration re-fetches its own stage
-        load_stage(it + 1 < n_it ? it + 1 : it);
+        if (it + 1 < n_it) advance_stage();
+        load_stage();
         LU_SCHED_FENCE();
 #pragma unroll
         for (int kk2 = 0; kk2 < KP; kk2 += 2) {
@@ -251,6 +268,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.chunk = ((a.M + splits - 1) / splits + KP - 1) / KP * KP;
     a.HWo = d->Hout * d->Wout;
     a.Wout = d->Wout;
+    a.Hout = d->Hout;
     a.Hin = d->Hin;
     a.Win = d->Win;
     a.k = d->k;
