@@ -1,0 +1,75 @@
+"""N>1 path, world_size 2 over gloo on CPU (host-emulated kernels): one data-parallel training step with
+SyncBN on two ranks x 1 slot must equal the single-process step on the 2-slot batch -- same loss, same
+updated weights (loss sums all-reduced before the gradient, gradients SUMMED, BN statistics
+pooled).  Also checks that rank-local BN (the fast mode) really differs, i.e. the switch does something."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+from conftest import tiny_net
+from engine_backend import engine_backend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from engine_backend import engine_backend
+from conftest import tiny_net
+import train2D, Networks
+from lu_native.dp import DataParallel
+sync_bn = bool(int(sys.argv[1]))
+with engine_backend('emu'):
+    dp = DataParallel(backend='gloo')
+    d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
+    tr = train2D.Trainer(Networks.ULSTMnet2D, tiny_net(3), 'NHWC', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=sync_bn, seed=3)
+    sl = slice(dp.rank, dp.rank + 1)
+    _, _, loss = tr.train_step(d['x'][sl], d['gt'][sl])
+    tr.model.reset_states_per_batch(np.ones(1, np.float32))
+    _, _, loss2 = tr.train_step(d['x'][sl, ::-1].copy(), d['gt'][sl, ::-1].copy())
+    if dp.rank == 0:
+        np.savez(os.path.join(%(tmp)r, 'dp_out_%%d.npz' %% int(sync_bn)), params=tr.engine.flat_params.numpy(),
+                 loss=np.array([float(loss), float(loss2)]))
+    dp.barrier()
+'''
+
+
+def test_dp2_equals_single_process(tmp_path):
+    import train2D
+    import Networks
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 2, 16, 16, 1)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(2, 2, 16, 16, 1)).astype(np.float32)
+    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    for sync_bn in (1, 0):
+        port = 29600 + (os.getpid() + sync_bn) % 1500
+        procs = [subprocess.Popen([sys.executable, str(script), str(sync_bn)],
+                                  env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r),
+                                           MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o[-3000:]
+    with engine_backend('emu'):
+        tr = train2D.Trainer(Networks.ULSTMnet2D, tiny_net(3), 'NHWC', [0.15, 0.25, 0.6], 1e-3, seed=3)
+        _, _, l1 = tr.train_step(x, gt)
+        tr.model.reset_states_per_batch(np.ones(2, np.float32))
+        _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
+        ref = tr.engine.flat_params.numpy().copy()
+        ref_loss = np.array([float(l1), float(l2)])
+    sync = np.load(tmp_path / 'dp_out_1.npz')
+    local = np.load(tmp_path / 'dp_out_0.npz')
+    assert np.abs(sync['loss'] - ref_loss).max() <= 1e-5, (sync['loss'], ref_loss)
+    # Adam normalises the step size, so compare weights loosely in count and tightly in the bulk
+    diff = np.abs(sync['params'] - ref)
+    assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= 2e-3, (diff.max(), (diff > 1e-4).mean())
+    # rank-local BN is a different (documented) model: it must NOT coincide with the pooled statistics
+    assert np.abs(local['loss'] - ref_loss).max() > 1e-6

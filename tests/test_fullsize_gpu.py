@@ -54,9 +54,11 @@ def test_config2_window_split_and_slot_independence(full_engine):
     e2 = _clone_engine(full_engine)
     a = e2.forward(torch.from_numpy(_to_tb(x[:, :4])).to(dev), 4, B, False).view(4, B, H, W, 3)
     b = e2.forward(torch.from_numpy(_to_tb(x[:, 4:])).to(dev), 4, B, False).view(4, B, H, W, 3)
-    assert torch.equal(full[:4], a) and torch.equal(full[4:], b)          # same kernels, same order: bit-exact
+    # not bit-exact: the frame count changes which launches take a K split (different fp32 summation order)
+    tol = 1e-4 * max(1.0, float(full.abs().max()))
+    assert float((full[:4] - a).abs().max()) <= tol and float((full[4:] - b).abs().max()) <= tol
     for (s1, s2) in zip(e1.states, e2.states):
-        assert torch.equal(s1[0][0], s2[0][0]) and torch.equal(s1[0][1], s2[0][1])
+        assert float((s1[0][0] - s2[0][0]).abs().max()) <= 1e-4 and float((s1[0][1] - s2[0][1]).abs().max()) <= 1e-4
     e3 = _clone_engine(full_engine)
     solo = e3.forward(torch.from_numpy(_to_tb(x[2:3])).to(dev), T, 1, False).view(T, H, W, 3)
     # tile-starved launches pick a different K split for B=1, so allow fp32 re-association noise
