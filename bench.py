@@ -195,12 +195,23 @@ def main():
         tot_ms = sum(a.elapsed_time(b) for a, b in ev)
         n_launch = len(ev)
         flops = sum(per_launch) * T          # every level runs T fused steps per training step
+        traffic = None
+        try:     # HBM/L2-fabric bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
+                pmc = json.load(fh)['kernels']
+            key = [k for k in pmc if 'conv_fwd_kernel<4, true, 1>' in k]
+            if key and H == 256 and B == 4 and T == 8:
+                traffic = round(pmc[key[0]]['traffic_bytes_per_launch'])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         if n_launch and tot_ms > 0:
             achieved = flops / (tot_ms * 1e-3) / 1e12
             roofline = {'kernel': 'conv_fwd_kernel<4,true,LU_EPI_LSTM> (fused ConvLSTM step: two-source 5x5 implicit '
                                   'GEMM + gate epilogue)', 'bound': 'mfma', 'achieved': round(achieved, 2),
                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                        'traffic': None, 'launches_per_step': n_launch,
+                        'traffic': traffic, 'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, '
+                        'profiles/r01_pmc_traffic.json; algorithmic bytes/launch avg = 531e6)',
+                        'launches_per_step': n_launch,
                         'avg_launch_ms': round(tot_ms / n_launch, 4),
                         'flops_per_launch_avg': flops / n_launch}
     total_flops, _ = step_flops(net, H, W, B, T)

@@ -95,7 +95,9 @@ class Trainer(object):
         return {'step': self.step, 'params': e.flat_params.cpu(), 'bn': {k: v.cpu() for k, v in e.S.items()},
                 'adam_m': None if self.optimizer.m is None else self.optimizer.m.cpu(),
                 'adam_v': None if self.optimizer.v is None else self.optimizer.v.cpu(),
-                'adam_iterations': self.optimizer.iterations, 'states': self.model.get_states()}
+                'adam_iterations': self.optimizer.iterations,
+                'states': [[[None, None] if st[0] is None else [torch.from_numpy(st[0]), torch.from_numpy(st[1])]
+                            for st in blk] for blk in self.model.get_states()]}
 
     def load_state_dict(self, sd, in_channels=1):
         e = self.engine
