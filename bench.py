@@ -233,6 +233,7 @@ def main():
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
+            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

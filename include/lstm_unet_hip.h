@@ -118,7 +118,7 @@ int lu_lstm_gates_fwd(const float* z, const float* c_prev, float* c_out, float* 
 
 /* backward of the gate block for one timestep:
  *   dh = dh_a (+ dh_b if non-NULL); dc = dh*o*(1-tanh(c)^2) + dc_in(if non-NULL)
- *   dz[rows,4F] (pre-activation grads), dc_prev_out = dc*f   */
+ *   dz[rows,4F] (pre-activation grads; may alias `gates` for an in-place update), dc_prev_out = dc*f   */
 int lu_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c_cur,
                       const float* dh_a, int64_t dh_a_frame_stride, const float* dh_b, const float* dc_in,
                       float* dz, float* dc_prev_out,

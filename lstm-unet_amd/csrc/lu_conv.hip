@@ -18,6 +18,7 @@
 // writing the concatenated tensor.  Sources whose channel count is not a multiple of 4 (the
 // 1-channel microscopy image) use a "thin" path where k enumerates flattened (tap, c).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
 #include "lu_device.h"
@@ -83,7 +84,9 @@ __device__ __forceinline__ void iter_advance(IterState& st, const ConvArgs& a) {
 
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 
-template <int NF, bool BVEC, int EPI>
+// GEN = general addressing (input dilation 2: the dgrad of a stride-2 conv); !GEN = the common dil == 1 case,
+// where a tap is a constant element offset from a per-row base computed once per source.
+template <int NF, bool BVEC, int EPI, bool GEN>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     constexpr int BN = 32 * NF;
     constexpr int QPR = BN / 4;          // float4 per B row
@@ -170,18 +173,36 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         rb0 = load_w(si, thin, tap_v, chunk, 0);
         if (NPB > 1) rb1 = load_w(si, thin, tap_v, chunk, 1);
     };
+    int64_t rowoff[4] = {0, 0, 0, 0};
+    int cached_s = -1;
     auto load_stage = [&](const IterState& st) {
         const SrcInfo& si = a.src[st.s];
         const int c = st.chunk * CK + 4 * q;
         const bool cok = c < si.C;
         const float* pv[4];
+        if (GEN) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
-            const int iy = vy >> a.dsh, ix = vx >> a.dsh;
-            const bool ok = cok && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win && ((vy | vx) & a.dsh) == 0;
-            const float* p = si.x + (int64_t)fr[i] * si.frame_stride + ((int64_t)iy * a.Win + ix) * si.pix_stride + c;
-            pv[i] = ok ? p : zp;
+            for (int i = 0; i < 4; ++i) {
+                const int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
+                const int iy = vy >> a.dsh, ix = vx >> a.dsh;
+                const bool ok = cok && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win && ((vy | vx) & a.dsh) == 0;
+                const float* p = si.x + (int64_t)fr[i] * si.frame_stride + ((int64_t)iy * a.Win + ix) * si.pix_stride + c;
+                pv[i] = ok ? p : zp;
+            }
+        } else {
+            if (st.s != cached_s) {      // once per source (uniform)
+                cached_s = st.s;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rowoff[i] = (int64_t)fr[i] * si.frame_stride + ((int64_t)vy0[i] * a.Win + vx0[i]) * si.pix_stride;
+            }
+            const float* tapbase = si.x + ((int64_t)st.kh * a.Win + st.kw) * si.pix_stride + c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = cok && (unsigned)(vy0[i] + st.kh) < (unsigned)a.Hin &&
+                                (unsigned)(vx0[i] + st.kw) < (unsigned)a.Win;
+                pv[i] = ok ? tapbase + rowoff[i] : zp;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pv[i]);
@@ -468,7 +489,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.gates_fs = d->gates_frame_stride;
         a.n_tiles = a.F / 32;
         dim3 grid((unsigned)(m_tiles8 * a.n_tiles));
-        LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM>), grid, block, stream, a);
+        LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
+        LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false>), grid, block, stream, a);
         return LU_CHECK_LAUNCH();
     }
     LU_REQUIRE(d->epilogue == LU_EPI_BIAS, "lu_conv2d_fwd: unknown epilogue %d", d->epilogue);
@@ -481,9 +503,11 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.ws = (float*)d->workspace;
     }
     dim3 grid((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
+    const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS>), grid, block, stream, a);            \
+        if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true>), grid, block, stream, a);             \
+        else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false>), grid, block, stream, a);                \
         int rc_ = LU_CHECK_LAUNCH();                                                            \
         if (rc_ || a.ksplit == 1) return rc_;                                                   \
         const int64_t tot_ = a.M * a.N;                                                         \

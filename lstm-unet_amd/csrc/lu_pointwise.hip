@@ -73,10 +73,12 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ z, const float* 
     }
 }
 
-__global__ void lstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+// `dz` may alias `gates` (in-place: each thread reads its four gate values before it writes the four
+// pre-activation gradients to the same addresses), hence no __restrict__ on those two.
+__global__ void lstm_gates_bwd_kernel(const float* gates, const float* __restrict__ c_prev,
                                       const float* __restrict__ c_cur, const float* __restrict__ dh_a, int64_t dha_fs,
                                       const float* __restrict__ dh_b, const float* __restrict__ dc_in,
-                                      float* __restrict__ dz, float* __restrict__ dc_prev_out, int64_t total,
+                                      float* dz, float* __restrict__ dc_prev_out, int64_t total,
                                       int64_t ppf, int F) {
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
         const int64_t row = i / F;

@@ -10,6 +10,7 @@
 // The pixel axis is split into `splits` slabs (workspace) that a second kernel sums in a fixed
 // order -- deterministic, no float atomics.
 // Thin inputs (C % 4 != 0, e.g. the 1-channel image): M enumerates flattened (tap, c) instead.
+#include <stdlib.h>
 #include <string.h>
 #include "lu_device.h"
 
@@ -32,7 +33,7 @@ struct WgradArgs {
 };
 
 template <int MF, int NF, int WM, int WN, bool THIN, bool YVEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int BMw = 32 * MF * WM, BNw = 32 * NF * WN;
     constexpr int QPA = BMw / 4, RPA = 256 / QPA, NPA = (KP + RPA - 1) / RPA;
     constexpr int QPB = BNw / 4, RPB = 256 / QPB, NPB = (KP + RPB - 1) / RPB;
@@ -71,8 +72,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const int bq = tid % QPB, brow0 = tid / QPB;
 
     // scalars, not arrays: hipcc promoted the small float4 staging arrays to LDS-backed allocas
-    float4 ra0, ra1, rb0, rb1;
-    ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra0, ra1, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(NPA <= 2 && NPB <= 4, "staging registers are named scalars");
     float rat0 = 0.f, rat1 = 0.f;
 
     // All global loads are unconditional; masked lanes read lu_zero16 (see lu_conv.hip for why).
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
     };
     Pix pa0 = pix_init(THIN ? (tid >> 5) : arow0), pa1 = pix_init(THIN ? (tid >> 5) + 8 : arow0 + RPA);
-    Pix pb0 = pix_init(brow0), pb1 = pix_init(brow0 + RPB);
+    Pix pb0 = pix_init(brow0), pb1 = pix_init(brow0 + RPB), pb2 = pix_init(brow0 + 2 * RPB), pb3 = pix_init(brow0 + 3 * RPB);
 
     auto load_a = [&](const Pix& c, int row) -> float4 {
         const int ch = c0 + 4 * aq;
@@ -142,12 +144,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
         rb0 = load_b(pb0, brow0);
         if (NPB > 1) rb1 = load_b(pb1, brow0 + RPB);
+        if (NPB > 2) rb2 = load_b(pb2, brow0 + 2 * RPB);
+        if (NPB > 3) rb3 = load_b(pb3, brow0 + 3 * RPB);
     };
     auto advance_stage = [&]() {
         pix_advance(pa0);
         if (THIN || NPA > 1) pix_advance(pa1);
         pix_advance(pb0);
         if (NPB > 1) pix_advance(pb1);
+        if (NPB > 2) pix_advance(pb2);
+        if (NPB > 3) pix_advance(pb3);
     };
     auto store_stage = [&](int buf) {
         if (!THIN) {
@@ -159,6 +165,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
         if (RPB <= KP || brow0 < KP) *reinterpret_cast<float4*>(&Bs[buf][brow0 * BNw + 4 * bq]) = rb0;
         if (NPB > 1) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + RPB) * BNw + 4 * bq]) = rb1;
+        if (NPB > 2) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + 2 * RPB) * BNw + 4 * bq]) = rb2;
+        if (NPB > 3) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + 3 * RPB) * BNw + 4 * bq]) = rb3;
     };
 
     f32x16 acc[MF][NF];
@@ -281,9 +289,9 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     const bool xvec = (d->C % 4 == 0) && (d->x_pix_stride % 4 == 0) && (d->x_frame_stride % 4 == 0) && aligned16(d->x);
     const bool yvec = (d->N % 4 == 0) && (d->dy_pix_stride % 4 == 0) && (d->dy_frame_stride % 4 == 0) && aligned16(d->dy);
     dim3 block(256);
-    const unsigned n_tiles = (unsigned)((d->N + 127) / 128);
 #define LU_WG(MF_, NF_, WM_, WN_, THIN_, YV_, GY_)                                                          \
     do {                                                                                                    \
+        const unsigned n_tiles = (unsigned)((d->N + 32 * NF_ * WN_ - 1) / (32 * NF_ * WN_));                 \
         dim3 grid(n_tiles, (unsigned)(GY_), (unsigned)splits);                                              \
         LU_LAUNCH((wgrad_kernel<MF_, NF_, WM_, WN_, THIN_, YV_>), grid, block, stream, a);                  \
     } while (0)
@@ -291,6 +299,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         const int gy = (a.kk * d->C + 31) / 32;
         if (yvec) LU_WG(1, 1, 1, 4, true, true, gy);
         else LU_WG(1, 1, 1, 4, true, false, gy);
+    } else if (d->C > 64 && d->N >= 256 && yvec && !getenv("LU_WGRAD_SMALL")) {
+        // 128 x 256 tile: 64 MFMAs per pipeline stage per wave, half the x re-reads (ConvLSTM kernels: N = 4F >= 512)
+        a.c_tiles = (d->C + 127) / 128;
+        LU_WG(2, 4, 2, 2, false, true, a.kk * a.c_tiles);
     } else if (d->C > 64) {
         a.c_tiles = (d->C + 127) / 128;
         if (yvec) LU_WG(2, 2, 2, 2, false, true, a.kk * a.c_tiles);

@@ -76,6 +76,7 @@ def wgrad_splits(pixels, k, Cin, N, target_blocks=6144):
     target_blocks = int(os.environ.get('LU_WGRAD_BLOCKS', target_blocks))     # tuning knob (bench A/B)
     ct = max(1, -(-Cin // 128)) if Cin % 4 == 0 else -(-(k * k * Cin) // 32)
     taps = k * k if Cin % 4 == 0 else 1
-    tiles = taps * ct * max(1, -(-N // 128))
+    bn = 256 if (Cin % 4 == 0 and Cin > 64 and N >= 256 and N % 4 == 0) else 128
+    tiles = taps * ct * max(1, -(-N // bn))
     s = max(1, min(target_blocks // max(tiles, 1), pixels // 2048))
     return max(1, min(s, 256))

@@ -220,7 +220,7 @@ class Engine:
         h_all, c_all, gates, x_seq = rec['h_all'], rec['c_all'], rec['gates'], rec['x']
         _, _, H, W, F = h_all.shape
         dev = h_all.device
-        dz = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32)
+        dz = gates      # in place: the saved gates of step t are dead once dz_t is formed (halves the BPTT tape)
         dh5 = dh_seq.view(T, B, H, W, F)
         dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
         dh_rec = None

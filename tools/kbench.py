@@ -1,0 +1,51 @@
+"""Per-kernel micro-benchmark at config-2 layer shapes (HIP events on the launch stream).
+usage: python tools/kbench.py [tag]   -- env vars select kernel variants (see lu_conv.hip / lu_wgrad.hip)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'lstm-unet_amd'))
+import torch
+from lu_native import ops
+
+dev = torch.device('cuda', 0)
+tag = sys.argv[1] if len(sys.argv) > 1 else ''
+which = os.environ.get('KB', 'fwd,dgrad,wgrad').split(',')
+
+
+def timeit(fn, flops, name, reps=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    print('%-8s %-34s %8.3f ms  %6.1f TFLOP/s' % (tag, name, ms, flops / ms / 1e9), flush=True)
+
+
+def r(*s, scale=1.0):
+    return torch.randn(*s, device=dev) * scale
+
+levels = [('L0', 256, 1, 128), ('L1', 128, 128, 256), ('L2', 64, 256, 256), ('L3', 32, 256, 512)]
+B, k = 4, 5
+for name, hw, cin, F in levels:
+    if 'fwd' in which:
+        x, h, c = r(B, hw, hw, cin), r(B, hw, hw, F, scale=0.5), r(B, hw, hw, F)
+        kx, kh, b = r(k, k, cin, 4 * F, scale=0.05), r(k, k, F, 4 * F, scale=0.02), r(4 * F)
+        ho, co, g = torch.empty_like(h), torch.empty_like(c), torch.empty(B, hw, hw, 4 * F, device=dev)
+        fl = 2.0 * k * k * (cin + F) * 4 * F * hw * hw * B
+        timeit(lambda: ops.convlstm_step(x, h, c, kx, kh, b, ho, co, g), fl, 'lstm_step_fused ' + name)
+    if 'dgrad' in which:
+        dz = r(B, hw, hw, 4 * F)
+        kh = r(k, k, F, 4 * F, scale=0.02)
+        wt = ops.flip_transpose(kh)
+        out = torch.empty(B, hw, hw, F, device=dev)
+        p = (k - 1) // 2
+        fl = 2.0 * k * k * F * 4 * F * hw * hw * B
+        timeit(lambda: ops.conv_raw([(dz, wt)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad ' + name)
+    if 'wgrad' in which:
+        T = 8
+        xs, dy = r(T * B, hw, hw, F), r(T * B, hw, hw, 4 * F)
+        dw = torch.empty(k, k, F, 4 * F, device=dev)
+        fl = 2.0 * k * k * F * 4 * F * hw * hw * B * T
+        timeit(lambda: ops.conv2d_wgrad(xs, dy, dw, 1), fl, 'rec_wgrad ' + name, reps=2)
+        del xs, dy
