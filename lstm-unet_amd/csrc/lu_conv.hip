@@ -255,10 +255,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
 
     const int arow = wave * 64 + (lane & 31);
     const int khalf = 4 * (lane >> 5);
-    auto mma_stage = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float af[2][4];
+    // one stage = 8 groups of 2*NF MFMAs; group g uses k = 8*(g/4) + {g%4, 4 + g%4}
+    float af[2][4];
+    auto mma_group = [&](int buf, int g) {
+        const int s = g >> 2, j = g & 3;
+        if (j == 0) {
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 float4 t = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * mf) * A_LD + 8 * s + khalf]);
@@ -267,17 +268,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
                 af[mf][2] = t.z;
                 af[mf][3] = t.w;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float bv[NF];
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
-#pragma unroll
-                for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(af[mf][j], bv[nf], acc[mf][nf]);
-            }
         }
+        float bv[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(af[mf][j], bv[nf], acc[mf][nf]);
+    };
+    auto mma_stage = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) mma_group(buf, g);
     };
 
     // ---- thin sources: a few synchronous stages (K = k*k*C is tiny), kept out of the hot loop ----
@@ -320,12 +322,20 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
             // No `if (more)` around the prefetch / LDS store: hipcc merges the two equally-guarded blocks and
             // drags the weight-tile ds_writes (and their vmcnt wait) in front of the MFMAs.  The last
             // iteration simply re-fetches its own stage into the idle buffer (1/n_it extra traffic).
+            // The wave issues in order, but a 64-cycle MFMA leaves ~15 issue slots free behind it: the address
+            // arithmetic + global loads of the next stage go after the FIRST MFMA group and its LDS stores before
+            // the LAST one, so their issue time hides under MFMA execution instead of idling the matrix pipe.
+            mma_group(buf, 0);
+            LU_SCHED_FENCE();
             if (it + 1 < it1) iter_advance(st, a);
             load_stage(st);
             LU_SCHED_FENCE();
-            mma_stage(buf);
+#pragma unroll
+            for (int g = 1; g < 7; ++g) mma_group(buf, g);
             LU_SCHED_FENCE();
-            store_stage(buf ^ 1);
+            store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
+            LU_SCHED_FENCE();
+            mma_group(buf, 7);
             __syncthreads();
         }
     }

@@ -183,26 +183,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
+    auto mma_pair = [&](int buf, int kk2) {     // one k-pair (2 pixels): MF*NF MFMAs
+        float av[MF], bv[NF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) av[mf] = As[buf][(kk2 + khalf) * BMw + wm * 32 * MF + mf * 32 + l31];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(kk2 + khalf) * BNw + wn * 32 * NF + nf * 32 + l31];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(av[mf], bv[nf], acc[mf][nf]);
+    };
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
-        // unguarded prefetch/store (see lu_conv.hip): the last iteration re-fetches its own stage
+        // prefetch of the next stage is issued behind the first MFMA group, its LDS stores before the last one
+        // (see lu_conv.hip); unguarded: the last iteration re-fetches its own stage
+        mma_pair(buf, 0);
+        LU_SCHED_FENCE();
         if (it + 1 < n_it) advance_stage();
         load_stage();
         LU_SCHED_FENCE();
 #pragma unroll
-        for (int kk2 = 0; kk2 < KP; kk2 += 2) {
-            float av[MF], bv[NF];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) av[mf] = As[buf][(kk2 + khalf) * BMw + wm * 32 * MF + mf * 32 + l31];
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(kk2 + khalf) * BNw + wn * 32 * NF + nf * 32 + l31];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(av[mf], bv[nf], acc[mf][nf]);
-        }
+        for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
         LU_SCHED_FENCE();
         store_stage(buf ^ 1);
+        LU_SCHED_FENCE();
+        mma_pair(buf, KP - 2);
         __syncthreads();
     }
 
