@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--hw', type=int, nargs=2, default=None, help='non-square frames, e.g. 832 992 (config-4)')
     ap.add_argument('--batch', type=int, default=4, help='clip slots per GPU')
     ap.add_argument('--unroll', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -157,6 +158,8 @@ def main():
     dev = torch.device('cuda', dev_index)
     net = Params.CTCParams.net_kernel_params
     H = W = args.size
+    if args.hw:
+        H, W = args.hw
     B, T = args.batch, args.unroll
     trainer = train2D.Trainer(Params.CTCParams.net_model, net, 'NCHW', Params.CTCParams.class_weights,
                               Params.CTCParams.learning_rate, dp=dp, sync_bn=args.sync_bn, seed=0)
@@ -164,7 +167,7 @@ def main():
 
     def one_step(i):
         img, seg, keep = batches[i % len(batches)]
-        trainer.train_step(img, seg, want_outputs=False)
+        trainer.train_step(img, seg, want_outputs=True)    # (softmax, predictions, loss) as train2D.py:87-103 returns
         trainer.model.reset_states_per_batch(keep)
 
     for i in range(args.warmup):
@@ -227,9 +230,11 @@ def main():
             'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE config-2 per GPU: %dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet '
-                                   'Params.py widths (5x5 ConvLSTM 128/256/256/512, 3x3 convs), fp32, random-init' %
-                                   (H, W, T, B), 'global_batch': B * dp.world_size, 'seq_len': T,
+            'config': {'workload': ('BASELINE config-2 per GPU: ' if (H, W, T, B) == (256, 256, 8, 4) else
+                                    ('BASELINE config-4: ' if (H, W, T, B) == (832, 992, 16, 2) else '')) +
+                                   '%dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet Params.py widths (5x5 ConvLSTM '
+                                   '128/256/256/512, 3x3 convs), fp32, random-init' % (H, W, T, B),
+                       'global_batch': B * dp.world_size, 'seq_len': T,
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
