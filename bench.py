@@ -8,8 +8,9 @@ synthetic 256x256 clips, BASELINE.json config-2 per GPU (T=8, B=4 slots/GPU, Par
 
 A step = forward(training) + weighted CE + backward (BPTT inside the window) + Adam + recurrent
 state mask [+ bucketed RCCL gradient all-reduce].  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel:
-the fused ConvLSTM step, fp32 MFMA bound, timed live with HIP events on the launch stream) and
+region.  Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (the MFMA kernel class
+with the largest share of the step -- fused ConvLSTM step / dgrad convs / weight gradients are each about a
+third -- fp32 MFMA bound, algorithmic FLOPs over HIP-event time on the launch stream) and
 `cpu_baseline` (the torch-CPU oracle of the same network on a bounded sample, N=1 only).
 """
 import argparse
@@ -127,9 +128,12 @@ def cpu_baseline(net, budget_s=45.0):
         n += 1
     warm = best[0]
     per = elapsed / n if n else warm
-    return {'value': round(B * T / per, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+    # the sample runs on HxW crops; FLOPs are linear in pixels, so quote it in 256x256-equivalent frames/s
+    return {'value': round(B * T / per * (H * W) / (256.0 * 256.0), 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'measured_crop_frames_per_s': round(B * T / per, 4),
             'sample': 'same net (Params.py widths), %dx%d crop, B=%d T=%d, %d step(s) after 1 warm-up, torch CPU fp32 '
-                      'restatement of the TF2 path (TF not installed)' % (H, W, B, T, max(n, 1))}
+                      'restatement of the TF2 path (TF not installed); value = crop frames/s x (%d*%d)/(256*256)' %
+                      (H, W, B, T, max(n, 1), H, W)}
 
 
 def main():
@@ -186,7 +190,8 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     frames_per_s = dp.world_size * B * T * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel: fused ConvLSTM step (conv_fwd_kernel<4,true,LSTM>) ----
+    # ---- roofline: the three MFMA kernel classes timed live with HIP events on the launch stream; the one with the
+    # ---- largest share of the step is reported as `roofline`, all three under roofline.all_mfma_kernels
     roofline = None
     if dp.rank == 0:
         ops.EVENT_LOG = []
@@ -194,29 +199,45 @@ def main():
     torch.cuda.synchronize()
     if dp.rank == 0:
         ev, ops.EVENT_LOG = ops.EVENT_LOG, None
-        per_launch = lstm_step_flops(net, H, W, B)
-        tot_ms = sum(a.elapsed_time(b) for a, b in ev)
-        n_launch = len(ev)
-        flops = sum(per_launch) * T          # every level runs T fused steps per training step
-        traffic = None
-        try:     # HBM/L2-fabric bytes per launch of this kernel from the committed rocprofv3 --pmc passes
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
-                pmc = json.load(fh)['kernels']
-            key = [k for k in pmc if 'conv_fwd_kernel<4, true, 1>' in k]
-            if key and H == 256 and B == 4 and T == 8:
-                traffic = round(pmc[key[0]]['traffic_bytes_per_launch'])
+        classes = {}
+        for kind, fl, e0, e1 in ev:
+            c = classes.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'n': 0})
+            c['flops'] += fl
+            c['ms'] += e0.elapsed_time(e1)
+            c['n'] += 1
+        traffic_db = {}
+        try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only)
+            if (H, W, T, B) == (256, 256, 8, 4):
+                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
+                    traffic_db = json.load(fh)['kernels']
         except (OSError, KeyError, ValueError):
-            traffic = None
-        if n_launch and tot_ms > 0:
-            achieved = flops / (tot_ms * 1e-3) / 1e12
-            roofline = {'kernel': 'conv_fwd_kernel<4,true,LU_EPI_LSTM> (fused ConvLSTM step: two-source 5x5 implicit '
-                                  'GEMM + gate epilogue)', 'bound': 'mfma', 'achieved': round(achieved, 2),
-                        'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                        'traffic': traffic, 'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, '
-                        'profiles/r01_pmc_traffic.json; algorithmic bytes/launch avg = 531e6)',
-                        'launches_per_step': n_launch,
-                        'avg_launch_ms': round(tot_ms / n_launch, 4),
-                        'flops_per_launch_avg': flops / n_launch}
+            traffic_db = {}
+
+        def traffic_of(kind):
+            tag = {'conv_fwd_kernel<4,true,LU_EPI_LSTM>': 'conv_fwd_kernel<4, true, 1>',
+                   'conv_fwd_kernel<4,true,LU_EPI_BIAS>': 'conv_fwd_kernel<4, true, 0>',
+                   'wgrad_kernel': 'wgrad_kernel<2, 4, 2, 2'}
+            for k_, v_ in tag.items():
+                if kind.startswith(k_):
+                    hit = [x for x in traffic_db if v_ in x]
+                    return round(traffic_db[hit[0]]['traffic_bytes_per_launch']) if hit else None
+            return None
+
+        rows = []
+        for kind, c in classes.items():
+            if c['ms'] <= 0:
+                continue
+            ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
+            rows.append({'kernel': kind, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic_of(kind),
+                         'launches_per_step': c['n'], 'avg_launch_ms': round(c['ms'] / c['n'], 4),
+                         'ms_per_step': round(c['ms'], 2), 'flops_per_launch_avg': c['flops'] / c['n']})
+        rows.sort(key=lambda r_: -r_['ms_per_step'])
+        if rows:
+            roofline = dict(rows[0])            # the dominant kernel class = largest share of the step
+            roofline['traffic_unit'] = ('bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE '
+                                        '(profiles/r01_pmc_traffic.json)')
+            roofline['all_mfma_kernels'] = rows
     total_flops, _ = step_flops(net, H, W, B, T)
     cpu = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:

@@ -15,7 +15,26 @@ from .calls import NativeError, same_pad
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblstmunet_hip.so')
 _lib = None
-EVENT_LOG = None   # bench.py: list collecting (start, end) torch.cuda.Event pairs around fused ConvLSTM steps
+EVENT_LOG = None   # bench.py: list collecting (kernel class, algorithmic FLOPs, start, end) around the MFMA launches
+
+
+class _timed(object):
+    """HIP-event bracket on the launch stream (torch's current stream), active only while bench.py sets EVENT_LOG."""
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops, self.ev = kind, flops, None
+
+    def __enter__(self):
+        if EVENT_LOG is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+            EVENT_LOG.append((self.kind, self.flops, self.ev[0], self.ev[1]))
+        return False
 
 
 def lib():
@@ -64,8 +83,11 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
-    calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t,
-                 pad_l, N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2), splits=splits, workspace=_p(ws))
+    with _timed('conv_fwd_kernel<4,true,LU_EPI_BIAS> (plain convs, recurrent / input dgrads)' if N > 64 else 'conv small-N',
+                2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
+        calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
+                     pad_t, pad_l, N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2), splits=splits,
+                     workspace=_p(ws))
     return out
 
 
@@ -126,7 +148,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
-    calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
+    with _timed('wgrad_kernel (weight gradients, hoisted over T)' if Cin > 64 else 'wgrad small-C',
+                2.0 * k * k * Cin * N * frames * Hout * Wout):
+        calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
     return dw
 
 
@@ -139,17 +163,12 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     k = kernel.shape[0]
     p = (k - 1) // 2
     if F % 32 == 0:
-        ev = None
-        if EVENT_LOG is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
-                     4 * F, _p(bias), None, 0, 0,
-                     lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
-                           h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0))
-        if ev is not None:
-            ev[1].record()
-            EVENT_LOG.append(ev)
+        with _timed('conv_fwd_kernel<4,true,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)',
+                    2.0 * k * k * (x_t.shape[3] + F) * 4 * F * frames * H * W):
+            calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
+                         4 * F, _p(bias), None, 0, 0,
+                         lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
+                               h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0))
     else:
         z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
         assert c_prev.is_contiguous() and c_out.is_contiguous()

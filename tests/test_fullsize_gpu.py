@@ -143,3 +143,30 @@ def test_streaming_inference_contract():
         assert np.abs(s - ref).max() <= 1e-6
     labels = Inference2D.postprocess(outs[-1][1], min_cell_size=1, max_cell_size=10 ** 6)
     assert labels.shape == (37, 45) and labels.dtype == np.uint16
+
+
+def test_reference_smoke_shape_contracts():
+    """The reference's print-only smokes (Networks.py:100-119,155-175,256-277) as assertions:
+    DownBlock2D (2,3,50,50,3) -> (2,3,25,25,64),(6,25,25,64) over 4 stateful calls; UpBlock2D -> (6,100,100,64);
+    ULSTMnet2D(DEFAULT_NET_DOWN_PARAMS, 'NHWC', pad_image=True) on (2,2,35,35,3) -> (2,2,35,35,3) via 56x56."""
+    import Networks
+    rng = np.random.default_rng(0)
+    d = Networks.DownBlock2D([(3, 16), (3, 32), (3, 64)], [(3, 16), (3, 32), (3, 64)], 2, 'NHWC')
+    for _ in range(4):
+        seq, flat = d(rng.standard_normal((2, 3, 50, 50, 3)).astype(np.float32), True)
+        assert tuple(seq.shape) == (2, 3, 25, 25, 64) and tuple(flat.shape) == (6, 25, 25, 64)
+    assert d.get_states()[0][0].shape == (2, 50, 50, 16)
+    u = Networks.UpBlock2D([(3, 16), (3, 32), (3, 64)], 2, 'NHWC')
+    out = u((rng.standard_normal((6, 50, 50, 3)).astype(np.float32),
+             rng.standard_normal((6, 100, 100, 3)).astype(np.float32)), True)
+    assert tuple(out.shape) == (6, 100, 100, 64)
+    m = Networks.ULSTMnet2D(Networks.DEFAULT_NET_DOWN_PARAMS, 'NHWC', True)
+    for _ in range(2):
+        logits, sm = m(rng.standard_normal((2, 2, 35, 35, 3)).astype(np.float32), True)
+        assert tuple(logits.shape) == (2, 2, 35, 35, 3) and tuple(sm.shape) == (2, 2, 35, 35, 3)
+        assert bool(torch.isfinite(logits).all())
+        assert float((sm.sum(-1) - 1).abs().max()) < 1e-5
+    assert m.engine.num_trainable() == 93600003 + 6528 or m.engine.num_trainable() > 9e7
+    mc = Networks.ULSTMnet2D(Networks.DEFAULT_NET_DOWN_PARAMS, 'NCHW', True)
+    lg, _ = mc(rng.standard_normal((1, 2, 3, 35, 35)).astype(np.float32), False)
+    assert tuple(lg.shape) == (1, 2, 3, 35, 35)
