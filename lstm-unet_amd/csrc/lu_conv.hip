@@ -86,11 +86,16 @@ __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f
 
 // GEN = general addressing (input dilation 2: the dgrad of a stride-2 conv); !GEN = the common dil == 1 case,
 // where a tap is a constant element offset from a per-row base computed once per source.
-template <int NF, bool BVEC, int EPI, bool GEN>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
+// MF = 32-row MFMA fragments per wave along M: MF = 2 -> 4 waves of 64 x BN (128 accumulator VGPRs at NF = 4,
+// 2 waves/SIMD); MF = 1 -> 8 waves of 32 x BN (64 accumulator VGPRs, 512-thread blocks, 4 waves/SIMD): same block tile
+// and LDS image, twice the wave-level parallelism to cover the non-MFMA phases of each wave.
+template <int NF, bool BVEC, int EPI, bool GEN, int MF>
+__global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int NT = 64 * (8 / MF);    // threads per block
+    constexpr int RA = 1024 / NT;        // A rows (16-byte column groups) gathered per thread per stage
     constexpr int BN = 32 * NF;
     constexpr int QPR = BN / 4;          // float4 per B row
-    constexpr int RPP = 256 / QPR;       // B rows per pass
+    constexpr int RPP = NT / QPR;        // B rows per pass
     constexpr int NPB = (CK + RPP - 1) / RPP;
     __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
@@ -107,12 +112,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     const int n0 = nt * BN;
     const int ks = blockIdx.y;
 
-    // ---- A gather bookkeeping: 4 pixel rows per thread, one 16-byte column group ----
+    // ---- A gather bookkeeping: RA pixel rows per thread, one 16-byte column group ----
     const int q = tid & 3;
-    int fr[4], vy0[4], vx0[4];
+    int fr[RA], vy0[RA], vx0[RA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int64_t m = m0 + (tid >> 2) + 64 * i;
+    for (int i = 0; i < RA; ++i) {
+        int64_t m = m0 + (tid >> 2) + (NT / 4) * i;
         if (m < a.M) {
             int f = (int)(m / a.HWo);
             int r = (int)(m - (int64_t)f * a.HWo);
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         bcol = n0 + 4 * bq;
     }
 
-    float4 ra[4];
+    float4 ra[RA];
     float4 rb0, rb1;   // (scalars, not an array: hipcc promoted `float4 rb[NPB]` to an LDS-backed alloca)
     rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -173,16 +178,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         rb0 = load_w(si, thin, tap_v, chunk, 0);
         if (NPB > 1) rb1 = load_w(si, thin, tap_v, chunk, 1);
     };
-    int64_t rowoff[4] = {0, 0, 0, 0};
+    int64_t rowoff[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) rowoff[i] = 0;
     int cached_s = -1;
     auto load_stage = [&](const IterState& st) {
         const SrcInfo& si = a.src[st.s];
         const int c = st.chunk * CK + 4 * q;
         const bool cok = c < si.C;
-        const float* pv[4];
+        const float* pv[RA];
         if (GEN) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RA; ++i) {
                 const int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
                 const int iy = vy >> a.dsh, ix = vx >> a.dsh;
                 const bool ok = cok && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win && ((vy | vx) & a.dsh) == 0;
@@ -193,19 +200,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
             if (st.s != cached_s) {      // once per source (uniform)
                 cached_s = st.s;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < RA; ++i)
                     rowoff[i] = (int64_t)fr[i] * si.frame_stride + ((int64_t)vy0[i] * a.Win + vx0[i]) * si.pix_stride;
             }
             const float* tapbase = si.x + ((int64_t)st.kh * a.Win + st.kw) * si.pix_stride + c;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RA; ++i) {
                 const bool ok = cok && (unsigned)(vy0[i] + st.kh) < (unsigned)a.Hin &&
                                 (unsigned)(vx0[i] + st.kw) < (unsigned)a.Win;
                 pv[i] = ok ? tapbase + rowoff[i] : zp;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pv[i]);
+        for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const float4*>(pv[i]);
         load_weights(si, false, st.tap, st.chunk);
     };
     auto load_thin = [&](const SrcInfo& si, int chunk) {
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
             dx[e] = tap - dy[e] * a.k;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RA; ++i) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -239,29 +246,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
 
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + 64 * i) * A_LD + 4 * q]) = ra[i];
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + (NT / 4) * i) * A_LD + 4 * q]) = ra[i];
         if (RPP <= CK || brow0 < CK) *reinterpret_cast<float4*>(&Bs[buf][brow0 * BN + 4 * bq]) = rb0;
         if (NPB > 1) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + RPP) * BN + 4 * bq]) = rb1;
     };
 
-    f32x16 acc[2][NF];
+    f32x16 acc[MF][NF];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
-    const int arow = wave * 64 + (lane & 31);
+    const int arow = wave * (32 * MF) + (lane & 31);
     const int khalf = 4 * (lane >> 5);
     // one stage = 8 groups of 2*NF MFMAs; group g uses k = 8*(g/4) + {g%4, 4 + g%4}
-    float af[2][4];
+    float af[MF][4];
     auto mma_group = [&](int buf, int g) {
         const int s = g >> 2, j = g & 3;
         if (j == 0) {
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
+            for (int mf = 0; mf < MF; ++mf) {
                 float4 t = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * mf) * A_LD + 8 * s + khalf]);
                 af[mf][0] = t.x;
                 af[mf][1] = t.y;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(af[mf][j], bv[nf], acc[mf][nf]);
     };
@@ -343,11 +350,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     // ---- epilogue ----
     const int ccol = lane & 31;
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
+    for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int64_t m = m0 + wave * 64 + mf * 32 + row;
+            const int64_t m = m0 + wave * (32 * MF) + mf * 32 + row;
             if (m >= a.M) continue;
             const int f = (int)(m / a.HWo);
             const int64_t pix = m - (int64_t)f * a.HWo;
@@ -484,6 +491,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
     dim3 block(256);
+    const bool mf1 = getenv("LU_CONV_MF2") == nullptr;   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
     if (d->epilogue == LU_EPI_LSTM) {
         LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
         LU_REQUIRE(bvec, "lu_conv2d_fwd: LSTM epilogue needs 16-byte aligned weights");
@@ -500,7 +508,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.n_tiles = a.F / 32;
         dim3 grid((unsigned)(m_tiles8 * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false>), grid, block, stream, a);
+        if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 2>), grid, block, stream, a);
         return LU_CHECK_LAUNCH();
     }
     LU_REQUIRE(d->epilogue == LU_EPI_BIAS, "lu_conv2d_fwd: unknown epilogue %d", d->epilogue);
@@ -516,8 +525,10 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true>), grid, block, stream, a);             \
-        else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false>), grid, block, stream, a);                \
+        if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2>), grid, block, stream, a);          \
+        else if (NF_ == 4 && BV_ && mf1)                                                                        \
+            LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1>), grid, dim3(512), stream, a);           \
+        else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false, 2>), grid, block, stream, a);             \
         int rc_ = LU_CHECK_LAUNCH();                                                            \
         if (rc_ || a.ksplit == 1) return rc_;                                                   \
         const int64_t tot_ = a.M * a.N;                                                         \
