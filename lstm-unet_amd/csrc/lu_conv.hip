@@ -47,6 +47,7 @@ struct ConvArgs {
     int32_t HWo, Wout, Hin, Win;
     int32_t k, kk, stride, dsh /* dil-1 */, pad_t, pad_l;
     int32_t N, n_tiles, m_tiles;
+    int32_t dbg;           // tools/kbench.py ablation bits (LU_CONV_DBG): 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
     int32_t out_pix_stride;
@@ -335,15 +336,15 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
             mma_group(buf, 0);
             LU_SCHED_FENCE();
             if (it + 1 < it1) iter_advance(st, a);
-            load_stage(st);
+            if (!(a.dbg & 1)) load_stage(st);
             LU_SCHED_FENCE();
 #pragma unroll
             for (int g = 1; g < 7; ++g) mma_group(buf, g);
             LU_SCHED_FENCE();
-            store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
+            if (!(a.dbg & 2)) store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
             LU_SCHED_FENCE();
             mma_group(buf, 7);
-            __syncthreads();
+            if (!(a.dbg & 4)) __syncthreads();
         }
     }
 
@@ -490,6 +491,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
+    a.dbg = getenv("LU_CONV_DBG") ? atoi(getenv("LU_CONV_DBG")) : 0;
     dim3 block(256);
     const bool mf1 = getenv("LU_CONV_MF2") == nullptr;   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
     if (d->epilogue == LU_EPI_LSTM) {
