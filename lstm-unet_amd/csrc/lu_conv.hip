@@ -90,7 +90,9 @@ __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f
 // MF = 32-row MFMA fragments per wave along M: MF = 2 -> 4 waves of 64 x BN (128 accumulator VGPRs at NF = 4,
 // 2 waves/SIMD); MF = 1 -> 8 waves of 32 x BN (64 accumulator VGPRs, 512-thread blocks, 4 waves/SIMD): same block tile
 // and LDS image, twice the wave-level parallelism to cover the non-MFMA phases of each wave.
-template <int NF, bool BVEC, int EPI, bool GEN, int MF>
+// DMA = stage tiles with LDS-DMA (global_load_lds): the A image is then unpadded [256][16] with the 16-byte slot
+// index XOR-swizzled by (row >> 2) & 3 (the swizzle is applied on the SOURCE channel group; LDS stays lane-linear).
+template <int NF, bool BVEC, int EPI, bool GEN, int MF, bool DMA>
 __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(ConvArgs a) {
     constexpr int NT = 64 * (8 / MF);    // threads per block
     constexpr int RA = 1024 / NT;        // A rows (16-byte column groups) gathered per thread per stage
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     constexpr int QPR = BN / 4;          // float4 per B row
     constexpr int RPP = NT / QPR;        // B rows per pass
     constexpr int NPB = (CK + RPP - 1) / RPP;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
+    constexpr int ALD = DMA ? CK : A_LD;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * ALD];
     __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,6 +219,44 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
         for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const float4*>(pv[i]);
         load_weights(si, false, st.tap, st.chunk);
     };
+    // LDS-DMA version of load_stage + store_stage: lane-linear LDS image, swizzle folded into the source address
+    auto dma_stage = [&](const IterState& st, int buf) {
+        const SrcInfo& si = a.src[st.s];
+        if (!GEN && st.s != cached_s) {
+            cached_s = st.s;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                rowoff[i] = (int64_t)fr[i] * si.frame_stride + ((int64_t)vy0[i] * a.Win + vx0[i]) * si.pix_stride;
+        }
+        const float* tapbase = si.x + ((int64_t)st.kh * a.Win + st.kw) * si.pix_stride;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int row = (tid >> 2) + (NT / 4) * i;
+            const int c = st.chunk * CK + 4 * (q ^ ((row >> 2) & 3));     // this LDS slot holds channel group q ^ f(row)
+            const float* p;
+            bool ok;
+            if (GEN) {
+                const int vy = vy0[i] + st.kh, vx = vx0[i] + st.kw;
+                const int iy = vy >> a.dsh, ix = vx >> a.dsh;
+                ok = c < si.C && vy >= 0 && vx >= 0 && iy < a.Hin && ix < a.Win && ((vy | vx) & a.dsh) == 0;
+                p = si.x + (int64_t)fr[i] * si.frame_stride + ((int64_t)iy * a.Win + ix) * si.pix_stride + c;
+            } else {
+                ok = c < si.C && (unsigned)(vy0[i] + st.kh) < (unsigned)a.Hin && (unsigned)(vx0[i] + st.kw) < (unsigned)a.Win;
+                p = tapbase + rowoff[i] + c;
+            }
+            lu_glds16(ok ? p : zp, &As[buf][(wave * 16 + (NT / 4) * i) * ALD]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const int row = brow0 + RPP * pp;
+            const int c = st.chunk * CK + row;
+            const bool ok = row < CK && c < si.C && ((EPI == LU_EPI_LSTM) || bcol < a.N);
+            const float* wp = si.w + (int64_t)st.tap * si.w_tap_stride + (int64_t)c * si.w_row_stride + bcol;
+            // rows of 64 lanes: lane -> (row = tid / QPR, 16-byte column tid % QPR) is linear in tid
+            if (RPP * (pp + 1) <= CK || row < CK) lu_glds16(ok ? wp : zp, &Bs[buf][(wave * 64 + NT * pp) * 4]);
+        }
+    };
+
     auto load_thin = [&](const SrcInfo& si, int chunk) {
         const int kkC = a.kk * si.C;
         int dy[4], dx[4], cc[4];
@@ -248,7 +289,11 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + (NT / 4) * i) * A_LD + 4 * q]) = ra[i];
+        {
+            const int row = (tid >> 2) + (NT / 4) * i;
+            const int slot = DMA ? (q ^ ((row >> 2) & 3)) : q;
+            *reinterpret_cast<float4*>(&As[buf][row * ALD + 4 * slot]) = ra[i];
+        }
         if (RPP <= CK || brow0 < CK) *reinterpret_cast<float4*>(&Bs[buf][brow0 * BN + 4 * bq]) = rb0;
         if (NPB > 1) *reinterpret_cast<float4*>(&Bs[buf][(brow0 + RPP) * BN + 4 * bq]) = rb1;
     };
@@ -270,7 +315,10 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
         if (j == 0) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
-                float4 t = *reinterpret_cast<const float4*>(&As[buf][(arow + 32 * mf) * A_LD + 8 * s + khalf]);
+                const int row = arow + 32 * mf;
+                const int grp = 2 * s + (khalf >> 2);     // 16-byte channel group wanted by this half-wave
+                const int slot = DMA ? (grp ^ ((row >> 2) & 3)) : grp;
+                float4 t = *reinterpret_cast<const float4*>(&As[buf][row * ALD + 4 * slot]);
                 af[mf][0] = t.x;
                 af[mf][1] = t.y;
                 af[mf][2] = t.z;
@@ -322,8 +370,12 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
             st.kh = st.tap / a.k;
             st.kw = st.tap - st.kh * a.k;
         }
-        load_stage(st);
-        store_stage(0);
+        if (DMA) {
+            dma_stage(st, 0);
+        } else {
+            load_stage(st);
+            store_stage(0);
+        }
         __syncthreads();
         for (int it = it0; it < it1; ++it) {
             const int buf = (it - it0) & 1;
@@ -336,14 +388,23 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
             mma_group(buf, 0);
             LU_SCHED_FENCE();
             if (it + 1 < it1) iter_advance(st, a);
-            if (!(a.dbg & 1)) load_stage(st);
-            LU_SCHED_FENCE();
+            if (DMA) {
+                // straight into the other LDS buffer (last read before the previous barrier); __syncthreads() below
+                // waits vmcnt(0) for the pending LDS writes
+                if (!(a.dbg & 1)) dma_stage(st, buf ^ 1);
+                LU_SCHED_FENCE();
 #pragma unroll
-            for (int g = 1; g < 7; ++g) mma_group(buf, g);
-            LU_SCHED_FENCE();
-            if (!(a.dbg & 2)) store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
-            LU_SCHED_FENCE();
-            mma_group(buf, 7);
+                for (int g = 1; g < 8; ++g) mma_group(buf, g);
+            } else {
+                if (!(a.dbg & 1)) load_stage(st);
+                LU_SCHED_FENCE();
+#pragma unroll
+                for (int g = 1; g < 7; ++g) mma_group(buf, g);
+                LU_SCHED_FENCE();
+                if (!(a.dbg & 2)) store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
+                LU_SCHED_FENCE();
+                mma_group(buf, 7);
+            }
             if (!(a.dbg & 4)) __syncthreads();
         }
     }
@@ -493,6 +554,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.ksplit = 1;
     a.dbg = getenv("LU_CONV_DBG") ? atoi(getenv("LU_CONV_DBG")) : 0;
     dim3 block(256);
+    const bool dma = getenv("LU_CONV_NODMA") == nullptr;  // LDS-DMA tile staging (A/B knob for tools/kbench.py)
     const bool mf1 = getenv("LU_CONV_MF2") == nullptr;   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
     if (d->epilogue == LU_EPI_LSTM) {
         LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
@@ -510,8 +572,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.n_tiles = a.F / 32;
         dim3 grid((unsigned)(m_tiles8 * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1>), grid, dim3(512), stream, a);
-        else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 2>), grid, block, stream, a);
+        if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
+        else if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, false>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 2, false>), grid, block, stream, a);
         return LU_CHECK_LAUNCH();
     }
     LU_REQUIRE(d->epilogue == LU_EPI_BIAS, "lu_conv2d_fwd: unknown epilogue %d", d->epilogue);
@@ -527,10 +590,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2>), grid, block, stream, a);          \
+        if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a);   \
+        else if (NF_ == 4 && BV_ && mf1 && dma)                                                                 \
+            LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1, true>), grid, dim3(512), stream, a);     \
         else if (NF_ == 4 && BV_ && mf1)                                                                        \
-            LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1>), grid, dim3(512), stream, a);           \
-        else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false, 2>), grid, block, stream, a);             \
+            LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1, false>), grid, dim3(512), stream, a);    \
+        else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false, 2, false>), grid, block, stream, a);      \
         int rc_ = LU_CHECK_LAUNCH();                                                            \
         if (rc_ || a.ksplit == 1) return rc_;                                                   \
         const int64_t tot_ = a.M * a.N;                                                         \

@@ -13,6 +13,11 @@
 static inline f32x16 lu_mfma(float a, float b, f32x16 c) { return lu_emu::mfma_32x32x2(a, b, c); }
 static inline float lu_shfl_xor(float v, int m) { return lu_emu::shfl_xor(v, m); }
 static inline float lu_shfl_down(float v, int d) { return lu_emu::shfl_down(v, d); }
+// global_load_lds_dwordx4: every lane copies 16 bytes from ITS global pointer to (wave-uniform LDS base + lane*16)
+static inline void lu_glds16(const float* gptr, float* lds_wave_base) {
+    const int lane = lu_emu::g_rt.cur->lin & 63;
+    memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, gptr, 16);
+}
 #define LU_CHECK_LAUNCH() 0
 #define LU_SCHED_FENCE() ((void)0)
 #else
@@ -26,6 +31,12 @@ __device__ __forceinline__ f32x16 lu_mfma(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ float lu_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float lu_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+// LDS-DMA (global_load_lds_dwordx4): each lane copies 16 bytes from ITS global pointer straight into LDS at
+// (wave-uniform base + lane*16) -- no VGPR staging, no ds_write; completion is tracked by vmcnt.
+__device__ __forceinline__ void lu_glds16(const float* gptr, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 #define LU_CHECK_LAUNCH() lu_check_launch()
 // pins instruction order across this point: sched_barrier stops the machine scheduler, the empty asm with a
 // memory clobber stops the IR optimiser (which otherwise hoists the next stage's LDS stores -- and the vmcnt

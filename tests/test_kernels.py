@@ -46,6 +46,7 @@ def ck(be, rc, what):
 CONV_CASES = [  # frames, H, W, C, N, k, stride
     (1, 8, 8, 16, 32, 3, 1), (2, 9, 7, 8, 12, 3, 1), (1, 10, 12, 20, 40, 5, 1), (2, 8, 10, 1, 8, 5, 1),
     (1, 9, 9, 3, 70, 3, 2), (1, 8, 8, 24, 130, 3, 2), (1, 6, 6, 8, 3, 1, 1), (3, 5, 5, 4, 33, 5, 2),
+    (2, 9, 9, 20, 136, 3, 1), (1, 7, 8, 36, 128, 5, 1), (1, 8, 8, 16, 72, 3, 2),     # wide tiles: LDS-DMA staged variant
 ]
 
 
@@ -102,7 +103,7 @@ def _torch_conv_grads(x, w, dy, stride):
 
 @pytest.mark.parametrize('case', [(2, 8, 9, 8, 12, 3, 1), (1, 7, 7, 4, 8, 5, 1), (2, 8, 8, 8, 16, 3, 2),
                                   (1, 9, 7, 12, 8, 3, 2), (1, 8, 8, 4, 4, 5, 2), (1, 6, 6, 3, 5, 3, 1),
-                                  (1, 6, 5, 8, 3, 1, 1)])
+                                  (1, 6, 5, 8, 3, 1, 1), (1, 7, 9, 72, 24, 3, 1), (1, 8, 8, 132, 8, 3, 2)])
 def test_conv_dgrad_wgrad(be, case):
     fr, H, W, Cc, N, k, s = case
     x, w = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.3)
