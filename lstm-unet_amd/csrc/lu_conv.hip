@@ -47,6 +47,7 @@ struct ConvArgs {
     int32_t HWo, Wout, Hin, Win;
     int32_t k, kk, stride, dsh /* dil-1 */, pad_t, pad_l;
     int32_t N, n_tiles, m_tiles;
+    int32_t tiles_x, tiles_pf;   // halo kernel: 8x32-pixel tiles per row / per frame
     int32_t dbg;           // tools/kbench.py ablation bits (LU_CONV_DBG): 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
@@ -84,6 +85,51 @@ __device__ __forceinline__ void iter_advance(IterState& st, const ConvArgs& a) {
 }
 
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
+
+// Epilogue for ONE accumulator row (pixel `pix` of frame `f`, linear row index m) of a lane: v[nf] are the lane's
+// values in the NF column fragments (column = 32*nf + (lane & 31)).
+template <int NF, int EPI>
+__device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float (&v)[NF], int f, int64_t pix, int64_t m,
+                                                  int nt, int n0, int ks, int ccol) {
+    if (EPI == LU_EPI_LSTM) {
+        const int ch = nt * 32 + ccol;  // F % 32 == 0 is enforced by the host
+        const int F = a.F;
+        float zi = v[0], zf = v[NF > 1 ? 1 : 0], zg = v[NF > 2 ? 2 : 0], zo = v[NF > 3 ? 3 : 0];
+        if (a.bias) {
+            zi += a.bias[ch];
+            zf += a.bias[F + ch];
+            zg += a.bias[2 * F + ch];
+            zo += a.bias[3 * F + ch];
+        }
+        const float gi = hard_sigmoid(zi), gf = hard_sigmoid(zf), gg = tanhf(zg), go = hard_sigmoid(zo);
+        const float cp = a.c_prev[(int64_t)f * a.c_prev_fs + pix * F + ch];
+        const float cn = gf * cp + gi * gg;
+        const float hn = go * tanhf(cn);
+        a.c_out[(int64_t)f * a.c_out_fs + pix * F + ch] = cn;
+        a.h_out[(int64_t)f * a.h_fs + pix * F + ch] = hn;
+        if (a.gates_out) {
+            float* gp = a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
+            gp[0] = gi;
+            gp[F] = gf;
+            gp[2 * F] = gg;
+            gp[3 * F] = go;
+        }
+    } else if (a.ksplit > 1) {
+        float* op = a.ws + ((int64_t)ks * a.M + m) * a.N;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const int col = n0 + 32 * nf + ccol;
+            if (col < a.N) op[col] = v[nf];
+        }
+    } else {
+        float* op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const int col = n0 + 32 * nf + ccol;
+            if (col < a.N) op[col] = v[nf] + (a.bias ? a.bias[col] : 0.f);
+        }
+    }
+}
 
 // GEN = general addressing (input dilation 2: the dgrad of a stride-2 conv); !GEN = the common dil == 1 case,
 // where a tap is a constant element offset from a per-row base computed once per source.
@@ -410,7 +456,6 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     }
 
     // ---- epilogue ----
-    const int ccol = lane & 31;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
@@ -420,46 +465,221 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
             if (m >= a.M) continue;
             const int f = (int)(m / a.HWo);
             const int64_t pix = m - (int64_t)f * a.HWo;
-            if (EPI == LU_EPI_LSTM) {
-                const int ch = nt * 32 + ccol;  // F % 32 == 0 is enforced by the host
-                const int F = a.F;
-                float zi = acc[mf][0][r], zf = acc[mf][NF > 1 ? 1 : 0][r], zg = acc[mf][NF > 2 ? 2 : 0][r],
-                      zo = acc[mf][NF > 3 ? 3 : 0][r];
-                if (a.bias) {
-                    zi += a.bias[ch];
-                    zf += a.bias[F + ch];
-                    zg += a.bias[2 * F + ch];
-                    zo += a.bias[3 * F + ch];
-                }
-                const float gi = hard_sigmoid(zi), gf = hard_sigmoid(zf), gg = tanhf(zg), go = hard_sigmoid(zo);
-                const float cp = a.c_prev[(int64_t)f * a.c_prev_fs + pix * F + ch];
-                const float cn = gf * cp + gi * gg;
-                const float hn = go * tanhf(cn);
-                a.c_out[(int64_t)f * a.c_out_fs + pix * F + ch] = cn;
-                a.h_out[(int64_t)f * a.h_fs + pix * F + ch] = hn;
-                if (a.gates_out) {
-                    float* gp = a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
-                    gp[0] = gi;
-                    gp[F] = gf;
-                    gp[2 * F] = gg;
-                    gp[3 * F] = go;
-                }
-            } else if (a.ksplit > 1) {
-                float* op = a.ws + ((int64_t)ks * a.M + m) * a.N;
+            float v[NF];
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
-                    const int col = n0 + 32 * nf + ccol;
-                    if (col < a.N) op[col] = acc[mf][nf][r];
-                }
-            } else {
-                float* op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride;
+            for (int nf = 0; nf < NF; ++nf) v[nf] = acc[mf][nf][r];
+            conv_epilogue_row<NF, EPI>(a, v, f, pix, m, nt, n0, ks, lane & 31);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Halo-reuse variant for stride-1 K x K convolutions (K = 3, 5) with wide outputs (NF = 4): the block owns an
+// 8 x 32-pixel patch of ONE frame (wave w = patch row w, lane & 31 = x) and stages the (8+K-1) x (32+K-1) input halo of a
+// 16-channel chunk in LDS ONCE; the K*K taps then read shifted rows of that halo, so per tap only the 16 x 128
+// weight tile is fetched.  Activation traffic per block drops ~15x (k = 5) versus the per-tap gather above, which
+// an ablation showed costs ~10 % of the MFMA rate.  Same MFMA/LDS fragment scheme, same epilogues.
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int EPI>
+__global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
+    constexpr int NF = 4, BN = 128, NT = 512, TH = 8, TW = 32;
+    constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;    // halo width / height / pixels
+    constexpr int HPASS = (HP * 4 + NT - 1) / NT;                        // 16-byte loads per thread per halo
+    constexpr int PAD = (K - 1) / 2;
+    static_assert(HP * A_LD >= BM * A_LD, "halo buffer doubles as the [256][20] tile of the thin-source prologue");
+    __shared__ __attribute__((aligned(16))) float Ah[HP * A_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int slot = bid >> 3;
+    const int nt = slot % a.n_tiles;
+    const int tile = (slot / a.n_tiles) * 8 + (bid & 7);     // XCD-aware order, see conv_fwd_kernel
+    if (tile >= a.m_tiles) return;
+    const int f = tile / a.tiles_pf;
+    const int t2 = tile - f * a.tiles_pf;
+    const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
+    const int n0 = nt * BN;
+    const int ks = blockIdx.y;
+    const float* const zp = lu_zero16;
+
+    // ---- halo gather bookkeeping (independent of source / chunk) ----
+    int hoff[HPASS];
+    bool hok[HPASS];
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
-                    const int col = n0 + 32 * nf + ccol;
-                    if (col < a.N) op[col] = acc[mf][nf][r] + (a.bias ? a.bias[col] : 0.f);
+    for (int i = 0; i < HPASS; ++i) {
+        const int hp = (tid + NT * i) >> 2;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        hok[i] = hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        hoff[i] = iy * a.Win + ix;
+    }
+    const int q = tid & 3;
+    // ---- B bookkeeping: 16 rows x 32 float4, one per thread ----
+    const int bq = tid & 31, brow = tid >> 5;
+    const int bcol = (EPI == LU_EPI_LSTM) ? (bq >> 3) * a.F + nt * 32 + 4 * (bq & 7) : n0 + 4 * bq;
+
+    float4 rh[HPASS];
+    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_halo = [&](const IterState& st) {
+        const SrcInfo& si = a.src[st.s];
+        const int c = st.chunk * CK + 4 * q;
+        const float* base = si.x + (int64_t)f * si.frame_stride + c;
+#pragma unroll
+        for (int i = 0; i < HPASS; ++i) {
+            const float* p = base + (int64_t)hoff[i] * si.pix_stride;
+            rh[i] = *reinterpret_cast<const float4*>((hok[i] && c < si.C) ? p : zp);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HPASS; ++i) {
+            const int hp = (tid + NT * i) >> 2;
+            if (hp < HP) *reinterpret_cast<float4*>(&Ah[hp * A_LD + 4 * q]) = rh[i];
+        }
+    };
+    auto load_b = [&](const SrcInfo& si, bool thin, int tap_v, int chunk) {
+        int tap, c;
+        bool rok;
+        if (!thin) {
+            tap = tap_v;
+            c = chunk * CK + brow;
+            rok = c < si.C;
+        } else {
+            const int j = chunk * CK + brow;
+            rok = j < a.kk * si.C;
+            tap = j / si.C;
+            c = j - tap * si.C;
+        }
+        const float* wp = si.w + (int64_t)tap * si.w_tap_stride + (int64_t)c * si.w_row_stride + bcol;
+        const bool ok = rok && ((EPI == LU_EPI_LSTM) || bcol < a.N);
+        rb = *reinterpret_cast<const float4*>(ok ? wp : zp);
+    };
+    auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][brow * BN + 4 * bq]) = rb; };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+
+    const int khalf = 4 * (lane >> 5);
+    float af[4];
+    // group g of a stage: k = 8*(g/4) + {g%4, 4 + g%4}; the A fragment row is the halo pixel (wave + kh, x + kw)
+    auto mma_group = [&](int buf, int g, int arow) {
+        const int s = g >> 2, j = g & 3;
+        if (j == 0) {
+            float4 t = *reinterpret_cast<const float4*>(&Ah[arow * A_LD + 8 * s + khalf]);
+            af[0] = t.x;
+            af[1] = t.y;
+            af[2] = t.z;
+            af[3] = t.w;
+        }
+        float bv[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[nf] = lu_mfma(af[j], bv[nf], acc[nf]);
+    };
+
+    // ---- thin sources (e.g. the 1-channel image): per-tap gather into the buffer used as a [256][20] tile ----
+    if (ks == 0) {
+        const int oyr[2] = {y0 + ((tid >> 2) >> 5), y0 + (((tid >> 2) + 128) >> 5)};
+        const int oxr = x0 + ((tid >> 2) & 31);
+        for (int ts = 0; ts < a.n_thin; ++ts) {
+            const SrcInfo& si = a.tsrc[ts];
+            const int kkC = a.kk * si.C;
+            for (int ch = 0; ch < si.nchunk; ++ch) {
+                float4 rt[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jj = ch * CK + 4 * q + e;
+                        const int tap = jj / si.C, cc = jj - tap * si.C;
+                        const int dy = tap / K, dx = tap - dy * K;
+                        const int iy = oyr[i] + dy - PAD, ix = oxr + dx - PAD;
+                        const bool ok = jj < kkC && oyr[i] < a.Hin && oxr < a.Win && iy >= 0 && iy < a.Hin && ix >= 0 &&
+                                        ix < a.Win;
+                        const float* p = si.x + (int64_t)f * si.frame_stride + ((int64_t)iy * a.Win + ix) * si.pix_stride + cc;
+                        v[e] = *(ok ? p : zp);
+                    }
+                    rt[i] = make_float4(v[0], v[1], v[2], v[3]);
                 }
+                load_b(si, true, 0, ch);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    *reinterpret_cast<float4*>(&Ah[((tid >> 2) + 128 * i) * A_LD + 4 * q]) = rt[i];
+                store_b(0);
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < 8; ++g) mma_group(0, g, wave * 32 + (lane & 31));
+                __syncthreads();
             }
         }
+    }
+
+    // ---- vector sources ----
+    int it0 = 0, it1 = a.n_it;
+    if (a.ksplit > 1) {
+        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per;
+        it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
+    }
+    if (it1 > it0) {
+        IterState st{0, 0, 0, 0, 0};
+        {
+            int r = it0;
+            while (r >= a.src[st.s].nchunk * a.kk) {
+                r -= a.src[st.s].nchunk * a.kk;
+                ++st.s;
+            }
+            st.chunk = r / a.kk;
+            st.tap = r - st.chunk * a.kk;
+            st.kh = st.tap / K;
+            st.kw = st.tap - st.kh * K;
+        }
+        load_halo(st);
+        load_b(a.src[st.s], false, st.tap, st.chunk);
+        store_halo();
+        store_b(0);
+        __syncthreads();
+        for (int it = it0; it < it1; ++it) {
+            const int buf = (it - it0) & 1;
+            const int arow = (wave + st.kh) * HWD + (lane & 31) + st.kw;
+            IterState nx = st;
+            if (it + 1 < it1) iter_advance(nx, a);
+            const bool new_halo = (it + 1 < it1) && nx.tap == 0;     // the next stage starts another (source, chunk)
+            mma_group(buf, 0, arow);
+            LU_SCHED_FENCE();
+            load_b(a.src[nx.s], false, nx.tap, nx.chunk);
+            if (new_halo) load_halo(nx);
+            LU_SCHED_FENCE();
+#pragma unroll
+            for (int g = 1; g < 8; ++g) mma_group(buf, g, arow);
+            LU_SCHED_FENCE();
+            if (new_halo) {
+                __syncthreads();      // every wave is done with the old halo
+                store_halo();
+            }
+            store_b(buf ^ 1);
+            __syncthreads();
+            st = nx;
+        }
+    }
+
+    // ---- epilogue: wave = patch row, accumulator row = x ----
+    const int oy = y0 + wave;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (oy >= a.Hin || ox >= a.Win) continue;
+        const int64_t pix = (int64_t)oy * a.Win + ox;
+        float v[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) v[nf] = acc[nf][r];
+        conv_epilogue_row<NF, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0, ks, lane & 31);
     }
 }
 
@@ -548,13 +768,26 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.bias = d->bias;
     a.out = d->out;
     a.out_frame_stride = d->out_frame_stride;
-    const int64_t m_tiles = (a.M + BM - 1) / BM;
+    int64_t m_tiles = (a.M + BM - 1) / BM;
+    // halo-reuse kernel: stride-1 SAME 3x3 / 5x5, wide 16-byte-aligned outputs, <= 25 % of the 8x32 patches wasted
+    const int64_t tiles_y = (d->Hout + 7) / 8, tiles_x = (d->Wout + 31) / 32;
+    const bool halo = d->stride == 1 && d->dil == 1 && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
+                      d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
+                      a.n_src > 0 && tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
+                      getenv("LU_CONV_NOHALO") == nullptr;
+    if (halo) {
+        a.tiles_x = (int32_t)tiles_x;
+        a.tiles_pf = (int32_t)(tiles_y * tiles_x);
+        m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
+    }
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
     a.dbg = getenv("LU_CONV_DBG") ? atoi(getenv("LU_CONV_DBG")) : 0;
     dim3 block(256);
-    const bool dma = getenv("LU_CONV_NODMA") == nullptr;  // LDS-DMA tile staging (A/B knob for tools/kbench.py)
+    // LDS-DMA tile staging measured 4-5 % SLOWER than VGPR staging here (123.5 vs 129.9 TFLOP/s on the recurrent
+    // dgrads): opt-in only, kept as a measured negative result.
+    const bool dma = getenv("LU_CONV_DMA") != nullptr;
     const bool mf1 = getenv("LU_CONV_MF2") == nullptr;   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
     if (d->epilogue == LU_EPI_LSTM) {
         LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
@@ -572,7 +805,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.n_tiles = a.F / 32;
         dim3 grid((unsigned)(m_tiles8 * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
+        if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
         else if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, false>), grid, dim3(512), stream, a);
         else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 2, false>), grid, block, stream, a);
         return LU_CHECK_LAUNCH();
@@ -590,7 +825,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a);   \
+        if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
+        else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
+        else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \
         else if (NF_ == 4 && BV_ && mf1 && dma)                                                                 \
             LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1, true>), grid, dim3(512), stream, a);     \
         else if (NF_ == 4 && BV_ && mf1)                                                                        \

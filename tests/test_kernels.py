@@ -71,6 +71,29 @@ def test_conv_ksplit_and_many_mtiles(be):
     close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, splits=4), ref, 5e-5)
 
 
+def test_conv_halo_variant(be):
+    """8x32-patch halo-reuse kernel (stride-1 3x3 / 5x5, N > 64): ragged patches, two sources incl. a thin one,
+    K split, and the fused ConvLSTM epilogue on it."""
+    for (fr, H, W, Cc, N, k) in [(1, 16, 32, 20, 136, 3), (2, 16, 30, 36, 128, 5), (1, 17, 40, 16, 72, 5)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        close(KH.conv2d(be, [x], [w], b, k, 1), npo.conv2d_same(x, w, b, 1), 5e-5)
+    xi, xh = rnd(1, 16, 32, 1), rnd(1, 16, 32, 40)
+    wi, wh = rnd(5, 5, 1, 72, scale=0.3), rnd(5, 5, 40, 72, scale=0.1)
+    ref = npo.conv2d_same(xi, wi) + npo.conv2d_same(xh, wh)
+    close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1), ref, 5e-5)
+    close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, splits=3), ref, 5e-5)
+    F = 32
+    x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
+    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    h1, c1 = npo.convlstm_step(x, h, c, ker, rec, b)
+    hg, cg, gates = KH.convlstm_step_fused(be, x, h, c, ker, rec, b)
+    close(hg, h1, 2e-5)
+    close(cg, c1, 2e-5)
+    z = npo.conv2d_same(x, ker, b) + npo.conv2d_same(h, rec)
+    close(gates[..., 3 * F:], npo.hard_sigmoid(z[..., 3 * F:]), 2e-5)
+    close(gates[..., F:2 * F], npo.hard_sigmoid(z[..., F:2 * F]), 2e-5)
+
+
 def test_conv_two_sources_and_strided_views(be):
     """UpBlock2D concat([up, skip]) (Networks.py:145) as two sources reading channel slices."""
     xa, xb = rnd(2, 6, 7, 12), rnd(2, 6, 7, 1)
