@@ -238,6 +238,118 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Kernel-row variant for stride-1 K x K convolutions (K = 3, 5; W % 16 == 0; C >= 64): one block accumulates ALL K
+// horizontal taps (kw = 0..K-1) of one kernel row kh for a 64 (c) x 128 (n) tile.  A pipeline stage is a run of
+// 16 consecutive pixels of one image row: the dy tile [16][128] is shared by the K taps and the x tile is the
+// same run widened by K-1 pixels ([16+K-1][64]); tap kw simply reads it shifted by kw rows.  Load bytes per FLOP
+// drop 2.3x versus one-tap-per-block; 8 waves (2 x 4), K accumulators each -> 4 waves/SIMD.
+// ---------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
+    constexpr int BMw = 64, BNw = 128, XP = KP + K - 1, NT = 512;
+    __shared__ __attribute__((aligned(16))) float Xs[2][XP * BMw];
+    __shared__ __attribute__((aligned(16))) float Ys[2][KP * BNw];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int n0 = blockIdx.x * BNw;
+    const int kh = blockIdx.y / a.c_tiles;
+    const int c0 = (blockIdx.y - kh * a.c_tiles) * BMw;
+    const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+    int64_t p_end = p_begin + a.chunk;
+    if (p_end > a.M) p_end = a.M;
+    const int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
+    const float* const zp = lu_zero16;
+
+    // the pixel run of a stage is uniform over the block: (frame, row, first column) advance by 16 pixels per stage
+    int64_t pf = 0;          // frame index
+    int oy = 0, ox0 = 0;
+    {
+        const int64_t p = p_begin < a.M ? p_begin : 0;
+        pf = p / a.HWo;
+        const int r = (int)(p - pf * a.HWo);
+        oy = r / a.Wout;
+        ox0 = r - oy * a.Wout;
+    }
+    const int xrow = tid >> 4, xq = tid & 15;      // x tile: XP rows x 16 float4 (threads < XP*16)
+    const int yrow = tid >> 5, yq = tid & 31;      // dy tile: 16 rows x 32 float4
+    float4 rx = make_float4(0.f, 0.f, 0.f, 0.f), ry = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_stage = [&](int it) {
+        const int iy = oy + kh - a.pad_t;
+        const int ix = ox0 - a.pad_l + xrow;
+        const int c = c0 + 4 * xq;
+        const bool okx = xrow < XP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.C;
+        const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
+        rx = *reinterpret_cast<const float4*>(okx ? px : zp);
+        const int n = n0 + 4 * yq;
+        const bool oky = p_begin + (int64_t)it * KP + yrow < p_end && n < a.N;
+        const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0 + yrow) * a.dy_ps + n;
+        ry = *reinterpret_cast<const float4*>(oky ? py : zp);
+    };
+    auto store_stage = [&](int buf) {
+        if (xrow < XP) *reinterpret_cast<float4*>(&Xs[buf][xrow * BMw + 4 * xq]) = rx;
+        *reinterpret_cast<float4*>(&Ys[buf][yrow * BNw + 4 * yq]) = ry;
+    };
+    auto advance = [&]() {
+        ox0 += KP;
+        if (ox0 >= a.Wout) {          // W % 16 == 0: a run never straddles two rows
+            ox0 = 0;
+            if (++oy == a.Hout) {
+                oy = 0;
+                ++pf;
+            }
+        }
+    };
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (n_it > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+    const int khalf = lane >> 5, l31 = lane & 31;
+    auto mma_pair = [&](int buf, int kk2) {
+        const float bv = Ys[buf][(kk2 + khalf) * BNw + wn * 32 + l31];
+        float av[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
+#pragma unroll
+        for (int t = 0; t < K; ++t) acc[t] = lu_mfma(av[t], bv, acc[t]);
+    };
+    for (int it = 0; it < n_it; ++it) {
+        const int buf = it & 1;
+        mma_pair(buf, 0);
+        LU_SCHED_FENCE();
+        if (it + 1 < n_it) advance();
+        load_stage(it + 1 < n_it ? it + 1 : it);
+        LU_SCHED_FENCE();
+#pragma unroll
+        for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
+        LU_SCHED_FENCE();
+        store_stage(buf ^ 1);
+        LU_SCHED_FENCE();
+        mma_pair(buf, KP - 2);
+        __syncthreads();
+    }
+
+    float* slab = a.ws + (int64_t)blockIdx.z * a.slab;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const int tap = kh * K + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int n = n0 + wn * 32 + l31;
+            if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][r];
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ dw,
                                     int C, int N, int64_t tap_stride, int row_stride, float beta) {
     const int64_t total = slab;
@@ -301,7 +413,14 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         dim3 grid(n_tiles, (unsigned)(GY_), (unsigned)splits);                                              \
         LU_LAUNCH((wgrad_kernel<MF_, NF_, WM_, WN_, THIN_, YV_>), grid, block, stream, a);                  \
     } while (0)
-    if (!xvec) {
+    const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
+                             d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
+    if (row_variant) {
+        a.c_tiles = (d->C + 63) / 64;
+        dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
+        if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((wgrad_row_kernel<3>), grid, dim3(512), stream, a);
+    } else if (!xvec) {
         const int gy = (a.kk * d->C + 31) / 32;
         if (yvec) LU_WG(1, 1, 1, 4, true, true, gy);
         else LU_WG(1, 1, 1, 4, true, false, gy);

@@ -69,7 +69,7 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     return d
 
 
-def wgrad_splits(pixels, k, Cin, N, target_blocks=6144):
+def wgrad_splits(pixels, k, Cin, N, target_blocks=6144, row_variant=False):
     """Pixel-axis split.  The wgrad kernel holds 4 workgroups per CU (1024 slots on 256 CUs); with only ~1000
     long-running blocks the slowest CU (4 blocks vs 3) sets the time, so aim for several thousand shorter
     blocks (>= 2048 pixels = 128 pipeline stages each) and let the dispatcher balance them."""
@@ -78,5 +78,7 @@ def wgrad_splits(pixels, k, Cin, N, target_blocks=6144):
     taps = k * k if Cin % 4 == 0 else 1
     bn = 256 if (Cin % 4 == 0 and Cin > 64 and N >= 256 and N % 4 == 0) else 128
     tiles = taps * ct * max(1, -(-N // bn))
+    if row_variant:      # kernel-row kernel: (k rows) x (64-channel tiles) x (128-column tiles)
+        tiles = k * -(-Cin // 64) * -(-N // 128)
     s = max(1, min(target_blocks // max(tiles, 1), pixels // 2048))
     return max(1, min(s, 256))

@@ -141,7 +141,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
     k = dw.shape[0]
     _, pt, _ = same_pad(Hin, k, stride)
     _, pl, _ = same_pad(Win, k, stride)
-    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N)
+    row_variant = (stride == 1 and k in (3, 5) and Wout % 16 == 0 and Cin >= 64 and Cin % 4 == 0 and N % 4 == 0 and
+                   x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0)     # mirrors lu_conv2d_wgrad's kernel choice
+    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant)
     d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
                          frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
                          splits, beta)

@@ -146,6 +146,11 @@ def test_wgrad_wide_channels_and_beta(be):
     x, dy = rnd(1, 6, 6, 40), rnd(1, 6, 6, 8)
     _, gw = _torch_conv_grads(x, rnd(3, 3, 40, 8), dy, 1)
     close(KH.conv2d_wgrad(be, x, dy, 3, 1), gw, 1e-4)
+    for (fr, H, W, Cc, N, k) in [(2, 5, 16, 72, 136, 3), (1, 4, 32, 64, 128, 5), (1, 3, 16, 132, 72, 5)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)         # kernel-row variant (W % 16 == 0, C >= 64)
+        _, gw = _torch_conv_grads(x, rnd(k, k, Cc, N), dy, 1)
+        close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=1), gw, 2e-4)
+        close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=3), gw, 2e-4)
     x, dy = rnd(2, 5, 7, 72), rnd(2, 5, 7, 264)            # 128x256 tile variant (ConvLSTM-sized N), ragged edges
     _, gw = _torch_conv_grads(x, rnd(3, 3, 72, 264), dy, 1)
     close(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=2), gw, 2e-4)
