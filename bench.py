@@ -214,14 +214,10 @@ def main():
             traffic_db = {}
 
         def traffic_of(kind):
-            tag = {'conv_fwd_kernel<4,true,LU_EPI_LSTM>': 'conv_fwd_kernel<4, true, 1>',
-                   'conv_fwd_kernel<4,true,LU_EPI_BIAS>': 'conv_fwd_kernel<4, true, 0>',
-                   'wgrad_kernel': 'wgrad_kernel<2, 4, 2, 2'}
-            for k_, v_ in tag.items():
-                if kind.startswith(k_):
-                    hit = [x for x in traffic_db if v_ in x]
-                    return round(traffic_db[hit[0]]['traffic_bytes_per_launch']) if hit else None
-            return None
+            name = kind.split(' ')[0]      # e.g. conv_halo_kernel<5,LU_EPI_LSTM>  ->  rocprof's conv_halo_kernel<5, 1>
+            name = name.replace(',LU_EPI_LSTM>', ', 1>').replace(',LU_EPI_BIAS>', ', 0>')
+            hit = [x for x in traffic_db if name in x]
+            return round(traffic_db[hit[0]]['traffic_bytes_per_launch']) if hit else None
 
         rows = []
         for kind, c in classes.items():

@@ -83,8 +83,10 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
-    with _timed('conv_fwd_kernel<4,true,LU_EPI_BIAS> (plain convs, recurrent / input dgrads)' if N > 64 else 'conv small-N',
-                2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
+    halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
+    kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
+        'conv_fwd_kernel (strided / dilated / narrow convs)'
+    with _timed(kind, 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
                      pad_t, pad_l, N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2), splits=splits,
                      workspace=_p(ws))
@@ -150,8 +152,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
-    with _timed('wgrad_kernel (weight gradients, hoisted over T)' if Cin > 64 else 'wgrad small-C',
-                2.0 * k * k * Cin * N * frames * Hout * Wout):
+    kind = ('wgrad_row_kernel<%d> (+ its slab reduce; weight gradients hoisted over T)' % k) if row_variant else \
+        'wgrad_kernel (strided / thin / narrow layers)'
+    with _timed(kind, 2.0 * k * k * Cin * N * frames * Hout * Wout):
         calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
     return dw
 
@@ -165,7 +168,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     k = kernel.shape[0]
     p = (k - 1) // 2
     if F % 32 == 0:
-        with _timed('conv_fwd_kernel<4,true,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)',
+        with _timed('conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
                     2.0 * k * k * (x_t.shape[3] + F) * 4 * F * frames * H * W):
             calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
                          4 * F, _p(bias), None, 0, 0,
