@@ -6,6 +6,7 @@
 // emulated through a per-wave exchange buffer with the exact gfx950 lane->element maps.
 // It is never built into, loaded by, or reachable from the product library.
 #pragma once
+#include <setjmp.h>
 #include <ucontext.h>
 #include <cmath>
 #include <cstdint>
@@ -29,7 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace lu_emu {
 
 struct Fiber {
-    ucontext_t ctx;
+    ucontext_t ctx;      // first entry only (makecontext); later switches use _setjmp/_longjmp: no sigprocmask syscalls
+    jmp_buf jb;
+    bool started = false;
     char* stack = nullptr;
     dim3 tid;
     int lin = 0;
@@ -38,6 +41,7 @@ struct Fiber {
 
 struct Runtime {
     ucontext_t main_ctx;
+    jmp_buf main_jb;
     std::vector<Fiber> fibers;
     Fiber* cur = nullptr;
     dim3 blockIdx_, blockDim_, gridDim_;
@@ -50,7 +54,9 @@ struct Runtime {
 };
 inline Runtime g_rt;
 
-inline void yield_to_main() { swapcontext(&g_rt.cur->ctx, &g_rt.main_ctx); }
+inline void yield_to_main() {
+    if (!_setjmp(g_rt.cur->jb)) _longjmp(g_rt.main_jb, 1);
+}
 
 inline void block_barrier() {
     Runtime& r = g_rt;
@@ -85,8 +91,7 @@ inline void wave_barrier() {
 inline void fiber_entry() {
     g_rt.body();
     g_rt.cur->state = 2;
-    // a finished thread no longer participates in barriers: re-evaluate pending ones
-    swapcontext(&g_rt.cur->ctx, &g_rt.main_ctx);
+    _longjmp(g_rt.main_jb, 1);      // never resumed
 }
 
 inline void run_block() {
@@ -98,6 +103,7 @@ inline void run_block() {
         Fiber& f = r.fibers[i];
         if (!f.stack) f.stack = (char*)malloc(STK);
         f.state = 0;
+        f.started = false;
         f.lin = i;
         f.tid = dim3(i % r.blockDim_.x, (i / r.blockDim_.x) % r.blockDim_.y, i / (r.blockDim_.x * r.blockDim_.y));
         getcontext(&f.ctx);
@@ -114,7 +120,14 @@ inline void run_block() {
             Fiber& f = r.fibers[i];
             if (f.state != 0) continue;
             r.cur = &f;
-            swapcontext(&r.main_ctx, &f.ctx);
+            if (!_setjmp(r.main_jb)) {
+                if (f.started) {
+                    _longjmp(f.jb, 1);
+                } else {
+                    f.started = true;
+                    setcontext(&f.ctx);
+                }
+            }
             progressed = true;
             if (f.state == 2) ++done;
         }

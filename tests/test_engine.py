@@ -75,6 +75,10 @@ CASES = [  # name, net, cin, B, T, H, W, pad_image
     ('unfused-k3', tiny_net(3), 1, 2, 2, 16, 16, False),
     ('fused-k3-pad', tiny_net(3, (32, 8, 8, 32), (8, 8, 8, 8)), 1, 1, 2, 13, 16, True),
     ('fused-train', tiny_net(3, (8, 32, 8, 32), (8, 8, 8, 8)), 1, 1, 3, 16, 16, False),
+    # 2 levels, stacked ConvLSTMs per block with different kernel sizes, 3 convs in a block, 1x1 conv, 2 input channels
+    ('two-level-stacked-lstm', {'down_conv_kernels': [[(3, 8), (3, 8), (3, 4)], [(1, 8)]],
+                                'lstm_kernels': [[(3, 8), (5, 4)], [(3, 12)]],
+                                'up_conv_kernels': [[(3, 8)], [(3, 8), (1, 3)]]}, 2, 2, 2, 10, 12, False),
 ]
 GPU_CASES = [
     ('c1', c1_net(), 1, 1, 4, 128, 128, False),
