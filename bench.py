@@ -146,6 +146,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='clip slots per GPU')
     ap.add_argument('--unroll', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-infer', action='store_true', help='skip the secondary streaming-inference measurement')
     ap.add_argument('--sync-bn', action='store_true')
     args = ap.parse_args()
 
@@ -234,6 +235,24 @@ def main():
             roofline['traffic_unit'] = ('bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE '
                                         '(profiles/r01_pmc_traffic.json)')
             roofline['all_mfma_kernels'] = rows
+    # ---- secondary metric: streaming inference (Inference2D.py:45-62: B=1, T=1, pad_image=True, stateful) ----
+    infer = None
+    if dp.rank == 0 and dp.world_size == 1 and not args.no_infer:
+        import Networks
+        m = Networks.ULSTMnet2D(net, 'NCHW', True, seed=0)
+        frames_in = [torch.randn(1, 1, 1, H, W, device=dev) for _ in range(4)]
+        for i in range(3):
+            m(frames_in[i % 4], training=False)
+        torch.cuda.synchronize()
+        t_inf = time.perf_counter()
+        n_inf = 20
+        for i in range(n_inf):
+            _, sm_ = m(frames_in[i % 4], training=False)
+        torch.cuda.synchronize()
+        infer = {'frames_per_s': round(n_inf / (time.perf_counter() - t_inf), 2), 'frames': n_inf,
+                 'what': 'streaming forward, B=1 T=1, %dx%d (+reflect pad to %dx%d), softmax returned per frame' %
+                         (H, W, H + 16, W + 16)}
+        del m
     total_flops, _ = step_flops(net, H, W, B, T)
     cpu = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
@@ -256,6 +275,7 @@ def main():
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'inference': infer,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

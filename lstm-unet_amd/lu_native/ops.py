@@ -15,6 +15,7 @@ from .calls import NativeError, same_pad
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblstmunet_hip.so')
 _lib = None
+FUSED_MIN_TILES = 160   # fused ConvLSTM step needs this many 256x32ch tiles to fill the chip (tests set 0)
 EVENT_LOG = None   # bench.py: list collecting (kernel class, algorithmic FLOPs, start, end) around the MFMA launches
 
 
@@ -167,7 +168,10 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     F = rec.shape[2]
     k = kernel.shape[0]
     p = (k - 1) // 2
-    if F % 32 == 0:
+    # The fused epilogue cannot take a K split, so tile-starved steps (streaming inference: B = 1) run the conv with
+    # a split into pre-activations and the stand-alone gate kernel instead.
+    tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
+    if F % 32 == 0 and tiles >= FUSED_MIN_TILES:
         with _timed('conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
                     2.0 * k * k * (x_t.shape[3] + F) * 4 * F * frames * H * W):
             calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,

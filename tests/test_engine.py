@@ -92,6 +92,14 @@ def _all_cases(request_dev):
     return CASES + (GPU_CASES if request_dev.type == 'cuda' else [])
 
 
+@pytest.fixture(autouse=True)
+def _force_fused_path(monkeypatch):
+    """Small test shapes would take the tile-starved (unfused, K-split) ConvLSTM route; force the fused epilogue
+    kernel wherever F %% 32 == 0 so both routes are covered (the unfused one by the F < 32 layers)."""
+    from lu_native import ops
+    monkeypatch.setattr(ops, 'FUSED_MIN_TILES', 0)
+
+
 def test_forward_and_inference_parity(dev):
     for name, net, cin, B, T, H, W, pad in _all_cases(dev):
         rng = np.random.default_rng(1)
