@@ -76,6 +76,8 @@ typedef struct lu_conv_desc {
     int32_t splits;
     int32_t _pad2;
     void* workspace;
+    int64_t out_row_stride;         /* elements between output rows; 0 = dense (Wout * out_pix_stride).  Lets a launch
+                                     * write one parity plane of a stride-2 input gradient in place. */
 } lu_conv_desc;
 
 size_t lu_conv2d_workspace_bytes(const lu_conv_desc* d);
@@ -85,6 +87,14 @@ int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream);
  * input-gradient convolution.  w is [k][k][C_tot][N]. */
 int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N, int c_off, int C_sub,
                              lu_stream_t stream);
+
+/* Input gradient of a STRIDE-2 convolution without multiplying zeros: the four output parity classes
+ * (py, px) are four small stride-1 convolutions of dy.  This packs their kernels:
+ *   sub[cls = 2*py+px][ty][tx][n][c] = w[kh][kw][c][n],  kh = py + pad_t - 2*(ty - pady[py]), kw likewise
+ * (zero outside the k x k support); the caller then launches lu_conv2d_fwd four times with kernel size ks,
+ * pads (pady[py], padx[px]) and out_row_stride / out_pix_stride doubled. */
+int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int ks, int C, int N, int pad_t, int pad_l,
+                             int pady0, int pady1, int padx0, int padx1, lu_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient:  dw[kh,kw,c,n] (+)= sum_{f,oy,ox} x[f, oy*stride+kh-pad_t, ox*stride+kw-pad_l, c] * dy[f,oy,ox,n]

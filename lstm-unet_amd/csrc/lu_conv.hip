@@ -55,6 +55,7 @@ struct ConvArgs {
     const float* bias;
     float* out;
     int64_t out_frame_stride;
+    int64_t out_row_stride;   // elements between output rows (0: dense = Wout * out_pix_stride)
     // lstm epilogue
     int32_t F;
     const float* c_prev;
@@ -123,6 +124,10 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float
         }
     } else {
         float* op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride;
+        if (a.out_row_stride) {      // strided output rows (parity planes of a stride-2 input gradient)
+            const int64_t oy = pix / a.Wout;
+            op = a.out + (int64_t)f * a.out_frame_stride + oy * a.out_row_stride + (pix - oy * a.Wout) * a.out_pix_stride;
+        }
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const int col = n0 + 32 * nf + ccol;
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
 // out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic)
 __global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t M, int N, int HWo,
                                      const float* __restrict__ bias, float* __restrict__ out, int64_t out_fs,
-                                     int out_ps) {
+                                     int out_ps, int Wout, int64_t out_rs) {
     const int64_t total = M * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / N;
@@ -694,7 +699,13 @@ __global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, i
         float s = bias ? bias[n] : 0.f;
         for (int k = 0; k < ksplit; ++k) s += ws[(int64_t)k * total + i];
         const int64_t f = m / HWo;
-        out[f * out_fs + (m - f * HWo) * out_ps + n] = s;
+        const int64_t pix = m - f * HWo;
+        if (out_rs) {
+            const int64_t oy = pix / Wout;
+            out[f * out_fs + oy * out_rs + (pix - oy * Wout) * out_ps + n] = s;
+        } else {
+            out[f * out_fs + pix * out_ps + n] = s;
+        }
     }
 }
 
@@ -715,6 +726,28 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
     for (int r = ty; r < 32; r += 8) {
         int co = co0 + r, ci = ci0 + tx;
         if (co < N && ci < C_sub) wt[((int64_t)tap * N + co) * C_sub + ci] = tile[tx][r];
+    }
+}
+
+// Sub-kernels of the input gradient of a stride-2 convolution, one per output parity class (py, px):
+//   dX[2a+py, 2b+px, c] = sum_{ty,tx,n} dY[a + ty - pad_y, b + tx - pad_x, n] * sub[cls][ty][tx][n][c]
+// with sub[cls][ty][tx][n][c] = w[kh][kw][c][n], kh = py + pt - 2*(ty - pad_y) (zero when outside [0,k)).
+__global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ sub, int k, int ks, int C,
+                                        int N, int pt, int pl, int pady0, int pady1, int padx0, int padx1) {
+    const int64_t total = (int64_t)4 * ks * ks * N * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int n = (int)(t % N);
+        t /= N;
+        const int tx = (int)(t % ks);
+        t /= ks;
+        const int ty = (int)(t % ks);
+        const int cls = (int)(t / ks);
+        const int py = cls >> 1, px = cls & 1;
+        const int kh = py + pt - 2 * (ty - (py ? pady1 : pady0));
+        const int kw = px + pl - 2 * (tx - (px ? padx1 : padx0));
+        sub[i] = (kh >= 0 && kh < k && kw >= 0 && kw < k) ? w[(((int64_t)kh * k + kw) * C + c) * N + n] : 0.f;
     }
 }
 
@@ -768,12 +801,13 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.bias = d->bias;
     a.out = d->out;
     a.out_frame_stride = d->out_frame_stride;
+    a.out_row_stride = d->out_row_stride;
     int64_t m_tiles = (a.M + BM - 1) / BM;
     // halo-reuse kernel: stride-1 SAME 3x3 / 5x5, wide 16-byte-aligned outputs, <= 25 % of the 8x32 patches wasted
     const int64_t tiles_y = (d->Hout + 7) / 8, tiles_x = (d->Wout + 31) / 32;
     const bool halo = d->stride == 1 && d->dil == 1 && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
-                      a.n_src > 0 && tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
+                      a.n_src > 0 && d->out_row_stride == 0 && tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
                       getenv("LU_CONV_NOHALO") == nullptr;
     if (halo) {
         a.tiles_x = (int32_t)tiles_x;
@@ -838,7 +872,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         const int64_t tot_ = a.M * a.N;                                                         \
         const unsigned rg_ = (unsigned)((tot_ + 255) / 256 < 8192 ? (tot_ + 255) / 256 : 8192); \
         LU_LAUNCH(ksplit_reduce_kernel, dim3(rg_), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N,   \
-                  a.HWo, a.bias, a.out, a.out_frame_stride, a.out_pix_stride);                  \
+                  a.HWo, a.bias, a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);        \
         return LU_CHECK_LAUNCH();                                                               \
     }
     LU_CONV_CASE(4, true)
@@ -850,6 +884,16 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
 #undef LU_CONV_CASE
     lu_set_error("lu_conv2d_fwd: no kernel variant");
     return 1;
+}
+
+extern "C" int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int ks, int C, int N, int pt, int pl,
+                                        int pady0, int pady1, int padx0, int padx1, lu_stream_t stream) {
+    LU_REQUIRE(w && sub && k > 0 && ks > 0 && C > 0 && N > 0, "lu_stride2_dgrad_weights: bad arguments");
+    const int64_t total = (int64_t)4 * ks * ks * N * C;
+    const unsigned g = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    LU_LAUNCH(s2_dgrad_weights_kernel, dim3(g), dim3(256), stream, w, sub, k, ks, C, N, pt, pl, pady0, pady1, padx0,
+              padx1);
+    return LU_CHECK_LAUNCH();
 }
 
 extern "C" size_t lu_conv2d_workspace_bytes(const lu_conv_desc* d) {

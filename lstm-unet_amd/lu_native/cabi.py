@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
                 ('bias', c_f32p), ('out', c_f32p), ('out_frame_stride', i64),
                 ('c_prev', c_f32p), ('c_out', c_f32p), ('h_out', c_f32p), ('gates_out', c_f32p),
                 ('c_prev_frame_stride', i64), ('c_out_frame_stride', i64), ('h_frame_stride', i64),
-                ('gates_frame_stride', i64), ('splits', i32), ('_pad2', i32), ('workspace', C.c_void_p)]
+                ('gates_frame_stride', i64), ('splits', i32), ('_pad2', i32), ('workspace', C.c_void_p),
+                ('out_row_stride', i64)]
 
 
 class WgradDesc(C.Structure):
@@ -39,6 +40,7 @@ PROTOTYPES = {
     'lu_abi_version': (C.c_int, []),
     'lu_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), S]),
     'lu_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'lu_stride2_dgrad_weights': (C.c_int, [P, P] + [C.c_int] * 10 + [S]),
     'lu_weight_flip_transpose': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, S]),
     'lu_conv2d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'lu_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), S]),

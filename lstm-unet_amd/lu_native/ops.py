@@ -77,8 +77,9 @@ def _src(x, w):
     return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data_ptr(), w.stride(1), w.stride(2))
 
 
-def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out):
-    """One lu_conv2d_fwd launch (bias epilogue); picks a K-split + workspace for tile-starved problems."""
+def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out, out_view=None, flops=None):
+    """One lu_conv2d_fwd launch (bias epilogue); picks a K-split + workspace for tile-starved problems.
+    out_view = (ptr, frame_stride, pix_stride, row_stride) overrides the dense addressing of `out`."""
     channels = sum(x.shape[3] for x, _ in pairs)
     splits = calls.conv_splits(frames, Hout, Wout, N, k, channels)
     ws = None
@@ -87,10 +88,13 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
-    with _timed(kind, 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
+    optr, ofs, ops_, ors = out_view if out_view is not None else (out.data_ptr(), out.stride(0), out.stride(2), 0)
+    if out_view is not None:
+        halo = False
+        kind = 'conv_fwd_kernel (strided / dilated / narrow convs)'
+    with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
-                     pad_t, pad_l, N, _p(bias), out.data_ptr(), out.stride(0), out.stride(2), splits=splits,
-                     workspace=_p(ws))
+                     pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors)
     return out
 
 
@@ -128,12 +132,43 @@ def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None):
     Hin, Win = in_hw
     _, pt, _ = same_pad(Hin, k, stride)
     _, pl, _ = same_pad(Win, k, stride)
+    if stride == 2 and c_off == 0 and (c_sub is None or c_sub == w.shape[2]) and out is None and k > 1:
+        return _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl)
     wt = flip_transpose(w, c_off, c_sub)
     frames, Hd, Wd, N = dy.shape
     Cs = wt.shape[3]
     if out is None:
         out = torch.empty((frames, Hin, Win, Cs), device=dy.device, dtype=torch.float32)
     return conv_raw([(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs, None, out)
+
+
+def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl):
+    """Input gradient of a stride-2 convolution as four stride-1 convolutions of dy, one per output parity class,
+    each written in place into its (2a+py, 2b+px) plane -- no multiplications by the zeros of a dilated dy."""
+    assert w.is_contiguous() and dy.is_contiguous()
+    k, _, Cc, N = w.shape
+    frames, Hd, Wd, _ = dy.shape
+    ks = (k + 1) // 2
+
+    def axis(par, pad):      # taps kh of parity class `par`: dY row = a + o, o = (par + pad - kh) / 2
+        offs = [(par + pad - kh) // 2 for kh in range(k) if (par + pad - kh) % 2 == 0]
+        return -min(offs), len(offs)
+
+    (py0, ny0), (py1, ny1) = axis(0, pt), axis(1, pt)
+    (px0, nx0), (px1, nx1) = axis(0, pl), axis(1, pl)
+    sub = torch.empty((4, ks, ks, N, Cc), device=w.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_stride2_dgrad_weights(w.data_ptr(), sub.data_ptr(), k, ks, Cc, N, pt, pl, py0, py1, px0,
+                                                      px1, _stream()), 'lu_stride2_dgrad_weights')
+    out = torch.empty((frames, Hin, Win, Cc), device=dy.device, dtype=torch.float32)
+    for py, (pady, ny) in enumerate(((py0, ny0), (py1, ny1))):
+        for px, (padx, nx) in enumerate(((px0, nx0), (px1, nx1))):
+            Hs, Ws = (Hin - py + 1) // 2, (Win - px + 1) // 2
+            if Hs <= 0 or Ws <= 0:
+                continue
+            view = (out.data_ptr() + 4 * (py * Win + px) * Cc, Hin * Win * Cc, 2 * Cc, 2 * Win * Cc)
+            conv_raw([(dy, sub[2 * py + px])], frames, Hd, Wd, Hs, Ws, ks, 1, 1, pady, padx, Cc, None, out, out_view=view,
+                     flops=2.0 * ny * nx * N * Cc * frames * Hs * Ws)
+    return out
 
 
 def conv2d_wgrad(x, dy, dw, stride, beta=0.0):

@@ -109,6 +109,36 @@ def flip_transpose(be, w, c_off=0, C_sub=None):
     return be.host(wt)
 
 
+def conv2d_dgrad_s2_parity(be, dy, w, in_hw):
+    """Stride-2 input gradient as four parity-plane convolutions (mirrors lu_native.ops._conv2d_dgrad_stride2)."""
+    k, _, Cc, N = w.shape
+    Hin, Win = in_hw
+    frames, Hd, Wd, _ = dy.shape
+    _, pt, _ = calls.same_pad(Hin, k, 2)
+    _, pl, _ = calls.same_pad(Win, k, 2)
+    ks = (k + 1) // 2
+
+    def axis(par, pad):
+        offs = [(par + pad - kh) // 2 for kh in range(k) if (par + pad - kh) % 2 == 0]
+        return -min(offs)
+
+    pady, padx = [axis(0, pt), axis(1, pt)], [axis(0, pl), axis(1, pl)]
+    sub = be.empty((4, ks, ks, N, Cc))
+    wd, dyd = be.dev(w), be.dev(dy)
+    calls.check(be.lib, be.lib.lu_stride2_dgrad_weights(be.ptr(wd), be.ptr(sub), k, ks, Cc, N, pt, pl, pady[0], pady[1],
+                                                        padx[0], padx[1], be.stream), 's2w')
+    out = be.empty((frames, Hin, Win, Cc))
+    for py in range(2):
+        for px in range(2):
+            Hs, Ws = (Hin - py + 1) // 2, (Win - px + 1) // 2
+            if Hs <= 0 or Ws <= 0:
+                continue
+            src = calls.conv_src(be.ptr(dyd), Hd * Wd * N, N, N, be.ptr(sub, (2 * py + px) * ks * ks * N * Cc), N * Cc, Cc)
+            calls.conv2d(be.lib, be.stream, [src], frames, Hd, Wd, Hs, Ws, ks, 1, 1, pady[py], padx[px], Cc, None,
+                         be.ptr(out, (py * Win + px) * Cc), Hin * Win * Cc, 2 * Cc, out_row_stride=2 * Win * Cc)
+    return be.host(out)
+
+
 def conv2d_dgrad(be, dy, w, in_hw, stride):
     k = w.shape[0]
     Hin, Win = in_hw

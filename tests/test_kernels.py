@@ -126,7 +126,8 @@ def _torch_conv_grads(x, w, dy, stride):
 
 @pytest.mark.parametrize('case', [(2, 8, 9, 8, 12, 3, 1), (1, 7, 7, 4, 8, 5, 1), (2, 8, 8, 8, 16, 3, 2),
                                   (1, 9, 7, 12, 8, 3, 2), (1, 8, 8, 4, 4, 5, 2), (1, 6, 6, 3, 5, 3, 1),
-                                  (1, 6, 5, 8, 3, 1, 1), (1, 7, 9, 72, 24, 3, 1), (1, 8, 8, 132, 8, 3, 2)])
+                                  (1, 6, 5, 8, 3, 1, 1), (1, 7, 9, 72, 24, 3, 1), (1, 8, 8, 132, 8, 3, 2), (2, 7, 9, 8, 12, 5, 2),
+                                  (1, 9, 8, 4, 72, 3, 2)])
 def test_conv_dgrad_wgrad(be, case):
     fr, H, W, Cc, N, k, s = case
     x, w = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.3)
@@ -134,6 +135,8 @@ def test_conv_dgrad_wgrad(be, case):
     dy = rnd(fr, Ho, Wo, N)
     gx, gw = _torch_conv_grads(x, w, dy, s)
     close(KH.conv2d_dgrad(be, dy, w, (H, W), s), gx, 5e-5)
+    if s == 2:      # the parity-plane formulation the engine uses (no zero multiplications)
+        close(KH.conv2d_dgrad_s2_parity(be, dy, w, (H, W)), gx, 5e-5)
     close(KH.conv2d_wgrad(be, x, dy, k, s, splits=1), gw, 1e-4)
     close(KH.conv2d_wgrad(be, x, dy, k, s, splits=3), gw, 1e-4)
 
