@@ -48,6 +48,7 @@ struct ConvArgs {
     int32_t k, kk, stride, dsh /* dil-1 */, pad_t, pad_l;
     int32_t N, n_tiles, m_tiles;
     int32_t tiles_x, tiles_pf;   // halo kernel: 8x32-pixel tiles per row / per frame
+    int32_t xcd_by_n;            // halo kernel: give each XCD its own n-tiles (weights stay L2-resident per XCD)
     int32_t dbg;           // tools/kbench.py ablation bits (LU_CONV_DBG): 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
@@ -498,8 +499,16 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = blockIdx.x;
     const int slot = bid >> 3;
-    const int nt = slot % a.n_tiles;
-    const int tile = (slot / a.n_tiles) * 8 + (bid & 7);     // XCD-aware order, see conv_fwd_kernel
+    int nt = slot % a.n_tiles;
+    int tile = (slot / a.n_tiles) * 8 + (bid & 7);     // XCD-aware order, see conv_fwd_kernel
+    if (a.xcd_by_n) {
+        // n_tiles % 8 == 0: XCD x (= bid % 8) owns n-tiles [x*g, (x+1)*g): the 64 blocks resident on an XCD stream the
+        // SAME 16x128 weight tiles (a few MB per XCD, L2-resident) instead of every n-tile's; the patch halo, fetched
+        // once per 25 taps, is what crosses XCDs.
+        const int g = a.n_tiles >> 3;
+        nt = (bid & 7) * g + (slot % g);
+        tile = slot / g;
+    }
     if (tile >= a.m_tiles) return;
     const int f = tile / a.tiles_pf;
     const int t2 = tile - f * a.tiles_pf;
@@ -814,6 +823,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.tiles_pf = (int32_t)(tiles_y * tiles_x);
         m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
     }
+    const bool want_xcd_n = getenv("LU_CONV_XCD_N") != nullptr;
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
@@ -837,7 +847,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.h_fs = d->h_frame_stride;
         a.gates_fs = d->gates_frame_stride;
         a.n_tiles = a.F / 32;
-        dim3 grid((unsigned)(m_tiles8 * a.n_tiles));
+        a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
+        dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
         if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
