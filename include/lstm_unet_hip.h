@@ -74,11 +74,20 @@ typedef struct lu_conv_desc {
      * 256 CUs (coarse-level recurrent dgrads): partial tiles go to `workspace`
      * (lu_conv2d_workspace_bytes) and are summed in a fixed order.  LU_EPI_BIAS only; 0/1 = off. */
     int32_t splits;
-    int32_t _pad2;
+    int32_t precision;              /* 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: bf16 MFMA operands, fp32 accumulate
+                                     * (v_mfma_f32_32x32x16_bf16) -- activations stay fp32 in HBM and are rounded to bf16 while
+                                     * staged; every src[i].w must then point to weights packed by lu_pack_weights_bf16
+                                     * (w_tap_stride / w_row_stride ignored).  Stride-1 3x3 / 5x5, N > 64 only. */
     void* workspace;
     int64_t out_row_stride;         /* elements between output rows; 0 = dense (Wout * out_pix_stride).  Lets a launch
                                      * write one parity plane of a stride-2 input gradient in place. */
 } lu_conv_desc;
+
+/* bf16 weight image for precision == 1: [tap][ceil(C/32)][N][32] bf16 (zero-filled beyond C), built from a
+ * [k*k][C][N] fp32 matrix addressed as w + tap*w_tap_stride + c*w_row_stride + n. */
+size_t lu_pack_weights_bf16_bytes(int k, int C, int N);
+int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
+                         lu_stream_t stream);
 
 size_t lu_conv2d_workspace_bytes(const lu_conv_desc* d);
 int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream);

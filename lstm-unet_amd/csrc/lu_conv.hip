@@ -697,6 +697,189 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16-MFMA variant of the halo kernel (mixed precision: fp32 activations / weights / accumulators in HBM, bf16
+// MFMA operands): v_mfma_f32_32x32x16_bf16 runs at 16x the fp32-MFMA rate, so the same 8x32-patch structure is used
+// with 32-channel chunks.  The halo is converted to bf16 while it is staged ([HP][32+8] bf16: one ds_read_b128 = one
+// A fragment of 8 k); weights arrive pre-packed by pack_weights_bf16_kernel as [tap][chunk][N][32] bf16 so a thread's
+// 16-byte load is 8 consecutive k of one output column = one B fragment row.  Same epilogues, same K split.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CKB = 32;      // channels per stage (two k = 16 MFMA steps)
+constexpr int LDB = CKB + 8; // bf16 elements per LDS row (80 B: conflict-free ds_read_b128, see A_LD)
+
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C,
+                                         int N, unsigned short* __restrict__ out) {
+    const int nchunk = (C + CKB - 1) / CKB;
+    const int64_t total = (int64_t)kk * nchunk * N * CKB;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % CKB);
+        int64_t t = i / CKB;
+        const int n = (int)(t % N);
+        t /= N;
+        const int chunk = (int)(t % nchunk);
+        const int tap = (int)(t / nchunk);
+        const int c = chunk * CKB + kc;
+        out[i] = c < C ? lu_f2bf(w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n]) : (unsigned short)0;
+    }
+}
+
+template <int K, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
+    constexpr int NF = 4, BN = 128, NT = 512, TH = 8, TW = 32;
+    constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
+    constexpr int HPASS = (HP * 8 + NT - 1) / NT;      // float4 (4 channels) loads per thread per halo
+    constexpr int PAD = (K - 1) / 2;
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[HP * LDB];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x;
+    const int slot = bid >> 3;
+    const int nt = slot % a.n_tiles;
+    const int tile = (slot / a.n_tiles) * 8 + (bid & 7);
+    if (tile >= a.m_tiles) return;
+    const int f = tile / a.tiles_pf;
+    const int t2 = tile - f * a.tiles_pf;
+    const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
+    const int n0 = nt * BN;
+    const int ks = blockIdx.y;
+    const float* const zp = lu_zero16;
+
+    int hoff[HPASS];
+    bool hok[HPASS];
+#pragma unroll
+    for (int i = 0; i < HPASS; ++i) {
+        const int hp = (tid + NT * i) >> 3;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        hok[i] = hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        hoff[i] = iy * a.Win + ix;
+    }
+    const int q = tid & 7;                 // 4-channel group inside the 32-channel chunk
+    // weight tile: 128 columns x 4 pieces of 8 k
+    const int bnl = tid >> 2, bpiece = tid & 3;
+    const int bn_glob = (EPI == LU_EPI_LSTM) ? (bnl >> 5) * a.F + nt * 32 + (bnl & 31) : n0 + bnl;
+    const bool bn_ok = (EPI == LU_EPI_LSTM) || bn_glob < a.N;
+
+    float4 rh[HPASS];
+    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);      // 16 raw bytes = 8 bf16
+    auto load_halo = [&](const IterState& st) {
+        const SrcInfo& si = a.src[st.s];
+        const int c = st.chunk * CKB + 4 * q;
+        const float* base = si.x + (int64_t)f * si.frame_stride + c;
+        if (si.thin) {       // C % 4 != 0 or unaligned rows (the 1-channel image): per-channel scalar loads
+#pragma unroll
+            for (int i = 0; i < HPASS; ++i) {
+                const float* p = base + (int64_t)hoff[i] * si.pix_stride;
+                rh[i].x = *((hok[i] && c + 0 < si.C) ? p + 0 : zp);
+                rh[i].y = *((hok[i] && c + 1 < si.C) ? p + 1 : zp);
+                rh[i].z = *((hok[i] && c + 2 < si.C) ? p + 2 : zp);
+                rh[i].w = *((hok[i] && c + 3 < si.C) ? p + 3 : zp);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < HPASS; ++i) {
+            const float* p = base + (int64_t)hoff[i] * si.pix_stride;
+            rh[i] = *reinterpret_cast<const float4*>((hok[i] && c < si.C) ? p : zp);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HPASS; ++i) {
+            const int hp = (tid + NT * i) >> 3;
+            if (hp < HP) {
+                const unsigned lo = (unsigned)lu_f2bf(rh[i].x) | ((unsigned)lu_f2bf(rh[i].y) << 16);
+                const unsigned hi = (unsigned)lu_f2bf(rh[i].z) | ((unsigned)lu_f2bf(rh[i].w) << 16);
+                unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hp * LDB + 4 * q]);
+                dst[0] = lo;
+                dst[1] = hi;
+            }
+        }
+    };
+    auto load_b = [&](const IterState& st) {
+        const SrcInfo& si = a.src[st.s];        // si.w -> packed bf16 [tap][chunk][N][32]
+        const unsigned short* wp = reinterpret_cast<const unsigned short*>(si.w) +
+                                   (((int64_t)st.tap * si.nchunk + st.chunk) * a.N + bn_glob) * CKB + 8 * bpiece;
+        rb = *reinterpret_cast<const float4*>(bn_ok ? reinterpret_cast<const float*>(wp) : zp);
+    };
+    auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][bnl * LDB + 8 * bpiece]) = rb; };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+
+    const int khalf8 = 8 * (lane >> 5);
+    auto mma_step = [&](int buf, int j, int arow) {      // one k = 16 step: A fragment + 4 B fragments
+        const lu_bf16x8 av = *reinterpret_cast<const lu_bf16x8*>(&Ah[arow * LDB + 16 * j + khalf8]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const lu_bf16x8 bv = *reinterpret_cast<const lu_bf16x8*>(&Bs[buf][(32 * nf + (lane & 31)) * LDB + 16 * j + khalf8]);
+            acc[nf] = lu_mfma_bf16(av, bv, acc[nf]);
+        }
+    };
+
+    int it0 = 0, it1 = a.n_it;
+    if (a.ksplit > 1) {
+        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per;
+        it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
+    }
+    if (it1 > it0) {
+        IterState st{0, 0, 0, 0, 0};
+        {
+            int r = it0;
+            while (r >= a.src[st.s].nchunk * a.kk) {
+                r -= a.src[st.s].nchunk * a.kk;
+                ++st.s;
+            }
+            st.chunk = r / a.kk;
+            st.tap = r - st.chunk * a.kk;
+            st.kh = st.tap / K;
+            st.kw = st.tap - st.kh * K;
+        }
+        load_halo(st);
+        load_b(st);
+        store_halo();
+        store_b(0);
+        __syncthreads();
+        for (int it = it0; it < it1; ++it) {
+            const int buf = (it - it0) & 1;
+            const int arow = (wave + st.kh) * HWD + (lane & 31) + st.kw;
+            IterState nx = st;
+            if (it + 1 < it1) iter_advance(nx, a);
+            const bool new_halo = (it + 1 < it1) && nx.tap == 0;
+            load_b(nx);
+            if (new_halo) load_halo(nx);
+            LU_SCHED_FENCE();
+            mma_step(buf, 0, arow);
+            mma_step(buf, 1, arow);
+            LU_SCHED_FENCE();
+            if (new_halo) {
+                __syncthreads();
+                store_halo();
+            }
+            store_b(buf ^ 1);
+            __syncthreads();
+            st = nx;
+        }
+    }
+
+    const int oy = y0 + wave;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (oy >= a.Hin || ox >= a.Win) continue;
+        const int64_t pix = (int64_t)oy * a.Win + ox;
+        float v[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) v[nf] = acc[nf][r];
+        conv_epilogue_row<NF, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0, ks, lane & 31);
+    }
+}
+
 // out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic)
 __global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t M, int N, int HWo,
                                      const float* __restrict__ bias, float* __restrict__ out, int64_t out_fs,
@@ -783,7 +966,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         const lu_conv_src& in = d->src[s];
         LU_REQUIRE(in.x && in.w && in.C > 0, "lu_conv2d_fwd: source %d incomplete", s);
         const bool vec = (in.C % 4 == 0) && (in.pix_stride % 4 == 0) && (in.frame_stride % 4 == 0) && aligned16(in.x);
-        SrcInfo& si = vec ? a.src[a.n_src++] : a.tsrc[a.n_thin++];
+        SrcInfo& si = (vec || d->precision == 1) ? a.src[a.n_src++] : a.tsrc[a.n_thin++];
         si.x = in.x;
         si.w = in.w;
         si.frame_stride = in.frame_stride;
@@ -793,7 +976,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         si.w_row_stride = in.w_row_stride;
         si.thin = vec ? 0 : 1;
         si.nchunk = vec ? (in.C + CK - 1) / CK : (a.kk * in.C + CK - 1) / CK;
-        if (vec) a.n_it += si.nchunk * a.kk;
+        if (d->precision == 1) {     // bf16 operands: 32-channel chunks, packed weights (lu_pack_weights_bf16)
+            si.nchunk = (in.C + CKB - 1) / CKB;
+            a.n_it += si.nchunk * a.kk;
+        } else if (vec) {
+            a.n_it += si.nchunk * a.kk;
+        }
         bvec = bvec && (in.w_row_stride % 4 == 0) && (in.w_tap_stride % 4 == 0) && aligned16(in.w);
     }
     a.M = (int64_t)d->frames * d->Hout * d->Wout;
@@ -816,14 +1004,17 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const int64_t tiles_y = (d->Hout + 7) / 8, tiles_x = (d->Wout + 31) / 32;
     const bool halo = d->stride == 1 && d->dil == 1 && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
-                      a.n_src > 0 && d->out_row_stride == 0 && tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
-                      getenv("LU_CONV_NOHALO") == nullptr;
+                      a.n_src > 0 && d->out_row_stride == 0 &&
+                      (d->precision == 1 || (tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
+                                             getenv("LU_CONV_NOHALO") == nullptr));
     if (halo) {
         a.tiles_x = (int32_t)tiles_x;
         a.tiles_pf = (int32_t)(tiles_y * tiles_x);
         m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
     }
     const bool want_xcd_n = getenv("LU_CONV_XCD_N") != nullptr;
+    if (d->precision == 1)
+        LU_REQUIRE(halo && d->N % 4 == 0, "lu_conv2d_fwd: bf16 mode covers stride-1 3x3 / 5x5 convolutions with N > 64 only");
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
@@ -850,7 +1041,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
         else if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, false>), grid, dim3(512), stream, a);
@@ -870,7 +1063,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
+        if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
+        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
+        else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \
         else if (NF_ == 4 && BV_ && mf1 && dma)                                                                 \
@@ -904,6 +1099,20 @@ extern "C" int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int k
     const unsigned g = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     LU_LAUNCH(s2_dgrad_weights_kernel, dim3(g), dim3(256), stream, w, sub, k, ks, C, N, pt, pl, pady0, pady1, padx0,
               padx1);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" size_t lu_pack_weights_bf16_bytes(int k, int C, int N) {
+    return (size_t)k * k * ((C + CKB - 1) / CKB) * (size_t)N * CKB * sizeof(unsigned short);
+}
+
+extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N,
+                                    void* out, lu_stream_t stream) {
+    LU_REQUIRE(w && out && k > 0 && C > 0 && N > 0, "lu_pack_weights_bf16: bad arguments");
+    const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * N * CKB;
+    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N,
+              (unsigned short*)out);
     return LU_CHECK_LAUNCH();
 }
 

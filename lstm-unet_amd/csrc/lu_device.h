@@ -4,6 +4,7 @@
 // build container; it is never defined in the product build.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 #include "../../include/lstm_unet_hip.h"
 
 #ifdef LU_EMU
@@ -11,6 +12,7 @@
 #define LU_LAUNCH(kernel, grid, block, stream, ...) \
     lu_emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
 static inline f32x16 lu_mfma(float a, float b, f32x16 c) { return lu_emu::mfma_32x32x2(a, b, c); }
+static inline f32x16 lu_mfma_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 c) { return lu_emu::mfma_32x32x16_bf16(a, b, c); }
 static inline float lu_shfl_xor(float v, int m) { return lu_emu::shfl_xor(v, m); }
 static inline float lu_shfl_down(float v, int d) { return lu_emu::shfl_down(v, d); }
 // global_load_lds_dwordx4: every lane copies 16 bytes from ITS global pointer to (wave-uniform LDS base + lane*16)
@@ -28,6 +30,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain; 64 cycles / SIMD
 __device__ __forceinline__ f32x16 lu_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+typedef short lu_bf16x8 __attribute__((ext_vector_type(8)));   // raw bf16 bit patterns
+// v_mfma_f32_32x32x16_bf16: bf16 operands (8 per lane), fp32 accumulate; 16x the fp32-MFMA rate
+__device__ __forceinline__ f32x16 lu_mfma_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 c) {
+    typedef __bf16 hw_bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hw_bf16x8, a), __builtin_bit_cast(hw_bf16x8, b), c, 0,
+                                                   0, 0);
 }
 __device__ __forceinline__ float lu_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float lu_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
@@ -67,3 +76,11 @@ void lu_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int64_t lu_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// fp32 -> bf16 bits, round to nearest even (finite inputs)
+__device__ __host__ static inline unsigned short lu_f2bf(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}

@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
                 ('bias', c_f32p), ('out', c_f32p), ('out_frame_stride', i64),
                 ('c_prev', c_f32p), ('c_out', c_f32p), ('h_out', c_f32p), ('gates_out', c_f32p),
                 ('c_prev_frame_stride', i64), ('c_out_frame_stride', i64), ('h_frame_stride', i64),
-                ('gates_frame_stride', i64), ('splits', i32), ('_pad2', i32), ('workspace', C.c_void_p),
+                ('gates_frame_stride', i64), ('splits', i32), ('precision', i32), ('workspace', C.c_void_p),
                 ('out_row_stride', i64)]
 
 
@@ -39,6 +39,8 @@ PROTOTYPES = {
     'lu_last_error': (C.c_char_p, []),
     'lu_abi_version': (C.c_int, []),
     'lu_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), S]),
+    'lu_pack_weights_bf16_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'lu_pack_weights_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'lu_stride2_dgrad_weights': (C.c_int, [P, P] + [C.c_int] * 10 + [S]),
     'lu_weight_flip_transpose': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, S]),

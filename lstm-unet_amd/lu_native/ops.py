@@ -61,7 +61,7 @@ def _chk(*tensors):
             continue
         if not t.is_cuda:
             raise NativeError('lu_native ops need device tensors (got %s); no CPU fallback exists' % t.device)
-        if t.dtype != torch.float32 and t.dtype != torch.float64:
+        if t.dtype not in (torch.float32, torch.float64, torch.int16):    # int16: packed bf16 weight images
             raise NativeError('unexpected dtype %s' % t.dtype)
 
 
@@ -69,8 +69,30 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class PackedW(object):
+    """bf16 image of a [k,k,C,N] kernel for the bf16-MFMA convolution (lu_pack_weights_bf16 layout)."""
+    __slots__ = ('data', 'shape')
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+
+def pack_bf16(w):
+    """fp32 [k,k,C,N] kernel (channel-slice views allowed) -> PackedW; fp32 stays the master copy."""
+    _chk(w)
+    assert w.dim() == 4 and w.stride(3) == 1 and w.stride(0) == w.shape[1] * w.stride(1)
+    k, _, Cc, N = w.shape
+    data = torch.empty(lib().lu_pack_weights_bf16_bytes(k, Cc, N) // 2, device=w.device, dtype=torch.int16)
+    calls.check(lib(), lib().lu_pack_weights_bf16(w.data_ptr(), w.stride(1), w.stride(2), k, Cc, N, data.data_ptr(),
+                                                  _stream()), 'lu_pack_weights_bf16')
+    return PackedW(data, w.shape)
+
+
 def _src(x, w):
-    """x: [frames,H,W,C] (channel-slice views allowed), w: [k,k,C,N] (channel-slice views allowed)."""
+    """x: [frames,H,W,C] (channel-slice views allowed), w: [k,k,C,N] (channel-slice views allowed) or PackedW."""
+    if isinstance(w, PackedW):
+        assert x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2) and w.shape[2] == x.shape[3]
+        return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data.data_ptr(), 0, 0)
     assert x.dim() == 4 and w.dim() == 4 and x.stride(3) == 1 and w.stride(3) == 1, (x.shape, x.stride(), w.shape)
     assert x.stride(1) == x.shape[2] * x.stride(2), 'rows of x must be dense'
     assert w.shape[2] == x.shape[3] and w.stride(0) == w.shape[1] * w.stride(1)
@@ -85,23 +107,27 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
+    bf16 = any(isinstance(w, PackedW) for _, w in pairs)
     halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
+    if bf16:
+        kind = 'conv_halo_bf16_kernel<%d,LU_EPI_BIAS> (bf16-MFMA recurrent / input dgrads, plain convs)' % k
     optr, ofs, ops_, ors = out_view if out_view is not None else (out.data_ptr(), out.stride(0), out.stride(2), 0)
     if out_view is not None:
         halo = False
         kind = 'conv_fwd_kernel (strided / dilated / narrow convs)'
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
-                     pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors)
+                     pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors,
+                     precision=1 if bf16 else 0)
     return out
 
 
 def conv2d(pairs, bias, stride=1, out=None):
     """SAME convolution summed over (activation, weight) pairs -> [frames,Ho,Wo,N]."""
     x0, w0 = pairs[0]
-    _chk(bias, out, *[t for p in pairs for t in p])
+    _chk(bias, out, *[t.data if isinstance(t, PackedW) else t for p in pairs for t in p])
     frames, Hin, Win = x0.shape[:3]
     k, N = w0.shape[0], w0.shape[3]
     Hout, pt, _ = same_pad(Hin, k, stride)
@@ -198,7 +224,8 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
 def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out):
     """One ConvLSTM2D cell step (reference Networks.py:48-50,62-63).  Fused two-source conv + gate
     epilogue when F % 32 == 0, otherwise conv -> pre-activations -> gate kernel."""
-    _chk(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out)
+    bf16 = isinstance(kernel, PackedW)
+    _chk(x_t, h_prev, c_prev, kernel.data if bf16 else kernel, rec.data if bf16 else rec, bias, h_out, c_out, gates_out)
     frames, H, W, _ = x_t.shape
     F = rec.shape[2]
     k = kernel.shape[0]
@@ -207,12 +234,14 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     # a split into pre-activations and the stand-alone gate kernel instead.
     tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
     if F % 32 == 0 and tiles >= FUSED_MIN_TILES:
-        with _timed('conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
+        with _timed(('conv_halo_bf16_kernel<%d,LU_EPI_LSTM> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
+                    'conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
                     2.0 * k * k * (x_t.shape[3] + F) * 4 * F * frames * H * W):
             calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
                          4 * F, _p(bias), None, 0, 0,
                          lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
-                               h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0))
+                               h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0),
+                         precision=1 if bf16 else 0)
     else:
         z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
         assert c_prev.is_contiguous() and c_out.is_contiguous()

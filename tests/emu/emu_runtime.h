@@ -26,6 +26,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short lu_bf16x8 __attribute__((ext_vector_type(8)));   // raw bf16 bit patterns
 
 namespace lu_emu {
 
@@ -50,6 +51,8 @@ struct Runtime {
     int wave_arrived[16] = {0};
     float xa[16][64];
     float xb[16][64];
+    short xa8[16][64][8];
+    short xb8[16][64][8];
     std::function<void()> body;
 };
 inline Runtime g_rt;
@@ -169,6 +172,35 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
         int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         float acc = c[reg];
         for (int k = 0; k < 2; ++k) acc = fmaf(r.xa[w][row + 32 * k], r.xb[w][col + 32 * k], acc);
+        c[reg] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+
+inline float bf16_bits_to_float(short b) {
+    unsigned u = ((unsigned)(unsigned short)b) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i = l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][n = l&31], j < 8; D as above.
+inline f32x16 mfma_32x32x16_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 c) {
+    Runtime& r = g_rt;
+    int lane = r.cur->lin & 63, w = r.cur->lin >> 6;
+    for (int j = 0; j < 8; ++j) {
+        r.xa8[w][lane][j] = a[j];
+        r.xb8[w][lane][j] = b[j];
+    }
+    wave_barrier();
+    int col = lane & 31;
+    for (int reg = 0; reg < 16; ++reg) {
+        int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float acc = c[reg];
+        for (int half = 0; half < 2; ++half)
+            for (int j = 0; j < 8; ++j)
+                acc = fmaf(bf16_bits_to_float(r.xa8[w][row + 32 * half][j]), bf16_bits_to_float(r.xb8[w][col + 32 * half][j]), acc);
         c[reg] = acc;
     }
     wave_barrier();

@@ -74,7 +74,21 @@ def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1):
+def bf16_round(a):
+    """fp32 -> nearest-even bf16 -> fp32 (what the bf16 kernels do to their MFMA operands)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def pack_bf16(be, wd, k, Cin, N):
+    nbytes = be.lib.lu_pack_weights_bf16_bytes(k, Cin, N)
+    out = be.empty((nbytes // 4 + 4,))
+    calls.check(be.lib, be.lib.lu_pack_weights_bf16(be.ptr(wd), Cin * N, N, k, Cin, N, be.ptr(out), be.stream), 'pack')
+    return out
+
+
+def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1, precision=0):
     """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy."""
     frames, Hin, Win = srcs[0].shape[:3]
     if N is None:
@@ -91,11 +105,14 @@ def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None
         Cin = x.shape[3]
         xd, wd = be.dev(x), be.dev(w)
         keep += [xd, wd]
+        if precision == 1:
+            wd = pack_bf16(be, wd, k, Cin, N)
+            keep.append(wd)
         cs.append(calls.conv_src(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(wd), Cin * N, N))
     bd = None if bias is None else be.dev(bias)
     wsb = be.empty((splits * frames * Hout * Wout * N,)) if splits > 1 else None
     calls.conv2d(be.lib, be.stream, cs, frames, Hin, Win, Hout, Wout, k, stride, dil, pt, pl, N, be.ptr(bd),
-                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb))
+                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb), precision=precision)
     return be.host(out)
 
 
@@ -163,7 +180,7 @@ def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0):
     return be.host(dw)
 
 
-def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias):
+def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias, precision=0):
     frames, H, W, Cin = x_t.shape
     F = rec.shape[2]
     k = kernel.shape[0]
@@ -171,8 +188,12 @@ def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias):
     xd, hd, cd, kd, rd, bd = [be.dev(a) for a in (x_t, h, c, kernel, rec, bias)]
     srcs = [calls.conv_src(be.ptr(xd), H * W * Cin, Cin, Cin, be.ptr(kd), Cin * 4 * F, 4 * F),
             calls.conv_src(be.ptr(hd), H * W * F, F, F, be.ptr(rd), F * 4 * F, 4 * F)]
+    if precision == 1:
+        kp, rp = pack_bf16(be, kd, k, Cin, 4 * F), pack_bf16(be, rd, k, F, 4 * F)
+        srcs = [calls.conv_src(be.ptr(xd), H * W * Cin, Cin, Cin, be.ptr(kp), 0, 0),
+                calls.conv_src(be.ptr(hd), H * W * F, F, F, be.ptr(rp), 0, 0)]
     p = (k - 1) // 2
     calls.conv2d(be.lib, be.stream, srcs, frames, H, W, H, W, k, 1, 1, p, p, 4 * F, be.ptr(bd), None, 0, 0,
                  lstm=(be.ptr(cd), H * W * F, be.ptr(c_out), H * W * F, be.ptr(h_out), H * W * F, be.ptr(gates),
-                       H * W * 4 * F))
+                       H * W * 4 * F), precision=precision)
     return be.host(h_out), be.host(c_out), be.host(gates)

@@ -94,6 +94,37 @@ def test_conv_halo_variant(be):
     close(gates[..., F:2 * F], npo.hard_sigmoid(z[..., F:2 * F]), 2e-5)
 
 
+def test_conv_bf16_mfma_variant(be):
+    """Mixed-precision halo kernel (precision = 1): operands rounded to bf16, fp32 accumulation.  Against the oracle
+    on the SAME bf16-rounded operands only the summation order differs (tolerance as for the fp32 kernels); against
+    the unrounded oracle the error is the bf16 operand rounding (2^-9 relative per operand)."""
+    R = KH.bf16_round
+    for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
+                                     (1, 8, 33, 100, 96, 3, 2)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1)
+        close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
+        full = npo.conv2d_same(x, w, b, 1)
+        assert np.abs(got - full).max() <= 2.0 ** -7 * np.abs(full).max()
+    xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources (UpBlock concat)
+    wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
+    ref = npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb))
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1), ref, 5e-5)
+    F = 32                                                         # fused ConvLSTM step
+    x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
+    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    h1, c1 = npo.convlstm_step(R(x), R(h), c, R(ker), R(rec), b)
+    hg, cg, _ = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1)
+    close(hg, h1, 3e-5)
+    close(cg, c1, 3e-5)
+    xi, xh = rnd(1, 16, 32, 1), rnd(1, 16, 32, 40)                 # thin (1-channel image) + vector source
+    wi, wh = rnd(5, 5, 1, 72, scale=0.3), rnd(5, 5, 40, 72, scale=0.1)
+    ref = npo.conv2d_same(R(xi), R(wi)) + npo.conv2d_same(R(xh), R(wh))
+    close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1), ref, 5e-5)
+    with pytest.raises(RuntimeError):                             # strided convolutions are not covered in bf16 mode
+        KH.conv2d(be, [rnd(1, 16, 32, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=1)
+
+
 def test_conv_two_sources_and_strided_views(be):
     """UpBlock2D concat([up, skip]) (Networks.py:145) as two sources reading channel slices."""
     xa, xb = rnd(2, 6, 7, 12), rnd(2, 6, 7, 1)

@@ -34,6 +34,11 @@ for name, hw, cin, F in levels:
         ho, co, g = torch.empty_like(h), torch.empty_like(c), torch.empty(B, hw, hw, 4 * F, device=dev)
         fl = 2.0 * k * k * (cin + F) * 4 * F * hw * hw * B
         timeit(lambda: ops.convlstm_step(x, h, c, kx, kh, b, ho, co, g), fl, 'lstm_step_fused ' + name)
+        if 'bf16' in which:
+            pk, ph = ops.pack_bf16(kx), ops.pack_bf16(kh)
+            ho2, co2 = torch.empty_like(h), torch.empty_like(c)
+            timeit(lambda: ops.convlstm_step(x, h, c, pk, ph, b, ho2, co2, g), fl, 'lstm_step_fused_bf16 ' + name)
+            print('   max |h_bf16 - h_f32| = %.3e  (|h| max %.3f)' % ((ho2 - ho).abs().max().item(), ho.abs().max().item()))
     if 'dgrad' in which:
         dz = r(B, hw, hw, 4 * F)
         kh = r(k, k, F, 4 * F, scale=0.02)
@@ -42,6 +47,9 @@ for name, hw, cin, F in levels:
         p = (k - 1) // 2
         fl = 2.0 * k * k * F * 4 * F * hw * hw * B
         timeit(lambda: ops.conv_raw([(dz, wt)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad ' + name)
+        if 'bf16' in which:
+            pw = ops.pack_bf16(wt)
+            timeit(lambda: ops.conv_raw([(dz, pw)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad_bf16 ' + name)
     if 'wgrad' in which:
         T = 8
         xs, dy = r(T * B, hw, hw, F), r(T * B, hw, hw, 4 * F)
