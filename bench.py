@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
 
 
 def conv_flops(k, cin, cout, h, w):
@@ -148,6 +149,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer', action='store_true', help='skip the secondary streaming-inference measurement')
     ap.add_argument('--sync-bn', action='store_true')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else)")
     args = ap.parse_args()
 
     import Params
@@ -167,7 +170,8 @@ def main():
         H, W = args.hw
     B, T = args.batch, args.unroll
     trainer = train2D.Trainer(Params.CTCParams.net_model, net, 'NCHW', Params.CTCParams.class_weights,
-                              Params.CTCParams.learning_rate, dp=dp, sync_bn=args.sync_bn, seed=0)
+                              Params.CTCParams.learning_rate, dp=dp, sync_bn=args.sync_bn, seed=0,
+                              precision=args.precision)
     batches = synthetic_batches(4, B, T, H, W, dp.rank, dev)
 
     def one_step(i):
@@ -208,7 +212,7 @@ def main():
             c['n'] += 1
         traffic_db = {}
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only)
-            if (H, W, T, B) == (256, 256, 8, 4):
+            if (H, W, T, B) == (256, 256, 8, 4) and args.precision == 'fp32':
                 with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
                     traffic_db = json.load(fh)['kernels']
         except (OSError, KeyError, ValueError):
@@ -225,8 +229,9 @@ def main():
             if c['ms'] <= 0:
                 continue
             ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            rows.append({'kernel': kind, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic_of(kind),
+            peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in kind else PEAK_FP32_MFMA_TFLOPS
+            rows.append({'kernel': kind, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic_of(kind),
                          'launches_per_step': c['n'], 'avg_launch_ms': round(c['ms'] / c['n'], 4),
                          'ms_per_step': round(c['ms'], 2), 'flops_per_launch_avg': c['flops'] / c['n']})
         rows.sort(key=lambda r_: -r_['ms_per_step'])
@@ -239,7 +244,7 @@ def main():
     infer = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_infer:
         import Networks
-        m = Networks.ULSTMnet2D(net, 'NCHW', True, seed=0)
+        m = Networks.ULSTMnet2D(net, 'NCHW', True, seed=0, precision=args.precision)
         frames_in = [torch.randn(1, 1, 1, H, W, device=dev) for _ in range(4)]
         for i in range(3):
             m(frames_in[i % 4], training=False)
@@ -265,11 +270,13 @@ def main():
             'metric': 'training frames/sec (seq_len*batch) at 256x256',
             'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
             'config': {'workload': ('BASELINE config-2 per GPU: ' if (H, W, T, B) == (256, 256, 8, 4) else
                                     ('BASELINE config-4: ' if (H, W, T, B) == (832, 992, 16, 2) else '')) +
                                    '%dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet Params.py widths (5x5 ConvLSTM '
-                                   '128/256/256/512, 3x3 convs), fp32, random-init' % (H, W, T, B),
+                                   '128/256/256/512, 3x3 convs), %s, random-init' %
+                                   (H, W, T, B, 'fp32' if args.precision == 'fp32' else
+                                    'bf16 MFMA operands on the wide stride-1 convs (fp32 master weights / accumulate / wgrad)'),
                        'global_batch': B * dp.world_size, 'seq_len': T,
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),

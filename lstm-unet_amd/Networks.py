@@ -211,7 +211,7 @@ class ULSTMnet2D(object):
     """ConvLSTM encoder / conv decoder U-Net (reference Networks.py:178-291)."""
 
     def __init__(self, net_params=DEFAULT_NET_DOWN_PARAMS, data_format='NCHW', pad_image=True, seed=0, dp=None,
-                 sync_bn=False):
+                 sync_bn=False, precision='fp32'):
         self.data_format = data_format
         self._nchw = _is_nchw(data_format)
         self.data_format_keras = 'channels_first' if self._nchw else 'channels_last'
@@ -236,7 +236,8 @@ class ULSTMnet2D(object):
             self.UpLayers.append(_Descr('UpBlock2D', kernels=cf, up_factor=2 if i > 0 else 1,
                                         return_logits=i + 1 == n))
             self.last_depth = cf[-1][1]
-        self._engine = Engine(net_params, pad_image=bool(pad_image), seed=seed, dp=dp, sync_bn=sync_bn)
+        self._engine = Engine(net_params, pad_image=bool(pad_image), seed=seed, dp=dp, sync_bn=sync_bn,
+                              precision=precision)
         self._flat_param = None
 
     # -- torch-style parameter access (one flat leaf: all weights live in one HBM buffer) --

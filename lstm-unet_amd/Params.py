@@ -55,8 +55,8 @@ _TRAIN_DEFAULTS = dict(
     tb_sub_folder='LSTMUNet', write_to_tb_interval=500, save_log_dir=ROOT_SAVE_DIR,
     # debugging
     dry_run=False, profile=False,
-    # MI355X data-parallel option: pool BatchNorm statistics over all ranks
-    sync_bn=False,
+    # MI355X options: pool BatchNorm statistics over all data-parallel ranks; MFMA operand precision
+    sync_bn=False, precision='fp32',
 )
 
 _INFER_DEFAULTS = dict(

@@ -35,7 +35,16 @@ def model_pads(h, w, total_stride, pad_image):
 
 
 class Engine:
-    def __init__(self, net_params, pad_image=True, seed=0, dp=None, sync_bn=False, plan_fn=None):
+    def __init__(self, net_params, pad_image=True, seed=0, dp=None, sync_bn=False, plan_fn=None, precision='fp32'):
+        """precision: 'fp32' (default; v_mfma_f32_32x32x2_f32 everywhere -- the parity configuration) or 'bf16'
+        (BASELINE config 5: stride-1 3x3 / 5x5 convolutions with more than 64 output channels -- ConvLSTM steps, their
+        recurrent / input gradients, the wide encoder / decoder convs -- feed bf16-rounded operands to
+        v_mfma_f32_32x32x16_bf16; fp32 master weights, activations, accumulators, statistics, loss and optimiser)."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        self._packed_version = -1
+        self._packed = {}    # (param name, role, c_off, c_sub) -> ops.PackedW; dropped whenever the weights change
         self.net_params = net_params
         self._plan_fn = plan_fn if plan_fn is not None else (lambda cin: make_plan(net_params, cin))
         self.pad_image = bool(pad_image)
@@ -108,6 +117,7 @@ class Engine:
             if dst is None:
                 raise KeyError(k)
             dst.copy_(t.reshape(dst.shape))
+        self.weights_changed()
 
     def export_params(self):
         out = {k: v.detach().cpu().numpy().copy() for k, v in self.P.items()}
@@ -115,6 +125,24 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ helpers
+    def weights_changed(self):
+        """Optimiser step / checkpoint load: the cached bf16 weight images are stale."""
+        self._packed.clear()
+
+    def _bf16_conv(self, k, stride, n_out):
+        return self.precision == 'bf16' and stride == 1 and k in (3, 5) and n_out > 64 and n_out % 4 == 0
+
+    def _pack(self, name, role, make, co=0, cs=None):
+        ver = self.flat_params._version       # in-place torch updates (copy_, torch optimisers) bump it; the raw-pointer
+        if ver != self._packed_version:       # Adam kernel does not, hence Adam.apply_gradients -> weights_changed()
+            self._packed.clear()
+            self._packed_version = ver
+        key = (name, role, co, cs)
+        pw = self._packed.get(key)
+        if pw is None:
+            pw = self._packed[key] = ops.pack_bf16(make())
+        return pw
+
     def _bn_forward(self, prefix, y, training, rec):
         gamma, beta = self.P[prefix + '.gamma'], self.P[prefix + '.beta']
         mm, mv = self.S[prefix + '.moving_mean'], self.S[prefix + '.moving_var']
@@ -133,8 +161,12 @@ class Engine:
 
     def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape):
         """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151)."""
-        w = self.P[f'{prefix}.conv.{ci}.kernel']
-        pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
+        wname = f'{prefix}.conv.{ci}.kernel'
+        w = self.P[wname]
+        if self._bf16_conv(w.shape[0], spec['stride'], w.shape[3]):
+            pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs: w[:, :, co:co + cs, :], co, cs)) for (x, co, cs) in srcs]
+        else:
+            pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
         y = ops.conv2d(pairs, self.P[f'{prefix}.conv.{ci}.bias'], spec['stride'])
         rec = None
         if tape is not None:
@@ -173,7 +205,8 @@ class Engine:
         dxs = []
         for (x, co, cs), need in zip(rec['srcs'], need_dx):
             ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'])
-            dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs) if need else None)
+            dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
+                                        bf16=self._bf16_conv(w.shape[0], spec['stride'], cs)) if need else None)
         rec['srcs'] = None
         return dxs
 
@@ -185,6 +218,9 @@ class Engine:
         dev = x_seq.device
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
+        if self._bf16_conv(spec['k'], 1, 4 * F):
+            kernel = self._pack(pre + '.kernel', 'fwd', lambda w=kernel: w)
+            rec_k = self._pack(pre + '.recurrent_kernel', 'fwd', lambda w=rec_k: w)
         h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         st = self.states[bi][li]
@@ -225,6 +261,8 @@ class Engine:
         dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
         dh_rec = None
         rec_kt = ops.flip_transpose(rec_k) if T > 1 else None
+        if rec_kt is not None and self._bf16_conv(spec['k'], 1, F):
+            rec_kt = ops.pack_bf16(rec_kt)
         p = (spec['k'] - 1) // 2
         for t in reversed(range(T)):
             ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc[(t + 1) & 1] if t < T - 1 else None,
@@ -239,7 +277,7 @@ class Engine:
         ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1)
         ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
         ops.bias_grad(dz_seq, self.G[pre + '.bias'])
-        dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1) if need_dx else None
+        dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1, bf16=self._bf16_conv(spec['k'], 1, kernel.shape[2])) if need_dx else None
         rec['h_all'] = rec['c_all'] = rec['x'] = None
         return dx
 
@@ -411,3 +449,4 @@ class Adam:
         t = self.iterations
         alpha = self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
         ops.adam_step(e.flat_params, e.flat_grads, self.m, self.v, alpha, self.b1, self.b2, self.eps, grad_scale)
+        e.weights_changed()

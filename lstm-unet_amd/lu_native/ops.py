@@ -150,7 +150,7 @@ def flip_transpose(w, c_off=0, c_sub=None):
     return wt
 
 
-def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None):
+def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None, bf16=False):
     """Gradient w.r.t. (channels [c_off, c_off+c_sub) of) the input of conv2d(x, w, stride): a
     convolution of the (zero-dilated when stride == 2) dy with the flipped / transposed kernel."""
     _chk(dy, w)
@@ -163,6 +163,8 @@ def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None):
     wt = flip_transpose(w, c_off, c_sub)
     frames, Hd, Wd, N = dy.shape
     Cs = wt.shape[3]
+    if bf16:      # caller checked: stride 1, 3x3 / 5x5, more than 64 input channels
+        wt = pack_bf16(wt)
     if out is None:
         out = torch.empty((frames, Hin, Win, Cs), device=dy.device, dtype=torch.float32)
     return conv_raw([(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs, None, out)

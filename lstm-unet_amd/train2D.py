@@ -35,10 +35,11 @@ class Trainer(object):
     """Owns model + optimiser + DP plumbing; exposes train_step / val_step."""
 
     def __init__(self, net_model, net_kernel_params, data_format='NCHW', class_weights=(0.15, 0.25, 0.6),
-                 learning_rate=1e-5, dp=None, sync_bn=False, seed=0):
+                 learning_rate=1e-5, dp=None, sync_bn=False, seed=0, precision='fp32'):
         self.dp = dp if dp is not None else DataParallel()
         self.data_format = data_format
-        self.model = net_model(net_kernel_params, data_format, False, seed=seed, dp=self.dp, sync_bn=sync_bn)
+        self.model = net_model(net_kernel_params, data_format, False, seed=seed, dp=self.dp, sync_bn=sync_bn,
+                               precision=precision)
         self.engine = self.model.engine
         self.optimizer = Adam(self.engine, lr=learning_rate)
         self.class_weights = list(class_weights)
@@ -134,7 +135,8 @@ def train(params):
     dp = DataParallel()
     is_main = dp.rank == 0
     trainer = Trainer(params.net_model, params.net_kernel_params, params.data_format, params.class_weights,
-                      params.learning_rate, dp=dp, sync_bn=getattr(params, 'sync_bn', False))
+                      params.learning_rate, dp=dp, sync_bn=getattr(params, 'sync_bn', False),
+                      precision=getattr(params, 'precision', 'fp32'))
     model = trainer.model
     train_data_provider, val_data_provider = params.train_data_provider, params.val_data_provider
     train_data_provider.start_queues(None)
@@ -311,6 +313,8 @@ def build_arg_parser():
         parser.add_argument(*names, **kw)
     parser.add_argument('--sync_bn', dest='sync_bn', action='store_const', const=True,
                         help='[MI355X] pool BatchNorm statistics over all DP ranks')
+    parser.add_argument('--precision', dest='precision', choices=['fp32', 'bf16'],
+                        help='[MI355X] fp32 (default) or bf16-MFMA operands for the wide stride-1 convolutions')
     return parser
 
 

@@ -228,6 +228,53 @@ def test_public_api_and_autograd_path(dev):
     assert worst <= 2e-3
 
 
+BF16_NET = {'down_conv_kernels': [[(3, 72), (3, 72)], [(3, 8)]], 'lstm_kernels': [[(3, 32)], [(5, 32)]],
+            'up_conv_kernels': [[(3, 72)], [(3, 72), (1, 3)]]}
+
+
+def test_bf16_precision_mode(dev, monkeypatch):
+    """Engine(precision='bf16') (BASELINE config 5): the wide stride-1 convolutions run on the bf16-MFMA kernel and the
+    step stays close to the fp32 step.  Stated tolerances: logits within 3e-2 * max|logit| of the fp32 engine, loss within
+    2e-2 relative, label maps equal outside a 5e-2 top-2 tie band, every gradient tensor within 0.1 L2-relative."""
+    from lu_native import calls, ops
+    from lu_native.engine import Engine
+    seen = []
+    real = calls.conv2d
+    monkeypatch.setattr(calls, 'conv2d', lambda *a, **k: (seen.append(k.get('precision', 0)), real(*a, **k))[1])
+    net, cin, B, T, H, W = BF16_NET, 1, 2, 3, 16, 32
+    rng = np.random.default_rng(21)
+    p = perturbed_params(net, cin, 4)
+    x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+    cwt = torch.tensor([0.15, 0.25, 0.6], dtype=torch.float32, device=dev)
+    res = {}
+    for prec in ('fp32', 'bf16'):
+        del seen[:]
+        e = Engine(net, pad_image=False, precision=prec)
+        e.build(cin, dev)
+        e.load_params(p)
+        lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+        g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+        sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+        e.backward(ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0).view(lg.shape))
+        res[prec] = (lg.cpu().numpy().astype(np.float64), float(ops.wce_loss(sums).cpu()[0]),
+                     {k: v.cpu().numpy().astype(np.float64) for k, v in e.G.items()})
+        n_bf16 = sum(seen)
+        assert (n_bf16 == 0) if prec == 'fp32' else (n_bf16 >= 2 * T + 6), (prec, n_bf16, len(seen))
+    (l32, loss32, g32), (l16, loss16, g16) = res['fp32'], res['bf16']
+    assert np.abs(l16 - l32).max() <= 3e-2 * np.abs(l32).max()
+    assert np.abs(l16 - l32).max() > 0.0
+    assert abs(loss16 - loss32) <= 2e-2 * abs(loss32)
+    top2 = np.sort(l32, -1)
+    band = (top2[..., -1] - top2[..., -2]) < 5e-2 * np.abs(l32).max()
+    assert np.all((l16.argmax(-1) == l32.argmax(-1)) | band)
+    fl = grad_floor(g32)
+    worst = max((float(np.linalg.norm(g16[k] - g32[k]) / max(np.linalg.norm(g32[k]), fl)), k) for k in g32)
+    assert worst[0] <= 0.1, worst
+    ref = npo.model_forward(net, p, x, training=True, pad_image=False)           # and both sit next to the oracle
+    assert np.abs(from_tb(l16, B, T) - ref['logits']).max() <= 3e-2 * np.abs(ref['logits']).max()
+
+
 @pytest.mark.gpu
 def test_layerwise_backward_consistency():
     """Config-1 backward on the GPU: every Conv->BN->LeakyReLU unit's backward (BN sums, input gradient
