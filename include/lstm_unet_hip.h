@@ -119,6 +119,8 @@ typedef struct lu_wgrad_desc {
     int64_t dw_tap_stride; int32_t dw_row_stride;
     int32_t splits;           /* >= 1 */
     float beta;               /* 0: overwrite, 1: accumulate */
+    int32_t precision;        /* 0: fp32 MFMA.  1: x and dy may be rounded to bf16 MFMA operands (fp32 accumulate) where the
+                               * bf16 kernel applies (stride-1 3x3 / 5x5, C >= 64, W % 32 == 0); other shapes stay fp32 */
     void* workspace;          /* lu_conv2d_wgrad_workspace_bytes(d) bytes */
 } lu_wgrad_desc;
 

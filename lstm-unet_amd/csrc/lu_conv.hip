@@ -789,8 +789,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
         for (int i = 0; i < HPASS; ++i) {
             const int hp = (tid + NT * i) >> 3;
             if (hp < HP) {
-                const unsigned lo = (unsigned)lu_f2bf(rh[i].x) | ((unsigned)lu_f2bf(rh[i].y) << 16);
-                const unsigned hi = (unsigned)lu_f2bf(rh[i].z) | ((unsigned)lu_f2bf(rh[i].w) << 16);
+                const unsigned lo = lu_pack2bf(rh[i].x, rh[i].y);
+                const unsigned hi = lu_pack2bf(rh[i].z, rh[i].w);
                 unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hp * LDB + 4 * q]);
                 dst[0] = lo;
                 dst[1] = hi;

@@ -13,6 +13,7 @@
     lu_emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
 static inline f32x16 lu_mfma(float a, float b, f32x16 c) { return lu_emu::mfma_32x32x2(a, b, c); }
 static inline f32x16 lu_mfma_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 c) { return lu_emu::mfma_32x32x16_bf16(a, b, c); }
+static inline lu_bf16x4 lu_lds_tr16(const unsigned short* p) { return lu_emu::lds_read_tr16_b64(p); }
 static inline float lu_shfl_xor(float v, int m) { return lu_emu::shfl_xor(v, m); }
 static inline float lu_shfl_down(float v, int d) { return lu_emu::shfl_down(v, d); }
 // global_load_lds_dwordx4: every lane copies 16 bytes from ITS global pointer to (wave-uniform LDS base + lane*16)
@@ -37,6 +38,13 @@ __device__ __forceinline__ f32x16 lu_mfma_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 
     typedef __bf16 hw_bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hw_bf16x8, a), __builtin_bit_cast(hw_bf16x8, b), c, 0,
                                                    0, 0);
+}
+typedef short lu_bf16x4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: transposing LDS read.  Each lane passes the address of 4 consecutive bf16 (8-byte aligned); per
+// 16-lane group, lanes 4j .. 4j+3 address row j of a 4 x 16 block and lane t receives column t (rows 0..3).  It turns a
+// pixel-major [k][channel] LDS image into the k-contiguous fragments the bf16 MFMA wants (tools/probe/tr_probe.hip).
+__device__ __forceinline__ lu_bf16x4 lu_lds_tr16(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lu_bf16x4*)p);
 }
 __device__ __forceinline__ float lu_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float lu_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
@@ -77,6 +85,19 @@ void lu_set_error(const char* fmt, ...);
 
 static inline int64_t lu_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// two fp32 -> packed bf16 pair (lo in bits 0..15), round to nearest even: one v_cvt_pk_bf16_f32 on the device
+#ifdef LU_EMU
+static inline unsigned lu_pack2bf(float lo, float hi);
+#else
+__device__ __forceinline__ unsigned lu_pack2bf(float lo, float hi) {
+    typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+    hw_bf16x2 v;
+    v.x = (__bf16)lo;
+    v.y = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+#endif
+
 // fp32 -> bf16 bits, round to nearest even (finite inputs)
 __device__ __host__ static inline unsigned short lu_f2bf(float f) {
     unsigned u;
@@ -84,3 +105,6 @@ __device__ __host__ static inline unsigned short lu_f2bf(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+#ifdef LU_EMU
+static inline unsigned lu_pack2bf(float lo, float hi) { return (unsigned)lu_f2bf(lo) | ((unsigned)lu_f2bf(hi) << 16); }
+#endif

@@ -350,6 +350,138 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16-MFMA kernel-row variant (precision = 1; W % 32 == 0).  Same block tile as wgrad_row_kernel (64 c x 128 n x
+// K taps of one kernel row, 8 waves), 32-pixel runs per stage = two v_mfma_f32_32x32x16_bf16 k-steps per tap.  The
+// operands stay pixel-major in LDS ([pixel][channel] bf16, converted while staged), i.e. k runs DOWN the rows, so the
+// k-contiguous MFMA fragments are fetched with the transposing LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels
+// per 16-lane group); a tap is a row shift of the x tile, which keeps every read 8-byte aligned.  Row pitches of
+// 192 B (x) and 320 B (dy) put the 4 rows of a group on distinct 64-byte bank segments.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
+
+template <int K>
+__global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
+    constexpr int BMw = 64, BNw = 128, XP = PRB + K - 1, NT = 512;
+    constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 elements per LDS row
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2][XP * XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Ys[2][PRB * YLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int n0 = blockIdx.x * BNw;
+    const int kh = blockIdx.y / a.c_tiles;
+    const int c0 = (blockIdx.y - kh * a.c_tiles) * BMw;
+    const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+    int64_t p_end = p_begin + a.chunk;
+    if (p_end > a.M) p_end = a.M;
+    const int n_it = p_end > p_begin ? (int)((p_end - p_begin + PRB - 1) / PRB) : 0;
+    const float* const zp = lu_zero16;
+
+    int64_t pf = 0;
+    int oy = 0, ox0 = 0;
+    {
+        const int64_t p = p_begin < a.M ? p_begin : 0;
+        pf = p / a.HWo;
+        const int r = (int)(p - pf * a.HWo);
+        oy = r / a.Wout;
+        ox0 = r - oy * a.Wout;
+    }
+    // x tile: XP rows x 16 float4 (two passes, the second one partial); dy tile: 32 rows x 32 float4 (two passes)
+    const int xrow0 = tid >> 4, xq = tid & 15, xrow1 = xrow0 + NT / 16;
+    const int yrow0 = tid >> 5, yq = tid & 31, yrow1 = yrow0 + NT / 32;
+    float4 rx0 = make_float4(0.f, 0.f, 0.f, 0.f), rx1 = rx0, ry0 = rx0, ry1 = rx0;
+    auto load_stage = [&]() {
+        const int iy = oy + kh - a.pad_t;
+        const int c = c0 + 4 * xq;
+        const bool rowok = iy >= 0 && iy < a.Hin && c < a.C;
+        const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + (ox0 - a.pad_l)) * a.x_ps + c;
+        const int ix0 = ox0 - a.pad_l + xrow0, ix1 = ox0 - a.pad_l + xrow1;
+        rx0 = *reinterpret_cast<const float4*>((rowok && ix0 >= 0 && ix0 < a.Win) ? px + (int64_t)xrow0 * a.x_ps : zp);
+        rx1 = *reinterpret_cast<const float4*>((rowok && xrow1 < XP && ix1 >= 0 && ix1 < a.Win) ? px + (int64_t)xrow1 * a.x_ps
+                                                                                               : zp);
+        const int n = n0 + 4 * yq;
+        const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n;
+        ry0 = *reinterpret_cast<const float4*>(n < a.N ? py + (int64_t)yrow0 * a.dy_ps : zp);
+        ry1 = *reinterpret_cast<const float4*>(n < a.N ? py + (int64_t)yrow1 * a.dy_ps : zp);
+    };
+    auto put = [&](unsigned short* dst, const float4& v) {
+        unsigned* d2 = reinterpret_cast<unsigned*>(dst);
+        d2[0] = lu_pack2bf(v.x, v.y);
+        d2[1] = lu_pack2bf(v.z, v.w);
+    };
+    auto store_stage = [&](int buf) {
+        put(&Xs[buf][xrow0 * XLD + 4 * xq], rx0);
+        if (xrow1 < XP) put(&Xs[buf][xrow1 * XLD + 4 * xq], rx1);
+        put(&Ys[buf][yrow0 * YLD + 4 * yq], ry0);
+        put(&Ys[buf][yrow1 * YLD + 4 * yq], ry1);
+    };
+    auto advance = [&]() {
+        ox0 += PRB;
+        if (ox0 >= a.Wout) {          // W % 32 == 0: a run never straddles two rows
+            ox0 = 0;
+            if (++oy == a.Hout) {
+                oy = 0;
+                ++pf;
+            }
+        }
+    };
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (n_it > 0) {
+        load_stage();
+        store_stage(0);
+    }
+    __syncthreads();
+    // this lane's address inside a 4-row x 32-column transposed fetch: row (lane & 15) >> 2 (+ 8 for the upper half-wave),
+    // columns 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int xoff = frow * XLD + wm * 32 + fcol, yoff = frow * YLD + wn * 32 + fcol;
+    auto frag = [&](const unsigned short* base, int ld) {      // 8 consecutive k (rows) of this lane's column
+        const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + 4 * ld);
+        lu_bf16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    };
+    const int l31 = lane & 31;
+    for (int it = 0; it < n_it; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_it) advance();
+        load_stage();                  // the last iteration re-fetches its own run (stays in cache); keeps the loop branch-free
+        LU_SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < PRB / 16; ++j) {
+            const lu_bf16x8 bv = frag(&Ys[buf][yoff + 16 * j * YLD], YLD);
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const lu_bf16x8 av = frag(&Xs[buf][xoff + (16 * j + t) * XLD], XLD);
+                acc[t] = lu_mfma_bf16(av, bv, acc[t]);
+            }
+        }
+        LU_SCHED_FENCE();
+        store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* slab = a.ws + (int64_t)blockIdx.z * a.slab;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const int tap = kh * K + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int n = n0 + wn * 32 + l31;
+            if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][r];
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ dw,
                                     int C, int N, int64_t tap_stride, int row_stride, float beta) {
     const int64_t total = slab;
@@ -391,7 +523,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.C = d->C;
     a.N = d->N;
     a.M = (int64_t)d->frames * d->Hout * d->Wout;
-    a.chunk = ((a.M + splits - 1) / splits + KP - 1) / KP * KP;
+    a.chunk = ((a.M + splits - 1) / splits + PRB - 1) / PRB * PRB;     // multiple of both kernels' pixel runs (16 / 32)
     a.HWo = d->Hout * d->Wout;
     a.Wout = d->Wout;
     a.Hout = d->Hout;
@@ -415,7 +547,12 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     } while (0)
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
                              d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
-    if (row_variant) {
+    if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
+        a.c_tiles = (d->C + 63) / 64;
+        dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
+        if (d->k == 5) LU_LAUNCH((wgrad_row_bf16_kernel<5>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((wgrad_row_bf16_kernel<3>), grid, dim3(512), stream, a);
+    } else if (row_variant) {
         a.c_tiles = (d->C + 63) / 64;
         dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
         if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5>), grid, dim3(512), stream, a);

@@ -30,7 +30,7 @@ class WgradDesc(C.Structure):
                 ('frames', i32), ('Hin', i32), ('Win', i32), ('Hout', i32), ('Wout', i32),
                 ('k', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
                 ('dw', c_f32p), ('dw_tap_stride', i64), ('dw_row_stride', i32), ('splits', i32),
-                ('beta', f32), ('workspace', C.c_void_p)]
+                ('beta', f32), ('precision', i32), ('workspace', C.c_void_p)]
 
 
 P = C.c_void_p

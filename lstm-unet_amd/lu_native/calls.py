@@ -59,13 +59,14 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
 
 
 def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, Wout, k, stride, pad_t, pad_l,
-               dw, dw_tap_stride, dw_row_stride, splits, beta):
+               dw, dw_tap_stride, dw_row_stride, splits, beta, precision=0):
     d = cabi.WgradDesc()
     d.x, d.x_frame_stride, d.x_pix_stride, d.C = x, x_fs, x_ps, Cin
     d.dy, d.dy_frame_stride, d.dy_pix_stride, d.N = dy, dy_fs, dy_ps, N
     d.frames, d.Hin, d.Win, d.Hout, d.Wout = frames, Hin, Win, Hout, Wout
     d.k, d.stride, d.pad_t, d.pad_l = k, stride, pad_t, pad_l
     d.dw, d.dw_tap_stride, d.dw_row_stride, d.splits, d.beta = dw, dw_tap_stride, dw_row_stride, splits, beta
+    d.precision = precision
     return d
 
 

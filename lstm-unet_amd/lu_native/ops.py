@@ -199,7 +199,7 @@ def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl):
     return out
 
 
-def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
+def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False):
     """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy."""
     _chk(x, dy, dw)
     frames, Hin, Win, Cin = x.shape
@@ -212,12 +212,14 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0):
     splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant)
     d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
                          frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
-                         splits, beta)
+                         splits, beta, precision=1 if bf16 else 0)
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
     kind = ('wgrad_row_kernel<%d> (+ its slab reduce; weight gradients hoisted over T)' % k) if row_variant else \
         'wgrad_kernel (strided / thin / narrow layers)'
+    if bf16 and row_variant and Wout % 32 == 0:
+        kind = 'wgrad_row_bf16_kernel<%d> (+ its slab reduce; bf16-MFMA weight gradients hoisted over T)' % k
     with _timed(kind, 2.0 * k * k * Cin * N * frames * Hout * Wout):
         calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
     return dw

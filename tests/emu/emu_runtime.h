@@ -27,6 +27,7 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short lu_bf16x8 __attribute__((ext_vector_type(8)));   // raw bf16 bit patterns
+typedef short lu_bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace lu_emu {
 
@@ -205,6 +206,21 @@ inline f32x16 mfma_32x32x16_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 c) {
     }
     wave_barrier();
     return c;
+}
+
+// ds_read_b64_tr_b16 (probed on gfx950, tools/probe/tr_probe.hip): every lane supplies the address of 4 consecutive
+// 16-bit elements; within each 16-lane group the 4 x 16 block formed by lanes (4j .. 4j+3) = row j is transposed, so
+// lane t of the group receives column t: element j comes from lane 4j + (t >> 2), position t & 3.
+inline lu_bf16x4 lds_read_tr16_b64(const unsigned short* p) {
+    Runtime& r = g_rt;
+    int lane = r.cur->lin & 63, w = r.cur->lin >> 6;
+    for (int j = 0; j < 4; ++j) r.xa8[w][lane][j] = (short)p[j];
+    wave_barrier();
+    const int g = lane & ~15, t = lane & 15;
+    lu_bf16x4 o;
+    for (int j = 0; j < 4; ++j) o[j] = r.xa8[w][g + 4 * j + (t >> 2)][t & 3];
+    wave_barrier();
+    return o;
 }
 
 inline float shfl_xor(float v, int mask) {

@@ -165,7 +165,7 @@ def conv2d_dgrad(be, dy, w, in_hw, stride):
     return conv2d(be, [dy], [wt], None, k, 1, stride, pad=(k - 1 - pt, k - 1 - pl), out_hw=(Hin, Win))
 
 
-def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0):
+def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0, precision=0):
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     _, pt, _ = calls.same_pad(Hin, k, stride)
@@ -173,7 +173,7 @@ def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0):
     dw = be.empty((k, k, Cin, N)) if dw0 is None else be.dev(dw0)
     xd, dyd = be.dev(x), be.dev(dy)
     d = calls.wgrad_desc(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(dyd), Hout * Wout * N, N, N, frames, Hin, Win,
-                         Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta)
+                         Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta, precision=precision)
     ws = be.empty((be.lib.lu_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4 + 4,))
     d.workspace = be.ptr(ws)
     calls.check(be.lib, be.lib.lu_conv2d_wgrad(C.byref(d), be.stream), 'wgrad')

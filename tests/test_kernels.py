@@ -190,6 +190,23 @@ def test_wgrad_wide_channels_and_beta(be):
     close(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=2), gw, 2e-4)
 
 
+def test_wgrad_bf16_mfma_variant(be):
+    """Kernel-row weight gradient on the bf16 MFMA (precision = 1, W % 32 == 0): x and dy rounded to bf16, fp32
+    accumulation -- exact up to summation order against the fp32 reference on bf16-rounded operands.  Shapes the bf16
+    kernel does not cover (W % 32 != 0) silently stay on the fp32 kernels."""
+    R = KH.bf16_round
+    for (fr, H, W, Cc, N, k, sp) in [(2, 5, 32, 72, 136, 3, 1), (1, 4, 64, 64, 128, 5, 3), (1, 3, 32, 132, 72, 5, 2)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        _, gw = _torch_conv_grads(R(x), rnd(k, k, Cc, N), R(dy), 1)
+        got = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1)
+        close(got, gw, 2e-4)
+        _, gfull = _torch_conv_grads(x, rnd(k, k, Cc, N), dy, 1)
+        assert np.abs(got - gfull).max() > 0 and np.abs(got - gfull).max() <= 2.0 ** -6 * np.abs(gfull).max()
+    x, dy = rnd(1, 4, 16, 64), rnd(1, 4, 16, 128)             # W % 32 != 0 -> fp32 kernel, full precision
+    _, gw = _torch_conv_grads(x, rnd(3, 3, 64, 128), dy, 1)
+    close(KH.conv2d_wgrad(be, x, dy, 3, 1, precision=1), gw, 2e-4)
+
+
 @pytest.mark.parametrize('k,cin', [(3, 8), (5, 1)])
 def test_convlstm_fused_step(be, k, cin):
     """Fused two-source conv + gate epilogue == Keras ConvLSTM2D cell step."""

@@ -56,4 +56,8 @@ for name, hw, cin, F in levels:
         dw = torch.empty(k, k, F, 4 * F, device=dev)
         fl = 2.0 * k * k * F * 4 * F * hw * hw * B * T
         timeit(lambda: ops.conv2d_wgrad(xs, dy, dw, 1), fl, 'rec_wgrad ' + name, reps=2)
+        if 'bf16' in which:
+            dw2 = torch.empty_like(dw)
+            timeit(lambda: ops.conv2d_wgrad(xs, dy, dw2, 1, bf16=True), fl, 'rec_wgrad_bf16 ' + name, reps=2)
+            print('   max |dw_bf16 - dw_f32| / max|dw| = %.3e' % ((dw2 - dw).abs().max().item() / dw.abs().max().item()))
         del xs, dy
