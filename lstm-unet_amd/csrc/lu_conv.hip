@@ -699,40 +699,51 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // bf16-MFMA variant of the halo kernel (mixed precision: fp32 activations / weights / accumulators in HBM, bf16
-// MFMA operands): v_mfma_f32_32x32x16_bf16 runs at 16x the fp32-MFMA rate, so the same 8x32-patch structure is used
-// with 32-channel chunks.  The halo is converted to bf16 while it is staged ([HP][32+8] bf16: one ds_read_b128 = one
-// A fragment of 8 k); weights arrive pre-packed by pack_weights_bf16_kernel as [tap][chunk][N][32] bf16 so a thread's
-// 16-byte load is 8 consecutive k of one output column = one B fragment row.  Same epilogues, same K split.
+// MFMA operands).  v_mfma_f32_32x32x16_bf16 runs at 16x the fp32-MFMA rate, so everything around it has to shrink:
+//   * same 8 x 32-pixel patch x 128 columns per block, 32-channel chunks; the halo is converted to bf16 while it is
+//     staged ([HP][32+8] bf16: one ds_read_b128 = one A fragment of 8 k) and stays put for the K*K taps;
+//   * the weights never touch LDS: pack_weights_bf16_kernel lays them out in MFMA B-fragment order
+//     ([tap][chunk][column fragment][k-step][lane][8 bf16]), so one coalesced 16-byte global load per lane IS the
+//     fragment.  The 8 waves are a 2 (pixel-row groups of 4) x 4 (column fragments) grid: a wave re-uses its B
+//     fragment for 4 patch rows and prefetches the fragments of the next two stages into registers;
+//   * consequently the tap loop has no barrier at all -- waves only meet when the halo is replaced (every K*K stages);
+//   * ConvLSTM epilogue: the four gates of a channel sit in four different waves, so the accumulators are exchanged
+//     through LDS (the halo buffer is dead by then) before the usual gate epilogue.  Same K split as the fp32 kernel.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int CKB = 32;      // channels per stage (two k = 16 MFMA steps)
-constexpr int LDB = CKB + 8; // bf16 elements per LDS row (80 B: conflict-free ds_read_b128, see A_LD)
+constexpr int LDB = CKB + 8; // bf16 elements per halo pixel in LDS (80 B: conflict-free ds_read_b128, see A_LD)
 
+// packed index of (tap, chunk, column n, channel c):  fragment-major, then k-step, lane, element
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C,
                                          int N, unsigned short* __restrict__ out) {
-    const int nchunk = (C + CKB - 1) / CKB;
-    const int64_t total = (int64_t)kk * nchunk * N * CKB;
+    const int nchunk = (C + CKB - 1) / CKB, nfr = (N + 31) / 32;
+    const int64_t total = (int64_t)kk * nchunk * nfr * 1024;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kc = (int)(i % CKB);
-        int64_t t = i / CKB;
-        const int n = (int)(t % N);
-        t /= N;
+        const int e = (int)(i & 7), ln = (int)((i >> 3) & 63), j = (int)((i >> 9) & 1);
+        int64_t t = i >> 10;
+        const int fr = (int)(t % nfr);
+        t /= nfr;
         const int chunk = (int)(t % nchunk);
         const int tap = (int)(t / nchunk);
-        const int c = chunk * CKB + kc;
-        out[i] = c < C ? lu_f2bf(w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n]) : (unsigned short)0;
+        const int n = fr * 32 + (ln & 31);
+        const int c = chunk * CKB + 16 * j + 8 * (ln >> 5) + e;
+        out[i] = (c < C && n < N) ? lu_f2bf(w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n]) : (unsigned short)0;
     }
 }
 
-template <int K, int EPI>
+template <int K, int EPI, int RW>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch, half the weight traffic)
 __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
-    constexpr int NF = 4, BN = 128, NT = 512, TH = 8, TW = 32;
+    constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
     constexpr int HPASS = (HP * 8 + NT - 1) / NT;      // float4 (4 channels) loads per thread per halo
     constexpr int PAD = (K - 1) / 2;
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[HP * LDB];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDB];
+    constexpr int EX_LD = BN + 4;                      // floats per pixel of the gate-exchange buffer
+    constexpr int AH_ELEMS = HP * LDB;
+    constexpr int EX_ELEMS = (EPI == LU_EPI_LSTM) ? 2 * TW * EX_LD * 2 : 0;     // in 16-bit units
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[AH_ELEMS > EX_ELEMS ? AH_ELEMS : EX_ELEMS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
     const int bid = blockIdx.x;
     const int slot = bid >> 3;
     const int nt = slot % a.n_tiles;
@@ -756,13 +767,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
         hoff[i] = iy * a.Win + ix;
     }
     const int q = tid & 7;                 // 4-channel group inside the 32-channel chunk
-    // weight tile: 128 columns x 4 pieces of 8 k
-    const int bnl = tid >> 2, bpiece = tid & 3;
-    const int bn_glob = (EPI == LU_EPI_LSTM) ? (bnl >> 5) * a.F + nt * 32 + (bnl & 31) : n0 + bnl;
-    const bool bn_ok = (EPI == LU_EPI_LSTM) || bn_glob < a.N;
+    // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
+    const int nfr = (a.N + 31) >> 5;
+    const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
+    const bool frag_ok = frag < nfr;
 
     float4 rh[HPASS];
-    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);      // 16 raw bytes = 8 bf16
     auto load_halo = [&](const IterState& st) {
         const SrcInfo& si = a.src[st.s];
         const int c = st.chunk * CKB + 4 * q;
@@ -797,27 +807,37 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
             }
         }
     };
-    auto load_b = [&](const IterState& st) {
-        const SrcInfo& si = a.src[st.s];        // si.w -> packed bf16 [tap][chunk][N][32]
+    // B fragments of one stage (two k-steps), straight from the packed weights
+    auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
+        const SrcInfo& si = a.src[st.s];
         const unsigned short* wp = reinterpret_cast<const unsigned short*>(si.w) +
-                                   (((int64_t)st.tap * si.nchunk + st.chunk) * a.N + bn_glob) * CKB + 8 * bpiece;
-        rb = *reinterpret_cast<const float4*>(bn_ok ? reinterpret_cast<const float*>(wp) : zp);
+                                   (((int64_t)st.tap * si.nchunk + st.chunk) * nfr + frag) * 1024 + lane * 8;
+        const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : zp;
+        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 512) : zp;
+        b0 = *reinterpret_cast<const float4*>(p0);
+        b1 = *reinterpret_cast<const float4*>(p1);
     };
-    auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][bnl * LDB + 8 * bpiece]) = rb; };
 
-    f32x16 acc[NF];
+    f32x16 acc[RW];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int khalf8 = 8 * (lane >> 5);
-    auto mma_step = [&](int buf, int j, int arow) {      // one k = 16 step: A fragment + 4 B fragments
-        const lu_bf16x8 av = *reinterpret_cast<const lu_bf16x8*>(&Ah[arow * LDB + 16 * j + khalf8]);
+    auto mma_stage = [&](const IterState& st, const float4& b0, const float4& b1) {
+        const int arow = (RW * wm + st.kh) * HWD + (lane & 31) + st.kw;
+        const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
+        // k-step 0 for every row, then k-step 1: back-to-back MFMAs never depend on each other
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            const lu_bf16x8 bv = *reinterpret_cast<const lu_bf16x8*>(&Bs[buf][(32 * nf + (lane & 31)) * LDB + 16 * j + khalf8]);
-            acc[nf] = lu_mfma_bf16(av, bv, acc[nf]);
+        for (int i = 0; i < RW; ++i) {
+            const lu_bf16x8 a0 = *reinterpret_cast<const lu_bf16x8*>(&Ah[(arow + i * HWD) * LDB + khalf8]);
+            acc[i] = lu_mfma_bf16(a0, bv0, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const lu_bf16x8 a1 = *reinterpret_cast<const lu_bf16x8*>(&Ah[(arow + i * HWD) * LDB + khalf8 + 16]);
+            acc[i] = lu_mfma_bf16(a1, bv1, acc[i]);
         }
     };
 
@@ -840,43 +860,82 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
             st.kh = st.tap / K;
             st.kw = st.tap - st.kh * K;
         }
+        // register ring of B fragments: slot A = stage it, slot B = stage it + 1; a slot is refilled for stage it + 2
+        // as soon as its MFMAs have been issued
+        float4 bA0, bA1, bB0, bB1;
+        IterState sB = st;                       // state of stage it + 1 (clamped at the last stage)
+        if (it0 + 1 < it1) iter_advance(sB, a);
         load_halo(st);
-        load_b(st);
+        load_b(st, bA0, bA1);
+        load_b(sB, bB0, bB1);
         store_halo();
-        store_b(0);
         __syncthreads();
-        for (int it = it0; it < it1; ++it) {
-            const int buf = (it - it0) & 1;
-            const int arow = (wave + st.kh) * HWD + (lane & 31) + st.kw;
-            IterState nx = st;
-            if (it + 1 < it1) iter_advance(nx, a);
-            const bool new_halo = (it + 1 < it1) && nx.tap == 0;
-            load_b(nx);
-            if (new_halo) load_halo(nx);
+        // one pipeline step: stage `it` with fragments (c0, c1) at state sc; sn = state of stage it + 1
+        auto step = [&](int it, IterState& sc, IterState& sn, float4& c0, float4& c1) {
+            const bool new_halo = (it + 1 < it1) && sn.tap == 0;
+            if (new_halo && !(a.dbg & 1)) load_halo(sn);
             LU_SCHED_FENCE();
-            mma_step(buf, 0, arow);
-            mma_step(buf, 1, arow);
+            if (!(a.dbg & 8)) mma_stage(sc, c0, c1);
             LU_SCHED_FENCE();
-            if (new_halo) {
-                __syncthreads();
-                store_halo();
+            // refill this slot for stage it + 2 (its state becomes sc)
+            sc = sn;
+            if (it + 2 < it1) {
+                iter_advance(sc, a);
+                if (!(a.dbg & 1)) load_b(sc, c0, c1);
             }
-            store_b(buf ^ 1);
-            __syncthreads();
-            st = nx;
+            if (new_halo) {
+                __syncthreads();          // every wave is done with the old halo
+                store_halo();
+                __syncthreads();
+            }
+        };
+        IterState sA = st;
+        for (int it = it0; it < it1; it += 2) {
+            step(it, sA, sB, bA0, bA1);
+            if (it + 1 < it1) step(it + 1, sB, sA, bB0, bB1);
         }
     }
 
-    const int oy = y0 + wave;
+    if (EPI == LU_EPI_LSTM) {
+        // exchange: wave (wm, wn) holds gate wn of rows 4 wm .. 4 wm + 3; the gate epilogue wants the four gates of a
+        // (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
+        float* Ex = reinterpret_cast<float*>(Ah);      // [2 row groups][32 px][EX_LD]
+        const int ch = tid & 31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (oy >= a.Hin || ox >= a.Win) continue;
-        const int64_t pix = (int64_t)oy * a.Win + ox;
-        float v[NF];
+        for (int i = 0; i < RW; ++i) {
+            __syncthreads();                            // pass 0: all halo reads finished; later: previous pass consumed
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) v[nf] = acc[nf][r];
-        conv_epilogue_row<NF, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0, ks, lane & 31);
+            for (int r = 0; r < 16; ++r) {
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Ex[(wm * TW + px) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pr = (tid >> 5) + 16 * e;     // (row group, pixel) pair 0..63
+                const int g = pr >> 5, px = pr & 31;
+                const int oy = y0 + RW * g + i, ox = x0 + px;
+                if (oy >= a.Hin || ox >= a.Win) continue;
+                const int64_t pix = (int64_t)oy * a.Win + ox;
+                float v[4];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) v[nf] = Ex[(g * TW + px) * EX_LD + 32 * nf + ch];
+                conv_epilogue_row<4, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0, ks, ch);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int oy = y0 + RW * wm + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (oy >= a.Hin || ox >= a.Win) continue;
+            const int64_t pix = (int64_t)oy * a.Win + ox;
+            float v[1] = {acc[i][r]};
+            conv_epilogue_row<1, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0 + 32 * wn, ks, lane & 31);
+        }
     }
 }
 
@@ -1001,7 +1060,15 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.out_row_stride = d->out_row_stride;
     int64_t m_tiles = (a.M + BM - 1) / BM;
     // halo-reuse kernel: stride-1 SAME 3x3 / 5x5, wide 16-byte-aligned outputs, <= 25 % of the 8x32 patches wasted
-    const int64_t tiles_y = (d->Hout + 7) / 8, tiles_x = (d->Wout + 31) / 32;
+    const int64_t tiles_x = (d->Wout + 31) / 32;
+    int th = 8;      // patch height; the bf16 kernel takes 16-row patches when that still leaves >= 1 block per CU
+    if (d->precision == 1 && d->k == 5) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
+        const int64_t nt_est = d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128;
+        const char* force = getenv("LU_CONV_BF16_PATCH");      // "8" / "16": tests and A/B runs
+        const int64_t sp = d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits;
+        if (force ? atoi(force) == 16 : (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * nt_est * sp >= 256) th = 16;
+    }
+    const int64_t tiles_y = (d->Hout + th - 1) / th;
     const bool halo = d->stride == 1 && d->dil == 1 && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
                       a.n_src > 0 && d->out_row_stride == 0 &&
@@ -1041,8 +1108,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
-        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 8>), grid, dim3(512), stream, a);
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 4>), grid, dim3(512), stream, a);
+        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_LSTM, 4>), grid, dim3(512), stream, a);
         else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
@@ -1063,8 +1131,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
-        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
+        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 8>), grid, dim3(512), stream, a); \
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 4>), grid, dim3(512), stream, a); \
+        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_BIAS, 4>), grid, dim3(512), stream, a);   \
         else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \
@@ -1103,13 +1172,13 @@ extern "C" int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int k
 }
 
 extern "C" size_t lu_pack_weights_bf16_bytes(int k, int C, int N) {
-    return (size_t)k * k * ((C + CKB - 1) / CKB) * (size_t)N * CKB * sizeof(unsigned short);
+    return (size_t)k * k * ((C + CKB - 1) / CKB) * (size_t)((N + 31) / 32) * 1024 * sizeof(unsigned short);
 }
 
 extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N,
                                     void* out, lu_stream_t stream) {
     LU_REQUIRE(w && out && k > 0 && C > 0 && N > 0, "lu_pack_weights_bf16: bad arguments");
-    const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * N * CKB;
+    const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 1024;
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N,
               (unsigned short*)out);

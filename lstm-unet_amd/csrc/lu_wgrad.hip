@@ -360,14 +360,16 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 
-template <int K>
-__global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
-    constexpr int BMw = 64, BNw = 128, XP = PRB + K - 1, NT = 512;
-    constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 elements per LDS row
+template <int K, int CT>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+__global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
+    constexpr int BMw = CT, BNw = 128, XP = PRB + K - 1, NT = 512;
+    constexpr int WMC = CT / 32, WNN = 8 / WMC, NFW = BNw / (32 * WNN);
+    constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 per LDS row: pitch = 64 B (mod 256 B)
+    constexpr int XQ = BMw / 4, XPASS = (XP * XQ + NT - 1) / NT, YPASS = PRB * (BNw / 4) / NT;
     __shared__ __attribute__((aligned(16))) unsigned short Xs[2][XP * XLD];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[2][PRB * YLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WMC, wn = wave / WMC;
     const int n0 = blockIdx.x * BNw;
     const int kh = blockIdx.y / a.c_tiles;
     const int c0 = (blockIdx.y - kh * a.c_tiles) * BMw;
@@ -386,23 +388,26 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
         oy = r / a.Wout;
         ox0 = r - oy * a.Wout;
     }
-    // x tile: XP rows x 16 float4 (two passes, the second one partial); dy tile: 32 rows x 32 float4 (two passes)
-    const int xrow0 = tid >> 4, xq = tid & 15, xrow1 = xrow0 + NT / 16;
-    const int yrow0 = tid >> 5, yq = tid & 31, yrow1 = yrow0 + NT / 32;
-    float4 rx0 = make_float4(0.f, 0.f, 0.f, 0.f), rx1 = rx0, ry0 = rx0, ry1 = rx0;
+    // x tile: XP rows x XQ float4; dy tile: 32 rows x 32 float4 -- item = tid + 512 * pass
+    const int xq = tid % XQ, xr0 = tid / XQ;
+    const int yq = tid & 31, yr0 = tid >> 5;
+    float4 rx[XPASS], ry[YPASS];
     auto load_stage = [&]() {
         const int iy = oy + kh - a.pad_t;
         const int c = c0 + 4 * xq;
         const bool rowok = iy >= 0 && iy < a.Hin && c < a.C;
         const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + (ox0 - a.pad_l)) * a.x_ps + c;
-        const int ix0 = ox0 - a.pad_l + xrow0, ix1 = ox0 - a.pad_l + xrow1;
-        rx0 = *reinterpret_cast<const float4*>((rowok && ix0 >= 0 && ix0 < a.Win) ? px + (int64_t)xrow0 * a.x_ps : zp);
-        rx1 = *reinterpret_cast<const float4*>((rowok && xrow1 < XP && ix1 >= 0 && ix1 < a.Win) ? px + (int64_t)xrow1 * a.x_ps
-                                                                                               : zp);
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int xr = xr0 + i * (NT / XQ);
+            const int ix = ox0 - a.pad_l + xr;
+            rx[i] = *reinterpret_cast<const float4*>((rowok && xr < XP && ix >= 0 && ix < a.Win) ? px + (int64_t)xr * a.x_ps : zp);
+        }
         const int n = n0 + 4 * yq;
         const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n;
-        ry0 = *reinterpret_cast<const float4*>(n < a.N ? py + (int64_t)yrow0 * a.dy_ps : zp);
-        ry1 = *reinterpret_cast<const float4*>(n < a.N ? py + (int64_t)yrow1 * a.dy_ps : zp);
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i)
+            ry[i] = *reinterpret_cast<const float4*>(n < a.N ? py + (int64_t)(yr0 + i * (NT / 32)) * a.dy_ps : zp);
     };
     auto put = [&](unsigned short* dst, const float4& v) {
         unsigned* d2 = reinterpret_cast<unsigned*>(dst);
@@ -410,10 +415,13 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
         d2[1] = lu_pack2bf(v.z, v.w);
     };
     auto store_stage = [&](int buf) {
-        put(&Xs[buf][xrow0 * XLD + 4 * xq], rx0);
-        if (xrow1 < XP) put(&Xs[buf][xrow1 * XLD + 4 * xq], rx1);
-        put(&Ys[buf][yrow0 * YLD + 4 * yq], ry0);
-        put(&Ys[buf][yrow1 * YLD + 4 * yq], ry1);
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int xr = xr0 + i * (NT / XQ);
+            if (xr < XP) put(&Xs[buf][xr * XLD + 4 * xq], rx[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) put(&Ys[buf][(yr0 + i * (NT / 32)) * YLD + 4 * yq], ry[i]);
     };
     auto advance = [&]() {
         ox0 += PRB;
@@ -426,11 +434,13 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
         }
     };
 
-    f32x16 acc[K];
+    f32x16 acc[K][NFW];
 #pragma unroll
     for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nf][r] = 0.f;
 
     if (n_it > 0) {
         load_stage();
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
     // columns 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
     const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const int xoff = frow * XLD + wm * 32 + fcol, yoff = frow * YLD + wn * 32 + fcol;
+    const int xoff = frow * XLD + wm * 32 + fcol, yoff = frow * YLD + wn * 32 * NFW + fcol;
     auto frag = [&](const unsigned short* base, int ld) {      // 8 consecutive k (rows) of this lane's column
         const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + 4 * ld);
         lu_bf16x8 v;
@@ -457,11 +467,14 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
         LU_SCHED_FENCE();
 #pragma unroll
         for (int j = 0; j < PRB / 16; ++j) {
-            const lu_bf16x8 bv = frag(&Ys[buf][yoff + 16 * j * YLD], YLD);
+            lu_bf16x8 bv[NFW];
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf][yoff + 16 * j * YLD + 32 * nf], YLD);
 #pragma unroll
             for (int t = 0; t < K; ++t) {
                 const lu_bf16x8 av = frag(&Xs[buf][xoff + (16 * j + t) * XLD], XLD);
-                acc[t] = lu_mfma_bf16(av, bv, acc[t]);
+#pragma unroll
+                for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
             }
         }
         LU_SCHED_FENCE();
@@ -474,11 +487,13 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_bf16_kernel(WgradArgs a) {
     for (int t = 0; t < K; ++t) {
         const int tap = kh * K + t;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int n = n0 + wn * 32 + l31;
-            if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][r];
-        }
+        for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 32 * NFW + 32 * nf + l31;
+                if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][nf][r];
+            }
     }
 }
 
@@ -548,10 +563,14 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
                              d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
     if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
-        a.c_tiles = (d->C + 63) / 64;
+        const char* force = getenv("LU_WGRAD_BF16_CT");         // "64" / "128": tests and A/B runs
+        const int ct = force ? atoi(force) : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
+        a.c_tiles = (d->C + ct - 1) / ct;
         dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
-        if (d->k == 5) LU_LAUNCH((wgrad_row_bf16_kernel<5>), grid, dim3(512), stream, a);
-        else LU_LAUNCH((wgrad_row_bf16_kernel<3>), grid, dim3(512), stream, a);
+        if (d->k == 5 && ct == 128) LU_LAUNCH((wgrad_row_bf16_kernel<5, 128>), grid, dim3(512), stream, a);
+        else if (d->k == 5) LU_LAUNCH((wgrad_row_bf16_kernel<5, 64>), grid, dim3(512), stream, a);
+        else if (ct == 128) LU_LAUNCH((wgrad_row_bf16_kernel<3, 128>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((wgrad_row_bf16_kernel<3, 64>), grid, dim3(512), stream, a);
     } else if (row_variant) {
         a.c_tiles = (d->C + 63) / 64;
         dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);

@@ -94,7 +94,13 @@ def test_conv_halo_variant(be):
     close(gates[..., F:2 * F], npo.hard_sigmoid(z[..., F:2 * F]), 2e-5)
 
 
-def test_conv_bf16_mfma_variant(be):
+@pytest.mark.parametrize('patch', ['8', '16'])
+def test_conv_bf16_mfma_variant(be, patch, monkeypatch):
+    monkeypatch.setenv('LU_CONV_BF16_PATCH', patch)       # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks)
+    _conv_bf16_cases(be)
+
+
+def _conv_bf16_cases(be):
     """Mixed-precision halo kernel (precision = 1): operands rounded to bf16, fp32 accumulation.  Against the oracle
     on the SAME bf16-rounded operands only the summation order differs (tolerance as for the fp32 kernels); against
     the unrounded oracle the error is the bf16 operand rounding (2^-9 relative per operand)."""
@@ -190,7 +196,13 @@ def test_wgrad_wide_channels_and_beta(be):
     close(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=2), gw, 2e-4)
 
 
-def test_wgrad_bf16_mfma_variant(be):
+@pytest.mark.parametrize('ct', ['64', '128'])
+def test_wgrad_bf16_mfma_variant(be, ct, monkeypatch):
+    monkeypatch.setenv('LU_WGRAD_BF16_CT', ct)         # 64- and 128-channel block tiles
+    _wgrad_bf16_cases(be)
+
+
+def _wgrad_bf16_cases(be):
     """Kernel-row weight gradient on the bf16 MFMA (precision = 1, W % 32 == 0): x and dy rounded to bf16, fp32
     accumulation -- exact up to summation order against the fp32 reference on bf16-rounded operands.  Shapes the bf16
     kernel does not cover (W % 32 != 0) silently stay on the fp32 kernels."""
