@@ -77,7 +77,8 @@ typedef struct lu_conv_desc {
     int32_t precision;              /* 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: bf16 MFMA operands, fp32 accumulate
                                      * (v_mfma_f32_32x32x16_bf16) -- activations stay fp32 in HBM and are rounded to bf16 while
                                      * staged; every src[i].w must then point to weights packed by lu_pack_weights_bf16
-                                     * (w_tap_stride / w_row_stride ignored).  Stride-1 3x3 / 5x5, N > 64 only. */
+                                     * (w_tap_stride / w_row_stride ignored).  Stride-1 3x3 / 5x5, N > 64, 16-byte aligned sources
+                                     * with C % 4 == 0 only (pad a thin input with zero channels: the packed image is zero there). */
     void* workspace;
     int64_t out_row_stride;         /* elements between output rows; 0 = dense (Wout * out_pix_stride).  Lets a launch
                                      * write one parity plane of a stride-2 input gradient in place. */

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <type_traits>
 #include "lu_device.h"
 
 namespace {
@@ -735,12 +736,13 @@ template <int K, int EPI, int RW>      // RW = patch rows per wave: 4 (8 x 32 pa
 __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
     constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
-    constexpr int HPASS = (HP * 8 + NT - 1) / NT;      // float4 (4 channels) loads per thread per halo
+    constexpr int HPASS = (HP * 8 + NT - 1) / NT;      // halo pieces: one float4 (4 channels of one pixel) per thread each
     constexpr int PAD = (K - 1) / 2;
     constexpr int EX_LD = BN + 4;                      // floats per pixel of the gate-exchange buffer
-    constexpr int AH_ELEMS = HP * LDB;
-    constexpr int EX_ELEMS = (EPI == LU_EPI_LSTM) ? 2 * TW * EX_LD * 2 : 0;     // in 16-bit units
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[AH_ELEMS > EX_ELEMS ? AH_ELEMS : EX_ELEMS];
+    constexpr int AH_ELEMS = HP * LDB;                 // one halo image; two of them live in dynamic LDS
+    static_assert(HPASS + 2 <= K * K, "the next halo is fetched one piece per tap and stored two taps later");
+    static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 2 <= 2 * AH_ELEMS, "gate exchange aliases the two halo images");
+    LU_DYN_LDS(unsigned short, Ah);                    // [2][AH_ELEMS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -755,63 +757,65 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
     const int n0 = nt * BN;
     const int ks = blockIdx.y;
     const float* const zp = lu_zero16;
-
-    int hoff[HPASS];
-    bool hok[HPASS];
-#pragma unroll
-    for (int i = 0; i < HPASS; ++i) {
-        const int hp = (tid + NT * i) >> 3;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        hok[i] = hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        hoff[i] = iy * a.Win + ix;
-    }
     const int q = tid & 7;                 // 4-channel group inside the 32-channel chunk
     // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
     const int nfr = (a.N + 31) >> 5;
     const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
     const bool frag_ok = frag < nfr;
-
-    float4 rh[HPASS];
-    auto load_halo = [&](const IterState& st) {
-        const SrcInfo& si = a.src[st.s];
-        const int c = st.chunk * CKB + 4 * q;
-        const float* base = si.x + (int64_t)f * si.frame_stride + c;
-        if (si.thin) {       // C % 4 != 0 or unaligned rows (the 1-channel image): per-channel scalar loads
-#pragma unroll
-            for (int i = 0; i < HPASS; ++i) {
-                const float* p = base + (int64_t)hoff[i] * si.pix_stride;
-                rh[i].x = *((hok[i] && c + 0 < si.C) ? p + 0 : zp);
-                rh[i].y = *((hok[i] && c + 1 < si.C) ? p + 1 : zp);
-                rh[i].z = *((hok[i] && c + 2 < si.C) ? p + 2 : zp);
-                rh[i].w = *((hok[i] && c + 3 < si.C) ? p + 3 : zp);
-            }
-            return;
+    // Per-source fields live in registers and are picked with selects: indexing a.src[st.s] inside the tap loop costs a
+    // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
+    const float* const x_s0 = a.src[0].x + (int64_t)f * a.src[0].frame_stride;
+    const float* const x_s1 = a.src[1].x + (int64_t)f * a.src[1].frame_stride;
+    const unsigned short* const w_s0 = reinterpret_cast<const unsigned short*>(a.src[0].w) + (int64_t)frag * 1024 + lane * 8;
+    const unsigned short* const w_s1 = reinterpret_cast<const unsigned short*>(a.src[1].w) + (int64_t)frag * 1024 + lane * 8;
+    const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
+    const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
+    const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
+    const int kk = K * K;
+    auto tap_advance = [&](IterState& st) {          // iter_advance without the kernarg look-ups
+        ++st.tap;
+        if (++st.kw == K) {
+            st.kw = 0;
+            ++st.kh;
         }
-#pragma unroll
-        for (int i = 0; i < HPASS; ++i) {
-            const float* p = base + (int64_t)hoff[i] * si.pix_stride;
-            rh[i] = *reinterpret_cast<const float4*>((hok[i] && c < si.C) ? p : zp);
+        if (st.tap < kk) return;
+        st.tap = st.kh = st.kw = 0;
+        if (++st.chunk == (st.s ? nch_s1 : nch_s0)) {
+            st.chunk = 0;
+            ++st.s;
         }
     };
-    auto store_halo = [&]() {
-#pragma unroll
-        for (int i = 0; i < HPASS; ++i) {
-            const int hp = (tid + NT * i) >> 3;
-            if (hp < HP) {
-                const unsigned lo = lu_pack2bf(rh[i].x, rh[i].y);
-                const unsigned hi = lu_pack2bf(rh[i].z, rh[i].w);
-                unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hp * LDB + 4 * q]);
-                dst[0] = lo;
-                dst[1] = hi;
-            }
+    auto next_chunk = [&](IterState& st) {            // first tap of the next chunk
+        st.tap = st.kh = st.kw = 0;
+        if (++st.chunk == (st.s ? nch_s1 : nch_s0)) {
+            st.chunk = 0;
+            ++st.s;
+        }
+    };
+
+    // piece p of the halo of chunk `st`: pixel hp = (tid + 512 p) / 8, channels 4 q .. 4 q + 3 (recomputed per use: the
+    // addressing is a handful of integer ops once per K*K MFMA stages, the registers are worth more)
+    auto piece_load = [&](int p, const IterState& st, float4& r, bool want) {
+        const int hp = (tid + NT * p) >> 3;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        const bool ok = want && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int c = st.chunk * CKB + 4 * q;
+        const float* pp = (st.s ? x_s1 : x_s0) + (int64_t)(iy * a.Win + ix) * (st.s ? ps_s1 : ps_s0) + c;
+        r = *reinterpret_cast<const float4*>((ok && c < (st.s ? C_s1 : C_s0)) ? pp : zp);      // (16-byte aligned, C % 4 == 0)
+    };
+    auto piece_store = [&](int p, int hb, const float4& r) {
+        const int hp = (tid + NT * p) >> 3;
+        if (hp < HP) {
+            unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hb * AH_ELEMS + hp * LDB + 4 * q]);
+            dst[0] = lu_pack2bf(r.x, r.y);
+            dst[1] = lu_pack2bf(r.z, r.w);
         }
     };
     // B fragments of one stage (two k-steps), straight from the packed weights
     auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
-        const SrcInfo& si = a.src[st.s];
-        const unsigned short* wp = reinterpret_cast<const unsigned short*>(si.w) +
-                                   (((int64_t)st.tap * si.nchunk + st.chunk) * nfr + frag) * 1024 + lane * 8;
+        const unsigned short* wp = (st.s ? w_s1 : w_s0) +
+                                   ((int64_t)st.tap * (st.s ? nch_s1 : nch_s0) + st.chunk) * nfr * 1024;
         const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : zp;
         const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 512) : zp;
         b0 = *reinterpret_cast<const float4*>(p0);
@@ -825,80 +829,138 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int khalf8 = 8 * (lane >> 5);
-    auto mma_stage = [&](const IterState& st, const float4& b0, const float4& b1) {
+    auto mma_stage = [&](const IterState& st, int hb, const float4& b0, const float4& b1) {
         const int arow = (RW * wm + st.kh) * HWD + (lane & 31) + st.kw;
+        const unsigned short* ab = &Ah[hb * AH_ELEMS + arow * LDB + khalf8];
         const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
-        // k-step 0 for every row, then k-step 1: back-to-back MFMAs never depend on each other
+        // k-step 0 for every row, then k-step 1 (back-to-back MFMAs never depend on each other); all k-step-0 fragments
+        // are requested up front and every k-step-1 read hides behind a k-step-0 MFMA
+#ifdef LU_ABL_NOLDS      // ablation build: MFMAs without the LDS fragment reads
+#pragma unroll
+        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv1, bv0, acc[i]);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv0, bv1, acc[i]);
+        (void)ab;
+        return;
+#endif
+        lu_bf16x8 a0[RW], a1[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * LDB);
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const lu_bf16x8 a0 = *reinterpret_cast<const lu_bf16x8*>(&Ah[(arow + i * HWD) * LDB + khalf8]);
-            acc[i] = lu_mfma_bf16(a0, bv0, acc[i]);
+            acc[i] = lu_mfma_bf16(a0[i], bv0, acc[i]);
+            a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * LDB + 16);
         }
 #pragma unroll
+        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
+        LU_SCHED_GROUP(0x100, RW);
+#pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const lu_bf16x8 a1 = *reinterpret_cast<const lu_bf16x8*>(&Ah[(arow + i * HWD) * LDB + khalf8 + 16]);
-            acc[i] = lu_mfma_bf16(a1, bv1, acc[i]);
+            LU_SCHED_GROUP(0x008, 1);
+            LU_SCHED_GROUP(0x100, 1);
         }
+        LU_SCHED_GROUP(0x008, RW);
     };
 
+    // K split: whole chunks per slice, so that every block starts at tap 0 of a chunk
     int it0 = 0, it1 = a.n_it;
     if (a.ksplit > 1) {
-        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
-        it0 = ks * per;
+        const int chunks = a.n_it / kk;
+        const int per = (chunks + a.ksplit - 1) / a.ksplit * kk;
+        it0 = ks * per < a.n_it ? ks * per : a.n_it;
         it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
     }
     if (it1 > it0) {
         IterState st{0, 0, 0, 0, 0};
         {
             int r = it0;
-            while (r >= a.src[st.s].nchunk * a.kk) {
-                r -= a.src[st.s].nchunk * a.kk;
-                ++st.s;
+            if (r >= nch_s0 * kk) {
+                r -= nch_s0 * kk;
+                st.s = 1;
             }
-            st.chunk = r / a.kk;
-            st.tap = r - st.chunk * a.kk;
-            st.kh = st.tap / K;
-            st.kw = st.tap - st.kh * K;
+            st.chunk = r / kk;       // r is a multiple of kk: tap = 0
         }
-        // register ring of B fragments: slot A = stage it, slot B = stage it + 1; a slot is refilled for stage it + 2
-        // as soon as its MFMAs have been issued
-        float4 bA0, bA1, bB0, bB1;
-        IterState sB = st;                       // state of stage it + 1 (clamped at the last stage)
-        if (it0 + 1 < it1) iter_advance(sB, a);
-        load_halo(st);
-        load_b(st, bA0, bA1);
-        load_b(sB, bB0, bB1);
-        store_halo();
+        // Register ring of B fragments, D stages deep: slot s holds stage it0 + s (mod D) and is refilled for the stage D
+        // further on as soon as its MFMAs are issued -- the distance has to cover the L2 latency under load.
+        constexpr int D = (RW == 8) ? 4 : 2;
+        float4 rb0[D], rb1[D];
+        IterState sS[D];
+        sS[0] = st;
+#pragma unroll
+        for (int j = 1; j < D; ++j) {
+            sS[j] = sS[j - 1];
+            if (it0 + j < it1) tap_advance(sS[j]);       // (clamped at the last stage)
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) load_b(sS[j], rb0[j], rb1[j]);
+        {
+            float4 rh[HPASS];                    // first halo: all pieces at once
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_load(p, st, rh[p], true);
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_store(p, 0, rh[p]);
+        }
         __syncthreads();
-        // one pipeline step: stage `it` with fragments (c0, c1) at state sc; sn = state of stage it + 1
-        auto step = [&](int it, IterState& sc, IterState& sn, float4& c0, float4& c1) {
-            const bool new_halo = (it + 1 < it1) && sn.tap == 0;
-            if (new_halo && !(a.dbg & 1)) load_halo(sn);
+        int hb = 0;                              // halo image in use
+        IterState nc = st;                       // chunk after the current one (valid while it exists)
+        next_chunk(nc);
+        float4 rp[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        int pend[2] = {-1, -1};
+        // One pipeline step = stage `it` in ring slot s.  While a chunk's taps run, the NEXT chunk's halo is fetched one
+        // piece per tap into the other LDS image (two staging registers, alternating with the stage parity).
+        auto step = [&](int it, auto slot) {
+            constexpr int s = decltype(slot)::value;
+            IterState& sc = sS[s];
+            const bool fetch = sc.tap < HPASS && it - sc.tap + kk < it1;      // a next chunk exists in this slice
+            const bool last_tap = sc.tap == kk - 1;
             LU_SCHED_FENCE();
-            if (!(a.dbg & 8)) mma_stage(sc, c0, c1);
+            mma_stage(sc, hb, rb0[s], rb1[s]);
             LU_SCHED_FENCE();
-            // refill this slot for stage it + 2 (its state becomes sc)
-            sc = sn;
-            if (it + 2 < it1) {
-                iter_advance(sc, a);
-                if (!(a.dbg & 1)) load_b(sc, c0, c1);
+            // The piece requested two stages ago is older than the B fragments the MFMAs above just waited for, so it has
+            // landed: no extra vmcnt wait.  Then request this tap's piece and refill the B slot for stage it + D.
+            // A piece load is issued every stage (the zero block when there is nothing to fetch) and the loop body has no
+            // conditional step: the number of loads in flight is then the same on every path and the compiler's vmcnt
+            // waits stay exact (a path-dependent count makes it wait for the youngest load, i.e. HBM latency per stage).
+            if (pend[s & 1] >= 0) {
+                piece_store(pend[s & 1], hb ^ 1, rp[s & 1]);
+                pend[s & 1] = -1;
             }
-            if (new_halo) {
-                __syncthreads();          // every wave is done with the old halo
-                store_halo();
-                __syncthreads();
+#ifndef LU_ABL_NOLOAD
+            piece_load(fetch ? sc.tap : 0, fetch ? nc : sc, rp[s & 1], fetch);
+#endif
+            if (fetch) pend[s & 1] = sc.tap;
+            sc = sS[(s + D - 1) % D];            // state of stage it + D - 1 ...
+            if (it + D < it1) tap_advance(sc);      // ... + 1 (past the end: re-reads the last fragments, unused)
+#ifndef LU_ABL_NOLOAD
+            load_b(sc, rb0[s], rb1[s]);
+#endif
+            if (last_tap && it + 1 < it1) {      // (HPASS + 2 <= K*K: the staged pieces have been retired by now)
+                __syncthreads();          // the next halo is complete and every wave is done with the old one
+                hb ^= 1;
+                next_chunk(nc);
             }
         };
-        IterState sA = st;
-        for (int it = it0; it < it1; it += 2) {
-            step(it, sA, sB, bA0, bA1);
-            if (it + 1 < it1) step(it + 1, sB, sA, bB0, bB1);
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2 % D>;
+        using S3 = std::integral_constant<int, 3 % D>;
+        int it = it0;
+        for (; it + D <= it1; it += D) {
+            step(it, S0());
+            step(it + 1, S1());
+            if (D == 4) {
+                step(it + 2, S2());
+                step(it + 3, S3());
+            }
         }
+        if (it < it1) step(it, S0());
+        if (it + 1 < it1) step(it + 1, S1());
+        if (D == 4 && it + 2 < it1) step(it + 2, S2());
     }
 
     if (EPI == LU_EPI_LSTM) {
-        // exchange: wave (wm, wn) holds gate wn of rows 4 wm .. 4 wm + 3; the gate epilogue wants the four gates of a
-        // (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
+        // exchange: wave (wm, wn) holds gate wn of rows RW wm .. RW wm + RW - 1; the gate epilogue wants the four gates of
+        // a (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
         float* Ex = reinterpret_cast<float*>(Ah);      // [2 row groups][32 px][EX_LD]
         const int ch = tid & 31;
 #pragma unroll
@@ -1004,6 +1066,9 @@ __global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __re
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// dynamic LDS of conv_halo_bf16_kernel<K, *, RW>: two bf16 halo images
+size_t halo_bf16_lds(int K, int RW) { return (size_t)2 * (2 * RW + K - 1) * (32 + K - 1) * LDB * sizeof(unsigned short); }
+
 }  // namespace
 
 extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
@@ -1036,6 +1101,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         si.thin = vec ? 0 : 1;
         si.nchunk = vec ? (in.C + CK - 1) / CK : (a.kk * in.C + CK - 1) / CK;
         if (d->precision == 1) {     // bf16 operands: 32-channel chunks, packed weights (lu_pack_weights_bf16)
+            LU_REQUIRE(vec, "lu_conv2d_fwd: bf16 mode needs 16-byte aligned sources with C %% 4 == 0 (source %d); pad thin "
+                            "inputs with zero channels", s);
             si.nchunk = (in.C + CKB - 1) / CKB;
             a.n_it += si.nchunk * a.kk;
         } else if (vec) {
@@ -1108,9 +1175,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 8>), grid, dim3(512), stream, a);
-        else if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 4>), grid, dim3(512), stream, a);
-        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_LSTM, 4>), grid, dim3(512), stream, a);
+        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 8>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 4>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_bf16_kernel<3, LU_EPI_LSTM, 4>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
@@ -1131,9 +1198,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 8>), grid, dim3(512), stream, a); \
-        else if (d->precision == 1 && d->k == 5) LU_LAUNCH((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 4>), grid, dim3(512), stream, a); \
-        else if (d->precision == 1) LU_LAUNCH((conv_halo_bf16_kernel<3, LU_EPI_BIAS, 4>), grid, dim3(512), stream, a);   \
+        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 8>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a); \
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 4>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a); \
+        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_bf16_kernel<3, LU_EPI_BIAS, 4>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);   \
         else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \

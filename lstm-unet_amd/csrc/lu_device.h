@@ -11,6 +11,8 @@
 #include "emu_runtime.h"
 #define LU_LAUNCH(kernel, grid, block, stream, ...) \
     lu_emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+#define LU_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...) LU_LAUNCH(kernel, grid, block, stream, __VA_ARGS__)
+#define LU_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(lu_emu::g_dyn_lds)
 static inline f32x16 lu_mfma(float a, float b, f32x16 c) { return lu_emu::mfma_32x32x2(a, b, c); }
 static inline f32x16 lu_mfma_bf16(lu_bf16x8 a, lu_bf16x8 b, f32x16 c) { return lu_emu::mfma_32x32x16_bf16(a, b, c); }
 static inline lu_bf16x4 lu_lds_tr16(const unsigned short* p) { return lu_emu::lds_read_tr16_b64(p); }
@@ -23,11 +25,24 @@ static inline void lu_glds16(const float* gptr, float* lds_wave_base) {
 }
 #define LU_CHECK_LAUNCH() 0
 #define LU_SCHED_FENCE() ((void)0)
+#define LU_SCHED_GROUP(mask, n) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LU_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+// launch with `lds_bytes` of dynamic LDS (extern __shared__); beyond the 64 KB static limit the kernel has to opt in once
+#define LU_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...)                                                  \
+    do {                                                                                                            \
+        static bool lu_dyn_ready_ = false;                                                                          \
+        if (!lu_dyn_ready_) {                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+            lu_dyn_ready_ = true;                                                                                   \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kernel, (grid), (block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__);               \
+    } while (0)
+#define LU_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain; 64 cycles / SIMD
 __device__ __forceinline__ f32x16 lu_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -58,6 +73,9 @@ __device__ __forceinline__ void lu_glds16(const float* gptr, float* lds_wave_bas
 // pins instruction order across this point: sched_barrier stops the machine scheduler, the empty asm with a
 // memory clobber stops the IR optimiser (which otherwise hoists the next stage's LDS stores -- and the vmcnt
 // wait they need -- above the MFMA block, destroying the load/compute overlap).  Emits no instruction.
+// scheduling recipe for the instructions between two fences: "next come n instructions of class `mask`"
+// (0x008 MFMA, 0x020 VMEM read, 0x100 LDS read, 0x200 LDS write)
+#define LU_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #define LU_SCHED_FENCE()                      \
     do {                                      \
         __builtin_amdgcn_sched_barrier(0);    \

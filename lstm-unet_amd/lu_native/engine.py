@@ -163,7 +163,9 @@ class Engine:
         """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151)."""
         wname = f'{prefix}.conv.{ci}.kernel'
         w = self.P[wname]
-        if self._bf16_conv(w.shape[0], spec['stride'], w.shape[3]):
+        vec = all(x.shape[3] % 4 == 0 and x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                  for (x, _, _) in srcs)      # the bf16 kernel reads 16-byte channel groups
+        if vec and self._bf16_conv(w.shape[0], spec['stride'], w.shape[3]):
             pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs: w[:, :, co:co + cs, :], co, cs)) for (x, co, cs) in srcs]
         else:
             pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
@@ -235,6 +237,11 @@ class Engine:
             c_all[0].copy_(st[1])
         gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32) if tape is not None else None
         x5 = x_seq.view(T, B, H, W, -1)
+        if isinstance(kernel, ops.PackedW) and x_seq.shape[3] % 4 != 0:
+            # the bf16 kernel reads 16-byte channel groups: thin inputs (the 1-channel image) get zero pad channels
+            cpad = -(-x_seq.shape[3] // 4) * 4
+            x5 = torch.zeros((T, B, H, W, cpad), device=dev, dtype=torch.float32)
+            x5[..., :x_seq.shape[3]] = x_seq.view(T, B, H, W, -1)
         for t in range(T):
             ops.convlstm_step(x5[t], h_all[t], c_all[t], kernel, rec_k, bias, h_all[t + 1], c_all[t + 1],
                               gates[t] if gates is not None else None)

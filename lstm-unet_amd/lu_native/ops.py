@@ -91,7 +91,9 @@ def pack_bf16(w):
 def _src(x, w):
     """x: [frames,H,W,C] (channel-slice views allowed), w: [k,k,C,N] (channel-slice views allowed) or PackedW."""
     if isinstance(w, PackedW):
-        assert x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2) and w.shape[2] == x.shape[3]
+        # x may carry zero pad channels beyond the kernel's (thin inputs padded to 4): same number of 32-channel chunks
+        assert x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2)
+        assert x.shape[3] >= w.shape[2] and -(-x.shape[3] // 32) == -(-w.shape[2] // 32), (x.shape, w.shape)
         return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data.data_ptr(), 0, 0)
     assert x.dim() == 4 and w.dim() == 4 and x.stride(3) == 1 and w.stride(3) == 1, (x.shape, x.stride(), w.shape)
     assert x.stride(1) == x.shape[2] * x.stride(2), 'rows of x must be dense'
@@ -240,7 +242,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     if F % 32 == 0 and tiles >= FUSED_MIN_TILES:
         with _timed(('conv_halo_bf16_kernel<%d,LU_EPI_LSTM> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
                     'conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
-                    2.0 * k * k * (x_t.shape[3] + F) * 4 * F * frames * H * W):
+                    2.0 * k * k * (kernel.shape[2] + F) * 4 * F * frames * H * W):
             calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
                          4 * F, _p(bias), None, 0, 0,
                          lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),

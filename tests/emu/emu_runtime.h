@@ -57,6 +57,8 @@ struct Runtime {
     std::function<void()> body;
 };
 inline Runtime g_rt;
+// dynamic LDS (extern __shared__): one block runs at a time, so one 160 KB arena serves every launch
+alignas(16) inline unsigned char g_dyn_lds[160 * 1024];
 
 inline void yield_to_main() {
     if (!_setjmp(g_rt.cur->jb)) _longjmp(g_rt.main_jb, 1);

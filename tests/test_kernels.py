@@ -123,10 +123,14 @@ def _conv_bf16_cases(be):
     hg, cg, _ = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1)
     close(hg, h1, 3e-5)
     close(cg, c1, 3e-5)
-    xi, xh = rnd(1, 16, 32, 1), rnd(1, 16, 32, 40)                 # thin (1-channel image) + vector source
+    xi, xh = rnd(1, 16, 32, 1), rnd(1, 16, 32, 40)                 # 1-channel image (zero-padded to 4) + vector source
     wi, wh = rnd(5, 5, 1, 72, scale=0.3), rnd(5, 5, 40, 72, scale=0.1)
     ref = npo.conv2d_same(R(xi), R(wi)) + npo.conv2d_same(R(xh), R(wh))
-    close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1), ref, 5e-5)
+    xi4 = np.concatenate([xi, np.zeros((1, 16, 32, 3), np.float32)], -1)
+    wi4 = np.concatenate([wi, np.zeros((5, 5, 3, 72), np.float32)], 2)
+    close(KH.conv2d(be, [xi4, xh], [wi4, wh], None, 5, 1, precision=1), ref, 5e-5)
+    with pytest.raises(RuntimeError):                             # thin sources must be padded by the caller
+        KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1)
     with pytest.raises(RuntimeError):                             # strided convolutions are not covered in bf16 mode
         KH.conv2d(be, [rnd(1, 16, 32, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=1)
 

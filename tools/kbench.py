@@ -37,7 +37,8 @@ for name, hw, cin, F in levels:
         if 'bf16' in which:
             pk, ph = ops.pack_bf16(kx), ops.pack_bf16(kh)
             ho2, co2 = torch.empty_like(h), torch.empty_like(c)
-            timeit(lambda: ops.convlstm_step(x, h, c, pk, ph, b, ho2, co2, g), fl, 'lstm_step_fused_bf16 ' + name)
+            xp = x if cin % 4 == 0 else torch.cat([x, torch.zeros(B, hw, hw, 4 - cin % 4, device=dev)], -1)
+            timeit(lambda: ops.convlstm_step(xp, h, c, pk, ph, b, ho2, co2, g), fl, 'lstm_step_fused_bf16 ' + name)
             print('   max |h_bf16 - h_f32| = %.3e  (|h| max %.3f)' % ((ho2 - ho).abs().max().item(), ho.abs().max().item()))
     if 'dgrad' in which:
         dz = r(B, hw, hw, 4 * F)
