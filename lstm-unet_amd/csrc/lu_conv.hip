@@ -517,6 +517,30 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     const int n0 = nt * BN;
     const int ks = blockIdx.y;
     const float* const zp = lu_zero16;
+    // Per-source fields live in registers and are picked with selects: indexing a.src[st.s] inside the tap loop costs a
+    // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
+    const float* const x_s0 = a.src[0].x + (int64_t)f * a.src[0].frame_stride;
+    const float* const x_s1 = a.src[1].x + (int64_t)f * a.src[1].frame_stride;
+    const float* const w_s0 = a.src[0].w;
+    const float* const w_s1 = a.src[1].w;
+    const int64_t wts_s0 = a.src[0].w_tap_stride, wts_s1 = a.src[1].w_tap_stride;
+    const int wrs_s0 = a.src[0].w_row_stride, wrs_s1 = a.src[1].w_row_stride;
+    const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
+    const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
+    const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
+    auto tap_advance = [&](IterState& st) {          // iter_advance without the kernarg look-ups
+        ++st.tap;
+        if (++st.kw == K) {
+            st.kw = 0;
+            ++st.kh;
+        }
+        if (st.tap < K * K) return;
+        st.tap = st.kh = st.kw = 0;
+        if (++st.chunk == (st.s ? nch_s1 : nch_s0)) {
+            st.chunk = 0;
+            ++st.s;
+        }
+    };
 
     // ---- halo gather bookkeeping (independent of source / chunk) ----
     int hoff[HPASS];
@@ -537,13 +561,14 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     float4 rh[HPASS];
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_halo = [&](const IterState& st) {
-        const SrcInfo& si = a.src[st.s];
         const int c = st.chunk * CK + 4 * q;
-        const float* base = si.x + (int64_t)f * si.frame_stride + c;
+        const float* base = (st.s ? x_s1 : x_s0) + c;
+        const int ps = st.s ? ps_s1 : ps_s0;
+        const bool cok = c < (st.s ? C_s1 : C_s0);
 #pragma unroll
         for (int i = 0; i < HPASS; ++i) {
-            const float* p = base + (int64_t)hoff[i] * si.pix_stride;
-            rh[i] = *reinterpret_cast<const float4*>((hok[i] && c < si.C) ? p : zp);
+            const float* p = base + (int64_t)hoff[i] * ps;
+            rh[i] = *reinterpret_cast<const float4*>((hok[i] && cok) ? p : zp);
         }
     };
     auto store_halo = [&]() {
@@ -568,6 +593,13 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         }
         const float* wp = si.w + (int64_t)tap * si.w_tap_stride + (int64_t)c * si.w_row_stride + bcol;
         const bool ok = rok && ((EPI == LU_EPI_LSTM) || bcol < a.N);
+        rb = *reinterpret_cast<const float4*>(ok ? wp : zp);
+    };
+    auto load_bv = [&](const IterState& st) {          // vector sources: weight row (tap, 16 chunk + brow)
+        const int c = st.chunk * CK + brow;
+        const float* wp = (st.s ? w_s1 : w_s0) + (int64_t)st.tap * (st.s ? wts_s1 : wts_s0) +
+                          (int64_t)c * (st.s ? wrs_s1 : wrs_s0) + bcol;
+        const bool ok = c < (st.s ? C_s1 : C_s0) && ((EPI == LU_EPI_LSTM) || bcol < a.N);
         rb = *reinterpret_cast<const float4*>(ok ? wp : zp);
     };
     auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][brow * BN + 4 * bq]) = rb; };
@@ -656,7 +688,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             st.kw = st.tap - st.kh * K;
         }
         load_halo(st);
-        load_b(a.src[st.s], false, st.tap, st.chunk);
+        load_bv(st);
         store_halo();
         store_b(0);
         __syncthreads();
@@ -664,11 +696,11 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             const int buf = (it - it0) & 1;
             const int arow = (wave + st.kh) * HWD + (lane & 31) + st.kw;
             IterState nx = st;
-            if (it + 1 < it1) iter_advance(nx, a);
+            if (it + 1 < it1) tap_advance(nx);
             const bool new_halo = (it + 1 < it1) && nx.tap == 0;     // the next stage starts another (source, chunk)
             mma_group(buf, 0, arow);
             LU_SCHED_FENCE();
-            load_b(a.src[nx.s], false, nx.tap, nx.chunk);
+            load_bv(nx);
             if (new_halo) load_halo(nx);
             LU_SCHED_FENCE();
 #pragma unroll
