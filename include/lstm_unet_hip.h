@@ -123,6 +123,12 @@ typedef struct lu_wgrad_desc {
     int32_t precision;        /* 0: fp32 MFMA.  1: x and dy may be rounded to bf16 MFMA operands (fp32 accumulate) where the
                                * bf16 kernel applies (stride-1 3x3 / 5x5, C >= 64, W % 32 == 0); other shapes stay fp32 */
     void* workspace;          /* lu_conv2d_wgrad_workspace_bytes(d) bytes */
+    float* dbias;             /* optional: bias gradient dbias[n] = dbias_beta*dbias[n] + sum_p dy[p,n], summed on the side by
+                               * the kernel-row variants (stride-1 3x3 / 5x5, C >= 64, W % 16 == 0, 16-byte aligned operands;
+                               * an error otherwise -- use lu_colsum).  Replaces `tape.gradient` w.r.t. the Conv2D / ConvLSTM2D
+                               * bias (train2D.py:92) without a second pass over dy. */
+    float dbias_beta;
+    int32_t _pad3;
 } lu_wgrad_desc;
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

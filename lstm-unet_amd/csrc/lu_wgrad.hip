@@ -30,6 +30,7 @@ struct WgradArgs {
     int32_t c_tiles;
     float* ws;          // [splits][kk*C*N]
     int64_t slab;
+    float* bias_ws;     // [splits][N] column sums of dy (bias gradient), or null; kernel-row variants only
 };
 
 template <int MF, int NF, int WM, int WN, bool THIN, bool YVEC>
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     constexpr int BMw = 64, BNw = 128, XP = KP + K - 1, NT = 512;
     __shared__ __attribute__((aligned(16))) float Xs[2][XP * BMw];
     __shared__ __attribute__((aligned(16))) float Ys[2][KP * BNw];
+    __shared__ __attribute__((aligned(16))) float Bsum[KP * BNw];     // bias-gradient partial sums (kernel row 0 blocks only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int n0 = blockIdx.x * BNw;
@@ -274,6 +276,20 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     const int xrow = tid >> 4, xq = tid & 15;      // x tile: XP rows x 16 float4 (threads < XP*16)
     const int yrow = tid >> 5, yq = tid & 31;      // dy tile: 16 rows x 32 float4
     float4 rx = make_float4(0.f, 0.f, 0.f, 0.f), ry = make_float4(0.f, 0.f, 0.f, 0.f);
+    // bias gradient = column sums of dy: the blocks of kernel row 0 / channel tile 0 see every dy element of their
+    // (column tile, pixel slab) exactly once in `ry`, so they add it up on the side (exact fp32, no extra HBM pass).
+    // The running sums live in LDS, one float4 slot per loader thread: nothing is held in registers across the MFMAs.
+    const bool want_bias = a.bias_ws != nullptr && blockIdx.y == 0;
+    float4* const bslot = reinterpret_cast<float4*>(&Bsum[yrow * BNw + 4 * yq]);
+    if (want_bias) *bslot = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto bias_acc = [&]() {
+        float4 t = *bslot;
+        t.x += ry.x;
+        t.y += ry.y;
+        t.z += ry.z;
+        t.w += ry.w;
+        *bslot = t;
+    };
     auto load_stage = [&](int it) {
         const int iy = oy + kh - a.pad_t;
         const int ix = ox0 - a.pad_l + xrow;
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     if (n_it > 0) {
         load_stage(0);
         store_stage(0);
+        if (want_bias) bias_acc();
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -332,6 +349,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
         LU_SCHED_FENCE();
         store_stage(buf ^ 1);
+        if (want_bias && it + 1 < n_it) bias_acc();      // (the last iteration re-fetched its own run: not counted twice)
         LU_SCHED_FENCE();
         mma_pair(buf, KP - 2);
         __syncthreads();
@@ -346,6 +364,16 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
             const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int n = n0 + wn * 32 + l31;
             if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][r];
+        }
+    }
+    if (want_bias) {          // 16 row-threads per column group -> one sum per column (fixed order: deterministic)
+        const float* red = Bsum;
+        __syncthreads();
+        if (tid < BNw) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < KP; ++r) s += red[r * BNw + tid];
+            if (n0 + tid < a.N) a.bias_ws[(int64_t)blockIdx.z * a.N + n0 + tid] = s;
         }
     }
 }
@@ -392,6 +420,18 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
     const int xq = tid % XQ, xr0 = tid / XQ;
     const int yq = tid & 31, yr0 = tid >> 5;
     float4 rx[XPASS], ry[YPASS];
+    // bias gradient (see wgrad_row_kernel): summed from the fp32 values before they are rounded to bf16
+    const bool want_bias = a.bias_ws != nullptr && blockIdx.y == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto bias_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) {
+            bsum.x += ry[i].x;
+            bsum.y += ry[i].y;
+            bsum.z += ry[i].z;
+            bsum.w += ry[i].w;
+        }
+    };
     auto load_stage = [&]() {
         const int iy = oy + kh - a.pad_t;
         const int c = c0 + 4 * xq;
@@ -445,6 +485,7 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
     if (n_it > 0) {
         load_stage();
         store_stage(0);
+        if (want_bias) bias_acc();
     }
     __syncthreads();
     // this lane's address inside a 4-row x 32-column transposed fetch: row (lane & 15) >> 2 (+ 8 for the upper half-wave),
@@ -479,6 +520,7 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
         }
         LU_SCHED_FENCE();
         store_stage(buf ^ 1);
+        if (want_bias && it + 1 < n_it) bias_acc();      // (the last iteration re-fetched its own run)
         __syncthreads();
     }
 
@@ -494,6 +536,17 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
                 const int n = n0 + wn * 32 * NFW + 32 * nf + l31;
                 if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][nf][r];
             }
+    }
+    if (want_bias) {          // 16 row-threads per column group -> one sum per column (fixed order: deterministic)
+        float* red = reinterpret_cast<float*>(Ys[0]);       // 16 x 128 floats = 8 KB <= one dy tile (the loop ended with a barrier)
+        *reinterpret_cast<float4*>(&red[yr0 * BNw + 4 * yq]) = bsum;
+        __syncthreads();
+        if (tid < BNw) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < NT / 32; ++r) s += red[r * BNw + tid];
+            if (n0 + tid < a.N) a.bias_ws[(int64_t)blockIdx.z * a.N + n0 + tid] = s;
+        }
     }
 }
 
@@ -512,6 +565,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
     }
 }
 
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ ws, int N, int splits, float* __restrict__ dbias,
+                                         float beta) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * N + n];
+    dbias[n] = (beta != 0.f ? beta * dbias[n] : 0.f) + s;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -519,7 +581,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 extern "C" size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d) {
     if (!d) return 0;
     int splits = d->splits > 0 ? d->splits : 1;
-    return (size_t)splits * d->k * d->k * (size_t)d->C * d->N * sizeof(float);
+    return (size_t)splits * (d->k * d->k * (size_t)d->C + (d->dbias ? 1 : 0)) * d->N * sizeof(float);
 }
 
 extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
@@ -551,6 +613,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.pad_l = d->pad_l;
     a.ws = (float*)d->workspace;
     a.slab = (int64_t)a.kk * d->C * d->N;
+    a.bias_ws = d->dbias ? a.ws + (int64_t)splits * a.slab : nullptr;
     const bool xvec = (d->C % 4 == 0) && (d->x_pix_stride % 4 == 0) && (d->x_frame_stride % 4 == 0) && aligned16(d->x);
     const bool yvec = (d->N % 4 == 0) && (d->dy_pix_stride % 4 == 0) && (d->dy_frame_stride % 4 == 0) && aligned16(d->dy);
     dim3 block(256);
@@ -562,6 +625,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     } while (0)
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
                              d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
+    LU_REQUIRE(!d->dbias || row_variant, "lu_conv2d_wgrad: dbias is produced by the kernel-row variants only (stride-1 3x3 / "
+                                         "5x5, C >= 64, W %% 16 == 0, aligned operands); use lu_colsum for this layer");
     if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
         const char* force = getenv("LU_WGRAD_BF16_CT");         // "64" / "128": tests and A/B runs
         const int ct = force ? atoi(force) : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
@@ -604,5 +669,9 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     unsigned rgrid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,
               d->N, d->dw_tap_stride, d->dw_row_stride, d->beta);
+    rc = LU_CHECK_LAUNCH();
+    if (rc || !d->dbias) return rc;
+    LU_LAUNCH(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), stream, (const float*)a.bias_ws,
+              d->N, splits, d->dbias, d->dbias_beta);
     return LU_CHECK_LAUNCH();
 }

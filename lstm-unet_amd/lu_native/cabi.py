@@ -2,6 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
+ABI_VERSION = 2          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -30,7 +31,8 @@ class WgradDesc(C.Structure):
                 ('frames', i32), ('Hin', i32), ('Win', i32), ('Hout', i32), ('Wout', i32),
                 ('k', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
                 ('dw', c_f32p), ('dw_tap_stride', i64), ('dw_row_stride', i32), ('splits', i32),
-                ('beta', f32), ('precision', i32), ('workspace', C.c_void_p)]
+                ('beta', f32), ('precision', i32), ('workspace', C.c_void_p),
+                ('dbias', c_f32p), ('dbias_beta', f32), ('_pad3', i32)]
 
 
 P = C.c_void_p

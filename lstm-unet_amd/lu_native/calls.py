@@ -59,7 +59,7 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
 
 
 def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, Wout, k, stride, pad_t, pad_l,
-               dw, dw_tap_stride, dw_row_stride, splits, beta, precision=0):
+               dw, dw_tap_stride, dw_row_stride, splits, beta, precision=0, dbias=None, dbias_beta=0.0):
     d = cabi.WgradDesc()
     d.x, d.x_frame_stride, d.x_pix_stride, d.C = x, x_fs, x_ps, Cin
     d.dy, d.dy_frame_stride, d.dy_pix_stride, d.N = dy, dy_fs, dy_ps, N
@@ -67,6 +67,7 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     d.k, d.stride, d.pad_t, d.pad_l = k, stride, pad_t, pad_l
     d.dw, d.dw_tap_stride, d.dw_row_stride, d.splits, d.beta = dw, dw_tap_stride, dw_row_stride, splits, beta
     d.precision = precision
+    d.dbias, d.dbias_beta = dbias, dbias_beta
     return d
 
 

@@ -203,10 +203,11 @@ class Engine:
             rec['y'] = None
         else:
             dy = dz
-        ops.bias_grad(dy, self.G[f'{prefix}.conv.{ci}.bias'])
         dxs = []
-        for (x, co, cs), need in zip(rec['srcs'], need_dx):
-            ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16')
+        for si, ((x, co, cs), need) in enumerate(zip(rec['srcs'], need_dx)):
+            # the bias gradient (column sums of dy) rides on the first source's weight-gradient launch
+            ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
+                             dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
                                         bf16=self._bf16_conv(w.shape[0], spec['stride'], cs)) if need else None)
         rec['srcs'] = None
@@ -282,9 +283,9 @@ class Engine:
         dz_seq = dz.view(T * B, H, W, 4 * F)
         # hoisted over all T: one big reduction per weight
         bf = self.precision == 'bf16'
-        ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, bf16=bf)
+        ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, bf16=bf,
+                         dbias=self.G[pre + '.bias'])       # + the bias gradient = column sums of dz, on the side
         ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1, bf16=bf)
-        ops.bias_grad(dz_seq, self.G[pre + '.bias'])
         dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1, bf16=self._bf16_conv(spec['k'], 1, kernel.shape[2])) if need_dx else None
         rec['h_all'] = rec['c_all'] = rec['x'] = None
         return dx

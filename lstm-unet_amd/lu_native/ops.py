@@ -46,7 +46,7 @@ def lib():
             raise NativeError('HIP kernel library missing: %s -- build it with `python -m lu_native.build` '
                               '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
         _lib = cabi.bind(LIB_PATH)
-        if _lib.lu_abi_version() != 1:
+        if _lib.lu_abi_version() != cabi.ABI_VERSION:
             raise NativeError('ABI version mismatch in %s' % LIB_PATH)
     return _lib
 
@@ -201,26 +201,36 @@ def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl):
     return out
 
 
-def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False):
-    """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy."""
-    _chk(x, dy, dw)
+def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta=0.0):
+    """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy.
+    dbias (optional [N]): the layer's bias gradient = column sums of dy -- summed on the side by the kernel-row wgrad
+    kernels where they apply, by a separate lu_colsum pass elsewhere."""
+    _chk(x, dy, dw, dbias)
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     k = dw.shape[0]
     _, pt, _ = same_pad(Hin, k, stride)
     _, pl, _ = same_pad(Win, k, stride)
     row_variant = (stride == 1 and k in (3, 5) and Wout % 16 == 0 and Cin >= 64 and Cin % 4 == 0 and N % 4 == 0 and
-                   x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0)     # mirrors lu_conv2d_wgrad's kernel choice
-    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant)
+                   x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0 and
+                   x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and Hout == Hin and Wout == Win and
+                   not os.environ.get('LU_WGRAD_NOROW'))     # mirrors lu_conv2d_wgrad's kernel choice
+    # the bf16 kernel's 128-channel tiles run one block per CU: half as many, longer blocks (measured best: ~3000)
+    bf16_row = bf16 and row_variant and Wout % 32 == 0
+    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant,
+                                target_blocks=3072 if bf16_row else 6144)
     d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
                          frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
-                         splits, beta, precision=1 if bf16 else 0)
+                         splits, beta, precision=1 if bf16 else 0,
+                         dbias=dbias.data_ptr() if (dbias is not None and row_variant) else None, dbias_beta=dbias_beta)
+    if dbias is not None and not row_variant:
+        bias_grad(dy, dbias, dbias_beta)
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
     kind = ('wgrad_row_kernel<%d> (+ its slab reduce; weight gradients hoisted over T)' % k) if row_variant else \
         'wgrad_kernel (strided / thin / narrow layers)'
-    if bf16 and row_variant and Wout % 32 == 0:
+    if bf16_row:
         kind = 'wgrad_row_bf16_kernel<%d> (+ its slab reduce; bf16-MFMA weight gradients hoisted over T)' % k
     with _timed(kind, 2.0 * k * k * Cin * N * frames * Hout * Wout):
         calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')

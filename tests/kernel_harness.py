@@ -165,19 +165,22 @@ def conv2d_dgrad(be, dy, w, in_hw, stride):
     return conv2d(be, [dy], [wt], None, k, 1, stride, pad=(k - 1 - pt, k - 1 - pl), out_hw=(Hin, Win))
 
 
-def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0, precision=0):
+def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0, precision=0, dbias0=None, dbias_beta=0.0):
+    """-> dw, or (dw, dbias) when dbias0 (initial contents of the bias-gradient buffer) is given."""
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     _, pt, _ = calls.same_pad(Hin, k, stride)
     _, pl, _ = calls.same_pad(Win, k, stride)
     dw = be.empty((k, k, Cin, N)) if dw0 is None else be.dev(dw0)
     xd, dyd = be.dev(x), be.dev(dy)
+    db = None if dbias0 is None else be.dev(dbias0)
     d = calls.wgrad_desc(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(dyd), Hout * Wout * N, N, N, frames, Hin, Win,
-                         Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta, precision=precision)
+                         Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta, precision=precision,
+                         dbias=be.ptr(db), dbias_beta=dbias_beta)
     ws = be.empty((be.lib.lu_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4 + 4,))
     d.workspace = be.ptr(ws)
     calls.check(be.lib, be.lib.lu_conv2d_wgrad(C.byref(d), be.stream), 'wgrad')
-    return be.host(dw)
+    return be.host(dw) if db is None else (be.host(dw), be.host(db))
 
 
 def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias, precision=0):

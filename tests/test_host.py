@@ -30,7 +30,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert declared == set(cabi.PROTOTYPES.keys()), declared ^ set(cabi.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.lu_abi_version() == 1
+    assert lib.lu_abi_version() == cabi.ABI_VERSION
     import ctypes
     d = cabi.ConvDesc()
     assert lib.lu_conv2d_fwd(ctypes.byref(d), None) != 0          # argument validation, no GPU touched

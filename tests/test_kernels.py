@@ -200,6 +200,22 @@ def test_wgrad_wide_channels_and_beta(be):
     close(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=2), gw, 2e-4)
 
 
+@pytest.mark.parametrize('precision', [0, 1])
+def test_wgrad_fused_bias_gradient(be, precision):
+    """dbias = column sums of dy, produced on the side by the kernel-row weight-gradient kernels (exact fp32 sums in
+    both precisions, fixed order); other layer shapes must reject the request (callers use lu_colsum there)."""
+    for (fr, H, W, Cc, N, k, sp) in [(2, 5, 32, 72, 136, 3, 3), (1, 4, 64, 128, 128, 5, 2)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        db0 = rnd(N)
+        dw, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=precision, dbias0=db0, dbias_beta=1.0)
+        close(db, dy.reshape(-1, N).astype(np.float64).sum(0) + db0, 2e-4)
+        dw2, db2 = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=precision, dbias0=db0, dbias_beta=0.0)
+        close(db2, dy.reshape(-1, N).astype(np.float64).sum(0), 2e-4)
+        assert np.array_equal(dw, KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=precision))
+    with pytest.raises(RuntimeError):
+        KH.conv2d_wgrad(be, rnd(1, 6, 6, 8), rnd(1, 6, 6, 8), 3, 1, dbias0=rnd(8))
+
+
 @pytest.mark.parametrize('ct', ['64', '128'])
 def test_wgrad_bf16_mfma_variant(be, ct, monkeypatch):
     monkeypatch.setenv('LU_WGRAD_BF16_CT', ct)         # 64- and 128-channel block tiles
