@@ -7,8 +7,8 @@
       keep       : [B] 1.0 while slot b's clip continues, 0.0 when this window ended it (:378,471)
     slot b always continues the same clip in the next batch (per-slot FIFO, :447-452)
 
-Only the synthetic provider is implemented (benchmarks / tests).  The RAM readers for
-Cell-Tracking-Challenge folders (cv2 + tf.queue in the reference) are SURVEY §8f-2 "next" rows.
+SyntheticSequence2D is the benchmark / test provider; CTCRAMReaderSequence2D reads Cell-Tracking-Challenge
+folders with Pillow + scipy instead of OpenCV and per-slot generators instead of tf.queue.
 """
 import numpy as np
 from scipy import ndimage
@@ -86,13 +86,243 @@ class SyntheticSequence2D(object):
         return np.expand_dims(image, axis), np.expand_dims(seg, axis), full, keep
 
 
-class CTCRAMReaderSequence2D(object):
-    """Placeholder with the reference's class name: the Cell-Tracking-Challenge RAM reader needs OpenCV and
-    dataset folders (DataHandeling.py:21-529) and is a SURVEY §8f-2 'next' row, not part of the hot path."""
+def _read_image(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im)
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('CTCRAMReaderSequence2D (real-data reader) is not part of the MI355X hot-path '
-                                  'build yet; use SyntheticSequence2D or feed get_batch()-shaped arrays')
+
+def affine_from_points(src, dst):
+    """2x3 matrix M with M @ [x, y, 1] = dst for the three point pairs (what cv2.getAffineTransform solves)."""
+    a = np.hstack([np.asarray(src, np.float64), np.ones((3, 1))])
+    return np.linalg.solve(a, np.asarray(dst, np.float64)).T
+
+
+def warp_affine(image, matrix, order, mode, cval=0.0):
+    """out(x, y) = image(M^-1 [x, y, 1]): forward-matrix warp onto the same canvas (cv2.warpAffine semantics; mode
+    'mirror' = BORDER_REFLECT_101, 'constant' + cval = BORDER_CONSTANT; order 1 bilinear / 0 nearest)."""
+    full = np.vstack([matrix, [0.0, 0.0, 1.0]])
+    inv = np.linalg.inv(full)
+    h, w = image.shape
+    ys, xs = np.mgrid[:h, :w].astype(np.float64)
+    sx = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
+    sy = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
+    return ndimage.map_coordinates(image, [sy, sx], order=order, mode=mode, cval=cval)
+
+
+class ClipAugmenter(object):
+    """One clip's geometric / photometric augmentation, drawn once per clip and applied to every frame
+    (DataHandeling.py:262-300): crop offset, flips, 90-degree rotations, temporal reverse / sub-sampling, and -- when
+    `elastic` -- a random affine (three control points jittered by 8 % of the crop) followed by a smooth random
+    displacement field (sigma = 15 % of the crop, amplitude = 2 crops before smoothing).  Labels go through the same
+    maps with nearest-neighbour sampling and -1 outside, and are then turned into {0,1,2} by the edge rule."""
+
+    def __init__(self, rng, frame_shape, crop, randomize, elastic):
+        H, W = frame_shape
+        h, w = crop
+        self.crop = crop
+        self.step = int(rng.integers(1, 4)) if randomize else 1
+        self.reverse = bool(rng.integers(0, 2)) if randomize else False
+        self.y0 = int(rng.integers(0, H - h)) if (randomize and H - h > 0) else 0
+        self.x0 = int(rng.integers(0, W - w)) if (randomize and W - w > 0) else 0
+        self.flip = rng.integers(0, 2, 2) if randomize else np.zeros(2, np.int64)
+        self.rot = int(rng.integers(0, 4)) if (randomize and h == w) else 0
+        self.randomize = randomize
+        self.rng = rng
+        self.matrix = self.field = None
+        if elastic:
+            centre = np.array([w // 2, h // 2], np.float64)       # (x, y)
+            sq = min(h, w) // 3
+            src = np.array([centre + sq, [centre[0] + sq, centre[1] - sq], centre - sq])
+            dst = src + rng.uniform(-0.08 * w, 0.08 * w, size=src.shape)
+            self.matrix = affine_from_points(src, dst)
+            sigma, alpha = 0.15 * w, 2.0 * w
+            dx = ndimage.gaussian_filter(rng.random((h, w)) * 2 - 1, sigma) * alpha
+            dy = ndimage.gaussian_filter(rng.random((h, w)) * 2 - 1, sigma) * alpha
+            yy, xx = np.mgrid[:h, :w]
+            self.field = [yy + dy, xx + dx]
+
+    def _geom(self, a, label):
+        if self.matrix is not None:
+            if label:
+                a = warp_affine(a, self.matrix, 0, 'constant', -1.0)
+                a = ndimage.map_coordinates(a, self.field, order=0, mode='constant', cval=-1.0)
+            else:
+                a = warp_affine(a, self.matrix, 1, 'mirror')
+                a = ndimage.map_coordinates(a, self.field, order=1, mode='reflect')
+        return a
+
+    def _orient(self, a):
+        if self.flip[0]:
+            a = a[::-1]
+        if self.flip[1]:
+            a = a[:, ::-1]
+        if self.rot:
+            a = np.rot90(a, self.rot)
+        return np.ascontiguousarray(a)
+
+    def frame(self, img, seg, img_max):
+        """img: z-scored frame, seg: instance ids (0 background, -1 unlabeled) -> (image, {-1,0,1,2} labels)."""
+        h, w = self.crop
+        img = img[self.y0:self.y0 + h, self.x0:self.x0 + w].astype(np.float64)
+        seg = seg[self.y0:self.y0 + h, self.x0:self.x0 + w].astype(np.float32).copy()
+        if self.randomize:      # contrast factor in [0.5, 1.5], brightness +-10 % of the sequence maximum
+            factor, delta = self.rng.random() + 0.5, (self.rng.random() - 0.5) * 0.2 * img_max
+            m = img.mean()
+            img = (img - m) * factor + m + delta
+        img = self._geom(img, False)
+        if self.matrix is not None:
+            if not np.all(seg == -1):
+                unlabeled = (seg == -1).astype(np.float32)
+                seg[:, 0] = seg[:, -1] = seg[0, :] = seg[-1, :] = 0       # instances never touch the canvas border
+                moved = self._geom(seg, True)
+                moved_unl = self._geom(unlabeled, True)
+                out = instances_to_classes(moved)
+                out[(moved_unl > 0.5) | (moved == -1)] = -1
+                seg = out
+        else:
+            seg = instances_to_classes(seg)
+        return self._orient(img).astype(np.float32), self._orient(seg).astype(np.float32)
+
+
+class CTCRAMReaderSequence2D(object):
+    """Cell-Tracking-Challenge training reader with the reference's constructor and batch contract
+    (DataHandeling.py:21-45, 454-493).  Every `(folder, sequence)` entry needs the reference's
+    `metadata_<sequence>.pickle` (`filelist` rows `(image, seg or None, tra, fully_annotated)`, `shape`); all frames are
+    held in RAM, z-scored per frame.
+
+    MI355X-native differences: images are read with Pillow (no OpenCV) and the tf.queue / thread machinery is replaced
+    by one deterministic generator per batch slot (`seed`, `rank`), optionally prefetched by `num_threads` > 1 worker
+    threads into bounded queues; under data-parallel training every rank builds the reader with its own `rank`, so
+    the slots of different GPUs follow different clips."""
+
+    def __init__(self, sequence_folder_list, image_crop_size=(128, 128), unroll_len=7, deal_with_end=0, batch_size=4,
+                 queue_capacity=32, num_threads=3, data_format='NCHW', randomize=True, return_dist=False, keep_sample=1,
+                 elastic_augmentation=True, seed=1, rank=0):
+        if return_dist:
+            raise NotImplementedError('return_dist (distance-map targets) is not used by the LSTM-UNet training path')
+        self.sequence_folder_list = list(sequence_folder_list)
+        self.sub_seq_size = tuple(image_crop_size)
+        self.unroll_len = unroll_len
+        self.deal_with_end = deal_with_end
+        self.batch_size = batch_size
+        self.queue_capacity = queue_capacity
+        self.num_threads = num_threads
+        self.data_format = data_format
+        self.randomize = randomize
+        self.keep_sample = keep_sample
+        self.elastic_augmentation = elastic_augmentation
+        self.sequence_data = {}
+        self._seed = (seed, rank)
+        self._load_rng = np.random.default_rng([seed, 7])     # label sub-sampling: identical on every rank
+        self._slots = None
+        self._queues = None
+        self._threads = []
+        self._stop = False
+        self.q_stat_list = []
+
+    # ---- loading -------------------------------------------------------------------------------------------
+    def _read_sequence_to_ram_(self):
+        import os
+        import pickle
+        for entry in self.sequence_folder_list:
+            folder, seq, train_set = (tuple(entry) + (True,))[:3] if isinstance(entry, (tuple, list)) else (entry, None, True)
+            with open(os.path.join(folder, 'metadata_{}.pickle'.format(seq)), 'rb') as fh:
+                meta = pickle.load(fh)
+            shape = tuple(meta['shape'])[-2:]
+            n = len(meta['filelist'])
+            images = np.zeros((n,) + shape, np.float32)
+            segs = np.full((n,) + shape, -1.0, np.float32)
+            full = np.zeros(n, np.float32)
+            for t, row in enumerate(meta['filelist']):
+                img = _read_image(os.path.join(folder, row[0])).astype(np.float32)
+                images[t] = (img - img.mean()) / img.std()
+                keep = (self._load_rng.random() < self.keep_sample) and train_set
+                if row[1] is None or not keep:
+                    continue                                 # unlabeled frame: all -1
+                try:
+                    seg = _read_image(os.path.join(folder, row[1])).astype(np.float32)
+                except (OSError, ValueError):
+                    full[t] = -1
+                    continue
+                if row[3] is True:                           # every cell annotated: 0 really is background
+                    full[t] = 1
+                else:                                        # partial annotation: unmarked pixels are unknown
+                    seg[seg == 0] = -1
+                segs[t] = seg
+            self.sequence_data[tuple(entry) if isinstance(entry, list) else entry] = {
+                'images': images, 'segs': segs, 'full_seg': full, 'metadata': meta, 'max': float(images.max())}
+
+    # ---- per-slot clip streams -----------------------------------------------------------------------------
+    def _clip_stream(self, slot):
+        """Endless frames of slot `slot`: (image, seg, full_seg, keep) with keep = 0 on the last frame of a clip."""
+        rng = np.random.default_rng([self._seed[0], self._seed[1], slot])
+        keys = list(self.sequence_data.keys())
+        T = self.unroll_len
+        while True:
+            data = self.sequence_data[keys[int(rng.integers(0, len(keys)))]]
+            aug = ClipAugmenter(rng, data['images'].shape[1:], self.sub_seq_size, self.randomize, self.elastic_augmentation)
+            idx = list(range(len(data['images'])))
+            if aug.reverse:
+                idx.reverse()
+            idx = idx[::aug.step]
+            rem = len(idx) % T
+            if rem:                                           # window alignment (DataHandeling.py:296-302)
+                if self.deal_with_end == 0:
+                    idx = idx[:-rem]
+                elif self.deal_with_end == 1:
+                    idx += idx[-2:-T + rem - 2:-1]
+                else:
+                    idx += idx[-1:] * (T - rem)
+            for j, t in enumerate(idx):
+                img, seg = aug.frame(data['images'][t], data['segs'][t], data['max'])
+                if not (np.isfinite(img).all() and np.isfinite(seg).all()):
+                    raise ValueError('non-finite values in frame {} after augmentation'.format(t))
+                yield img, seg, max(0.0, float(data['full_seg'][t])), 1.0 if j + 1 < len(idx) else 0.0
+
+    def start_queues(self, coord=None, debug=False):
+        import queue
+        import threading
+        self._read_sequence_to_ram_()
+        self._slots = [self._clip_stream(b) for b in range(self.batch_size)]
+        if self.num_threads > 1 and not debug:
+            self._queues = [queue.Queue(maxsize=self.queue_capacity) for _ in range(self.batch_size)]
+
+            def work(slots):
+                while not self._stop:
+                    for b in slots:
+                        if self._queues[b].full():
+                            continue
+                        self._queues[b].put(next(self._slots[b]))
+                    if all(self._queues[b].full() for b in slots):
+                        threading.Event().wait(0.005)
+
+            n = min(self.num_threads, self.batch_size)
+            for i in range(n):
+                th = threading.Thread(target=work, args=(list(range(i, self.batch_size, n)),), daemon=True)
+                th.start()
+                self._threads.append(th)
+            self.q_stat_list = [lambda q=q: q.qsize() / float(self.queue_capacity) for q in self._queues]
+        return self._threads
+
+    def stop(self):
+        self._stop = True
+
+    def get_batch(self):
+        if self._slots is None:
+            self.start_queues()
+        B, T = self.batch_size, self.unroll_len
+        h, w = self.sub_seq_size
+        image = np.empty((B, T, h, w), np.float32)
+        seg = np.empty((B, T, h, w), np.float32)
+        full = np.empty((B, T), np.float32)
+        keep = np.ones(B, np.float32)
+        for b in range(B):
+            for t in range(T):
+                item = self._queues[b].get() if self._queues is not None else next(self._slots[b])
+                image[b, t], seg[b, t], full[b, t], keep[b] = item      # keep: the flag of the window's last frame
+        axis = 2 if self.data_format[1] == 'C' else 4
+        return np.expand_dims(image, axis), np.expand_dims(seg, axis), full, keep
 
 
 class CTCInferenceReader(object):

@@ -5,8 +5,8 @@ Defaults live in two tables below and are installed as class attributes, so `CTC
 exactly as upstream; a dict of command-line overrides is applied per instance (unknown keys only warn, as in
 the reference's `_override_params_`, Params.py:17-23).
 
-Differences on purpose: the default data provider is the synthetic clip stream (the Cell-Tracking-Challenge RAM
-reader is a SURVEY §8f-2 "next" row); `--root_data_dir` is honoured (upstream ignores it, Params.py:104-107);
+Differences on purpose: the default data provider is the synthetic clip stream (no dataset ships here); the
+Cell-Tracking-Challenge RAM reader is selected with `data_provider='ctc'` / `--data_provider ctc`; `--root_data_dir` is honoured (upstream ignores it, Params.py:104-107);
 only rank 0 creates output directories under data-parallel launches; `sync_bn` is new.
 """
 import os
@@ -56,7 +56,7 @@ _TRAIN_DEFAULTS = dict(
     # debugging
     dry_run=False, profile=False,
     # MI355X options: pool BatchNorm statistics over all data-parallel ranks; MFMA operand precision
-    sync_bn=False, precision='fp32',
+    sync_bn=False, precision='fp32', data_provider=None,
 )
 
 _INFER_DEFAULTS = dict(
@@ -88,12 +88,17 @@ class CTCParams(ParamsBase):
 
     def __init__(self, params_dict):
         self._override_params_(params_dict)
+        if getattr(self, 'data_provider', None) == 'ctc':       # --data_provider ctc: the reference's provider
+            self.data_provider_class = DataHandeling.CTCRAMReaderSequence2D
+        elif getattr(self, 'data_provider', None) == 'synthetic':
+            self.data_provider_class = DataHandeling.SyntheticSequence2D
         root = os.path.expanduser(self.root_data_dir)
         self.train_data_base_folders = [(os.path.join(root, name), seq) for name, seq in self.train_sequence_list]
         self.val_data_base_folders = [(os.path.join(root, name), seq) for name, seq in self.val_sequence_list]
         shared = dict(image_crop_size=self.crop_size, unroll_len=self.unroll_len, deal_with_end=0,
                       batch_size=self.batch_size, data_format=self.data_format, randomize=True, return_dist=False,
-                      queue_capacity=self.train_q_capacity)
+                      queue_capacity=self.train_q_capacity,
+                      rank=int(os.environ.get('RANK', '0')))      # data parallel: every rank streams its own clips
         self.train_data_provider = self.data_provider_class(sequence_folder_list=self.train_data_base_folders,
                                                             num_threads=self.num_train_threads, **shared)
         self.val_data_provider = self.data_provider_class(sequence_folder_list=self.val_data_base_folders,

@@ -313,6 +313,9 @@ def build_arg_parser():
         parser.add_argument(*names, **kw)
     parser.add_argument('--sync_bn', dest='sync_bn', action='store_const', const=True,
                         help='[MI355X] pool BatchNorm statistics over all DP ranks')
+    parser.add_argument('--data_provider', dest='data_provider', choices=['synthetic', 'ctc'],
+                        help='[MI355X] synthetic clips (default) or the Cell-Tracking-Challenge RAM reader over '
+                             '--root_data_dir / --train_sequence_list (needs the metadata_<seq>.pickle files)')
     parser.add_argument('--precision', dest='precision', choices=['fp32', 'bf16'],
                         help='[MI355X] fp32 (default) or bf16-MFMA operands for the wide stride-1 convolutions')
     return parser

@@ -1,0 +1,119 @@
+"""Real-data clip reader: CTCRAMReaderSequence2D on a tiny Cell-Tracking-Challenge-shaped folder written
+to tmp_path -- batch contract of DataHandeling.py:454-493 (shapes, value sets, per-slot clip persistence, keep flags,
+window alignment), the annotation rules of :98-129, determinism per (seed, rank, slot), and the OpenCV-free warps."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import DataHandeling as D
+
+
+def _make_ctc(root, n_frames=11, shape=(40, 48), seq='01'):
+    rng = np.random.default_rng(0)
+    os.makedirs(os.path.join(root, seq), exist_ok=True)
+    os.makedirs(os.path.join(root, seq + '_GT', 'SEG'), exist_ok=True)
+    rows = []
+    for t in range(n_frames):
+        img = (rng.random(shape) * 900 + 100).astype(np.uint16)
+        inst = np.zeros(shape, np.uint16)
+        inst[5 + t % 3:15 + t % 3, 6:18] = 1
+        inst[20:30, 25 + t % 4:38 + t % 4] = 2
+        img[inst > 0] += 2000
+        name = os.path.join('.', seq, 't%03d.tif' % t)
+        Image.fromarray(img).save(os.path.join(root, name))
+        if t % 3 == 0:
+            rows.append((name, None, None, None))                       # unlabeled frame
+        else:
+            sname = os.path.join('.', seq + '_GT', 'SEG', 'man_seg%03d.tif' % t)
+            Image.fromarray(inst).save(os.path.join(root, sname))
+            rows.append((name, sname, None, True if t % 3 == 1 else False))   # fully / partially annotated
+    with open(os.path.join(root, 'metadata_%s.pickle' % seq), 'wb') as fh:
+        pickle.dump({'filelist': rows, 'shape': shape, 'max': 3000, 'min': 100}, fh)
+    return rows
+
+
+def _reader(root, **kw):
+    args = dict(sequence_folder_list=[(root, '01')], image_crop_size=(32, 32), unroll_len=3, deal_with_end=0, batch_size=2,
+                queue_capacity=16, num_threads=1, data_format='NCHW', randomize=True, elastic_augmentation=True)
+    args.update(kw)
+    return D.CTCRAMReaderSequence2D(**args)
+
+
+def test_batch_contract_and_annotation_rules(tmp_path):
+    root = str(tmp_path)
+    _make_ctc(root)
+    r = _reader(root)
+    r.start_queues()
+    data = r.sequence_data[(root, '01')]
+    assert np.allclose(data['images'].reshape(11, -1).mean(1), 0, atol=1e-4)          # per-frame z-score (:103)
+    assert np.allclose(data['images'].reshape(11, -1).std(1), 1, atol=1e-3)
+    assert (data['segs'][0] == -1).all() and data['full_seg'][0] == 0                  # unlabeled frame
+    assert data['full_seg'][1] == 1 and set(np.unique(data['segs'][1])) == {0.0, 1.0, 2.0}     # full: 0 = background
+    assert data['full_seg'][2] == 0 and set(np.unique(data['segs'][2])) == {-1.0, 1.0, 2.0}    # partial: 0 -> unknown
+    for fmt, shp in (('NCHW', (2, 3, 1, 32, 32)), ('NHWC', (2, 3, 32, 32, 1))):
+        r = _reader(root, data_format=fmt)
+        img, seg, full, keep = r.get_batch()
+        assert img.shape == shp and seg.shape == shp and full.shape == (2, 3) and keep.shape == (2,)
+        assert img.dtype == np.float32 and seg.dtype == np.float32
+        assert set(np.unique(seg)) <= {-1.0, 0.0, 1.0, 2.0}
+        assert set(np.unique(keep)) <= {0.0, 1.0}
+
+
+def test_slot_persistence_window_alignment_and_determinism(tmp_path):
+    root = str(tmp_path)
+    _make_ctc(root)
+    # without augmentation a slot walks the sequence in order; 11 frames trimmed to 9 = 3 windows of T=3
+    r = _reader(root, randomize=False, elastic_augmentation=False, batch_size=1)
+    r.start_queues()
+    ref = r.sequence_data[(root, '01')]['images']
+    keeps = []
+    for w in range(6):
+        img, seg, full, keep = r.get_batch()
+        keeps.append(float(keep[0]))
+        for t in range(3):
+            assert np.array_equal(img[0, t, 0], ref[(3 * w + t) % 9, :32, :32])        # next window continues the clip
+    assert keeps == [1.0, 1.0, 0.0, 1.0, 1.0, 0.0]                                     # keep = 0 ends the clip (:378,471)
+    # deal_with_end = 2 pads with the last frame instead of trimming: 12 frames = 4 windows
+    r = _reader(root, randomize=False, elastic_augmentation=False, batch_size=1, deal_with_end=2)
+    keeps = [float(r.get_batch()[3][0]) for _ in range(4)]
+    assert keeps == [1.0, 1.0, 1.0, 0.0]
+    # same (seed, rank) -> same stream; another rank -> other clips; threads only prefetch, same per-slot order
+    a = _reader(root, seed=5, rank=0).get_batch()
+    b = _reader(root, seed=5, rank=0).get_batch()
+    c = _reader(root, seed=5, rank=1).get_batch()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert not np.array_equal(a[0], c[0])
+    th = _reader(root, seed=5, rank=0, num_threads=2)
+    d = th.get_batch()
+    th.stop()
+    assert all(np.array_equal(x, y) for x, y in zip(a, d))
+
+
+def test_opencv_free_warps():
+    src = np.array([[10.0, 12.0], [30.0, 12.0], [10.0, 28.0]])
+    dst = np.array([[12.0, 11.0], [31.0, 14.0], [9.0, 30.0]])
+    m = D.affine_from_points(src, dst)
+    assert np.allclose(m @ np.hstack([src, np.ones((3, 1))]).T, dst.T, atol=1e-9)
+    img = np.zeros((20, 24))
+    img[5:9, 6:11] = 1.0
+    shift = np.array([[1.0, 0.0, 3.0], [0.0, 1.0, 2.0]])                                # x + 3, y + 2
+    out = D.warp_affine(img, shift, 0, 'constant', -1.0)
+    assert np.array_equal(out[7:11, 9:14], np.ones((4, 5))) and out[0, 0] == -1.0      # content moves with the matrix
+    ident = D.warp_affine(img, np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]), 1, 'mirror')
+    assert np.allclose(ident, img)
+
+
+def test_reader_feeds_training_shapes(tmp_path):
+    """Params.CTCParams can be pointed at the reader (the reference's default provider)."""
+    import Params
+    root = str(tmp_path / 'Fluo-N2DH-SIM+')
+    os.makedirs(root)
+    _make_ctc(root)
+    p = Params.CTCParams({'data_provider_class': D.CTCRAMReaderSequence2D, 'root_data_dir': str(tmp_path), 'dry_run': True,
+                          'train_sequence_list': [('Fluo-N2DH-SIM+', '01')], 'val_sequence_list': [('Fluo-N2DH-SIM+', '01')],
+                          'crop_size': (32, 32), 'batch_size': 2, 'unroll_len': 2, 'num_train_threads': 1, 'num_val_threads': 1})
+    img, seg, full, keep = p.train_data_provider.get_batch()
+    assert img.shape == (2, 2, 1, 32, 32) and seg.shape == img.shape
