@@ -1033,6 +1033,177 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// General bf16-MFMA convolution (precision = 1 where the halo kernel does not apply): stride 1 / 2, any k <= 7, any
+// pads, narrow outputs, strided output rows (parity planes of a stride-2 input gradient).  Implicit GEMM over
+// 256 linear pixels x 128 columns per block; a stage is one (tap, 32-channel chunk): the [256][32] activation slab is
+// gathered from HBM/L2 (fp32 -> bf16 while staged, two LDS buffers, one barrier per stage), the weights come from L2 in
+// MFMA-fragment order exactly as in conv_halo_bf16_kernel.  Waves: 2 (groups of 128 pixels) x 4 (column fragments).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
+    constexpr int NT = 512, RA = 4, MFW = 4;           // RA pixel rows gathered per thread; MFW 32-pixel fragments per wave
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int bid = blockIdx.x;
+    const int slot = bid >> 3;
+    const int nt = slot % a.n_tiles;
+    const int mt = (slot / a.n_tiles) * 8 + (bid & 7);
+    if (mt >= a.m_tiles) return;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * 128;
+    const int ks = blockIdx.y;
+    const float* const zp = lu_zero16;
+    const int nfr = (a.N + 31) >> 5;
+    const int frag = nt * 4 + wn;
+    const bool frag_ok = frag < nfr;
+
+    // gather bookkeeping: thread -> 16-byte channel group q of pixel rows (tid >> 3) + 64 i
+    const int q = tid & 7;
+    int fr[RA], vy0[RA], vx0[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int64_t m = m0 + (tid >> 3) + 64 * i;
+        if (m < a.M) {
+            const int f = (int)(m / a.HWo);
+            const int r = (int)(m - (int64_t)f * a.HWo);
+            const int oy = r / a.Wout, ox = r - oy * a.Wout;
+            fr[i] = f;
+            vy0[i] = oy * a.stride - a.pad_t;
+            vx0[i] = ox * a.stride - a.pad_l;
+        } else {
+            fr[i] = 0;
+            vy0[i] = vx0[i] = -(1 << 28);
+        }
+    }
+    const float* const x_s0 = a.src[0].x;
+    const float* const x_s1 = a.src[1].x;
+    const int64_t fs_s0 = a.src[0].frame_stride, fs_s1 = a.src[1].frame_stride;
+    const unsigned short* const w_s0 = reinterpret_cast<const unsigned short*>(a.src[0].w) + (int64_t)frag * 1024 + lane * 8;
+    const unsigned short* const w_s1 = reinterpret_cast<const unsigned short*>(a.src[1].w) + (int64_t)frag * 1024 + lane * 8;
+    const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
+    const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
+    const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
+    const int K = a.k, kk = a.kk;
+    auto tap_advance = [&](IterState& st) {
+        ++st.tap;
+        if (++st.kw == K) {
+            st.kw = 0;
+            ++st.kh;
+        }
+        if (st.tap < kk) return;
+        st.tap = st.kh = st.kw = 0;
+        if (++st.chunk == (st.s ? nch_s1 : nch_s0)) {
+            st.chunk = 0;
+            ++st.s;
+        }
+    };
+    float4 ra[RA];
+    auto load_a = [&](const IterState& st) {
+        const int c = st.chunk * CKB + 4 * q;
+        const bool cok = c < (st.s ? C_s1 : C_s0);
+        const float* xb = (st.s ? x_s1 : x_s0) + c;
+        const int64_t fs = st.s ? fs_s1 : fs_s0;
+        const int ps = st.s ? ps_s1 : ps_s0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int iy = vy0[i] + st.kh, ix = vx0[i] + st.kw;
+            const bool ok = cok && iy >= 0 && ix >= 0 && iy < a.Hin && ix < a.Win;
+            const float* p = xb + (int64_t)fr[i] * fs + ((int64_t)iy * a.Win + ix) * ps;
+            ra[i] = *reinterpret_cast<const float4*>(ok ? p : zp);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            unsigned* dst = reinterpret_cast<unsigned*>(&As[buf][((tid >> 3) + 64 * i) * LDB + 4 * q]);
+            dst[0] = lu_pack2bf(ra[i].x, ra[i].y);
+            dst[1] = lu_pack2bf(ra[i].z, ra[i].w);
+        }
+    };
+    auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
+        const unsigned short* wp = (st.s ? w_s1 : w_s0) + ((int64_t)st.tap * (st.s ? nch_s1 : nch_s0) + st.chunk) * nfr * 1024;
+        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : zp);
+        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 512) : zp);
+    };
+
+    f32x16 acc[MFW];
+#pragma unroll
+    for (int i = 0; i < MFW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int it0 = 0, it1 = a.n_it;
+    if (a.ksplit > 1) {
+        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per < a.n_it ? ks * per : a.n_it;
+        it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
+    }
+    if (it1 > it0) {
+        IterState st{0, 0, 0, 0, 0};
+        {
+            int r = it0;
+            if (r >= nch_s0 * kk) {
+                r -= nch_s0 * kk;
+                st.s = 1;
+            }
+            st.chunk = r / kk;
+            st.tap = r - st.chunk * kk;
+            st.kh = st.tap / K;
+            st.kw = st.tap - st.kh * K;
+        }
+        IterState nx = st;
+        if (it0 + 1 < it1) tap_advance(nx);
+        float4 bA0, bA1, bB0, bB1;           // B fragments of the current / next stage
+        load_a(st);
+        load_b(st, bA0, bA1);
+        load_b(nx, bB0, bB1);
+        store_a(0);
+        __syncthreads();
+        const int khalf8 = 8 * (lane >> 5);
+        auto stage = [&](int it, int buf, float4& c0, float4& c1) {       // (c0, c1): this stage's fragments; refilled for it + 2
+            load_a(nx);                      // next stage's slab: in flight across the MFMAs
+            LU_SCHED_FENCE();
+            const unsigned short* ab = &As[buf][(128 * wm + (lane & 31)) * LDB + khalf8];
+            const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, c0), bv1 = __builtin_bit_cast(lu_bf16x8, c1);
+#pragma unroll
+            for (int i = 0; i < MFW; ++i) {
+                const lu_bf16x8 a0 = *reinterpret_cast<const lu_bf16x8*>(ab + 32 * i * LDB);
+                acc[i] = lu_mfma_bf16(a0, bv0, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < MFW; ++i) {
+                const lu_bf16x8 a1 = *reinterpret_cast<const lu_bf16x8*>(ab + 32 * i * LDB + 16);
+                acc[i] = lu_mfma_bf16(a1, bv1, acc[i]);
+            }
+            LU_SCHED_FENCE();
+            store_a(buf ^ 1);                // buf ^ 1 was last read before the previous barrier
+            st = nx;
+            if (it + 2 < it1) tap_advance(nx);
+            load_b(nx, c0, c1);              // (past the end: re-reads the last fragments, unused)
+            __syncthreads();
+        };
+        int it = it0;
+        for (; it + 1 < it1; it += 2) {
+            stage(it, 0, bA0, bA1);
+            stage(it + 1, 1, bB0, bB1);
+        }
+        if (it < it1) stage(it, 0, bA0, bA1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < MFW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 128 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= a.M) continue;
+            const int f = (int)(m / a.HWo);
+            const int64_t pix = m - (int64_t)f * a.HWo;
+            float v[1] = {acc[i][r]};
+            conv_epilogue_row<1, LU_EPI_BIAS>(a, v, f, pix, m, nt, n0 + 32 * wn, ks, lane & 31);
+        }
+}
+
 // out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic)
 __global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t M, int N, int HWo,
                                      const float* __restrict__ bias, float* __restrict__ out, int64_t out_fs,
@@ -1180,7 +1351,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     }
     const bool want_xcd_n = getenv("LU_CONV_XCD_N") != nullptr;
     if (d->precision == 1)
-        LU_REQUIRE(halo && d->N % 4 == 0, "lu_conv2d_fwd: bf16 mode covers stride-1 3x3 / 5x5 convolutions with N > 64 only");
+        LU_REQUIRE(d->dil == 1 && (halo || d->epilogue == LU_EPI_BIAS),
+                   "lu_conv2d_fwd: bf16 mode has no input dilation, and the ConvLSTM epilogue needs a stride-1 3x3 / 5x5 layer");
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
@@ -1226,14 +1398,30 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.ksplit = d->splits;
         a.ws = (float*)d->workspace;
     }
+    if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
+        a.n_tiles = (d->N + 127) / 128;
+        dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
+        if (halo && d->k == 5 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 8>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (halo && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 4>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (halo)
+            LU_LAUNCH_DYN((conv_halo_bf16_kernel<3, LU_EPI_BIAS, 4>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else
+            LU_LAUNCH(conv_gather_bf16_kernel, gridb, dim3(512), stream, a);
+        int rcb = LU_CHECK_LAUNCH();
+        if (rcb || a.ksplit == 1) return rcb;
+        const int64_t totb = a.M * a.N;
+        const unsigned rgb = (unsigned)((totb + 255) / 256 < 8192 ? (totb + 255) / 256 : 8192);
+        LU_LAUNCH(ksplit_reduce_kernel, dim3(rgb), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N, a.HWo, a.bias,
+                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);
+        return LU_CHECK_LAUNCH();
+    }
     dim3 grid((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
     const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 8>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a); \
-        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 4>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a); \
-        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_bf16_kernel<3, LU_EPI_BIAS, 4>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);   \
-        else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
+        if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \
         else if (NF_ == 4 && BV_ && mf1 && dma)                                                                 \

@@ -165,7 +165,9 @@ class Engine:
         w = self.P[wname]
         vec = all(x.shape[3] % 4 == 0 and x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
                   for (x, _, _) in srcs)      # the bf16 kernel reads 16-byte channel groups
-        if vec and self._bf16_conv(w.shape[0], spec['stride'], w.shape[3]):
+        # bf16: halo kernel where it applies, the gather kernel otherwise -- except narrow outputs (N < 64: 128-column
+        # blocks would idle 3 of 4 column fragments; measured slower than the fp32 32/64-column tiles)
+        if vec and self.precision == 'bf16' and w.shape[3] >= 64:
             pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs: w[:, :, co:co + cs, :], co, cs)) for (x, co, cs) in srcs]
         else:
             pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
@@ -209,7 +211,7 @@ class Engine:
             ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
                              dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
-                                        bf16=self._bf16_conv(w.shape[0], spec['stride'], cs)) if need else None)
+                                        bf16=self.precision == 'bf16' and cs >= 64) if need else None)
         rec['srcs'] = None
         return dxs
 

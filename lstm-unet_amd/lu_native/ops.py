@@ -114,10 +114,10 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
     if bf16:
-        kind = 'conv_halo_bf16_kernel<%d,LU_EPI_BIAS> (bf16-MFMA recurrent / input dgrads, plain convs)' % k
+        kind = ('conv_halo_bf16_kernel<%d,LU_EPI_BIAS> (bf16-MFMA recurrent / input dgrads, plain convs)' % k) \
+            if (halo and out_view is None) else 'conv_gather_bf16_kernel (bf16-MFMA strided / narrow / parity-plane convs)'
     optr, ofs, ops_, ors = out_view if out_view is not None else (out.data_ptr(), out.stride(0), out.stride(2), 0)
-    if out_view is not None:
-        halo = False
+    if out_view is not None and not bf16:
         kind = 'conv_fwd_kernel (strided / dilated / narrow convs)'
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
@@ -160,19 +160,20 @@ def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None, bf16=False
     Hin, Win = in_hw
     _, pt, _ = same_pad(Hin, k, stride)
     _, pl, _ = same_pad(Win, k, stride)
+    bf16 = bf16 and dy.shape[3] % 4 == 0 and dy.is_contiguous()      # the bf16 kernels read 16-byte channel groups
     if stride == 2 and c_off == 0 and (c_sub is None or c_sub == w.shape[2]) and out is None and k > 1:
-        return _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl)
+        return _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16)
     wt = flip_transpose(w, c_off, c_sub)
     frames, Hd, Wd, N = dy.shape
     Cs = wt.shape[3]
-    if bf16:      # caller checked: stride 1, 3x3 / 5x5, more than 64 input channels
+    if bf16 and stride == 1:      # (the zero-dilated form of a stride-2 layer's gradient has no bf16 kernel)
         wt = pack_bf16(wt)
     if out is None:
         out = torch.empty((frames, Hin, Win, Cs), device=dy.device, dtype=torch.float32)
     return conv_raw([(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs, None, out)
 
 
-def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl):
+def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16=False):
     """Input gradient of a stride-2 convolution as four stride-1 convolutions of dy, one per output parity class,
     each written in place into its (2a+py, 2b+px) plane -- no multiplications by the zeros of a dilated dy."""
     assert w.is_contiguous() and dy.is_contiguous()
@@ -196,7 +197,8 @@ def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl):
             if Hs <= 0 or Ws <= 0:
                 continue
             view = (out.data_ptr() + 4 * (py * Win + px) * Cc, Hin * Win * Cc, 2 * Cc, 2 * Win * Cc)
-            conv_raw([(dy, sub[2 * py + px])], frames, Hd, Wd, Hs, Ws, ks, 1, 1, pady, padx, Cc, None, out, out_view=view,
+            wsub = pack_bf16(sub[2 * py + px]) if bf16 else sub[2 * py + px]
+            conv_raw([(dy, wsub)], frames, Hd, Wd, Hs, Ws, ks, 1, 1, pady, padx, Cc, None, out, out_view=view,
                      flops=2.0 * ny * nx * N * Cc * frames * Hs * Ws)
     return out
 

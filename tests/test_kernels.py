@@ -131,8 +131,24 @@ def _conv_bf16_cases(be):
     close(KH.conv2d(be, [xi4, xh], [wi4, wh], None, 5, 1, precision=1), ref, 5e-5)
     with pytest.raises(RuntimeError):                             # thin sources must be padded by the caller
         KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1)
-    with pytest.raises(RuntimeError):                             # strided convolutions are not covered in bf16 mode
-        KH.conv2d(be, [rnd(1, 16, 32, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=1)
+
+
+def test_conv_bf16_gather_variant(be):
+    """General bf16 kernel (precision = 1 outside the halo kernel's domain): stride 2 (TF-SAME asymmetric pads), 1x1 and
+    7x7 kernels, narrow / ragged outputs, two sources, K split, strided output rows."""
+    R = KH.bf16_round
+    for (fr, H, W, Cc, N, k, s_, sp) in [(1, 9, 9, 4, 70, 3, 2, 1), (1, 8, 8, 24, 130, 3, 2, 1), (2, 6, 6, 8, 3, 1, 1, 1),
+                                         (3, 5, 5, 4, 33, 5, 2, 1), (1, 7, 8, 36, 40, 3, 1, 2), (1, 11, 9, 8, 20, 7, 1, 1),
+                                         (1, 16, 16, 48, 40, 3, 1, 3)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        got = KH.conv2d(be, [x], [w], b, k, s_, splits=sp, precision=1)
+        close(got, npo.conv2d_same(R(x), R(w), b, s_), 5e-5)
+    xa, xb = rnd(2, 6, 7, 12), rnd(2, 6, 7, 4)                     # two sources, narrow output
+    wa, wb = rnd(3, 3, 12, 20, scale=0.2), rnd(3, 3, 4, 20, scale=0.2)
+    ref = npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb))
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1), ref, 5e-5)
+    with pytest.raises(RuntimeError):                             # input dilation (the zero-dilated dgrad form) stays fp32
+        KH.conv2d(be, [rnd(1, 8, 8, 8)], [rnd(3, 3, 8, 8)], None, 3, 1, dil=2, pad=(1, 1), out_hw=(8, 8), precision=1)
 
 
 def test_conv_two_sources_and_strided_views(be):

@@ -62,3 +62,22 @@ for name, hw, cin, F in levels:
             timeit(lambda: ops.conv2d_wgrad(xs, dy, dw2, 1, bf16=True), fl, 'rec_wgrad_bf16 ' + name, reps=2)
             print('   max |dw_bf16 - dw_f32| / max|dw| = %.3e' % ((dw2 - dw).abs().max().item() / dw.abs().max().item()))
         del xs, dy
+
+if 'misc' in which:     # the layers outside the halo kernels' domain (config-2 shapes, all 32 frames at once)
+    FR = 32
+    for name, hw, cin, n, kk_, st in [('D0.conv0 s2', 256, 128, 128, 3, 2), ('D1.conv0 s2', 128, 256, 256, 3, 2),
+                                      ('U2.conv0 256->64', 128, 256, 64, 3, 1), ('U2.conv1 64->64', 128, 64, 64, 3, 1),
+                                      ('U3.conv1 32->32', 256, 32, 32, 3, 1), ('U3.conv2 1x1 32->3', 256, 32, 3, 1, 1)]:
+        x, w, b = r(FR, hw, hw, cin), r(kk_, kk_, cin, n, scale=0.05), r(n)
+        ho = -(-hw // st)
+        fl = 2.0 * kk_ * kk_ * cin * n * ho * ho * FR
+        timeit(lambda: ops.conv2d([(x, w)], b, st), fl, 'conv ' + name)
+        if 'bf16' in which:
+            pw = ops.pack_bf16(w)
+            timeit(lambda: ops.conv2d([(x, pw)], b, st), fl, 'conv_bf16 ' + name)
+        if st == 2:
+            dy = r(FR, ho, ho, n)
+            timeit(lambda: ops.conv2d_dgrad(dy, w, (hw, hw), 2), fl, 'dgrad ' + name)
+            if 'bf16' in which:
+                timeit(lambda: ops.conv2d_dgrad(dy, w, (hw, hw), 2, bf16=True), fl, 'dgrad_bf16 ' + name)
+        del x
