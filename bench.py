@@ -148,6 +148,7 @@ def main():
     ap.add_argument('--unroll', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer', action='store_true', help='skip the secondary streaming-inference measurement')
+    ap.add_argument('--no-bf16', action='store_true', help='skip the secondary bf16-mode measurement of the same step')
     ap.add_argument('--sync-bn', action='store_true')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else)")
@@ -259,6 +260,32 @@ def main():
                          (H, W, H + 16, W + 16)}
         del m
     total_flops, _ = step_flops(net, H, W, B, T)
+    # ---- secondary: the same step in the bf16 mixed-precision mode (BASELINE config-5 arithmetic), N = 1 only ----
+    mixed = None
+    if args.precision == 'fp32' and dp.world_size == 1 and not args.no_bf16:
+        del trainer
+        torch.cuda.empty_cache()
+        tr16 = train2D.Trainer(Params.CTCParams.net_model, net, 'NCHW', Params.CTCParams.class_weights,
+                               Params.CTCParams.learning_rate, dp=dp, sync_bn=args.sync_bn, seed=0, precision='bf16')
+
+        def step16(i):
+            img, seg, keep = batches[i % len(batches)]
+            tr16.train_step(img, seg, want_outputs=True)
+            tr16.model.reset_states_per_batch(keep)
+
+        for i in range(args.warmup):
+            step16(i)
+        torch.cuda.synchronize()
+        t16 = time.perf_counter()
+        for i in range(args.steps):
+            step16(args.warmup + i)
+        torch.cuda.synchronize()
+        e16 = time.perf_counter() - t16
+        mixed = {'frames_per_s': round(B * T * args.steps / e16, 3), 'ms_per_step': round(1e3 * e16 / args.steps, 3),
+                 'step_tflops_achieved': round(total_flops / 1e12 / (e16 / args.steps), 2), 'steps': args.steps,
+                 'what': 'same workload with --precision bf16: bf16 MFMA operands (v_mfma_f32_32x32x16_bf16) on the '
+                         'convolutions and weight gradients, fp32 accumulate / master weights / state / optimiser'}
+        del tr16
     cpu = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
         try:
@@ -283,6 +310,7 @@ def main():
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'inference': infer,
+            'bf16_mode': mixed,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
