@@ -78,7 +78,9 @@ typedef struct lu_conv_desc {
                                      * (v_mfma_f32_32x32x16_bf16) -- activations stay fp32 in HBM and are rounded to bf16 while
                                      * staged; every src[i].w must then point to weights packed by lu_pack_weights_bf16
                                      * (w_tap_stride / w_row_stride ignored).  Stride-1 3x3 / 5x5, N > 64, 16-byte aligned sources
-                                     * with C % 4 == 0 only (pad a thin input with zero channels: the packed image is zero there). */
+                                     * with C % 4 == 0 only (pad a thin input with zero channels: the packed image is zero there).
+                                     * 2: fp32 MFMA with weights packed by lu_pack_weights_f32 (stride-1 3x3 / 5x5, N > 64, aligned
+                                     * sources; same arithmetic as 0). */
     void* workspace;
     int64_t out_row_stride;         /* elements between output rows; 0 = dense (Wout * out_pix_stride).  Lets a launch
                                      * write one parity plane of a stride-2 input gradient in place. */
@@ -86,6 +88,11 @@ typedef struct lu_conv_desc {
 
 /* bf16 weight image for precision == 1: [tap][ceil(C/32)][N][32] bf16 (zero-filled beyond C), built from a
  * [k*k][C][N] fp32 matrix addressed as w + tap*w_tap_stride + c*w_row_stride + n. */
+/* precision == 2: the same fragment-order image in fp32 ([tap][ceil(C/16)][ceil(N/32)][2][64 lanes][4 floats]): exact fp32 MFMA
+ * arithmetic (bit-identical to precision 0 without a K split), weights streamed from L2 instead of staged through LDS. */
+size_t lu_pack_weights_f32_bytes(int k, int C, int N);
+int lu_pack_weights_f32(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
+                        lu_stream_t stream);
 size_t lu_pack_weights_bf16_bytes(int k, int C, int N);
 int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
                          lu_stream_t stream);

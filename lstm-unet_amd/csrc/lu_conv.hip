@@ -764,17 +764,43 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t ta
     }
 }
 
-template <int K, int EPI, int RW>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch, half the weight traffic)
-__global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
+// fp32 counterpart of pack_weights_bf16_kernel: [tap][16-channel chunk][column fragment][s][lane][4 floats] with
+// channel = 16 chunk + 8 s + 4 (lane >> 5) + e, column = 32 fragment + (lane & 31): the four floats of a lane are the B
+// operands of the four MFMAs fed by one ds_read_b128 of the halo.
+__global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C, int N,
+                                        float* __restrict__ out) {
+    const int nchunk = (C + CK - 1) / CK, nfr = (N + 31) / 32;
+    const int64_t total = (int64_t)kk * nchunk * nfr * 512;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), sh = (int)((i >> 8) & 1);
+        int64_t t = i >> 9;
+        const int fr = (int)(t % nfr);
+        t /= nfr;
+        const int chunk = (int)(t % nchunk);
+        const int tap = (int)(t / nchunk);
+        const int n = fr * 32 + (ln & 31);
+        const int c = chunk * CK + 8 * sh + 4 * (ln >> 5) + e;
+        out[i] = (c < C && n < N) ? w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n] : 0.f;
+    }
+}
+
+// F32 = false: bf16 operands, 32-channel chunks.  F32 = true: the same structure on the exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), 16-channel chunks, weights packed by pack_weights_f32_kernel -- both halo images have an
+// 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
+template <int K, int EPI, int RW, bool F32>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
+__global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_frag_kernel(ConvArgs a) {
     constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
-    constexpr int HPASS = (HP * 8 + NT - 1) / NT;      // halo pieces: one float4 (4 channels of one pixel) per thread each
+    constexpr int CKS = F32 ? CK : CKB;                // channels per stage
+    constexpr int G = CKS / 4;                         // 16-byte global channel groups per halo pixel
+    constexpr int HPASS = (HP * G + NT - 1) / NT;      // halo pieces: one float4 (4 channels of one pixel) per thread each
     constexpr int PAD = (K - 1) / 2;
     constexpr int EX_LD = BN + 4;                      // floats per pixel of the gate-exchange buffer
-    constexpr int AH_ELEMS = HP * LDB;                 // one halo image; two of them live in dynamic LDS
+    constexpr int PITCH = 80;                          // bytes per halo pixel: (16 + 4) floats or (32 + 8) bf16
+    constexpr int AH_BYTES = HP * PITCH;               // one halo image; two of them live in dynamic LDS
     static_assert(HPASS + 2 <= K * K, "the next halo is fetched one piece per tap and stored two taps later");
-    static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 2 <= 2 * AH_ELEMS, "gate exchange aliases the two halo images");
-    LU_DYN_LDS(unsigned short, Ah);                    // [2][AH_ELEMS]
+    static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
+    LU_DYN_LDS(unsigned char, Ah);                     // [2][AH_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -789,7 +815,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
     const int n0 = nt * BN;
     const int ks = blockIdx.y;
     const float* const zp = lu_zero16;
-    const int q = tid & 7;                 // 4-channel group inside the 32-channel chunk
+    const int q = tid % G;                 // 4-channel group inside the chunk
     // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
     const int nfr = (a.N + 31) >> 5;
     const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
@@ -798,8 +824,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
     // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
     const float* const x_s0 = a.src[0].x + (int64_t)f * a.src[0].frame_stride;
     const float* const x_s1 = a.src[1].x + (int64_t)f * a.src[1].frame_stride;
-    const unsigned short* const w_s0 = reinterpret_cast<const unsigned short*>(a.src[0].w) + (int64_t)frag * 1024 + lane * 8;
-    const unsigned short* const w_s1 = reinterpret_cast<const unsigned short*>(a.src[1].w) + (int64_t)frag * 1024 + lane * 8;
+    const unsigned char* const w_s0 = reinterpret_cast<const unsigned char*>(a.src[0].w) + (int64_t)frag * 2048 + lane * 16;
+    const unsigned char* const w_s1 = reinterpret_cast<const unsigned char*>(a.src[1].w) + (int64_t)frag * 2048 + lane * 16;
     const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
     const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
     const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
@@ -828,28 +854,32 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
     // piece p of the halo of chunk `st`: pixel hp = (tid + 512 p) / 8, channels 4 q .. 4 q + 3 (recomputed per use: the
     // addressing is a handful of integer ops once per K*K MFMA stages, the registers are worth more)
     auto piece_load = [&](int p, const IterState& st, float4& r, bool want) {
-        const int hp = (tid + NT * p) >> 3;
+        const int hp = (tid + NT * p) / G;
         const int hy = hp / HWD, hx = hp - hy * HWD;
         const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
         const bool ok = want && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const int c = st.chunk * CKB + 4 * q;
+        const int c = st.chunk * CKS + 4 * q;
         const float* pp = (st.s ? x_s1 : x_s0) + (int64_t)(iy * a.Win + ix) * (st.s ? ps_s1 : ps_s0) + c;
         r = *reinterpret_cast<const float4*>((ok && c < (st.s ? C_s1 : C_s0)) ? pp : zp);      // (16-byte aligned, C % 4 == 0)
     };
     auto piece_store = [&](int p, int hb, const float4& r) {
-        const int hp = (tid + NT * p) >> 3;
+        const int hp = (tid + NT * p) / G;
         if (hp < HP) {
-            unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hb * AH_ELEMS + hp * LDB + 4 * q]);
-            dst[0] = lu_pack2bf(r.x, r.y);
-            dst[1] = lu_pack2bf(r.z, r.w);
+            if (F32) {
+                *reinterpret_cast<float4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
+            } else {
+                unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hb * AH_BYTES + hp * PITCH + 8 * q]);
+                dst[0] = lu_pack2bf(r.x, r.y);
+                dst[1] = lu_pack2bf(r.z, r.w);
+            }
         }
     };
     // B fragments of one stage (two k-steps), straight from the packed weights
     auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
-        const unsigned short* wp = (st.s ? w_s1 : w_s0) +
-                                   ((int64_t)st.tap * (st.s ? nch_s1 : nch_s0) + st.chunk) * nfr * 1024;
+        const unsigned char* wp = (st.s ? w_s1 : w_s0) +
+                                  ((int64_t)st.tap * (st.s ? nch_s1 : nch_s0) + st.chunk) * nfr * 2048;
         const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : zp;
-        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 512) : zp;
+        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 1024) : zp;
         b0 = *reinterpret_cast<const float4*>(p0);
         b1 = *reinterpret_cast<const float4*>(p1);
     };
@@ -860,28 +890,46 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const int khalf8 = 8 * (lane >> 5);
+    const int khalf16 = 16 * (lane >> 5);      // byte offset of this half-wave's k group inside a pixel: 8 bf16 / 4 floats
     auto mma_stage = [&](const IterState& st, int hb, const float4& b0, const float4& b1) {
         const int arow = (RW * wm + st.kh) * HWD + (lane & 31) + st.kw;
-        const unsigned short* ab = &Ah[hb * AH_ELEMS + arow * LDB + khalf8];
+        const unsigned char* ab = &Ah[hb * AH_BYTES + arow * PITCH + khalf16];
+        if (F32) {
+            // lanes 0-31 hold k = 8 s + j, lanes 32-63 k = 8 s + 4 + j (j = 0..3) of pixel row `arow`: one ds_read_b128 feeds
+            // four MFMAs; b0 / b1 carry the matching weight rows for s = 0 / 1.  MFMA order = (s, j) as in conv_halo_kernel.
+            float4 a0[RW], a1[RW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const float4*>(ab + i * HWD * PITCH);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) a1[i] = *reinterpret_cast<const float4*>(ab + i * HWD * PITCH + 32);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].x, b0.x, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].y, b0.y, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].z, b0.z, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].w, b0.w, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].x, b1.x, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].y, b1.y, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].z, b1.z, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].w, b1.w, acc[i]);
+            return;
+        }
         const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
         // k-step 0 for every row, then k-step 1 (back-to-back MFMAs never depend on each other); all k-step-0 fragments
         // are requested up front and every k-step-1 read hides behind a k-step-0 MFMA
-#ifdef LU_ABL_NOLDS      // ablation build: MFMAs without the LDS fragment reads
-#pragma unroll
-        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv1, bv0, acc[i]);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv0, bv1, acc[i]);
-        (void)ab;
-        return;
-#endif
         lu_bf16x8 a0[RW], a1[RW];
 #pragma unroll
-        for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * LDB);
+        for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             acc[i] = lu_mfma_bf16(a0[i], bv0, acc[i]);
-            a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * LDB + 16);
+            a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH + 32);
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
@@ -914,7 +962,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
         }
         // Register ring of B fragments, D stages deep: slot s holds stage it0 + s (mod D) and is refilled for the stage D
         // further on as soon as its MFMAs are issued -- the distance has to cover the L2 latency under load.
-        constexpr int D = (RW == 8) ? 4 : 2;
+        constexpr int D = (RW == 8 && !F32) ? 4 : 2;
         float4 rb0[D], rb1[D];
         IterState sS[D];
         sS[0] = st;
@@ -957,15 +1005,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
                 piece_store(pend[s & 1], hb ^ 1, rp[s & 1]);
                 pend[s & 1] = -1;
             }
-#ifndef LU_ABL_NOLOAD
             piece_load(fetch ? sc.tap : 0, fetch ? nc : sc, rp[s & 1], fetch);
-#endif
             if (fetch) pend[s & 1] = sc.tap;
             sc = sS[(s + D - 1) % D];            // state of stage it + D - 1 ...
             if (it + D < it1) tap_advance(sc);      // ... + 1 (past the end: re-reads the last fragments, unused)
-#ifndef LU_ABL_NOLOAD
             load_b(sc, rb0[s], rb1[s]);
-#endif
             if (last_tap && it + 1 < it1) {      // (HPASS + 2 <= K*K: the staged pieces have been retired by now)
                 __syncthreads();          // the next halo is complete and every wave is done with the old one
                 hb ^= 1;
@@ -1038,7 +1082,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_bf16_kernel(ConvArgs a) {
 // pads, narrow outputs, strided output rows (parity planes of a stride-2 input gradient).  Implicit GEMM over
 // 256 linear pixels x 128 columns per block; a stage is one (tap, 32-channel chunk): the [256][32] activation slab is
 // gathered from HBM/L2 (fp32 -> bf16 while staged, two LDS buffers, one barrier per stage), the weights come from L2 in
-// MFMA-fragment order exactly as in conv_halo_bf16_kernel.  Waves: 2 (groups of 128 pixels) x 4 (column fragments).
+// MFMA-fragment order exactly as in conv_halo_frag_kernel.  Waves: 2 (groups of 128 pixels) x 4 (column fragments).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
     constexpr int NT = 512, RA = 4, MFW = 4;           // RA pixel rows gathered per thread; MFW 32-pixel fragments per wave
@@ -1269,7 +1313,7 @@ __global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __re
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// dynamic LDS of conv_halo_bf16_kernel<K, *, RW>: two bf16 halo images
+// dynamic LDS of conv_halo_frag_kernel<K, *, RW, *>: two halo images of 80 bytes per pixel
 size_t halo_bf16_lds(int K, int RW) { return (size_t)2 * (2 * RW + K - 1) * (32 + K - 1) * LDB * sizeof(unsigned short); }
 
 }  // namespace
@@ -1293,7 +1337,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         const lu_conv_src& in = d->src[s];
         LU_REQUIRE(in.x && in.w && in.C > 0, "lu_conv2d_fwd: source %d incomplete", s);
         const bool vec = (in.C % 4 == 0) && (in.pix_stride % 4 == 0) && (in.frame_stride % 4 == 0) && aligned16(in.x);
-        SrcInfo& si = (vec || d->precision == 1) ? a.src[a.n_src++] : a.tsrc[a.n_thin++];
+        SrcInfo& si = (vec || d->precision != 0) ? a.src[a.n_src++] : a.tsrc[a.n_thin++];
         si.x = in.x;
         si.w = in.w;
         si.frame_stride = in.frame_stride;
@@ -1303,10 +1347,10 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         si.w_row_stride = in.w_row_stride;
         si.thin = vec ? 0 : 1;
         si.nchunk = vec ? (in.C + CK - 1) / CK : (a.kk * in.C + CK - 1) / CK;
-        if (d->precision == 1) {     // bf16 operands: 32-channel chunks, packed weights (lu_pack_weights_bf16)
-            LU_REQUIRE(vec, "lu_conv2d_fwd: bf16 mode needs 16-byte aligned sources with C %% 4 == 0 (source %d); pad thin "
-                            "inputs with zero channels", s);
-            si.nchunk = (in.C + CKB - 1) / CKB;
+        if (d->precision != 0) {     // fragment-packed weights: bf16 (32-channel chunks) or fp32 (16-channel chunks)
+            LU_REQUIRE(vec, "lu_conv2d_fwd: packed-weight modes need 16-byte aligned sources with C %% 4 == 0 (source %d); "
+                            "pad thin inputs with zero channels", s);
+            si.nchunk = d->precision == 1 ? (in.C + CKB - 1) / CKB : (in.C + CK - 1) / CK;
             a.n_it += si.nchunk * a.kk;
         } else if (vec) {
             a.n_it += si.nchunk * a.kk;
@@ -1332,17 +1376,19 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     // halo-reuse kernel: stride-1 SAME 3x3 / 5x5, wide 16-byte-aligned outputs, <= 25 % of the 8x32 patches wasted
     const int64_t tiles_x = (d->Wout + 31) / 32;
     int th = 8;      // patch height; the bf16 kernel takes 16-row patches when that still leaves >= 1 block per CU
-    if (d->precision == 1 && d->k == 5) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
+    if (d->precision != 0 && d->k == 5) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
         const int64_t nt_est = d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128;
         const char* force = getenv("LU_CONV_BF16_PATCH");      // "8" / "16": tests and A/B runs
         const int64_t sp = d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits;
-        if (force ? atoi(force) == 16 : (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * nt_est * sp >= 256) th = 16;
+        if (force ? atoi(force) == 16
+                  : (d->precision == 1 && (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * nt_est * sp >= 256))
+            th = 16;      // (fp32 fragment mode: 8-row patches, two blocks per CU, unless forced)
     }
     const int64_t tiles_y = (d->Hout + th - 1) / th;
     const bool halo = d->stride == 1 && d->dil == 1 && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
                       a.n_src > 0 && d->out_row_stride == 0 &&
-                      (d->precision == 1 || (tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
+                      (d->precision != 0 || (tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
                                              getenv("LU_CONV_NOHALO") == nullptr));
     if (halo) {
         a.tiles_x = (int32_t)tiles_x;
@@ -1350,9 +1396,13 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
     }
     const bool want_xcd_n = getenv("LU_CONV_XCD_N") != nullptr;
+    LU_REQUIRE(d->precision >= 0 && d->precision <= 2, "lu_conv2d_fwd: unknown precision %d", d->precision);
     if (d->precision == 1)
         LU_REQUIRE(d->dil == 1 && (halo || d->epilogue == LU_EPI_BIAS),
                    "lu_conv2d_fwd: bf16 mode has no input dilation, and the ConvLSTM epilogue needs a stride-1 3x3 / 5x5 layer");
+    if (d->precision == 2)
+        LU_REQUIRE(halo, "lu_conv2d_fwd: fragment-packed fp32 weights (precision 2) cover stride-1 3x3 / 5x5 layers with "
+                         "more than 64 output columns only");
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
@@ -1379,9 +1429,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
-        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 8>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_LSTM, 4>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_bf16_kernel<3, LU_EPI_LSTM, 4>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (d->precision == 2 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 2 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 2) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
@@ -1398,15 +1451,32 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.ksplit = d->splits;
         a.ws = (float*)d->workspace;
     }
+    if (d->precision == 2) {     // fp32 MFMA, fragment-packed weights (halo shapes only, checked above)
+        a.n_tiles = (d->N + 127) / 128;
+        dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
+        if (d->k == 5 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        int rcb = LU_CHECK_LAUNCH();
+        if (rcb || a.ksplit == 1) return rcb;
+        const int64_t totb = a.M * a.N;
+        const unsigned rgb = (unsigned)((totb + 255) / 256 < 8192 ? (totb + 255) / 256 : 8192);
+        LU_LAUNCH(ksplit_reduce_kernel, dim3(rgb), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N, a.HWo, a.bias,
+                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);
+        return LU_CHECK_LAUNCH();
+    }
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
         a.n_tiles = (d->N + 127) / 128;
         dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
         if (halo && d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 8>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_bf16_kernel<5, LU_EPI_BIAS, 4>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (halo)
-            LU_LAUNCH_DYN((conv_halo_bf16_kernel<3, LU_EPI_BIAS, 4>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else
             LU_LAUNCH(conv_gather_bf16_kernel, gridb, dim3(512), stream, a);
         int rcb = LU_CHECK_LAUNCH();
@@ -1469,6 +1539,19 @@ extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N,
               (unsigned short*)out);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" size_t lu_pack_weights_f32_bytes(int k, int C, int N) {
+    return (size_t)k * k * ((C + CK - 1) / CK) * (size_t)((N + 31) / 32) * 512 * sizeof(float);
+}
+
+extern "C" int lu_pack_weights_f32(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
+                                   lu_stream_t stream) {
+    LU_REQUIRE(w && out && k > 0 && C > 0 && N > 0, "lu_pack_weights_f32: bad arguments");
+    const int64_t total = (int64_t)k * k * ((C + CK - 1) / CK) * ((N + 31) / 32) * 512;
+    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    LU_LAUNCH(pack_weights_f32_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N, (float*)out);
     return LU_CHECK_LAUNCH();
 }
 

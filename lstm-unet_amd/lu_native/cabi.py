@@ -41,6 +41,8 @@ PROTOTYPES = {
     'lu_last_error': (C.c_char_p, []),
     'lu_abi_version': (C.c_int, []),
     'lu_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), S]),
+    'lu_pack_weights_f32_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'lu_pack_weights_f32': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_pack_weights_bf16_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'lu_pack_weights_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),

@@ -70,11 +70,12 @@ def _p(t):
 
 
 class PackedW(object):
-    """bf16 image of a [k,k,C,N] kernel for the bf16-MFMA convolution (lu_pack_weights_bf16 layout)."""
-    __slots__ = ('data', 'shape')
+    """MFMA-fragment-order image of a [k,k,C,N] kernel: precision 1 = bf16 (lu_pack_weights_bf16), 2 = fp32
+    (lu_pack_weights_f32); the value of lu_conv_desc.precision that goes with it."""
+    __slots__ = ('data', 'shape', 'precision')
 
-    def __init__(self, data, shape):
-        self.data, self.shape = data, tuple(shape)
+    def __init__(self, data, shape, precision=1):
+        self.data, self.shape, self.precision = data, tuple(shape), precision
 
 
 def pack_bf16(w):
@@ -88,12 +89,25 @@ def pack_bf16(w):
     return PackedW(data, w.shape)
 
 
+def pack_f32(w):
+    """fp32 [k,k,C,N] kernel (channel-slice views allowed) -> fragment-order fp32 PackedW (same arithmetic as the plain
+    layout; the convolution then streams its weights from L2 instead of staging them through LDS)."""
+    _chk(w)
+    assert w.dim() == 4 and w.stride(3) == 1 and w.stride(0) == w.shape[1] * w.stride(1)
+    k, _, Cc, N = w.shape
+    data = torch.empty(lib().lu_pack_weights_f32_bytes(k, Cc, N) // 4, device=w.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_pack_weights_f32(w.data_ptr(), w.stride(1), w.stride(2), k, Cc, N, data.data_ptr(),
+                                                 _stream()), 'lu_pack_weights_f32')
+    return PackedW(data, w.shape, 2)
+
+
 def _src(x, w):
     """x: [frames,H,W,C] (channel-slice views allowed), w: [k,k,C,N] (channel-slice views allowed) or PackedW."""
     if isinstance(w, PackedW):
         # x may carry zero pad channels beyond the kernel's (thin inputs padded to 4): same number of 32-channel chunks
         assert x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2)
-        assert x.shape[3] >= w.shape[2] and -(-x.shape[3] // 32) == -(-w.shape[2] // 32), (x.shape, w.shape)
+        ck = 32 if w.precision == 1 else 16
+        assert x.shape[3] >= w.shape[2] and -(-x.shape[3] // ck) == -(-w.shape[2] // ck), (x.shape, w.shape)
         return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data.data_ptr(), 0, 0)
     assert x.dim() == 4 and w.dim() == 4 and x.stride(3) == 1 and w.stride(3) == 1, (x.shape, x.stride(), w.shape)
     assert x.stride(1) == x.shape[2] * x.stride(2), 'rows of x must be dense'
@@ -109,7 +123,8 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
-    bf16 = any(isinstance(w, PackedW) for _, w in pairs)
+    prec = max([w.precision for _, w in pairs if isinstance(w, PackedW)] + [0])
+    bf16 = prec == 1
     halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
@@ -122,7 +137,7 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
                      pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors,
-                     precision=1 if bf16 else 0)
+                     precision=prec)
     return out
 
 
@@ -242,8 +257,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
 def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out):
     """One ConvLSTM2D cell step (reference Networks.py:48-50,62-63).  Fused two-source conv + gate
     epilogue when F % 32 == 0, otherwise conv -> pre-activations -> gate kernel."""
-    bf16 = isinstance(kernel, PackedW)
-    _chk(x_t, h_prev, c_prev, kernel.data if bf16 else kernel, rec.data if bf16 else rec, bias, h_out, c_out, gates_out)
+    packed = isinstance(kernel, PackedW)
+    bf16 = packed and kernel.precision == 1
+    _chk(x_t, h_prev, c_prev, kernel.data if packed else kernel, rec.data if packed else rec, bias, h_out, c_out, gates_out)
     frames, H, W, _ = x_t.shape
     F = rec.shape[2]
     k = kernel.shape[0]
@@ -259,7 +275,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
                          4 * F, _p(bias), None, 0, 0,
                          lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
                                h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0),
-                         precision=1 if bf16 else 0)
+                         precision=kernel.precision if packed else 0)
     else:
         z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
         assert c_prev.is_contiguous() and c_out.is_contiguous()

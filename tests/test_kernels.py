@@ -133,6 +133,34 @@ def _conv_bf16_cases(be):
         KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1)
 
 
+@pytest.mark.parametrize('patch', ['8', '16'])
+def test_conv_f32_fragment_weights_variant(be, patch, monkeypatch):
+    """precision = 2: the fragment-order halo kernel on the exact fp32 MFMA (weights packed by lu_pack_weights_f32 and
+    streamed from L2).  Same tap / channel order as the LDS-staged kernel, so without a K split the two agree bit for bit."""
+    monkeypatch.setenv('LU_CONV_BF16_PATCH', patch)
+    for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
+                                     (1, 8, 60, 100, 96, 3, 2)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=2)
+        close(got, npo.conv2d_same(x, w, b, 1), 5e-5)
+        if sp == 1:
+            assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1))
+    xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources
+    wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=2), npo.conv2d_same(xa, wa) + npo.conv2d_same(xb, wb), 5e-5)
+    F = 32                                                         # fused ConvLSTM step (gates exchanged through LDS)
+    x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
+    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    h1, c1 = npo.convlstm_step(x, h, c, ker, rec, b)
+    hg, cg, gates = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=2)
+    close(hg, h1, 2e-5)
+    close(cg, c1, 2e-5)
+    h0, c0, g0 = KH.convlstm_step_fused(be, x, h, c, ker, rec, b)
+    assert np.array_equal(hg, h0) and np.array_equal(cg, c0) and np.array_equal(gates, g0)
+    with pytest.raises(RuntimeError):
+        KH.conv2d(be, [rnd(1, 8, 8, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=2)
+
+
 def test_conv_bf16_gather_variant(be):
     """General bf16 kernel (precision = 1 outside the halo kernel's domain): stride 2 (TF-SAME asymmetric pads), 1x1 and
     7x7 kernels, narrow / ragged outputs, two sources, K split, strided output rows."""
