@@ -894,6 +894,21 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     auto mma_stage = [&](const IterState& st, int hb, const float4& b0, const float4& b1) {
         const int arow = (RW * wm + st.kh) * HWD + (lane & 31) + st.kw;
         const unsigned char* ab = &Ah[hb * AH_BYTES + arow * PITCH + khalf16];
+#ifdef LU_ABL_MFMA_ONLY      // ablation build (tools only): the MFMA stream without LDS reads -- practical MFMA ceiling
+        if (F32) {
+            for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+                for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(b0.x, b1.y, acc[i]);
+        } else {
+            const lu_bf16x8 u0 = __builtin_bit_cast(lu_bf16x8, b0), u1 = __builtin_bit_cast(lu_bf16x8, b1);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(u1, u0, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(u0, u1, acc[i]);
+        }
+        (void)ab;
+        return;
+#endif
         if (F32) {
             // lanes 0-31 hold k = 8 s + j, lanes 32-63 k = 8 s + 4 + j (j = 0..3) of pixel row `arow`: one ds_read_b128 feeds
             // four MFMAs; b0 / b1 carry the matching weight rows for s = 0 / 1.  MFMA order = (s, j) as in conv_halo_kernel.
@@ -1005,11 +1020,15 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
                 piece_store(pend[s & 1], hb ^ 1, rp[s & 1]);
                 pend[s & 1] = -1;
             }
+#ifndef LU_ABL_MFMA_ONLY
             piece_load(fetch ? sc.tap : 0, fetch ? nc : sc, rp[s & 1], fetch);
+#endif
             if (fetch) pend[s & 1] = sc.tap;
             sc = sS[(s + D - 1) % D];            // state of stage it + D - 1 ...
             if (it + D < it1) tap_advance(sc);      // ... + 1 (past the end: re-reads the last fragments, unused)
+#ifndef LU_ABL_MFMA_ONLY
             load_b(sc, rb0[s], rb1[s]);
+#endif
             if (last_tap && it + 1 < it1) {      // (HPASS + 2 <= K*K: the staged pieces have been retired by now)
                 __syncthreads();          // the next halo is complete and every wave is done with the old one
                 hb ^= 1;
