@@ -15,6 +15,7 @@ third -- fp32 MFMA bound, algorithmic FLOPs over HIP-event time on the launch st
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -213,17 +214,24 @@ def main():
             c['n'] += 1
         traffic_db = {}
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only)
-            if (H, W, T, B) == (256, 256, 8, 4) and args.precision == 'fp32':
-                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
+            if (H, W, T, B) == (256, 256, 8, 4):
+                name = 'r01_pmc_traffic.json' if args.precision == 'fp32' else 'r01_pmc_traffic_bf16.json'
+                with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     traffic_db = json.load(fh)['kernels']
         except (OSError, KeyError, ValueError):
             traffic_db = {}
 
         def traffic_of(kind):
-            name = kind.split(' ')[0]      # e.g. conv_halo_kernel<5,LU_EPI_LSTM>  ->  rocprof's conv_halo_kernel<5, 1>
-            name = name.replace(',LU_EPI_LSTM>', ', 1>').replace(',LU_EPI_BIAS>', ', 0>')
-            hit = [x for x in traffic_db if name in x]
-            return round(traffic_db[hit[0]]['traffic_bytes_per_launch']) if hit else None
+            """launch-weighted mean over the rocprof kernel names of this class, e.g. the event-log class
+            conv_halo_frag_kernel<5,LU_EPI_LSTM,*,bf16> covers rocprof's conv_halo_frag_kernel<5, 1, 8, false> and <5, 1, 4, false>."""
+            name = kind.split(' ')[0]
+            name = name.replace(',LU_EPI_LSTM', ', 1').replace(',LU_EPI_BIAS', ', 0').replace(',*,bf16>', ', [0-9], false>')
+            pat = re.escape(name).replace(re.escape('[0-9]'), '[0-9]')
+            if name.startswith('wgrad_row_bf16_kernel<'):      # rocprof: wgrad_row_bf16_kernel<5, 128>
+                pat = re.escape(name[:-1]) + r', \d+>'
+            hit = [v for k_, v in traffic_db.items() if re.search(pat, k_)]
+            n = sum(v['launches'] for v in hit)
+            return round(sum(v['traffic_bytes_per_launch'] * v['launches'] for v in hit) / n) if n else None
 
         rows = []
         for kind, c in classes.items():
@@ -239,7 +247,7 @@ def main():
         if rows:
             roofline = dict(rows[0])            # the dominant kernel class = largest share of the step
             roofline['traffic_unit'] = ('bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE '
-                                        '(profiles/r01_pmc_traffic.json)')
+                                        '(profiles/r01_pmc_traffic%s.json)' % ('' if args.precision == 'fp32' else '_bf16'))
             roofline['all_mfma_kernels'] = rows
     # ---- secondary metric: streaming inference (Inference2D.py:45-62: B=1, T=1, pad_image=True, stateful) ----
     infer = None

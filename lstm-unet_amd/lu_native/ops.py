@@ -129,7 +129,7 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
     if bf16:
-        kind = ('conv_halo_bf16_kernel<%d,LU_EPI_BIAS> (bf16-MFMA recurrent / input dgrads, plain convs)' % k) \
+        kind = ('conv_halo_frag_kernel<%d,LU_EPI_BIAS,*,bf16> (bf16-MFMA recurrent / input dgrads, plain convs)' % k) \
             if (halo and out_view is None) else 'conv_gather_bf16_kernel (bf16-MFMA strided / narrow / parity-plane convs)'
     optr, ofs, ops_, ors = out_view if out_view is not None else (out.data_ptr(), out.stride(0), out.stride(2), 0)
     if out_view is not None and not bf16:
@@ -268,7 +268,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     # a split into pre-activations and the stand-alone gate kernel instead.
     tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
     if F % 32 == 0 and tiles >= FUSED_MIN_TILES:
-        with _timed(('conv_halo_bf16_kernel<%d,LU_EPI_LSTM> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
+        with _timed(('conv_halo_frag_kernel<%d,LU_EPI_LSTM,*,bf16> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
                     'conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
                     2.0 * k * k * (kernel.shape[2] + F) * 4 * F * frames * H * W):
             calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
