@@ -1,0 +1,46 @@
+"""hipGraph replay of the streaming-inference forward (Inference2D.py:45-62: B = 1, T = 1, fixed frame size).
+
+One frame is ~200 short kernel launches; at bf16 rates the host-side launch path, not the GPU, sets the frame time.  The
+forward is shape-static and the recurrent state lives in persistent buffers that every launch updates in place, so the
+whole per-frame launch sequence is captured once into a graph (torch.cuda.CUDAGraph = hipGraph on ROCm; our kernels are
+plain launches on torch's current stream, which is the capture stream) and replayed per frame."""
+import torch
+
+
+class GraphedFrame(object):
+    """model: Networks.ULSTMnet2D; example: one frame in the public layout ([1,1,C,H,W] or [1,1,H,W,C])."""
+
+    def __init__(self, model, example, warmup=2):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        self.model = model
+        self.x = torch.as_tensor(example, dtype=torch.float32).to(dev).contiguous().clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # eager frames first: builds the engine, the state buffers, the weight caches
+            for _ in range(warmup):
+                model(self.x, training=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._saved = self._snapshot()         # the warm-up frames must not count as history
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits, self.softmax = model(self.x, training=False)
+        torch.cuda.synchronize()
+
+    def _snapshot(self):
+        return [[[t.clone() for t in st] for st in blk] for blk in self.model.engine.states]
+
+    def reset_states(self, states=None):
+        """Zero the recurrent state (or restore `states` from a snapshot) -- in place, the graph owns the buffers."""
+        for bi, blk in enumerate(self.model.engine.states):
+            for li, st in enumerate(blk):
+                for j, t in enumerate(st):
+                    if states is None:
+                        t.zero_()
+                    else:
+                        t.copy_(states[bi][li][j])
+
+    def __call__(self, frame):
+        self.x.copy_(torch.as_tensor(frame, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
+        self.graph.replay()
+        return self.logits, self.softmax

@@ -170,3 +170,23 @@ def test_reference_smoke_shape_contracts():
     mc = Networks.ULSTMnet2D(Networks.DEFAULT_NET_DOWN_PARAMS, 'NCHW', True)
     lg, _ = mc(rng.standard_normal((1, 2, 3, 35, 35)).astype(np.float32), False)
     assert tuple(lg.shape) == (1, 2, 3, 35, 35)
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_of_streaming_forward_is_bit_identical():
+    """lu_native.graph.GraphedFrame: the per-frame launch sequence captured into a hipGraph reproduces the eager
+    streaming forward bit for bit, including the in-place recurrent state (measured neutral for throughput: the frame is
+    bound by ~200 small kernels, not by the host launch path -- kept as an option)."""
+    import Networks
+    from conftest import tiny_net
+    from lu_native.graph import GraphedFrame
+    net = tiny_net(3, (32, 32, 32, 32), (16, 16, 16, 8))
+    torch.manual_seed(3)
+    frames = [torch.randn(1, 1, 1, 40, 48) for _ in range(4)]
+    eager = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1)
+    want = [eager(f, training=False)[1].clone() for f in frames]
+    graphed = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1)
+    g = GraphedFrame(graphed, frames[0])
+    g.reset_states()
+    for f, w in zip(frames, want):
+        assert torch.equal(g(f)[1], w)
