@@ -135,7 +135,9 @@ typedef struct lu_wgrad_desc {
                                * an error otherwise -- use lu_colsum).  Replaces `tape.gradient` w.r.t. the Conv2D / ConvLSTM2D
                                * bias (train2D.py:92) without a second pass over dy. */
     float dbias_beta;
-    int32_t _pad3;
+    int32_t phase;            /* 0: partial sums + reduce (default).  1: partial sums into the workspace only.  2: the
+                               * deterministic reduce of a previous phase-1 call (same descriptor).  Lets a profiler time
+                               * the MFMA kernel alone. */
 } lu_wgrad_desc;
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

@@ -623,11 +623,14 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         dim3 grid(n_tiles, (unsigned)(GY_), (unsigned)splits);                                              \
         LU_LAUNCH((wgrad_kernel<MF_, NF_, WM_, WN_, THIN_, YV_>), grid, block, stream, a);                  \
     } while (0)
+    LU_REQUIRE(d->phase >= 0 && d->phase <= 2, "lu_conv2d_wgrad: phase must be 0 (all), 1 (partial sums) or 2 (reduce)");
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
                              d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
     LU_REQUIRE(!d->dbias || row_variant, "lu_conv2d_wgrad: dbias is produced by the kernel-row variants only (stride-1 3x3 / "
                                          "5x5, C >= 64, W %% 16 == 0, aligned operands); use lu_colsum for this layer");
-    if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
+    if (d->phase == 2) {
+        // reduce only: the slabs were produced by an earlier phase-1 call with the same descriptor
+    } else if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
         const char* force = getenv("LU_WGRAD_BF16_CT");         // "64" / "128": tests and A/B runs
         const int ct = force ? atoi(force) : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
         a.c_tiles = (d->C + ct - 1) / ct;
@@ -664,7 +667,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     }
 #undef LU_WG
     int rc = LU_CHECK_LAUNCH();
-    if (rc) return rc;
+    if (rc || d->phase == 1) return rc;
     int64_t total = a.slab;
     unsigned rgrid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,

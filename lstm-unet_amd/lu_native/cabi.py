@@ -32,7 +32,7 @@ class WgradDesc(C.Structure):
                 ('k', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
                 ('dw', c_f32p), ('dw_tap_stride', i64), ('dw_row_stride', i32), ('splits', i32),
                 ('beta', f32), ('precision', i32), ('workspace', C.c_void_p),
-                ('dbias', c_f32p), ('dbias_beta', f32), ('_pad3', i32)]
+                ('dbias', c_f32p), ('dbias_beta', f32), ('phase', i32)]
 
 
 P = C.c_void_p

@@ -260,6 +260,23 @@ def test_wgrad_fused_bias_gradient(be, precision):
         KH.conv2d_wgrad(be, rnd(1, 6, 6, 8), rnd(1, 6, 6, 8), 3, 1, dbias0=rnd(8))
 
 
+def test_wgrad_two_phase_call(be):
+    """phase 1 (partial sums) + phase 2 (reduce) of lu_conv2d_wgrad == the one-call default, bit for bit."""
+    x, dy = rnd(2, 5, 16, 72), rnd(2, 5, 16, 136)
+    Cin, N, k = 72, 136, 3
+    whole = KH.conv2d_wgrad(be, x, dy, k, 1, splits=3)
+    dw = be.empty((k, k, Cin, N))
+    xd, dyd = be.dev(x), be.dev(dy)
+    d = calls.wgrad_desc(be.ptr(xd), 5 * 16 * Cin, Cin, Cin, be.ptr(dyd), 5 * 16 * N, N, N, 2, 5, 16, 5, 16, k, 1, 1, 1,
+                         be.ptr(dw), Cin * N, N, 3, 0.0)
+    ws = be.empty((be.lib.lu_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4 + 4,))
+    d.workspace = be.ptr(ws)
+    for phase in (1, 2):
+        d.phase = phase
+        ck(be, be.lib.lu_conv2d_wgrad(C.byref(d), be.stream), 'wgrad phase %d' % phase)
+    assert np.array_equal(be.host(dw), whole)
+
+
 @pytest.mark.parametrize('ct', ['64', '128'])
 def test_wgrad_bf16_mfma_variant(be, ct, monkeypatch):
     monkeypatch.setenv('LU_WGRAD_BF16_CT', ct)         # 64- and 128-channel block tiles
