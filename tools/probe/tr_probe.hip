@@ -1,4 +1,5 @@
 // Probe of ds_read_b64_tr_b16 lane/element mapping on gfx950 (tools only; prints what each lane receives).
+// build: hipcc --offload-arch=gfx950 -O2 tools/probe/tr_probe.hip -o tools/probe/tr_probe   (run on the GPU box; prints the mapping)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short s4 __attribute__((ext_vector_type(4)));
