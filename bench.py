@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0             # same guide: HBM3E spec (about 6.3 TB/s achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
 
 
@@ -233,9 +234,15 @@ def main():
             n = sum(v['launches'] for v in hit)
             return round(sum(v['traffic_bytes_per_launch'] * v['launches'] for v in hit) / n) if n else None
 
-        rows = []
+        rows, hbm_rows = [], []
         for kind, c in classes.items():
             if c['ms'] <= 0:
+                continue
+            if kind.startswith('hbm:'):       # bandwidth-bound kernels: algorithmic bytes / time against the 8 TB/s spec
+                gbs = c['flops'] / (c['ms'] * 1e-3) / 1e9
+                hbm_rows.append({'kernel': kind[4:], 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                 'frac': round(gbs / PEAK_HBM_GBS, 4), 'launches_per_step': c['n'],
+                                 'avg_launch_ms': round(c['ms'] / c['n'], 4), 'ms_per_step': round(c['ms'], 2)})
                 continue
             ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in kind else PEAK_FP32_MFMA_TFLOPS
@@ -249,6 +256,7 @@ def main():
             roofline['traffic_unit'] = ('bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE '
                                         '(profiles/r01_pmc_traffic%s.json)' % ('' if args.precision == 'fp32' else '_bf16'))
             roofline['all_mfma_kernels'] = rows
+            roofline['hbm_kernels'] = sorted(hbm_rows, key=lambda r_: -r_['ms_per_step'])
     # ---- secondary metric: streaming inference (Inference2D.py:45-62: B=1, T=1, pad_image=True, stateful) ----
     infer = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_infer:

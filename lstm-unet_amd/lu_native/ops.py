@@ -20,7 +20,9 @@ EVENT_LOG = None   # bench.py: list collecting (kernel class, algorithmic FLOPs,
 
 
 class _timed(object):
-    """HIP-event bracket on the launch stream (torch's current stream), active only while bench.py sets EVENT_LOG."""
+    """HIP-event bracket on the launch stream (torch's current stream), active only while bench.py sets EVENT_LOG.
+    `flops` is the launch's algorithmic work: FLOPs for the MFMA kernels, BYTES (kind prefixed 'hbm:') for the
+    bandwidth-bound ones."""
 
     def __init__(self, kind, flops):
         self.kind, self.flops, self.ev = kind, flops, None
@@ -293,10 +295,13 @@ def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc_in, dz, dc_prev_out):
     frames, H, W, F = c_cur.shape
     for t in (gates, c_prev, c_cur, dz, dc_prev_out):
         assert t.is_contiguous()
-    calls.check(lib(), lib().lu_lstm_gates_bwd(gates.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(), dh_a.data_ptr(),
-                                               dh_a.stride(0), _p(dh_b), _p(dc_in), dz.data_ptr(),
-                                               dc_prev_out.data_ptr(), frames, H * W, F, _stream()),
-                'lu_lstm_gates_bwd')
+    n_in = 4 + 2 + 1 + (dh_b is not None) + (dc_in is not None)       # gates, c_prev, c_cur, dh (+ dh_rec) (+ dc)
+    with _timed('hbm:lstm_gates_bwd_kernel (BPTT gate backward: dz in place of the saved gates, dc)',
+                4.0 * (n_in + 4 + 1) * F * frames * H * W):
+        calls.check(lib(), lib().lu_lstm_gates_bwd(gates.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(), dh_a.data_ptr(),
+                                                   dh_a.stride(0), _p(dh_b), _p(dc_in), dz.data_ptr(),
+                                                   dc_prev_out.data_ptr(), frames, H * W, F, _stream()),
+                    'lu_lstm_gates_bwd')
 
 
 def _colws(rows, Cc, device):
@@ -354,8 +359,9 @@ def bn_lrelu_apply(y, scale, shift, alpha, out=None):
     Cc = y.shape[-1]
     if out is None:
         out = torch.empty_like(y)
-    calls.check(lib(), lib().lu_bn_lrelu_apply(y.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), alpha,
-                                               y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_apply')
+    with _timed('hbm:bn_lrelu_apply_kernel (normalise + LeakyReLU: 1 read + 1 write)', 8.0 * y.numel()):
+        calls.check(lib(), lib().lu_bn_lrelu_apply(y.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), alpha,
+                                                   y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_apply')
     return out
 
 
@@ -375,10 +381,11 @@ def bn_lrelu_bwd_apply(y, dz, scale, shift, mean, invstd, alpha, sums, count, dg
     Cc = y.shape[-1]
     if out is None:
         out = torch.empty_like(y)
-    calls.check(lib(), lib().lu_bn_lrelu_bwd_apply(y.data_ptr(), dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                   mean.data_ptr(), invstd.data_ptr(), alpha, sums.data_ptr(),
-                                                   float(count), out.data_ptr(), _p(dgamma), _p(dbeta),
-                                                   y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_bwd_apply')
+    with _timed('hbm:bn_lrelu_bwd_apply_kernel (BN + LeakyReLU backward: 2 reads + 1 write)', 12.0 * y.numel()):
+        calls.check(lib(), lib().lu_bn_lrelu_bwd_apply(y.data_ptr(), dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                       mean.data_ptr(), invstd.data_ptr(), alpha, sums.data_ptr(),
+                                                       float(count), out.data_ptr(), _p(dgamma), _p(dbeta),
+                                                       y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_bwd_apply')
     return out
 
 
@@ -451,8 +458,9 @@ def wce_loss(sums):
 
 def adam_step(p, g, m, v, alpha, b1, b2, eps, grad_scale=1.0):
     _chk(p, g, m, v)
-    calls.check(lib(), lib().lu_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), alpha, b1,
-                                          b2, eps, grad_scale, _stream()), 'lu_adam_step')
+    with _timed('hbm:adam_kernel (tf.keras Adam on the flat buffers: 4 reads + 3 writes)', 28.0 * p.numel()):
+        calls.check(lib(), lib().lu_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), alpha, b1,
+                                              b2, eps, grad_scale, _stream()), 'lu_adam_step')
 
 
 def scale_frames(x, keep):
