@@ -1,4 +1,13 @@
-// lu_conv.hip -- implicit-GEMM convolution on the gfx950 fp32 matrix pipe.
+// lu_conv.hip -- implicit-GEMM convolution on the gfx950 matrix pipe.
+//
+// Kernels in this file (host dispatch: lu_conv2d_fwd at the bottom):
+//   conv_fwd_kernel         general fp32 path: any k <= 7, stride 1/2, input dilation 2, thin sources, narrow outputs
+//   conv_halo_kernel        fp32, stride-1 3x3 / 5x5 with > 64 output columns: 8 x 32 patch, halo staged once per chunk
+//   conv_halo_frag_kernel   the halo kernel with fragment-order weights streamed from L2 (bf16 MFMA = precision 1; the fp32
+//                           instantiation = precision 2 is a measured-neutral option)
+//   conv_gather_bf16_kernel bf16 MFMA for everything outside the halo kernel's domain (stride 2, parity planes, 1x1, 7x7)
+//   ksplit_reduce / flip_transpose / s2_dgrad_weights / pack_weights_*   helpers around them
+// The description below is the common scheme, written for conv_fwd_kernel.
 //
 // GEMM view: out[m, n] = sum_k A[m, k] * W[k, n],  m = (frame, oy, ox), n = output channel,
 // k = (source, kh, kw, c).  A is never materialised: every pipeline stage gathers a [256 px x 16 ch]
