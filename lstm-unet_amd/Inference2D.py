@@ -80,7 +80,8 @@ def inference(params):
     with open(os.path.join(params.model_path, 'model_params.pickle'), 'rb') as fobj:
         model_dict = pickle.load(fobj)
     model_cls = get_model(model_dict['name'])
-    model = model_cls(*model_dict['params'], data_format=params.data_format, pad_image=True)
+    model = model_cls(*model_dict['params'], data_format=params.data_format, pad_image=True,
+                      precision=getattr(params, 'precision', 'fp32'))
     model.load_weights(os.path.join(params.model_path, 'model.ckpt'))
     log_print('Restored from {}'.format(os.path.join(params.model_path, 'model.ckpt')))
     dataset = params.data_reader(params.sequence_path, params.filename_format,
@@ -137,6 +138,8 @@ FLAGS = [
     (('--save_intermediate_path',), dict(dest='save_intermediate_path', type=str,
                                          help='Path to save intermediate files, used only with --save_intermediate')),
     (('--dry_run',), dict(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
+    (('--precision',), dict(dest='precision', choices=['fp32', 'bf16'],
+                            help='[MI355X] fp32 (default) or bf16 MFMA operands for the wide convolutions')),
 ]
 
 

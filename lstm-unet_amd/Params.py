@@ -65,6 +65,7 @@ _INFER_DEFAULTS = dict(
     data_reader=DataHandeling.CTCInferenceReader, data_format='NCHW',
     FOV=0, min_cell_size=10, max_cell_size=100, edge_dist=2, pre_sequence_frames=4,
     dry_run=False, save_intermediate=True, save_intermediate_path='./tmp/output/PhC-C2DL-PSC/01',
+    precision='fp32',      # MI355X option: 'bf16' = bf16 MFMA operands
 )
 
 
