@@ -182,6 +182,30 @@ def train(params):
         pred = predictions.argmax(-1).cpu()
         return float((pred == lab.long()).float().mean())
 
+    # TensorBoard event files (train2D.py:119-137,163-176,205-211): scalars Loss / SEG, images Image / GT / Output of the
+    # window's last frame (first batch slot), every write_to_tb_interval steps -- written by rank 0 only
+    writers = None
+    if not params.dry_run and is_main:
+        import tb_events
+        writers = {'train': tb_events.SummaryWriter(os.path.join(params.experiment_log_dir, 'train')),
+                   'val': tb_events.SummaryWriter(os.path.join(params.experiment_log_dir, 'val'))}
+
+    def tboard(which, step, loss_mean, seg_mean, image, label, softmax_):
+        w = writers[which]
+        w.scalar('Loss', loss_mean.result(), step)
+        w.scalar('SEG', seg_mean.result(), step)
+        nchw = params.channel_axis == 1
+        img = np.asarray(image)[0, -1]
+        img = img[0] if nchw else img[..., 0]
+        img = img - img.min()
+        w.image('Image', img / max(float(img.max()), 1e-12), step)
+        lab = np.asarray(label)[0, -1]
+        lab = (lab[0] if nchw else lab[..., 0]).astype(np.int64)
+        w.image('GT', np.eye(3, dtype=np.float32)[np.clip(lab, 0, 2)] * (lab >= 0)[..., None], step)
+        sm_ = softmax_[0, -1].detach().cpu().numpy()
+        w.image('Output', np.transpose(sm_, (1, 2, 0)) if sm_.shape[0] == 3 else sm_, step)
+        w.flush()
+
     template = '{}: Step {}, Loss: {}, Accuracy: {}'
     val_states = model.get_states()
     try:
@@ -203,13 +227,16 @@ def train(params):
                 p = save_ckpt()
                 if p:
                     log_print('Saved checkpoint for step {}: {}'.format(step, p))
+            if writers is not None and not step % params.write_to_tb_interval:
+                tboard('train', step, train_loss, train_seg, image_sequence, seg_sequence, softmax)
+                log_print('Printed Training Step: {} to Tensorboard'.format(step))
             if not step % params.print_to_console_interval and is_main:
                 log_print(template.format('Training', step, train_loss.result(), train_acc.result() * 100))
             if not step % params.validation_interval:
                 train_states = model.get_states()
                 model.set_states(val_states)
                 v_img, v_seg, _, v_last = val_data_provider.get_batch()
-                _, v_pred, v_loss = trainer.val_step(v_img, v_seg)
+                v_sm, v_pred, v_loss = trainer.val_step(v_img, v_seg)
                 model.reset_states_per_batch(v_last)
                 val_loss(v_loss)
                 v_pub = v_pred.permute(0, 1, 4, 2, 3) if params.channel_axis == 1 else v_pred
@@ -217,6 +244,8 @@ def train(params):
                 val_acc(accuracy(v_seg, v_pred))
                 if is_main:
                     log_print(template.format('Validation', step, val_loss.result(), val_acc.result() * 100))
+                if writers is not None and not step % params.write_to_tb_interval:
+                    tboard('val', step, val_loss, val_seg, v_img, v_seg, v_sm)
                 val_states = model.get_states()
                 model.set_states(train_states)
     except (KeyboardInterrupt, ValueError, AWSError) as err:
@@ -233,6 +262,9 @@ def train(params):
             log_print('Saved Model to file: {}'.format(model_fname))
         elif params.dry_run:
             log_print('WARNING: dry_run flag is ON! Not Saving Model')
+        if writers is not None:
+            for w_ in writers.values():
+                w_.close()
         log_print('Done')
     return trainer
 

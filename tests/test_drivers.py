@@ -33,7 +33,7 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     args = dict(experiment_name='t', crop_size=(size, size), batch_size=2, unroll_len=2, num_iterations=3,
                 validation_interval=2, print_to_console_interval=1, save_checkpoint_iteration=2,
                 save_checkpoint_dir=str(tmp_path), save_log_dir=str(tmp_path), data_format='NCHW',
-                learning_rate=1e-3)
+                learning_rate=1e-3, write_to_tb_interval=2)
     params = Params.CTCParams(args)
     assert isinstance(params.train_data_provider, DataHandeling.SyntheticSequence2D) and params.channel_axis == 1
     trainer = train2D.train(params)
@@ -45,6 +45,20 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     assert meta['name'] == 'ULSTMnet2D' and meta['params'][0] == net
     ckpts = sorted(os.listdir(os.path.join(save_dir, 'tf_ckpts')))
     assert ckpts, 'no periodic checkpoint written'
+    # TensorBoard event files: Loss / SEG scalars and Image / GT / Output images at steps 2 and 4, train and val
+    import tb_events
+    for run in ('train', 'val'):
+        files = os.listdir(os.path.join(params.experiment_log_dir, run))
+        assert len(files) == 1 and files[0].startswith('events.out.tfevents.')
+        events = tb_events.read_events(os.path.join(params.experiment_log_dir, run, files[0]))      # verifies every CRC
+        assert events[0][2] == b'brain.Event:2'
+        tags = {}
+        for step, vals, _ in events[1:]:
+            for k, v in vals.items():
+                tags.setdefault(k, []).append(step)
+        assert set(tags) == {'Loss', 'SEG', 'Image', 'GT', 'Output'} and tags['Loss'] == [2, 4], (run, tags)
+        h, w, ch, png = [v for _, vals, _ in events for k, v in vals.items() if k == 'Output'][0]
+        assert (h, w, ch) == (size, size, 3) and png[:8] == b'\x89PNG\r\n\x1a\n'
     # resume from the checkpoint: weights / Adam state / step / recurrent state come back
     sd = torch.load(os.path.join(save_dir, 'tf_ckpts', ckpts[-1]), map_location='cpu')
     t2 = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', learning_rate=1e-3)

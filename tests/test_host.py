@@ -199,3 +199,21 @@ def test_dp_bucketed_allreduce_world2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o
+
+
+def test_tensorboard_event_writer(tmp_path):
+    """tb_events: CRC-32C known answer, TFRecord framing and proto fields read back (scalars exact in float32)."""
+    import tb_events
+    assert tb_events.crc32c(b'123456789') == 0xE3069283 and tb_events.crc32c(b'') == 0
+    w = tb_events.SummaryWriter(str(tmp_path))
+    w.scalar('Loss', 0.15625, 3)
+    w.image('Image', np.linspace(0, 1, 6 * 7).reshape(6, 7), 3)
+    w.image('GT', np.zeros((6, 7, 3), np.float32), 5)
+    w.close()
+    ev = tb_events.read_events(w.path)
+    assert ev[0][2] == b'brain.Event:2' and ev[1][:2] == (3, {'Loss': 0.15625})
+    assert ev[2][0] == 3 and ev[2][1]['Image'][:3] == (6, 7, 1) and ev[3][0] == 5 and ev[3][1]['GT'][:3] == (6, 7, 3)
+    from PIL import Image
+    import io
+    img = np.asarray(Image.open(io.BytesIO(ev[2][1]['Image'][3])))
+    assert img.shape == (6, 7) and img[0, 0] == 0 and img[-1, -1] == 255
