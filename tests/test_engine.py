@@ -276,6 +276,29 @@ def test_bf16_precision_mode(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_bf16_mode_ragged_inference_shapes():
+    """bf16 mode on frame sizes that are not multiples of anything (35 x 37, reflect-padded to 48 x 48 inside): streaming
+    forward with carried state, every frame within 3e-2 * max|logit| of the fp32 engine, labels equal outside the tie band."""
+    from lu_native.engine import Engine
+    net, cin = BF16_NET, 1
+    rng = np.random.default_rng(8)
+    p = perturbed_params(net, cin, 5)
+    frames = [rng.standard_normal((1, 35, 37, cin)).astype(np.float32) for _ in range(3)]
+    outs = {}
+    for prec in ('fp32', 'bf16'):
+        e = Engine(net, pad_image=True, precision=prec)
+        e.build(cin, torch.device('cuda', 0))
+        e.load_params(p)
+        outs[prec] = [e.forward(torch.from_numpy(f).cuda(), 1, 1, False).cpu().numpy().astype(np.float64) for f in frames]
+    for a, b in zip(outs['fp32'], outs['bf16']):
+        assert a.shape == (1, 35, 37, 3)
+        assert np.abs(a - b).max() <= 3e-2 * np.abs(a).max()
+        top2 = np.sort(a, -1)
+        band = (top2[..., -1] - top2[..., -2]) < 5e-2 * np.abs(a).max()
+        assert np.all((a.argmax(-1) == b.argmax(-1)) | band)
+
+
+@pytest.mark.gpu
 def test_layerwise_backward_consistency():
     """Config-1 backward on the GPU: every Conv->BN->LeakyReLU unit's backward (BN sums, input gradient
     of the BN, weight gradient) is re-evaluated in fp64 torch ON THE DEVICE from the very tensors the
