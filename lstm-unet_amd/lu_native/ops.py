@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblstmunet_hip.so')
 _lib = None
 FUSED_MIN_TILES = 160   # fused ConvLSTM step needs this many 256x32ch tiles to fill the chip (tests set 0)
+FUSED_MIN_TILES_BF16 = 0    # ... the bf16 kernel is better fused at every size (B = 1 streaming: 394 vs 384 frames/s)
 EVENT_LOG = None   # bench.py: list collecting (kernel class, algorithmic FLOPs, start, end) around the MFMA launches
 
 
@@ -273,7 +274,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     # The fused epilogue cannot take a K split, so tile-starved steps (streaming inference: B = 1) run the conv with
     # a split into pre-activations and the stand-alone gate kernel instead.
     tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
-    if F % 32 == 0 and tiles >= FUSED_MIN_TILES:
+    if F % 32 == 0 and tiles >= (FUSED_MIN_TILES_BF16 if bf16 else FUSED_MIN_TILES):
         with _timed(('conv_halo_frag_kernel<%d,LU_EPI_LSTM,*,bf16> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
                     'conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
                     2.0 * k * k * (kernel.shape[2] + F) * 4 * F * frames * H * W):
