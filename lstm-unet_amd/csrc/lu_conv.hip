@@ -102,7 +102,7 @@ __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f
 // values in the NF column fragments (column = 32*nf + (lane & 31)).
 template <int NF, int EPI>
 __device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float (&v)[NF], int f, int64_t pix, int64_t m,
-                                                  int nt, int n0, int ks, int ccol) {
+                                                  int nt, int n0, int ks, int ccol, int oy_known = -1) {
     if (EPI == LU_EPI_LSTM) {
         const int ch = nt * 32 + ccol;  // F % 32 == 0 is enforced by the host
         const int F = a.F;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float
     } else {
         float* op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride;
         if (a.out_row_stride) {      // strided output rows (parity planes of a stride-2 input gradient)
-            const int64_t oy = pix / a.Wout;
+            const int64_t oy = oy_known >= 0 ? oy_known : pix / a.Wout;
             op = a.out + (int64_t)f * a.out_frame_stride + oy * a.out_row_stride + (pix - oy * a.Wout) * a.out_pix_stride;
         }
 #pragma unroll
@@ -146,6 +146,32 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float
         }
     }
 }
+
+// (frame, pixel, row) of a linear output index, advanced by small positive steps without divisions: the general kernels'
+// epilogues walk the 16 accumulator rows of a fragment (steps of 1 or 5 pixels) after ONE decode per fragment -- with 64
+// decodes per thread the 64-bit divisions cost as much as a tenth of a short (stride-2 / parity-plane) block.
+struct RowCursor {
+    int f, pix, oy, ox;
+    __device__ __forceinline__ void set(const ConvArgs& a, int64_t m) {
+        f = (int)((uint32_t)m / (uint32_t)a.HWo);          // M < 2^31 (checked by the host)
+        pix = (int)m - f * a.HWo;
+        oy = pix / a.Wout;
+        ox = pix - oy * a.Wout;
+    }
+    __device__ __forceinline__ void advance(const ConvArgs& a, int d) {
+        pix += d;
+        ox += d;
+        while (ox >= a.Wout) {
+            ox -= a.Wout;
+            ++oy;
+        }
+        while (pix >= a.HWo) {
+            pix -= a.HWo;
+            ++f;
+            oy -= a.HWo / a.Wout;
+        }
+    }
+};
 
 // GEN = general addressing (input dilation 2: the dgrad of a stride-2 conv); !GEN = the common dil == 1 case,
 // where a tap is a constant element offset from a per-row base computed once per source.
@@ -474,17 +500,18 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     // ---- epilogue ----
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
+        const int64_t mb = m0 + wave * (32 * MF) + mf * 32 + 4 * (lane >> 5);      // accumulator row r = 0 of this lane
+        RowCursor rc;
+        rc.set(a, mb < a.M ? mb : 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int64_t m = m0 + wave * (32 * MF) + mf * 32 + row;
+            if (r) rc.advance(a, (r & 3) ? 1 : 5);          // rows 0,1,2,3, 8,9,10,11, 16,... (+ 4 for the upper half-wave)
+            const int64_t m = mb + (r & 3) + 8 * (r >> 2);
             if (m >= a.M) continue;
-            const int f = (int)(m / a.HWo);
-            const int64_t pix = m - (int64_t)f * a.HWo;
             float v[NF];
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) v[nf] = acc[mf][nf][r];
-            conv_epilogue_row<NF, EPI>(a, v, f, pix, m, nt, n0, ks, lane & 31);
+            conv_epilogue_row<NF, EPI>(a, v, rc.f, rc.pix, m, nt, n0, ks, lane & 31, rc.oy);
         }
     }
 }
@@ -1264,16 +1291,19 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
     }
 
 #pragma unroll
-    for (int i = 0; i < MFW; ++i)
+    for (int i = 0; i < MFW; ++i) {
+        const int64_t mb = m0 + 128 * wm + 32 * i + 4 * (lane >> 5);
+        RowCursor rc;
+        rc.set(a, mb < a.M ? mb : 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + 128 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (r) rc.advance(a, (r & 3) ? 1 : 5);
+            const int64_t m = mb + (r & 3) + 8 * (r >> 2);
             if (m >= a.M) continue;
-            const int f = (int)(m / a.HWo);
-            const int64_t pix = m - (int64_t)f * a.HWo;
             float v[1] = {acc[i][r]};
-            conv_epilogue_row<1, LU_EPI_BIAS>(a, v, f, pix, m, nt, n0 + 32 * wn, ks, lane & 31);
+            conv_epilogue_row<1, LU_EPI_BIAS>(a, v, rc.f, rc.pix, m, nt, n0 + 32 * wn, ks, lane & 31, rc.oy);
         }
+    }
 }
 
 // out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic)
@@ -1386,6 +1416,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         bvec = bvec && (in.w_row_stride % 4 == 0) && (in.w_tap_stride % 4 == 0) && aligned16(in.w);
     }
     a.M = (int64_t)d->frames * d->Hout * d->Wout;
+    LU_REQUIRE(a.M < ((int64_t)1 << 31), "lu_conv2d_fwd: more than 2^31 output pixels in one call");
     a.HWo = d->Hout * d->Wout;
     a.Wout = d->Wout;
     a.Hin = d->Hin;
