@@ -1197,8 +1197,9 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
             ++st.s;
         }
     };
-    float4 ra[RA];
-    auto load_a = [&](const IterState& st) {
+    constexpr int D = 4;           // register rings: activation slabs and B fragments are requested D - 1 / D stages ahead
+    float4 ra[D][RA];
+    auto load_a = [&](const IterState& st, float4 (&r)[RA]) {
         const int c = st.chunk * CKB + 4 * q;
         const bool cok = c < (st.s ? C_s1 : C_s0);
         const float* xb = (st.s ? x_s1 : x_s0) + c;
@@ -1209,15 +1210,15 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
             const int iy = vy0[i] + st.kh, ix = vx0[i] + st.kw;
             const bool ok = cok && iy >= 0 && ix >= 0 && iy < a.Hin && ix < a.Win;
             const float* p = xb + (int64_t)fr[i] * fs + ((int64_t)iy * a.Win + ix) * ps;
-            ra[i] = *reinterpret_cast<const float4*>(ok ? p : zp);
+            r[i] = *reinterpret_cast<const float4*>(ok ? p : zp);
         }
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, const float4 (&r)[RA]) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             unsigned* dst = reinterpret_cast<unsigned*>(&As[buf][((tid >> 3) + 64 * i) * LDB + 4 * q]);
-            dst[0] = lu_pack2bf(ra[i].x, ra[i].y);
-            dst[1] = lu_pack2bf(ra[i].z, ra[i].w);
+            dst[0] = lu_pack2bf(r[i].x, r[i].y);
+            dst[1] = lu_pack2bf(r[i].z, r[i].w);
         }
     };
     auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
@@ -1239,8 +1240,9 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
         it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
     }
     if (it1 > it0) {
-        IterState st{0, 0, 0, 0, 0};
+        IterState sS[D];               // sS[j]: state of the stage whose data lives in ring slot j
         {
+            IterState st{0, 0, 0, 0, 0};
             int r = it0;
             if (r >= nch_s0 * kk) {
                 r -= nch_s0 * kk;
@@ -1250,21 +1252,31 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
             st.tap = r - st.chunk * kk;
             st.kh = st.tap / K;
             st.kw = st.tap - st.kh * K;
+            sS[0] = st;
         }
-        IterState nx = st;
-        if (it0 + 1 < it1) tap_advance(nx);
-        float4 bA0, bA1, bB0, bB1;           // B fragments of the current / next stage
-        load_a(st);
-        load_b(st, bA0, bA1);
-        load_b(nx, bB0, bB1);
-        store_a(0);
+#pragma unroll
+        for (int j = 1; j < D; ++j) {
+            sS[j] = sS[j - 1];
+            if (it0 + j < it1) tap_advance(sS[j]);       // (clamped at the last stage)
+        }
+        float4 rb0[D], rb1[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) load_b(sS[j], rb0[j], rb1[j]);
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load_a(sS[j], ra[j]);
+        store_a(0, ra[0]);
         __syncthreads();
         const int khalf8 = 8 * (lane >> 5);
-        auto stage = [&](int it, int buf, float4& c0, float4& c1) {       // (c0, c1): this stage's fragments; refilled for it + 2
-            load_a(nx);                      // next stage's slab: in flight across the MFMAs
+        // Stage `it` in ring slot s: LDS buffer (it - it0) & 1 holds its slab, ra[s + 1] the next one (requested two stages ago);
+        // request the slab of stage it + D - 1 into the slot this stage's slab came from, run the MFMAs, publish the next
+        // slab, refill the B slot for stage it + D.  No conditional step in the loop body (exact vmcnt waits, see above).
+        auto stage = [&](int it, auto slot) {
+            constexpr int s = decltype(slot)::value;
+            const IterState sa = sS[(s + D - 1) % D];     // state of stage it + D - 1 (clamped at the last stage)
+            load_a(sa, ra[(s + D - 1) % D]);
             LU_SCHED_FENCE();
-            const unsigned short* ab = &As[buf][(128 * wm + (lane & 31)) * LDB + khalf8];
-            const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, c0), bv1 = __builtin_bit_cast(lu_bf16x8, c1);
+            const unsigned short* ab = &As[(it - it0) & 1][(128 * wm + (lane & 31)) * LDB + khalf8];
+            const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, rb0[s]), bv1 = __builtin_bit_cast(lu_bf16x8, rb1[s]);
 #pragma unroll
             for (int i = 0; i < MFW; ++i) {
                 const lu_bf16x8 a0 = *reinterpret_cast<const lu_bf16x8*>(ab + 32 * i * LDB);
@@ -1276,18 +1288,26 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
                 acc[i] = lu_mfma_bf16(a1, bv1, acc[i]);
             }
             LU_SCHED_FENCE();
-            store_a(buf ^ 1);                // buf ^ 1 was last read before the previous barrier
-            st = nx;
-            if (it + 2 < it1) tap_advance(nx);
-            load_b(nx, c0, c1);              // (past the end: re-reads the last fragments, unused)
+            store_a((it - it0 + 1) & 1, ra[(s + 1) % D]);       // that buffer was last read before the previous barrier
+            sS[s] = sa;                                   // state of stage it + D - 1 ...
+            if (it + D < it1) tap_advance(sS[s]);         // ... + 1: the stage this slot serves next
+            load_b(sS[s], rb0[s], rb1[s]);
             __syncthreads();
         };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        using S3 = std::integral_constant<int, 3>;
         int it = it0;
-        for (; it + 1 < it1; it += 2) {
-            stage(it, 0, bA0, bA1);
-            stage(it + 1, 1, bB0, bB1);
+        for (; it + D <= it1; it += D) {
+            stage(it, S0());
+            stage(it + 1, S1());
+            stage(it + 2, S2());
+            stage(it + 3, S3());
         }
-        if (it < it1) stage(it, 0, bA0, bA1);
+        if (it < it1) stage(it, S0());
+        if (it + 1 < it1) stage(it + 1, S1());
+        if (it + 2 < it1) stage(it + 2, S2());
     }
 
 #pragma unroll
