@@ -550,6 +550,154 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// All-taps variant for the narrow decoder layers (stride-1 3x3, C <= 64, N <= 64, W % 16 == 0): with so few channels a
+// 64 x 128 kernel-row tile is mostly padding and the layer is bound by reading x and dy once per kernel row (or, in
+// wgrad_kernel, once per tap).  Here one block owns the WHOLE 9 x C x N gradient of a pixel slab: a stage is a 16-pixel run
+// of one image row, the dy tile [16][64] is shared by all nine taps and the x tile holds the three input rows
+// [3][16 + 2][64]; the (tap, 32-channel, 32-column) accumulator tiles (at most 36) are dealt round-robin to the 8 waves.
+// x and dy are read exactly once.
+// ---------------------------------------------------------------------------------------------------------
+template <int MAXT>      // accumulator tiles per wave: ceil(9 * ceil(C/32) * ceil(N/32) / 8) = 2, 3 or 5
+__global__ __launch_bounds__(512, 2) void wgrad_small3_kernel(WgradArgs a) {
+    constexpr int K = 3, CT = 64, NTL = 64, XP = KP + K - 1, NT = 512;
+    __shared__ __attribute__((aligned(16))) float Xs[2][K * XP * CT];
+    __shared__ __attribute__((aligned(16))) float Ys[2][KP * NTL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cfr = (a.C + 31) >> 5, nfr = (a.N + 31) >> 5;            // 32-wide fragments in use (1 or 2 each)
+    const int n_tiles = K * K * cfr * nfr;
+    const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+    int64_t p_end = p_begin + a.chunk;
+    if (p_end > a.M) p_end = a.M;
+    const int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
+    const float* const zp = lu_zero16;
+
+    int64_t pf = 0;
+    int oy = 0, ox0 = 0;
+    {
+        const int64_t p = p_begin < a.M ? p_begin : 0;
+        pf = p / a.HWo;
+        const int r = (int)(p - pf * a.HWo);
+        oy = r / a.Wout;
+        ox0 = r - oy * a.Wout;
+    }
+    // x tile: K rows x XP pixels x 16 float4 = 864 items (two passes); dy tile: 16 pixels x 16 float4 (threads < 256)
+    const int xq = tid & 15;
+    const int xi0 = tid >> 4, xi1 = xi0 + NT / 16;               // item -> (kernel row, pixel) = (item / XP, item % XP)
+    const int yq = tid & 15, yrow = tid >> 4;
+    float4 rx0 = make_float4(0.f, 0.f, 0.f, 0.f), rx1 = rx0, ry = rx0;
+    const bool want_bias = a.bias_ws != nullptr;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_x = [&](int item) -> float4 {
+        const int kh = item / XP, xp = item - kh * XP;
+        const int iy = oy + kh - a.pad_t, ix = ox0 - a.pad_l + xp;
+        const int c = 4 * xq;
+        const bool ok = item < K * XP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.C;
+        const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
+        return *reinterpret_cast<const float4*>(ok ? px : zp);
+    };
+    auto load_stage = [&](int it) {
+        rx0 = load_x(xi0);
+        rx1 = load_x(xi1);
+        const int n = 4 * yq;
+        const bool oky = tid < 256 && p_begin + (int64_t)it * KP + yrow < p_end && n < a.N;
+        const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0 + yrow) * a.dy_ps + n;
+        ry = *reinterpret_cast<const float4*>(oky ? py : zp);
+    };
+    auto store_stage = [&](int buf) {
+        *reinterpret_cast<float4*>(&Xs[buf][xi0 * CT + 4 * xq]) = rx0;
+        if (xi1 < K * XP) *reinterpret_cast<float4*>(&Xs[buf][xi1 * CT + 4 * xq]) = rx1;
+        if (tid < 256) *reinterpret_cast<float4*>(&Ys[buf][yrow * NTL + 4 * yq]) = ry;
+    };
+    auto advance = [&]() {
+        ox0 += KP;
+        if (ox0 >= a.Wout) {
+            ox0 = 0;
+            if (++oy == a.Hout) {
+                oy = 0;
+                ++pf;
+            }
+        }
+    };
+
+    // this wave's accumulator tiles: id = wave + 8 j -> (tap, channel fragment, column fragment)
+    int t_x[MAXT], t_y[MAXT];          // LDS offsets of the tile's A column (x) and B column (dy)
+    bool t_ok[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int id = wave + 8 * j;
+        t_ok[j] = id < n_tiles;
+        const int tap = id / (cfr * nfr), rem = id - tap * (cfr * nfr);
+        const int cf = rem / nfr, nf = rem - cf * nfr;
+        const int kh = tap / K, kw = tap - kh * K;
+        t_x[j] = t_ok[j] ? (kh * XP + kw) * CT + 32 * cf + (lane & 31) : 0;
+        t_y[j] = t_ok[j] ? 32 * nf + (lane & 31) : 0;
+    }
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    if (n_it > 0) {
+        load_stage(0);
+        store_stage(0);
+        if (want_bias) {
+            bsum.x += ry.x; bsum.y += ry.y; bsum.z += ry.z; bsum.w += ry.w;
+        }
+    }
+    __syncthreads();
+    const int khalf = lane >> 5;
+    for (int it = 0; it < n_it; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_it) advance();
+        load_stage(it + 1 < n_it ? it + 1 : it);
+        LU_SCHED_FENCE();
+#pragma unroll
+        for (int kk2 = 0; kk2 < KP; kk2 += 2) {
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j) {      // (a slot beyond n_tiles recomputes tile 0 and is dropped: no branch here)
+                const float av = Xs[buf][(kk2 + khalf) * CT + t_x[j]];
+                const float bv = Ys[buf][(kk2 + khalf) * NTL + t_y[j]];
+                acc[j] = lu_mfma(av, bv, acc[j]);
+            }
+        }
+        LU_SCHED_FENCE();
+        store_stage(buf ^ 1);
+        if (want_bias && it + 1 < n_it) {
+            bsum.x += ry.x; bsum.y += ry.y; bsum.z += ry.z; bsum.w += ry.w;
+        }
+        __syncthreads();
+    }
+
+    float* slab = a.ws + (int64_t)blockIdx.z * a.slab;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int id = wave + 8 * j;
+        if (id >= n_tiles) continue;
+        const int tap = id / (cfr * nfr), rem = id - tap * (cfr * nfr);
+        const int cf = rem / nfr, nf = rem - cf * nfr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * cf + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int n = 32 * nf + (lane & 31);
+            if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[j][r];
+        }
+    }
+    if (want_bias) {          // 16 pixel-row threads per column group -> one sum per column (fixed order)
+        float* red = Ys[0];
+        __syncthreads();
+        if (tid < 256) *reinterpret_cast<float4*>(&red[yrow * NTL + 4 * yq]) = bsum;
+        __syncthreads();
+        if (tid < NTL) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < KP; ++r) sum += red[r * NTL + tid];
+            if (tid < a.N) a.bias_ws[(int64_t)blockIdx.z * a.N + tid] = sum;
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ dw,
                                     int C, int N, int64_t tap_stride, int row_stride, float beta) {
     const int64_t total = slab;
@@ -626,10 +774,19 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     LU_REQUIRE(d->phase >= 0 && d->phase <= 2, "lu_conv2d_wgrad: phase must be 0 (all), 1 (partial sums) or 2 (reduce)");
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
                              d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
-    LU_REQUIRE(!d->dbias || row_variant, "lu_conv2d_wgrad: dbias is produced by the kernel-row variants only (stride-1 3x3 / "
-                                         "5x5, C >= 64, W %% 16 == 0, aligned operands); use lu_colsum for this layer");
+    const bool small3 = xvec && yvec && d->stride == 1 && d->k == 3 && d->C <= 64 && d->N <= 64 && d->Wout % 16 == 0 &&
+                        d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOSMALL");
+    LU_REQUIRE(!d->dbias || row_variant || small3,
+               "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
+               "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
     if (d->phase == 2) {
         // reduce only: the slabs were produced by an earlier phase-1 call with the same descriptor
+    } else if (small3) {
+        const int tiles = 9 * ((d->C + 31) / 32) * ((d->N + 31) / 32);
+        dim3 grid(1, 1, (unsigned)splits);
+        if (tiles <= 16) LU_LAUNCH((wgrad_small3_kernel<2>), grid, dim3(512), stream, a);
+        else if (tiles <= 24) LU_LAUNCH((wgrad_small3_kernel<3>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((wgrad_small3_kernel<5>), grid, dim3(512), stream, a);
     } else if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
         const char* force = getenv("LU_WGRAD_BF16_CT");         // "64" / "128": tests and A/B runs
         const int ct = force ? atoi(force) : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);

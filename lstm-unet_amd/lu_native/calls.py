@@ -71,11 +71,13 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     return d
 
 
-def wgrad_splits(pixels, k, Cin, N, target_blocks=6144, row_variant=False):
+def wgrad_splits(pixels, k, Cin, N, target_blocks=6144, row_variant=False, small3=False):
     """Pixel-axis split.  The wgrad kernel holds 4 workgroups per CU (1024 slots on 256 CUs); with only ~1000
     long-running blocks the slowest CU (4 blocks vs 3) sets the time, so aim for several thousand shorter
     blocks (>= 2048 pixels = 128 pipeline stages each) and let the dispatcher balance them."""
     target_blocks = int(os.environ.get('LU_WGRAD_BLOCKS', target_blocks))     # tuning knob (bench A/B)
+    if small3:           # all-taps kernel of the narrow layers: one block per pixel slab, ~2 blocks per CU
+        return max(1, min(512, pixels // 2048))
     ct = max(1, -(-Cin // 128)) if Cin % 4 == 0 else -(-(k * k * Cin) // 32)
     taps = k * k if Cin % 4 == 0 else 1
     bn = 256 if (Cin % 4 == 0 and Cin > 64 and N >= 256 and N % 4 == 0) else 128

@@ -235,21 +235,29 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
                    x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0 and
                    x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and Hout == Hin and Wout == Win and
                    not os.environ.get('LU_WGRAD_NOROW'))     # mirrors lu_conv2d_wgrad's kernel choice
+    aligned = (Cin % 4 == 0 and N % 4 == 0 and x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and
+               dy.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+    small3 = (aligned and stride == 1 and k == 3 and Cin <= 64 and N <= 64 and Wout % 16 == 0 and Hout == Hin and Wout == Win and
+              not os.environ.get('LU_WGRAD_NOSMALL'))      # all-taps kernel of the narrow decoder layers (takes precedence)
+    if small3:
+        row_variant = False
     # the bf16 kernel's 128-channel tiles run one block per CU: half as many, longer blocks (measured best: ~3000)
     bf16_row = bf16 and row_variant and Wout % 32 == 0
-    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant,
+    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
                                 target_blocks=3072 if bf16_row else 6144)
     d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
                          frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
                          splits, beta, precision=1 if bf16 else 0,
-                         dbias=dbias.data_ptr() if (dbias is not None and row_variant) else None, dbias_beta=dbias_beta)
-    if dbias is not None and not row_variant:
+                         dbias=dbias.data_ptr() if (dbias is not None and (row_variant or small3)) else None,
+                         dbias_beta=dbias_beta)
+    if dbias is not None and not (row_variant or small3):
         bias_grad(dy, dbias, dbias_beta)
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
     kind = ('wgrad_row_kernel<%d> (weight gradients hoisted over T)' % k) if row_variant else \
-        'wgrad_kernel (strided / thin / narrow layers)'
+        ('wgrad_small3_kernel (narrow 3x3 layers, all nine taps per block)' if small3 else
+         'wgrad_kernel (strided / thin / narrow layers)')
     if bf16_row:
         kind = 'wgrad_row_bf16_kernel<%d> (bf16-MFMA weight gradients hoisted over T)' % k
     if EVENT_LOG is not None:      # bench.py's roofline pass: time the MFMA kernel alone, the slab reduce outside the bracket

@@ -291,6 +291,21 @@ def test_wgrad_fused_bias_gradient(be, precision):
         KH.conv2d_wgrad(be, rnd(1, 6, 6, 8), rnd(1, 6, 6, 8), 3, 1, dbias0=rnd(8))
 
 
+def test_wgrad_all_taps_narrow_layers(be):
+    """wgrad_small3_kernel: stride-1 3x3 layers with C <= 64 and N <= 64 (W % 16 == 0) -- all nine taps per block, ragged
+    channel counts, pixel splits, fused bias gradient."""
+    for (fr, H, W, Cc, N, sp) in [(2, 5, 16, 32, 32, 1), (1, 4, 32, 64, 64, 3), (1, 3, 16, 20, 36, 2), (2, 4, 16, 64, 32, 2),
+                                  (1, 5, 48, 8, 64, 4)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        _, gw = _torch_conv_grads(x, rnd(3, 3, Cc, N), dy, 1)
+        db0 = rnd(N)
+        dw, db = KH.conv2d_wgrad(be, x, dy, 3, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
+        close(dw, gw, 2e-4)
+        close(db, dy.reshape(-1, N).astype(np.float64).sum(0) + db0, 2e-4)
+        dw0 = rnd(3, 3, Cc, N)
+        close(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=sp, dw0=dw0, beta=1.0), gw + dw0, 2e-4)
+
+
 def test_wgrad_two_phase_call(be):
     """phase 1 (partial sums) + phase 2 (reduce) of lu_conv2d_wgrad == the one-call default, bit for bit."""
     x, dy = rnd(2, 5, 16, 72), rnd(2, 5, 16, 136)
