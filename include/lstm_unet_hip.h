@@ -84,6 +84,10 @@ typedef struct lu_conv_desc {
     void* workspace;
     int64_t out_row_stride;         /* elements between output rows; 0 = dense (Wout * out_pix_stride).  Lets a launch
                                      * write one parity plane of a stride-2 input gradient in place. */
+    int32_t k_h;                    /* kernel HEIGHT; 0 = k (square).  With k_h != k the tap window is k_h rows x k columns and
+                                     * src[i].w holds k_h*k taps (LU_EPI_BIAS, general kernels only): the parity planes of a
+                                     * stride-2 input gradient have 2x2, 2x1, 1x2 and 1x1 windows. */
+    int32_t _pad_end;
 } lu_conv_desc;
 
 /* bf16 weight image for precision == 1: [tap][ceil(C/32)][N][32] bf16 (zero-filled beyond C), built from a
@@ -97,6 +101,10 @@ size_t lu_pack_weights_bf16_bytes(int k, int C, int N);
 int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
                          lu_stream_t stream);
 
+/* the same image for a rectangular k_h x k tap window given as a list of `taps` = k_h*k taps (size: taps instead of k*k) */
+int lu_pack_weights_taps_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int taps, int C, int N, void* out,
+                              lu_stream_t stream);
+
 size_t lu_conv2d_workspace_bytes(const lu_conv_desc* d);
 int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream);
 
@@ -107,9 +115,11 @@ int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N,
 
 /* Input gradient of a STRIDE-2 convolution without multiplying zeros: the four output parity classes
  * (py, px) are four small stride-1 convolutions of dy.  This packs their kernels:
- *   sub[cls = 2*py+px][ty][tx][n][c] = w[kh][kw][c][n],  kh = py + pad_t - 2*(ty - pady[py]), kw likewise
- * (zero outside the k x k support); the caller then launches lu_conv2d_fwd four times with kernel size ks,
- * pads (pady[py], padx[px]) and out_row_stride / out_pix_stride doubled. */
+ *   plane cls = 2*py+px:  sub_cls[ty][tx][n][c] = w[kh][kw][c][n],  kh = py + pad_t - 2*(ty - pady[py]), kw likewise,
+ * for the ny[py] x nx[px] taps that fall inside the k x k support (ny[p] = #{kh : (p + pad_t - kh) even}); the four planes
+ * are stored back to back.  The caller then launches lu_conv2d_fwd four times with k = nx[px], k_h = ny[py], pads
+ * (pady[py], padx[px]) and out_row_stride / out_pix_stride doubled.  (`ks` = ceil(k/2) is kept for sizing: the buffer never
+ * needs more than 4*ks*ks*N*C floats.) */
 int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int ks, int C, int N, int pad_t, int pad_l,
                              int pady0, int pady1, int padx0, int padx1, lu_stream_t stream);
 

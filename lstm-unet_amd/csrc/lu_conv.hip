@@ -1370,19 +1370,25 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
 // Sub-kernels of the input gradient of a stride-2 convolution, one per output parity class (py, px):
 //   dX[2a+py, 2b+px, c] = sum_{ty,tx,n} dY[a + ty - pad_y, b + tx - pad_x, n] * sub[cls][ty][tx][n][c]
 // with sub[cls][ty][tx][n][c] = w[kh][kw][c][n], kh = py + pt - 2*(ty - pad_y) (zero when outside [0,k)).
-__global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ sub, int k, int ks, int C,
-                                        int N, int pt, int pl, int pady0, int pady1, int padx0, int padx1) {
-    const int64_t total = (int64_t)4 * ks * ks * N * C;
+__global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ sub, int k, int C, int N, int pt,
+                                        int pl, int pady0, int pady1, int padx0, int padx1, int ny0, int ny1, int nx0,
+                                        int nx1) {
+    // compact layout: plane cls = 2 py + px holds ny[py] x nx[px] taps, [ty][tx][n][c], planes back to back
+    const int64_t nc = (int64_t)N * C;
+    const int64_t sz[4] = {ny0 * nx0 * nc, ny0 * nx1 * nc, ny1 * nx0 * nc, ny1 * nx1 * nc};
+    const int64_t total = sz[0] + sz[1] + sz[2] + sz[3];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        int64_t t = i / C;
+        int cls = 0;
+        int64_t j = i;
+        while (j >= sz[cls]) j -= sz[cls++];
+        const int py = cls >> 1, px = cls & 1;
+        const int nx = px ? nx1 : nx0;
+        const int c = (int)(j % C);
+        int64_t t = j / C;
         const int n = (int)(t % N);
         t /= N;
-        const int tx = (int)(t % ks);
-        t /= ks;
-        const int ty = (int)(t % ks);
-        const int cls = (int)(t / ks);
-        const int py = cls >> 1, px = cls & 1;
+        const int tx = (int)(t % nx);
+        const int ty = (int)(t / nx);
         const int kh = py + pt - 2 * (ty - (py ? pady1 : pady0));
         const int kw = px + pl - 2 * (tx - (px ? padx1 : padx0));
         sub[i] = (kh >= 0 && kh < k && kw >= 0 && kw < k) ? w[(((int64_t)kh * k + kw) * C + c) * N + n] : 0.f;
@@ -1405,8 +1411,10 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     LU_REQUIRE(d->frames > 0 && d->Hout > 0 && d->Wout > 0 && d->N > 0, "lu_conv2d_fwd: empty problem");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.k = d->k;
-    a.kk = d->k * d->k;
+    const int k_h = d->k_h ? d->k_h : d->k;      // rectangular tap window k_h x k (parity planes of stride-2 gradients)
+    LU_REQUIRE(k_h >= 1 && k_h <= 7, "lu_conv2d_fwd: unsupported kernel height %d", k_h);
+    a.k = d->k;                                   // taps per kernel row
+    a.kk = k_h * d->k;
     bool bvec = (d->N % 4 == 0);
     a.n_it = 0;
     a.n_src = 0;
@@ -1464,7 +1472,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
             th = 16;      // (fp32 fragment mode: 8-row patches, two blocks per CU, unless forced)
     }
     const int64_t tiles_y = (d->Hout + th - 1) / th;
-    const bool halo = d->stride == 1 && d->dil == 1 && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
+    const bool halo = d->stride == 1 && d->dil == 1 && k_h == d->k && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
                       a.n_src > 0 && d->out_row_stride == 0 &&
                       (d->precision != 0 || (tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
@@ -1507,7 +1515,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.n_tiles = a.F / 32;
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
-        LU_REQUIRE(d->dil == 1 && d->stride == 1, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1");
+        LU_REQUIRE(d->dil == 1 && d->stride == 1 && k_h == d->k, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1, a square kernel");
         if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
@@ -1600,10 +1608,16 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
 extern "C" int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int ks, int C, int N, int pt, int pl,
                                         int pady0, int pady1, int padx0, int padx1, lu_stream_t stream) {
     LU_REQUIRE(w && sub && k > 0 && ks > 0 && C > 0 && N > 0, "lu_stride2_dgrad_weights: bad arguments");
-    const int64_t total = (int64_t)4 * ks * ks * N * C;
+    auto count = [&](int par, int pad) {      // taps kh of a parity class: (par + pad - kh) even, 0 <= kh < k
+        int n = 0;
+        for (int kh = 0; kh < k; ++kh) n += ((par + pad - kh) % 2 == 0);
+        return n;
+    };
+    const int ny0 = count(0, pt), ny1 = count(1, pt), nx0 = count(0, pl), nx1 = count(1, pl);
+    const int64_t total = (int64_t)(ny0 + ny1) * (nx0 + nx1) * N * C;
     const unsigned g = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    LU_LAUNCH(s2_dgrad_weights_kernel, dim3(g), dim3(256), stream, w, sub, k, ks, C, N, pt, pl, pady0, pady1, padx0,
-              padx1);
+    LU_LAUNCH(s2_dgrad_weights_kernel, dim3(g), dim3(256), stream, w, sub, k, C, N, pt, pl, pady0, pady1, padx0, padx1, ny0,
+              ny1, nx0, nx1);
     return LU_CHECK_LAUNCH();
 }
 
@@ -1617,6 +1631,16 @@ extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_
     const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 1024;
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N,
+              (unsigned short*)out);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_pack_weights_taps_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int taps, int C, int N,
+                                         void* out, lu_stream_t stream) {
+    LU_REQUIRE(w && out && taps > 0 && C > 0 && N > 0, "lu_pack_weights_taps_bf16: bad arguments");
+    const int64_t total = (int64_t)taps * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 1024;
+    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, taps, C, N,
               (unsigned short*)out);
     return LU_CHECK_LAUNCH();
 }

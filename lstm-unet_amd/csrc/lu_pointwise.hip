@@ -21,7 +21,7 @@ void lu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
-extern "C" int lu_abi_version(void) { return 2; }
+extern "C" int lu_abi_version(void) { return 3; }
 
 #ifndef LU_EMU
 int lu_check_launch() {

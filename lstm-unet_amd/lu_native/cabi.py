@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 2          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 3          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                 ('c_prev', c_f32p), ('c_out', c_f32p), ('h_out', c_f32p), ('gates_out', c_f32p),
                 ('c_prev_frame_stride', i64), ('c_out_frame_stride', i64), ('h_frame_stride', i64),
                 ('gates_frame_stride', i64), ('splits', i32), ('precision', i32), ('workspace', C.c_void_p),
-                ('out_row_stride', i64)]
+                ('out_row_stride', i64), ('k_h', i32), ('_pad_end', i32)]
 
 
 class WgradDesc(C.Structure):
@@ -43,6 +43,7 @@ PROTOTYPES = {
     'lu_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), S]),
     'lu_pack_weights_f32_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'lu_pack_weights_f32': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
+    'lu_pack_weights_taps_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_pack_weights_bf16_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'lu_pack_weights_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),

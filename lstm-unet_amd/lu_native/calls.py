@@ -41,7 +41,7 @@ def conv_splits(frames, Hout, Wout, N, k, channels):
 
 
 def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,
-           out_frame_stride, out_pix_stride, lstm=None, splits=1, workspace=None, out_row_stride=0, precision=0):
+           out_frame_stride, out_pix_stride, lstm=None, splits=1, workspace=None, out_row_stride=0, precision=0, k_h=0):
     d = cabi.ConvDesc()
     d.n_src = len(srcs)
     for i, s in enumerate(srcs):
@@ -50,7 +50,7 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
     d.k, d.stride, d.dil, d.pad_t, d.pad_l, d.N = k, stride, dil, pad_t, pad_l, N
     d.bias, d.out, d.out_frame_stride, d.out_pix_stride = bias, out, out_frame_stride, out_pix_stride
     d.epilogue = cabi.LU_EPI_BIAS
-    d.splits, d.workspace, d.out_row_stride, d.precision = splits, workspace, out_row_stride, precision
+    d.splits, d.workspace, d.out_row_stride, d.precision, d.k_h = splits, workspace, out_row_stride, precision, k_h
     if lstm is not None:
         d.epilogue = cabi.LU_EPI_LSTM
         (d.c_prev, d.c_prev_frame_stride, d.c_out, d.c_out_frame_stride, d.h_out, d.h_frame_stride,

@@ -104,6 +104,18 @@ def pack_f32(w):
     return PackedW(data, w.shape, 2)
 
 
+def pack_taps_bf16(w):
+    """[k_h, k_w, C, N] dense tap window -> bf16 PackedW (the packer only sees a list of k_h*k_w taps)."""
+    _chk(w)
+    assert w.is_contiguous()
+    kh, kw, Cc, N = w.shape
+    taps = kh * kw
+    data = torch.empty(taps * -(-Cc // 32) * -(-N // 32) * 1024, device=w.device, dtype=torch.int16)
+    calls.check(lib(), lib().lu_pack_weights_taps_bf16(w.data_ptr(), Cc * N, N, taps, Cc, N, data.data_ptr(), _stream()),
+                'lu_pack_weights_taps_bf16')
+    return PackedW(data, w.shape)
+
+
 def _src(x, w):
     """x: [frames,H,W,C] (channel-slice views allowed), w: [k,k,C,N] (channel-slice views allowed) or PackedW."""
     if isinstance(w, PackedW):
@@ -118,11 +130,12 @@ def _src(x, w):
     return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data_ptr(), w.stride(1), w.stride(2))
 
 
-def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out, out_view=None, flops=None):
+def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out, out_view=None, flops=None,
+             k_h=0):
     """One lu_conv2d_fwd launch (bias epilogue); picks a K-split + workspace for tile-starved problems.
     out_view = (ptr, frame_stride, pix_stride, row_stride) overrides the dense addressing of `out`."""
     channels = sum(x.shape[3] for x, _ in pairs)
-    splits = calls.conv_splits(frames, Hout, Wout, N, k, channels)
+    splits = calls.conv_splits(frames, Hout, Wout, N, k, channels) if not k_h else 1
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
@@ -140,7 +153,7 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
                      pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors,
-                     precision=prec)
+                     precision=prec, k_h=k_h)
     return out
 
 
@@ -205,19 +218,26 @@ def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16=False):
 
     (py0, ny0), (py1, ny1) = axis(0, pt), axis(1, pt)
     (px0, nx0), (px1, nx1) = axis(0, pl), axis(1, pl)
-    sub = torch.empty((4, ks, ks, N, Cc), device=w.device, dtype=torch.float32)
+    sub = torch.empty(((ny0 + ny1) * (nx0 + nx1), N, Cc), device=w.device, dtype=torch.float32)    # four compact planes
     calls.check(lib(), lib().lu_stride2_dgrad_weights(w.data_ptr(), sub.data_ptr(), k, ks, Cc, N, pt, pl, py0, py1, px0,
                                                       px1, _stream()), 'lu_stride2_dgrad_weights')
     out = torch.empty((frames, Hin, Win, Cc), device=dy.device, dtype=torch.float32)
+    off = 0
     for py, (pady, ny) in enumerate(((py0, ny0), (py1, ny1))):
         for px, (padx, nx) in enumerate(((px0, nx0), (px1, nx1))):
+            wsub = sub[off:off + ny * nx].view(ny, nx, N, Cc)         # the plane's ny x nx tap window
+            off += ny * nx
             Hs, Ws = (Hin - py + 1) // 2, (Win - px + 1) // 2
             if Hs <= 0 or Ws <= 0:
                 continue
+            if ny * nx == 0:          # (cannot happen for k >= 2; a class without taps has zero gradient)
+                out[:, py::2, px::2].zero_()
+                continue
             view = (out.data_ptr() + 4 * (py * Win + px) * Cc, Hin * Win * Cc, 2 * Cc, 2 * Win * Cc)
-            wsub = pack_bf16(sub[2 * py + px]) if bf16 else sub[2 * py + px]
-            conv_raw([(dy, wsub)], frames, Hd, Wd, Hs, Ws, ks, 1, 1, pady, padx, Cc, None, out, out_view=view,
-                     flops=2.0 * ny * nx * N * Cc * frames * Hs * Ws)
+            if bf16:
+                wsub = pack_taps_bf16(wsub)
+            conv_raw([(dy, wsub)], frames, Hd, Wd, Hs, Ws, nx, 1, 1, pady, padx, Cc, None, out, out_view=view,
+                     flops=2.0 * ny * nx * N * Cc * frames * Hs * Ws, k_h=ny)
     return out
 
 

@@ -144,22 +144,28 @@ def conv2d_dgrad_s2_parity(be, dy, w, in_hw):
 
     def axis(par, pad):
         offs = [(par + pad - kh) // 2 for kh in range(k) if (par + pad - kh) % 2 == 0]
-        return -min(offs)
+        return (-min(offs), len(offs)) if offs else (0, 0)
 
-    pady, padx = [axis(0, pt), axis(1, pt)], [axis(0, pl), axis(1, pl)]
-    sub = be.empty((4, ks, ks, N, Cc))
+    (py0, ny0), (py1, ny1) = axis(0, pt), axis(1, pt)
+    (px0, nx0), (px1, nx1) = axis(0, pl), axis(1, pl)
+    sub = be.empty(((ny0 + ny1) * (nx0 + nx1) * N * Cc,))          # four compact planes, back to back
     wd, dyd = be.dev(w), be.dev(dy)
-    calls.check(be.lib, be.lib.lu_stride2_dgrad_weights(be.ptr(wd), be.ptr(sub), k, ks, Cc, N, pt, pl, pady[0], pady[1],
-                                                        padx[0], padx[1], be.stream), 's2w')
+    calls.check(be.lib, be.lib.lu_stride2_dgrad_weights(be.ptr(wd), be.ptr(sub), k, ks, Cc, N, pt, pl, py0, py1, px0, px1,
+                                                        be.stream), 's2w')
     out = be.empty((frames, Hin, Win, Cc))
-    for py in range(2):
-        for px in range(2):
+    off = 0
+    for py, (pady, ny) in enumerate(((py0, ny0), (py1, ny1))):
+        for px, (padx, nx) in enumerate(((px0, nx0), (px1, nx1))):
+            taps = ny * nx
             Hs, Ws = (Hin - py + 1) // 2, (Win - px + 1) // 2
-            if Hs <= 0 or Ws <= 0:
-                continue
-            src = calls.conv_src(be.ptr(dyd), Hd * Wd * N, N, N, be.ptr(sub, (2 * py + px) * ks * ks * N * Cc), N * Cc, Cc)
-            calls.conv2d(be.lib, be.stream, [src], frames, Hd, Wd, Hs, Ws, ks, 1, 1, pady[py], padx[px], Cc, None,
-                         be.ptr(out, (py * Win + px) * Cc), Hin * Win * Cc, 2 * Cc, out_row_stride=2 * Win * Cc)
+            if Hs > 0 and Ws > 0 and taps > 0:
+                src = calls.conv_src(be.ptr(dyd), Hd * Wd * N, N, N, be.ptr(sub, off * N * Cc), N * Cc, Cc)
+                calls.conv2d(be.lib, be.stream, [src], frames, Hd, Wd, Hs, Ws, nx, 1, 1, pady, padx, Cc, None,
+                             be.ptr(out, (py * Win + px) * Cc), Hin * Win * Cc, 2 * Cc, out_row_stride=2 * Win * Cc, k_h=ny)
+            elif Hs > 0 and Ws > 0:                                 # a parity class without taps: zero gradient
+                o = be.host(out)
+                o[:, py::2, px::2, :] = 0.0
+            off += taps
     return be.host(out)
 
 
