@@ -71,10 +71,11 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     return d
 
 
-def wgrad_splits(pixels, k, Cin, N, target_blocks=6144, row_variant=False, small3=False):
+def wgrad_splits(pixels, k, Cin, N, target_blocks=3072, row_variant=False, small3=False):
     """Pixel-axis split.  The wgrad kernel holds 4 workgroups per CU (1024 slots on 256 CUs); with only ~1000
-    long-running blocks the slowest CU (4 blocks vs 3) sets the time, so aim for several thousand shorter
-    blocks (>= 2048 pixels = 128 pipeline stages each) and let the dispatcher balance them."""
+    long-running blocks the slowest CU (4 blocks vs 3) sets the time, so aim for a few thousand shorter
+    blocks (>= 2048 pixels = 128 pipeline stages each) and let the dispatcher balance them; beyond ~3000 the slab
+    reduce grows faster than the balance improves (re-measured with the kernel-row variants: 3072 vs 6144 +1-2 %)."""
     target_blocks = int(os.environ.get('LU_WGRAD_BLOCKS', target_blocks))     # tuning knob (bench A/B)
     if small3:           # all-taps kernel of the narrow layers: one block per pixel slab, ~2 blocks per CU
         return max(1, min(512, pixels // 2048))

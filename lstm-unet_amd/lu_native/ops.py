@@ -261,10 +261,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
               not os.environ.get('LU_WGRAD_NOSMALL'))      # all-taps kernel of the narrow decoder layers (takes precedence)
     if small3:
         row_variant = False
-    # the bf16 kernel's 128-channel tiles run one block per CU: half as many, longer blocks (measured best: ~3000)
     bf16_row = bf16 and row_variant and Wout % 32 == 0
     splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
-                                target_blocks=3072 if bf16_row else 6144)
+                                target_blocks=3072)      # re-measured after the kernel-row variants: ~3000 blocks >= 6000
     d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
                          frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
                          splits, beta, precision=1 if bf16 else 0,
