@@ -61,7 +61,7 @@ class Engine:
         self.tape = None
         self.segments = []   # [(name, start, end)] gradient buckets in backward-completion order
         self.on_bucket_ready = None  # callback(start, end) fired as each bucket's gradient completes
-        self.debug = None            # tools/diag_gpu.py: dict collecting clones of intermediate gradients
+        self.debug = None            # tests/diag/diag_gpu.py: dict collecting clones of intermediate gradients
 
     # ------------------------------------------------------------------ build
     def build(self, in_channels, device):

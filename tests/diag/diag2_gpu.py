@@ -1,6 +1,6 @@
 """GPU diagnostic 2: isolate the BN/LeakyReLU backward of down.2.conv.1 inside a real C1 backward."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import numpy as np, torch

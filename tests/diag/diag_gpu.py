@@ -1,7 +1,7 @@
 """GPU diagnostic: per-tensor gradient errors of the C1 train step vs the fp64 oracle, determinism,
 and per-shape conv fwd/dgrad/wgrad checks at the C1 layer shapes."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import numpy as np, torch

@@ -4,7 +4,7 @@ autograd for gradients and the Adam update).
 Gradient tolerances.  The loss is only piecewise smooth (hard-sigmoid and LeakyReLU kinks, BatchNorm over
 as few as 1024 pixels), so its gradient is ill-conditioned: perturbing the WEIGHTS of the fp64 oracle by a
 relative 1e-6 / 1e-5 moves its own gradients by up to 8e-3 / 4e-2 of a tensor's max at config-1 size
-(measured, tools/diag notes in DESIGN.md §9).  fp32 arithmetic therefore cannot agree with fp64 better than
+(measured with tests/diag/, notes in DESIGN.md §9).  fp32 arithmetic therefore cannot agree with fp64 better than
 that on the big case (and the second step starts from fp32-drifted weights/state); the small cases (few kink
 crossings) are held to 2e-3, config-1 to 0.15 max-relative / 0.05 L2-relative per tensor, and
 `test_layerwise_backward_consistency` checks every backward kernel of the big case against an fp64
