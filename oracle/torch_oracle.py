@@ -27,8 +27,17 @@ def _same_pad(n_in, k, s):
     return npo.tf_same_pad(n_in, k, s)
 
 
-def conv2d_same(x, w, b=None, stride=1):
-    """x [N,H,W,C], w [k,k,Cin,Cout] (Keras layout) -> [N,Ho,Wo,Cout]; TF-SAME zero padding."""
+def round_bf16(t):
+    """Round-to-nearest-even to bf16 through fp32 (what the bf16-mode kernels do to their MFMA operands), kept in t.dtype."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def conv2d_same(x, w, b=None, stride=1, rounded=False):
+    """x [N,H,W,C], w [k,k,Cin,Cout] (Keras layout) -> [N,Ho,Wo,Cout]; TF-SAME zero padding.
+    rounded: both operands are rounded to bf16 first (products / sums stay in x.dtype) -- the arithmetic of the
+    bf16-MFMA convolutions of Engine(precision='bf16')."""
+    if rounded:
+        x, w = round_bf16(x), round_bf16(w)
     k = w.shape[0]
     _, pt, pb = _same_pad(x.shape[1], k, stride)
     _, pl, pr = _same_pad(x.shape[2], k, stride)
@@ -58,16 +67,16 @@ def resize_bilinear(x, f):
     return y.permute(0, 2, 3, 1)
 
 
-def convlstm_seq(x, kernel, rec_kernel, bias, h0, c0):
+def convlstm_seq(x, kernel, rec_kernel, bias, h0, c0, rounded=False):
     b, t, hh, ww, _ = x.shape
     f = rec_kernel.shape[2]
     h = torch.zeros(b, hh, ww, f, dtype=x.dtype) if h0 is None else h0
     c = torch.zeros(b, hh, ww, f, dtype=x.dtype) if c0 is None else c0
     # hoist the input projection over all T (mathematically identical)
-    zx = conv2d_same(x.reshape(b * t, hh, ww, -1), kernel, bias).reshape(b, t, hh, ww, 4 * f)
+    zx = conv2d_same(x.reshape(b * t, hh, ww, -1), kernel, bias, rounded=rounded).reshape(b, t, hh, ww, 4 * f)
     outs = []
     for ti in range(t):
-        z = zx[:, ti] + conv2d_same(h, rec_kernel, None)
+        z = zx[:, ti] + conv2d_same(h, rec_kernel, None, rounded=rounded)
         i = hard_sigmoid(z[..., :f])
         fg = hard_sigmoid(z[..., f:2 * f])
         g = torch.tanh(z[..., 2 * f:3 * f])
@@ -93,7 +102,11 @@ class TorchULSTM:
     """Functional model over a name->tensor parameter dict (names as np_oracle.init_params)."""
 
     def __init__(self, net_params, in_channels, params, dtype=torch.float64, pad_image=False,
-                 bn_eps=1e-3, bn_momentum=0.99):
+                 bn_eps=1e-3, bn_momentum=0.99, bf16_operands=False):
+        """bf16_operands: restate Engine(precision='bf16') -- the convolutions that mode runs on the bf16 MFMA
+        (ConvLSTM gate convolutions with 3x3 / 5x5 kernels and 4F > 64 columns; Conv2D layers with >= 64 output
+        channels whose sources all have C % 4 == 0) see bf16-rounded operands, everything else stays in `dtype`."""
+        self.bf16_operands = bool(bf16_operands)
         self.net_params = net_params
         self.plan = npo.net_plan(net_params, in_channels)
         self.dtype = dtype
@@ -125,8 +138,10 @@ class TorchULSTM:
         out_skip = xp.reshape(b * t, hp, wp, cin)
         new_states = []
 
-        def cbl(prefix, ci, l, act, with_bn=True):
-            y = conv2d_same(act, P[f'{prefix}.conv.{ci}.kernel'], P[f'{prefix}.conv.{ci}.bias'], l['stride'])
+        def cbl(prefix, ci, l, act, with_bn=True, cins=None):
+            w_ = P[f'{prefix}.conv.{ci}.kernel']
+            rnd = self.bf16_operands and w_.shape[3] >= 64 and all(c % 4 == 0 for c in (cins or (w_.shape[2],)))
+            y = conv2d_same(act, w_, P[f'{prefix}.conv.{ci}.bias'], l['stride'], rounded=rnd)
             if not with_bn:
                 return y
             bnp = f'{prefix}.bn.{ci}'
@@ -150,9 +165,10 @@ class TorchULSTM:
             for li, _ in enumerate(blk['lstm']):
                 st = None if self.states is None else self.states[bi][li]
                 h0, c0 = (None, None) if st is None else st
-                seq, hT, cT = convlstm_seq(seq, P[f'down.{bi}.lstm.{li}.kernel'],
-                                           P[f'down.{bi}.lstm.{li}.recurrent_kernel'],
-                                           P[f'down.{bi}.lstm.{li}.bias'], h0, c0)
+                rk = P[f'down.{bi}.lstm.{li}.recurrent_kernel']
+                rnd = self.bf16_operands and rk.shape[0] in (3, 5) and rk.shape[3] > 64
+                seq, hT, cT = convlstm_seq(seq, P[f'down.{bi}.lstm.{li}.kernel'], rk,
+                                           P[f'down.{bi}.lstm.{li}.bias'], h0, c0, rounded=rnd)
                 # carried state is a constant for the next window (truncated BPTT)
                 blk_states.append((hT.detach(), cT.detach()))
             new_states.append(blk_states)
@@ -173,7 +189,8 @@ class TorchULSTM:
             n = len(blk['conv'])
             for ci, l in enumerate(blk['conv']):
                 last = blk['return_logits'] and ci == n - 1
-                act = cbl(f'up.{bi}', ci, l, act, with_bn=not last)
+                act = cbl(f'up.{bi}', ci, l, act, with_bn=not last,
+                          cins=(up_in.shape[-1], skip.shape[-1]) if ci == 0 else None)
             up_in = act
         logits = up_in.reshape((b, t) + tuple(up_in.shape[1:]))
         logits = logits[:, :, py[0]:py[0] + h, px[0]:px[0] + w, :]

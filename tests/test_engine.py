@@ -364,3 +364,94 @@ def test_layerwise_backward_consistency():
         assert len(report) == 16
         for name, e_dy, e_w, e_x in report:
             assert e_dy <= 1e-5 and e_w <= 1e-5 and e_x <= 1e-5, (name, e_dy, e_w, e_x)
+
+
+def _bptt_case(name):
+    if name == 'c1':
+        return c1_net(), 1, 1, 4, 128, 128
+    import Params
+    return Params.CTCParams.net_kernel_params, 1, 2, 3, 64, 64     # Params.py widths (5x5 ConvLSTM 128/256/256/512)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['c1', 'params-width-64'])
+def test_lstm_bptt_backward_consistency(case):
+    """The ConvLSTM BPTT chain at real layer shapes, re-evaluated in fp64 FROM THE SAME DEVICE TENSORS the kernels
+    consumed (saved post-activation gates, c_all, h_all, x, dh_seq): per step dz_t (gate backward -> recurrent dgrad ->
+    next gate backward, i.e. the whole chain t = T-1..0, linear in dh_seq once the saved gates fix the hard-sigmoid
+    branches), then -- from the DEVICE dz -- the three hoisted gradients (kernel, recurrent_kernel, bias) and the
+    input gradient of the layer.  Well-conditioned (no kink can flip between the two evaluations), so held to 1e-5 of
+    each tensor's maximum.  Reference semantics: Keras ConvLSTM2D cell as constructed at Networks.py:48-50, BPTT
+    truncated at the window edge (stateful=True), train2D.py:89-93."""
+    import torch.nn.functional as F
+    from lu_native import ops, engine as eng_mod
+    with engine_backend('hip') as dev:
+        net, cin, B, T, H, W = _bptt_case(case)
+        rng = np.random.default_rng(11)
+        p = perturbed_params(net, cin, 7)
+        x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+        gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+        cwt = torch.tensor([0.15, 0.25, 0.6], dtype=torch.float32, device=dev)
+        e = make_engine(net, p, cin, dev, False)
+        orig = eng_mod.Engine._lstm_backward
+        report = []
+
+        def conv64(inp, w, k):      # SAME stride-1 cross-correlation, channels-last in / out, fp64
+            return F.conv2d(inp.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, padding=(k - 1) // 2).permute(0, 2, 3, 1)
+
+        def patched(self, rec, dh_seq, need_dx):
+            bi, li, spec, T_, B_ = rec['bi'], rec['li'], rec['spec'], rec['T'], rec['B']
+            pre = f'down.{bi}.lstm.{li}'
+            k = spec['k']
+            gates_dev = rec['gates']                       # dz is written in place of the saved gates
+            g64 = gates_dev.double().clone()
+            c64, h64, x64 = rec['c_all'].double(), rec['h_all'].double(), rec['x'].double()
+            Fh = h64.shape[-1]
+            dh64 = dh_seq.double().clone().view(T_, B_, h64.shape[2], h64.shape[3], Fh)
+            Wk, Wr = self.P[pre + '.kernel'].double(), self.P[pre + '.recurrent_kernel'].double()
+            dx = orig(self, rec, dh_seq, need_dx)
+            dz_dev = gates_dev.double()
+            hsg = lambda a: torch.where((a > 0) & (a < 1), 0.2, 0.0).to(a.dtype)     # noqa: E731
+            dz_ref = torch.empty_like(g64)
+            dc_next, dh_rec = None, None
+            for t in reversed(range(T_)):
+                gi, gf, gg, go = g64[t].split(Fh, dim=-1)
+                dh = dh64[t] if dh_rec is None else dh64[t] + dh_rec
+                tc = torch.tanh(c64[t + 1])
+                dc = dh * go * (1 - tc * tc)
+                if dc_next is not None:
+                    dc = dc + dc_next
+                dz_ref[t] = torch.cat([dc * gg * hsg(gi), dc * c64[t] * hsg(gf), dc * gi * (1 - gg * gg),
+                                       dh * tc * hsg(go)], -1)
+                dc_next = dc * gf
+                if t > 0:
+                    hp = torch.zeros_like(h64[t], requires_grad=True)
+                    (dh_rec,) = torch.autograd.grad(conv64(hp, Wr, k), hp, dz_ref[t])
+            scale = float(dz_ref.abs().max())
+            err_dz = float((dz_dev - dz_ref).abs().max()) / scale
+            # hoisted gradients from the device dz
+            dzf = dz_dev.view((T_ * B_,) + tuple(dz_dev.shape[2:]))
+            wr = Wr.clone().requires_grad_(True)
+            (gr,) = torch.autograd.grad(conv64(h64[:T_].reshape((T_ * B_,) + tuple(h64.shape[2:])), wr, k), wr, dzf)
+            wk = Wk.clone().requires_grad_(True)
+            xin = x64.clone().requires_grad_(True)
+            gk, gx = torch.autograd.grad(conv64(xin, wk, k), [wk, xin], dzf)
+            gb = dzf.sum(dim=(0, 1, 2))
+            rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())      # noqa: E731
+            report.append((pre, err_dz, rel(self.G[pre + '.recurrent_kernel'], gr), rel(self.G[pre + '.kernel'], gk),
+                           rel(self.G[pre + '.bias'], gb), rel(dx, gx) if dx is not None else 0.0))
+            return dx
+
+        eng_mod.Engine._lstm_backward = patched
+        try:
+            lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+            g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+            sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+            e.backward(ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0).view(lg.shape))
+            torch.cuda.synchronize()
+        finally:
+            eng_mod.Engine._lstm_backward = orig
+        assert len(report) == 4
+        print('lstm bptt consistency (%s): %s' % (case, report))
+        for row in report:
+            assert max(row[1:]) <= 1e-5, row
