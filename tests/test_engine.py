@@ -168,6 +168,8 @@ def test_train_step_parity(dev):
             l2 = max((float(np.linalg.norm(e.G[k].cpu().numpy().astype(np.float64) - grads_ref[k].numpy()) /
                             max(np.linalg.norm(grads_ref[k].numpy()), fl)), k) for k in grads_ref)
             assert l2[0] <= GRAD_L2_TOL.get(name, 2e-3), (name, step, l2)
+            print('train_step_parity %s step %d: worst max-rel %.3e (%s), worst L2-rel %.3e (%s)' %
+                  (name, step, worst[0], worst[1], l2[0], l2[1]))
             opt.apply_gradients()
             perr = max(float(np.abs(e.P[k].cpu().numpy() - tm.P[k].numpy()).max()) for k in grads_ref)
             # Adam's first steps move every weight by ~lr; sign flips of tiny gradients can cost up to 2*lr
