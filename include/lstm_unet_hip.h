@@ -8,7 +8,11 @@
  * INTEGRATION.md shows the stub.
  *
  * Conventions
- *   - all tensors fp32, channels-last: [frames, H, W, C]; "frame" = one (batch-slot, time) image
+ *   - tensors are fp32 unless an entry point says otherwise (the bf16 BPTT tape of the mixed-precision mode travels as raw
+ *     bf16 bit patterns behind const void* / explicit dtype fields), channels-last: [frames, H, W, C]; "frame" = one
+ *     (batch-slot, time) image
+ *   - no process-global state: nothing is read from the environment; kernel-variant overrides used by tests and A/B
+ *     tools travel in the descriptors' `flags` fields
  *   - raw device pointers, caller allocates everything (workspace size via *_workspace_bytes)
  *   - functions only ENQUEUE on `stream` (a hipStream_t); they never synchronise, allocate or throw
  *   - return 0 on success, non-zero on error; text via lu_last_error() (thread-local)
@@ -46,10 +50,27 @@ typedef struct lu_conv_src {
     int32_t pix_stride;     /* elements between consecutive pixels of x (>= C) */
     int32_t C;              /* channels read from this source */
     int32_t w_row_stride;   /* elements between channel rows of w (>= N) */
-    int32_t _pad;
+    int32_t dtype;          /* LU_F32 (0) or LU_BF16 (1): element type of x.  LU_BF16 needs precision == 1, C % 8 == 0, 16-byte
+                             * aligned x, strides in ELEMENTS (multiples of 8); the kernel then stages the source without
+                             * converting it.  All sources of one launch share the element type. */
 } lu_conv_src;
 
+enum { LU_F32 = 0, LU_BF16 = 1 };
 enum { LU_EPI_BIAS = 0, LU_EPI_LSTM = 1 };
+/* lu_conv_desc.flags: kernel-variant overrides (tests / A-B tools; 0 = the library's own choice) and tape options */
+enum {
+    LU_CONV_F_PATCH8 = 1,        /* bf16 halo kernel: force 8 x 32-pixel patches */
+    LU_CONV_F_PATCH16 = 2,       /* ... force 16 x 32-pixel patches (5x5 only) */
+    LU_CONV_F_NO_HALO = 4,       /* fp32: take the general gather kernel where the halo kernel would apply */
+    LU_CONV_F_XCD_BY_N = 8,      /* halo kernel: give every XCD its own column tiles */
+    LU_CONV_F_LDS_DMA = 16,      /* general fp32 kernel: global_load_lds staging (measured slower) */
+    LU_CONV_F_MF2 = 32,          /* general fp32 kernel: 4-wave variant of the wide tiles */
+    LU_CONV_F_GENERAL = 64,      /* general fp32 kernel: the fully general (dilation-capable) instantiation */
+    LU_CONV_F_GATES_BF16 = 256,  /* LU_EPI_LSTM, precision 1: gates_out is a bf16 tensor (the bf16 BPTT tape) */
+    LU_CONV_F_SRC1_CENTER = 512  /* precision 1 halo kernel, two sources: src[1] contributes its CENTRE tap only (k*k = 1):
+                                  * the im2col image of a thin input (lu_im2col_bf16) as one 32-channel chunk, weights
+                                  * packed as ONE tap by lu_pack_weights_taps_bf16 */
+};
 
 typedef struct lu_conv_desc {
     lu_conv_src src[2];
@@ -87,7 +108,11 @@ typedef struct lu_conv_desc {
     int32_t k_h;                    /* kernel HEIGHT; 0 = k (square).  With k_h != k the tap window is k_h rows x k columns and
                                      * src[i].w holds k_h*k taps (LU_EPI_BIAS, general kernels only): the parity planes of a
                                      * stride-2 input gradient have 2x2, 2x1, 1x2 and 1x1 windows. */
-    int32_t _pad_end;
+    int32_t flags;                  /* LU_CONV_F_* */
+    void* h16_out;                  /* LU_EPI_LSTM, precision 1, optional: a second copy of h rounded to bf16 (pixel stride F) --
+                                     * the recurrent operand of the next step and the x operand of the hoisted weight
+                                     * gradient, so neither re-reads / re-rounds the fp32 sequence */
+    int64_t h16_frame_stride;
 } lu_conv_desc;
 
 /* bf16 weight image for precision == 1: [tap][ceil(C/32)][N][32] bf16 (zero-filled beyond C), built from a
@@ -148,7 +173,18 @@ typedef struct lu_wgrad_desc {
     int32_t phase;            /* 0: partial sums + reduce (default).  1: partial sums into the workspace only.  2: the
                                * deterministic reduce of a previous phase-1 call (same descriptor).  Lets a profiler time
                                * the MFMA kernel alone. */
+    int32_t x_dtype, dy_dtype;/* LU_F32 / LU_BF16: x / dy are bf16 tensors (precision 1, kernel-row bf16 variant only:
+                               * stride-1 3x3 / 5x5, C >= 64, C % 8 == 0, N % 8 == 0, W % 32 == 0); strides in elements */
+    int32_t flags;            /* LU_WGRAD_F_* */
 } lu_wgrad_desc;
+
+enum {
+    LU_WGRAD_F_NO_ROW = 1,       /* do not take the kernel-row variants */
+    LU_WGRAD_F_NO_SMALL3 = 2,    /* do not take the all-taps kernel of the narrow 3x3 layers */
+    LU_WGRAD_F_CT64 = 4,         /* bf16 kernel-row variant: force 64-channel tiles */
+    LU_WGRAD_F_CT128 = 8,        /* ... force 128-channel tiles */
+    LU_WGRAD_F_SMALL_TILE = 16   /* general kernel: 128 x 128 instead of 128 x 256 tiles */
+};
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);
 int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream);
@@ -170,6 +206,22 @@ int lu_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c_cu
                       const float* dh_a, int64_t dh_a_frame_stride, const float* dh_b, const float* dc_in,
                       float* dz, float* dc_prev_out,
                       int32_t frames, int64_t pix_per_frame, int32_t F, lu_stream_t stream);
+
+/* The same step on the bf16 BPTT tape of the mixed-precision mode: `gates` holds the saved post-activation gates as
+ * bf16 and receives dz as bf16 in place (what the recurrent / input gradients and the weight gradients consume as MFMA
+ * operands anyway); c, dh and dc stay fp32. */
+int lu_lstm_gates_bwd_bf16(void* gates_dz, const float* c_prev, const float* c_cur,
+                           const float* dh_a, int64_t dh_a_frame_stride, const float* dh_b, const float* dc_in,
+                           float* dc_prev_out, int32_t frames, int64_t pix_per_frame, int32_t F, lu_stream_t stream);
+
+/* element-wise conversions between fp32 and bf16 (round to nearest even) on n elements */
+int lu_convert_f32_bf16(const float* x, void* y, int64_t n, lu_stream_t stream);
+int lu_convert_bf16_f32(const void* x, float* y, int64_t n, lu_stream_t stream);
+
+/* im2col image of a thin input for LU_CONV_F_SRC1_CENTER: y[f, oy, ox, (kh*k + kw)*C + c] = bf16(x[f, oy+kh-p, ox+kw-p, c])
+ * (zero outside the frame, zero for channels >= k*k*C); y is [frames, H, W, 32] bf16, k*k*C <= 32, p = (k-1)/2. */
+int lu_im2col_bf16(const float* x, void* y, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t k,
+                   lu_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Column reductions over rows of a [rows, C] matrix (row stride ld):  deterministic two-stage.

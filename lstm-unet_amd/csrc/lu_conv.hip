@@ -47,6 +47,7 @@ struct SrcInfo {
     int32_t pix_stride, C, w_row_stride;
     int32_t thin;     // 1: scalar gather over flattened (tap, c)
     int32_t nchunk;   // vector: ceil(C/16); thin: ceil(k*k*C/16)
+    int32_t bf16;     // fragment kernel only: x is a bf16 tensor (strides in elements), staged without conversion
 };
 
 struct ConvArgs {
@@ -59,7 +60,11 @@ struct ConvArgs {
     int32_t N, n_tiles, m_tiles;
     int32_t tiles_x, tiles_pf;   // halo kernel: 8x32-pixel tiles per row / per frame
     int32_t xcd_by_n;            // halo kernel: give each XCD its own n-tiles (weights stay L2-resident per XCD)
-    int32_t dbg;           // tools/kbench.py ablation bits (LU_CONV_DBG): 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
+    int32_t src1_center;   // fragment kernel: source 1 contributes its centre tap only (im2col image of a thin input)
+    int32_t gates_bf16;    // LSTM epilogue of the fragment kernel: gates_out is bf16
+    unsigned short* h16_out;   // ... optional bf16 copy of h
+    int64_t h16_fs;
+    int32_t dbg;           // ablation bits, honoured only in -DLU_ABLATION tool builds: 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
     int32_t out_pix_stride;
@@ -75,6 +80,12 @@ struct ConvArgs {
     float* gates_out;
     int64_t c_prev_fs, c_out_fs, h_fs, gates_fs;
 };
+
+#ifdef LU_ABLATION      // tools-only build: loop ablations selected by lu_conv_desc.flags >> 16
+#define LU_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define LU_DBG(a, bit) 0
+#endif
 
 struct IterState {
     int s, chunk, tap, kh, kw;
@@ -115,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float
         }
         const float gi = hard_sigmoid(zi), gf = hard_sigmoid(zf), gg = tanhf(zg), go = hard_sigmoid(zo);
         const float cp = a.c_prev[(int64_t)f * a.c_prev_fs + pix * F + ch];
-        const float cn = gf * cp + gi * gg;
+        const float cn = fmaf(gf, cp, gi * gg);      // explicit: every copy of the cell update must contract the same way
         const float hn = go * tanhf(cn);
         a.c_out[(int64_t)f * a.c_out_fs + pix * F + ch] = cn;
         a.h_out[(int64_t)f * a.h_fs + pix * F + ch] = hn;
@@ -479,21 +490,21 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
             if (DMA) {
                 // straight into the other LDS buffer (last read before the previous barrier); __syncthreads() below
                 // waits vmcnt(0) for the pending LDS writes
-                if (!(a.dbg & 1)) dma_stage(st, buf ^ 1);
+                if (!LU_DBG(a, 1)) dma_stage(st, buf ^ 1);
                 LU_SCHED_FENCE();
 #pragma unroll
                 for (int g = 1; g < 8; ++g) mma_group(buf, g);
             } else {
-                if (!(a.dbg & 1)) load_stage(st);
+                if (!LU_DBG(a, 1)) load_stage(st);
                 LU_SCHED_FENCE();
 #pragma unroll
                 for (int g = 1; g < 7; ++g) mma_group(buf, g);
                 LU_SCHED_FENCE();
-                if (!(a.dbg & 2)) store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
+                if (!LU_DBG(a, 2)) store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
                 LU_SCHED_FENCE();
                 mma_group(buf, 7);
             }
-            if (!(a.dbg & 4)) __syncthreads();
+            if (!LU_DBG(a, 4)) __syncthreads();
         }
     }
 
@@ -823,13 +834,20 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap
 // F32 = false: bf16 operands, 32-channel chunks.  F32 = true: the same structure on the exact fp32 MFMA
 // (v_mfma_f32_32x32x2_f32), 16-channel chunks, weights packed by pack_weights_f32_kernel -- both halo images have an
 // 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
-template <int K, int EPI, int RW, bool F32>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
+// B16 = true (bf16 MFMA only): every source is ALREADY a bf16 tensor (the bf16 BPTT tape: h sequence, dz; the bf16 copy of a
+// block input; the im2col image of the thin first input) -- a piece is then 8 channels = 16 raw bytes, half as many
+// loads, no conversion.  The element type is a compile-time property of the launch: a run-time (even uniform) branch
+// around the loads makes the compiler's vmcnt accounting conservative (measured: 5-28 % slower).
+template <int K, int EPI, int RW, bool F32, bool B16>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
 __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_frag_kernel(ConvArgs a) {
+    static_assert(!(F32 && B16), "bf16 tensors feed the bf16 MFMA only");
     constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
     constexpr int CKS = F32 ? CK : CKB;                // channels per stage
-    constexpr int G = CKS / 4;                         // 16-byte global channel groups per halo pixel
-    constexpr int HPASS = (HP * G + NT - 1) / NT;      // halo pieces: one float4 (4 channels of one pixel) per thread each
+    constexpr int PC = B16 ? 8 : 4;                    // channels per 16-byte piece
+    constexpr int G = CKS / PC;                        // 16-byte global channel groups per halo pixel
+    constexpr int ESZ = B16 ? 2 : 4;                   // bytes per source element
+    constexpr int HPASS = (HP * G + NT - 1) / NT;      // halo pieces: 16 bytes of one pixel per thread each
     constexpr int PAD = (K - 1) / 2;
     constexpr int EX_LD = BN + 4;                      // floats per pixel of the gate-exchange buffer
     constexpr int PITCH = 80;                          // bytes per halo pixel: (16 + 4) floats or (32 + 8) bf16
@@ -850,21 +868,22 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
     const int ks = blockIdx.y;
-    const float* const zp = lu_zero16;
-    const int q = tid % G;                 // 4-channel group inside the chunk
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const int q = tid % G;                 // channel group inside the chunk
     // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
     const int nfr = (a.N + 31) >> 5;
     const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
     const bool frag_ok = frag < nfr;
     // Per-source fields live in registers and are picked with selects: indexing a.src[st.s] inside the tap loop costs a
     // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
-    const float* const x_s0 = a.src[0].x + (int64_t)f * a.src[0].frame_stride;
-    const float* const x_s1 = a.src[1].x + (int64_t)f * a.src[1].frame_stride;
+    const unsigned char* const x_s0 = reinterpret_cast<const unsigned char*>(a.src[0].x) + (int64_t)f * a.src[0].frame_stride * ESZ;
+    const unsigned char* const x_s1 = reinterpret_cast<const unsigned char*>(a.src[1].x) + (int64_t)f * a.src[1].frame_stride * ESZ;
     const unsigned char* const w_s0 = reinterpret_cast<const unsigned char*>(a.src[0].w) + (int64_t)frag * 2048 + lane * 16;
     const unsigned char* const w_s1 = reinterpret_cast<const unsigned char*>(a.src[1].w) + (int64_t)frag * 2048 + lane * 16;
     const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
     const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
     const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
+    const bool ctr1 = !F32 && a.src1_center != 0;      // source 1 = one chunk, centre tap only (it is the LAST stage)
     const int kk = K * K;
     auto tap_advance = [&](IterState& st) {          // iter_advance without the kernarg look-ups
         ++st.tap;
@@ -872,12 +891,13 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
             st.kw = 0;
             ++st.kh;
         }
-        if (st.tap < kk) return;
+        if (st.tap < kk && !(ctr1 && st.s)) return;
         st.tap = st.kh = st.kw = 0;
         if (++st.chunk == (st.s ? nch_s1 : nch_s0)) {
             st.chunk = 0;
             ++st.s;
         }
+        if (ctr1 && st.s) st.kh = st.kw = PAD;
     };
     auto next_chunk = [&](IterState& st) {            // first tap of the next chunk
         st.tap = st.kh = st.kw = 0;
@@ -887,26 +907,27 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         }
     };
 
-    // piece p of the halo of chunk `st`: pixel hp = (tid + 512 p) / 8, channels 4 q .. 4 q + 3 (recomputed per use: the
+    // piece p of the halo of chunk `st`: pixel hp = (tid + 512 p) / G, channels PC q .. PC q + PC - 1 (recomputed per use: the
     // addressing is a handful of integer ops once per K*K MFMA stages, the registers are worth more)
-    auto piece_load = [&](int p, const IterState& st, float4& r, bool want) {
+    auto piece_load = [&](int p, const IterState& st, lu_u4& r, bool want) {
         const int hp = (tid + NT * p) / G;
         const int hy = hp / HWD, hx = hp - hy * HWD;
         const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
         const bool ok = want && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const int c = st.chunk * CKS + 4 * q;
-        const float* pp = (st.s ? x_s1 : x_s0) + (int64_t)(iy * a.Win + ix) * (st.s ? ps_s1 : ps_s0) + c;
-        r = *reinterpret_cast<const float4*>((ok && c < (st.s ? C_s1 : C_s0)) ? pp : zp);      // (16-byte aligned, C % 4 == 0)
+        const int c = st.chunk * CKS + PC * q;
+        const int64_t off = ((int64_t)(iy * a.Win + ix) * (st.s ? ps_s1 : ps_s0) + c) * ESZ;
+        r = *((ok && c < (st.s ? C_s1 : C_s0)) ? reinterpret_cast<const lu_u4*>((st.s ? x_s1 : x_s0) + off) : zp);   // (16-byte aligned)
     };
-    auto piece_store = [&](int p, int hb, const float4& r) {
+    auto piece_store = [&](int p, int hb, const lu_u4& r) {
         const int hp = (tid + NT * p) / G;
         if (hp < HP) {
-            if (F32) {
-                *reinterpret_cast<float4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
+            if (F32 || B16) {      // raw copy: 4 floats / 8 bf16
+                *reinterpret_cast<lu_u4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
             } else {
-                unsigned* dst = reinterpret_cast<unsigned*>(&Ah[hb * AH_BYTES + hp * PITCH + 8 * q]);
-                dst[0] = lu_pack2bf(r.x, r.y);
-                dst[1] = lu_pack2bf(r.z, r.w);
+                lu_u2 v;
+                v.x = lu_pack2bf(lu_bits2f(r.x), lu_bits2f(r.y));
+                v.y = lu_pack2bf(lu_bits2f(r.z), lu_bits2f(r.w));
+                *reinterpret_cast<lu_u2*>(&Ah[hb * AH_BYTES + hp * PITCH + 8 * q]) = v;
             }
         }
     };
@@ -914,8 +935,8 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
         const unsigned char* wp = (st.s ? w_s1 : w_s0) +
                                   ((int64_t)st.tap * (st.s ? nch_s1 : nch_s0) + st.chunk) * nfr * 2048;
-        const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : zp;
-        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 1024) : zp;
+        const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : lu_zero16;
+        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_zero16;
         b0 = *reinterpret_cast<const float4*>(p0);
         b1 = *reinterpret_cast<const float4*>(p1);
     };
@@ -1025,7 +1046,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
 #pragma unroll
         for (int j = 0; j < D; ++j) load_b(sS[j], rb0[j], rb1[j]);
         {
-            float4 rh[HPASS];                    // first halo: all pieces at once
+            lu_u4 rh[HPASS];                     // first halo: all pieces at once
 #pragma unroll
             for (int p = 0; p < HPASS; ++p) piece_load(p, st, rh[p], true);
 #pragma unroll
@@ -1035,7 +1056,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         int hb = 0;                              // halo image in use
         IterState nc = st;                       // chunk after the current one (valid while it exists)
         next_chunk(nc);
-        float4 rp[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        lu_u4 rp[2] = {lu_u4{0u, 0u, 0u, 0u}, lu_u4{0u, 0u, 0u, 0u}};
         int pend[2] = {-1, -1};
         // One pipeline step = stage `it` in ring slot s.  While a chunk's taps run, the NEXT chunk's halo is fetched one
         // piece per tap into the other LDS image (two staging registers, alternating with the stage parity).
@@ -1093,27 +1114,72 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         // exchange: wave (wm, wn) holds gate wn of rows RW wm .. RW wm + RW - 1; the gate epilogue wants the four gates of
         // a (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
         float* Ex = reinterpret_cast<float*>(Ah);      // [2 row groups][32 px][EX_LD]
-        const int ch = tid & 31;
+        // One (pixel, channel quad) per thread and pass: 64 pixels x 8 quads = 512 threads; 16-byte loads / stores
+        // (8-byte for the bf16 tape) instead of one scalar per gate plane.
+        const int F = a.F;
+        const int pr = tid >> 3, cq = tid & 7;
+        const int g = pr >> 5, px = pr & 31;
+        const int ch = nt * 32 + 4 * cq;                // F % 32 == 0 is enforced by the host
+        float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), bf = bi, bg = bi, bo = bi;
+        if (a.bias) {
+            bi = *reinterpret_cast<const float4*>(a.bias + ch);
+            bf = *reinterpret_cast<const float4*>(a.bias + F + ch);
+            bg = *reinterpret_cast<const float4*>(a.bias + 2 * F + ch);
+            bo = *reinterpret_cast<const float4*>(a.bias + 3 * F + ch);
+        }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             __syncthreads();                            // pass 0: all halo reads finished; later: previous pass consumed
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int px = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ex[(wm * TW + px) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
+                const int pxr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Ex[(wm * TW + pxr) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
             }
             __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int pr = (tid >> 5) + 16 * e;     // (row group, pixel) pair 0..63
-                const int g = pr >> 5, px = pr & 31;
-                const int oy = y0 + RW * g + i, ox = x0 + px;
-                if (oy >= a.Hin || ox >= a.Win) continue;
-                const int64_t pix = (int64_t)oy * a.Win + ox;
-                float v[4];
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf) v[nf] = Ex[(g * TW + px) * EX_LD + 32 * nf + ch];
-                conv_epilogue_row<4, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0, ks, ch);
+            const int oy = y0 + RW * g + i, ox = x0 + px;
+            if (oy >= a.Hin || ox >= a.Win) continue;
+            const int64_t pix = (int64_t)oy * a.Win + ox;
+            const float* ex = &Ex[(g * TW + px) * EX_LD + 4 * cq];
+            const float4 zi = *reinterpret_cast<const float4*>(ex), zf = *reinterpret_cast<const float4*>(ex + 32),
+                         zg = *reinterpret_cast<const float4*>(ex + 64), zo = *reinterpret_cast<const float4*>(ex + 96);
+            const float4 cp = *reinterpret_cast<const float4*>(a.c_prev + (int64_t)f * a.c_prev_fs + pix * F + ch);
+            float4 gi, gf, gg, go, cn, hn;
+#define LU_GATE(m)                                      \
+    gi.m = hard_sigmoid(zi.m + bi.m);                   \
+    gf.m = hard_sigmoid(zf.m + bf.m);                   \
+    gg.m = tanhf(zg.m + bg.m);                          \
+    go.m = hard_sigmoid(zo.m + bo.m);                   \
+    cn.m = fmaf(gf.m, cp.m, gi.m * gg.m);               \
+    hn.m = go.m * tanhf(cn.m);
+            LU_GATE(x) LU_GATE(y) LU_GATE(z) LU_GATE(w)
+#undef LU_GATE
+            *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
+            *reinterpret_cast<float4*>(a.h_out + (int64_t)f * a.h_fs + pix * F + ch) = hn;
+            if (a.h16_out) {
+                lu_u2 hv;
+                hv.x = lu_pack2bf(hn.x, hn.y);
+                hv.y = lu_pack2bf(hn.z, hn.w);
+                *reinterpret_cast<lu_u2*>(a.h16_out + (int64_t)f * a.h16_fs + pix * F + ch) = hv;
+            }
+            if (a.gates_out) {
+                if (a.gates_bf16) {
+                    unsigned short* gp = reinterpret_cast<unsigned short*>(a.gates_out) + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
+                    lu_u2 v;
+                    v.x = lu_pack2bf(gi.x, gi.y); v.y = lu_pack2bf(gi.z, gi.w);
+                    *reinterpret_cast<lu_u2*>(gp) = v;
+                    v.x = lu_pack2bf(gf.x, gf.y); v.y = lu_pack2bf(gf.z, gf.w);
+                    *reinterpret_cast<lu_u2*>(gp + F) = v;
+                    v.x = lu_pack2bf(gg.x, gg.y); v.y = lu_pack2bf(gg.z, gg.w);
+                    *reinterpret_cast<lu_u2*>(gp + 2 * F) = v;
+                    v.x = lu_pack2bf(go.x, go.y); v.y = lu_pack2bf(go.z, go.w);
+                    *reinterpret_cast<lu_u2*>(gp + 3 * F) = v;
+                } else {
+                    float* gp = a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
+                    *reinterpret_cast<float4*>(gp) = gi;
+                    *reinterpret_cast<float4*>(gp + F) = gf;
+                    *reinterpret_cast<float4*>(gp + 2 * F) = gg;
+                    *reinterpret_cast<float4*>(gp + 3 * F) = go;
+                }
             }
         }
         return;
@@ -1432,12 +1498,22 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         si.C = in.C;
         si.w_row_stride = in.w_row_stride;
         si.thin = vec ? 0 : 1;
+        si.bf16 = in.dtype == LU_BF16 ? 1 : 0;
+        LU_REQUIRE(in.dtype == LU_F32 || (in.dtype == LU_BF16 && d->precision == 1),
+                   "lu_conv2d_fwd: source %d: bf16 activations need precision 1 (dtype %d)", s, in.dtype);
         si.nchunk = vec ? (in.C + CK - 1) / CK : (a.kk * in.C + CK - 1) / CK;
         if (d->precision != 0) {     // fragment-packed weights: bf16 (32-channel chunks) or fp32 (16-channel chunks)
             LU_REQUIRE(vec, "lu_conv2d_fwd: packed-weight modes need 16-byte aligned sources with C %% 4 == 0 (source %d); "
                             "pad thin inputs with zero channels", s);
             si.nchunk = d->precision == 1 ? (in.C + CKB - 1) / CKB : (in.C + CK - 1) / CK;
-            a.n_it += si.nchunk * a.kk;
+            if (s == 1 && (d->flags & LU_CONV_F_SRC1_CENTER)) {
+                LU_REQUIRE(d->precision == 1 && si.nchunk == 1 && d->epilogue == LU_EPI_LSTM,
+                           "lu_conv2d_fwd: LU_CONV_F_SRC1_CENTER needs precision 1, the ConvLSTM epilogue and C <= 32 on source 1");
+                a.src1_center = 1;
+                a.n_it += 1;
+            } else {
+                a.n_it += si.nchunk * a.kk;
+            }
         } else if (vec) {
             a.n_it += si.nchunk * a.kk;
         }
@@ -1465,9 +1541,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     int th = 8;      // patch height; the bf16 kernel takes 16-row patches when that still leaves >= 1 block per CU
     if (d->precision != 0 && d->k == 5) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
         const int64_t nt_est = d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128;
-        const char* force = getenv("LU_CONV_BF16_PATCH");      // "8" / "16": tests and A/B runs
+        const int force = (d->flags & LU_CONV_F_PATCH16) ? 16 : (d->flags & LU_CONV_F_PATCH8) ? 8 : 0;      // tests and A/B runs
         const int64_t sp = d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits;
-        if (force ? atoi(force) == 16
+        if (force ? force == 16
                   : (d->precision == 1 && (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * nt_est * sp >= 256))
             th = 16;      // (fp32 fragment mode: 8-row patches, two blocks per CU, unless forced)
     }
@@ -1476,13 +1552,23 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
                       a.n_src > 0 && d->out_row_stride == 0 &&
                       (d->precision != 0 || (tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
-                                             getenv("LU_CONV_NOHALO") == nullptr));
+                                             !(d->flags & LU_CONV_F_NO_HALO)));
     if (halo) {
         a.tiles_x = (int32_t)tiles_x;
         a.tiles_pf = (int32_t)(tiles_y * tiles_x);
         m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
     }
-    const bool want_xcd_n = getenv("LU_CONV_XCD_N") != nullptr;
+    const bool want_xcd_n = (d->flags & LU_CONV_F_XCD_BY_N) != 0;
+    bool src16 = false;      // all sources bf16 tensors (a property of the launch: mixed element types are rejected)
+    for (int s2 = 0; s2 < a.n_src; ++s2) {
+        LU_REQUIRE(!a.src[s2].bf16 || (halo && d->precision == 1),
+                   "lu_conv2d_fwd: bf16 activations are read by the bf16 halo kernel only (stride-1 3x3 / 5x5, N > 64)");
+        LU_REQUIRE(a.src[s2].bf16 == a.src[0].bf16, "lu_conv2d_fwd: the sources of one launch must share an element type");
+        LU_REQUIRE(!a.src[s2].bf16 || (a.src[s2].C % 8 == 0 && a.src[s2].pix_stride % 8 == 0 && a.src[s2].frame_stride % 8 == 0),
+                   "lu_conv2d_fwd: a bf16 source needs C, pixel and frame strides that are multiples of 8 (source %d)", s2);
+        src16 = a.src[s2].bf16 != 0;
+    }
+    LU_REQUIRE(!a.src1_center || (halo && a.n_src == 2), "lu_conv2d_fwd: LU_CONV_F_SRC1_CENTER needs the halo kernel and two sources");
     LU_REQUIRE(d->precision >= 0 && d->precision <= 2, "lu_conv2d_fwd: unknown precision %d", d->precision);
     if (d->precision == 1)
         LU_REQUIRE(d->dil == 1 && (halo || d->epilogue == LU_EPI_BIAS),
@@ -1493,12 +1579,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
-    a.dbg = getenv("LU_CONV_DBG") ? atoi(getenv("LU_CONV_DBG")) : 0;
+    a.dbg = (d->flags >> 16) & 7;      // (only -DLU_ABLATION tool builds look at it)
     dim3 block(256);
     // LDS-DMA tile staging measured 4-5 % SLOWER than VGPR staging here (123.5 vs 129.9 TFLOP/s on the recurrent
     // dgrads): opt-in only, kept as a measured negative result.
-    const bool dma = getenv("LU_CONV_DMA") != nullptr;
-    const bool mf1 = getenv("LU_CONV_MF2") == nullptr;   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
+    const bool dma = (d->flags & LU_CONV_F_LDS_DMA) != 0;
+    const bool mf1 = !(d->flags & LU_CONV_F_MF2);   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
     if (d->epilogue == LU_EPI_LSTM) {
         LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
         LU_REQUIRE(bvec, "lu_conv2d_fwd: LSTM epilogue needs 16-byte aligned weights");
@@ -1512,16 +1598,29 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.c_out_fs = d->c_out_frame_stride;
         a.h_fs = d->h_frame_stride;
         a.gates_fs = d->gates_frame_stride;
+        a.gates_bf16 = (d->flags & LU_CONV_F_GATES_BF16) ? 1 : 0;
+        a.h16_out = (unsigned short*)d->h16_out;
+        a.h16_fs = d->h16_frame_stride;
+        LU_REQUIRE((!a.gates_bf16 && !a.h16_out) || (d->precision == 1 && halo),
+                   "lu_conv2d_fwd: the bf16 tape outputs (h16_out, LU_CONV_F_GATES_BF16) belong to the bf16 halo kernel");
+        if (d->precision != 0 && halo)
+            LU_REQUIRE(aligned16(d->c_prev) && aligned16(d->c_out) && aligned16(d->h_out) && aligned16(d->bias) &&
+                           (!d->gates_out || (reinterpret_cast<uintptr_t>(d->gates_out) & 7) == 0) &&
+                           (!d->h16_out || (reinterpret_cast<uintptr_t>(d->h16_out) & 7) == 0),
+                       "lu_conv2d_fwd: the fragment kernel's ConvLSTM epilogue needs 16-byte aligned state / bias pointers");
         a.n_tiles = a.F / 32;
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1 && k_h == d->k, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1, a square kernel");
-        if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
-        else if (d->precision == 2 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 2 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 2) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        if (d->precision == 1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 1 && src16) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (d->precision == 2 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, true, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 2 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, true, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 2) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, true, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
         else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
@@ -1542,11 +1641,11 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.n_tiles = (d->N + 127) / 128;
         dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
         if (d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, true, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, true, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, true, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         int rcb = LU_CHECK_LAUNCH();
         if (rcb || a.ksplit == 1) return rcb;
         const int64_t totb = a.M * a.N;
@@ -1558,12 +1657,18 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
         a.n_tiles = (d->N + 127) / 128;
         dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
-        if (halo && d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        if (halo && src16 && d->k == 5 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (halo && src16 && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (halo && src16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (halo && d->k == 5 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (halo)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else
             LU_LAUNCH(conv_gather_bf16_kernel, gridb, dim3(512), stream, a);
         int rcb = LU_CHECK_LAUNCH();
@@ -1575,7 +1680,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         return LU_CHECK_LAUNCH();
     }
     dim3 grid((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
-    const bool gen = d->dil != 1 || getenv("LU_CONV_GEN") != nullptr;   // env: A/B knob for tools/kbench.py
+    const bool gen = d->dil != 1 || (d->flags & LU_CONV_F_GENERAL) != 0;   // A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
         if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \

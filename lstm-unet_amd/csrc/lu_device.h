@@ -91,6 +91,20 @@ int lu_check_launch();
 // into a flat pointer -> flat_load instead of global_load.)
 __device__ __attribute__((aligned(16))) static float lu_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
+// 16 raw bytes (one global_load_dwordx4 / ds_write_b128): staging registers of tiles whose element type is a template parameter
+typedef unsigned lu_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned lu_u2 __attribute__((ext_vector_type(2)));
+__device__ __host__ static inline float lu_bits2f(unsigned u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ __host__ static inline unsigned lu_f2bits(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
 void lu_set_error(const char* fmt, ...);
 
 #define LU_REQUIRE(cond, ...)          \

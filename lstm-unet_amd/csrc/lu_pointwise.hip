@@ -21,7 +21,7 @@ void lu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
-extern "C" int lu_abi_version(void) { return 3; }
+extern "C" int lu_abi_version(void) { return 4; }
 
 #ifndef LU_EMU
 int lu_check_launch() {
@@ -59,7 +59,7 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ z, const float* 
         const int ch = (int)(i - row * F);
         const float* zp = z + row * 4 * F + ch;
         const float gi = hsig(zp[0]), gf = hsig(zp[F]), gg = tanhf(zp[2 * F]), go = hsig(zp[3 * F]);
-        const float cn = gf * c_prev[i] + gi * gg;
+        const float cn = fmaf(gf, c_prev[i], gi * gg);      // (same contraction as the fused epilogues in lu_conv.hip)
         c_out[i] = cn;
         const int64_t f = row / ppf;
         h_out[f * h_fs + (row - f * ppf) * F + ch] = go * tanhf(cn);
@@ -97,6 +97,93 @@ __global__ void lstm_gates_bwd_kernel(const float* gates, const float* __restric
         dp[2 * F] = dc * gi * (1.f - gg * gg);
         dp[3 * F] = dh * tc * hsig_grad_from_out(go);
         dc_prev_out[i] = dc * gf;
+    }
+}
+
+// The same step on the bf16 BPTT tape: gates in / dz out (in place) as bf16, four channels per thread (8-byte tape
+// accesses, 16-byte fp32 accesses); F % 4 == 0.
+__device__ __forceinline__ float bf_lo(unsigned w) { return lu_bits2f(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return lu_bits2f(w & 0xffff0000u); }
+__global__ void lstm_gates_bwd_bf16_kernel(unsigned short* gates_dz, const float* __restrict__ c_prev,
+                                           const float* __restrict__ c_cur, const float* __restrict__ dh_a, int64_t dha_fs,
+                                           const float* __restrict__ dh_b, const float* __restrict__ dc_in,
+                                           float* __restrict__ dc_prev_out, int64_t total4, int64_t ppf, int F) {
+    const int F4 = F >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total4; i += (int64_t)gridDim.x * NT) {
+        const int64_t row = i / F4;
+        const int ch = 4 * (int)(i - row * F4);
+        const int64_t f = row / ppf;
+        const int64_t e = row * F + ch;
+        float4 dh = *reinterpret_cast<const float4*>(dh_a + f * dha_fs + (row - f * ppf) * F + ch);
+        if (dh_b) {
+            const float4 b = *reinterpret_cast<const float4*>(dh_b + e);
+            dh.x += b.x; dh.y += b.y; dh.z += b.z; dh.w += b.w;
+        }
+        unsigned short* gp = gates_dz + row * 4 * F + ch;
+        const lu_u2 ri = *reinterpret_cast<const lu_u2*>(gp), rf = *reinterpret_cast<const lu_u2*>(gp + F),
+                    rg = *reinterpret_cast<const lu_u2*>(gp + 2 * F), ro = *reinterpret_cast<const lu_u2*>(gp + 3 * F);
+        const float4 cc = *reinterpret_cast<const float4*>(c_cur + e), cp = *reinterpret_cast<const float4*>(c_prev + e);
+        float4 dcin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dc_in) dcin = *reinterpret_cast<const float4*>(dc_in + e);
+        float zi[4], zf[4], zg[4], zo[4], dcp[4];
+        const float gi[4] = {bf_lo(ri.x), bf_hi(ri.x), bf_lo(ri.y), bf_hi(ri.y)};
+        const float gf[4] = {bf_lo(rf.x), bf_hi(rf.x), bf_lo(rf.y), bf_hi(rf.y)};
+        const float gg[4] = {bf_lo(rg.x), bf_hi(rg.x), bf_lo(rg.y), bf_hi(rg.y)};
+        const float go[4] = {bf_lo(ro.x), bf_hi(ro.x), bf_lo(ro.y), bf_hi(ro.y)};
+        const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, ccv[4] = {cc.x, cc.y, cc.z, cc.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w},
+                    dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float tc = tanhf(ccv[j]);
+            const float dc = dhv[j] * go[j] * (1.f - tc * tc) + dci[j];
+            zi[j] = dc * gg[j] * hsig_grad_from_out(gi[j]);
+            zf[j] = dc * cpv[j] * hsig_grad_from_out(gf[j]);
+            zg[j] = dc * gi[j] * (1.f - gg[j] * gg[j]);
+            zo[j] = dhv[j] * tc * hsig_grad_from_out(go[j]);
+            dcp[j] = dc * gf[j];
+        }
+        lu_u2 v;
+        v.x = lu_pack2bf(zi[0], zi[1]); v.y = lu_pack2bf(zi[2], zi[3]);
+        *reinterpret_cast<lu_u2*>(gp) = v;
+        v.x = lu_pack2bf(zf[0], zf[1]); v.y = lu_pack2bf(zf[2], zf[3]);
+        *reinterpret_cast<lu_u2*>(gp + F) = v;
+        v.x = lu_pack2bf(zg[0], zg[1]); v.y = lu_pack2bf(zg[2], zg[3]);
+        *reinterpret_cast<lu_u2*>(gp + 2 * F) = v;
+        v.x = lu_pack2bf(zo[0], zo[1]); v.y = lu_pack2bf(zo[2], zo[3]);
+        *reinterpret_cast<lu_u2*>(gp + 3 * F) = v;
+        *reinterpret_cast<float4*>(dc_prev_out + e) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+    }
+}
+
+__global__ void convert_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = lu_f2bf(x[i]);
+}
+__global__ void convert_bf16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        y[i] = lu_bits2f((unsigned)x[i] << 16);
+}
+
+// y[f, oy, ox, (kh*k + kw)*C + c] = bf16(x[f, oy+kh-p, ox+kw-p, c]); 32 bf16 per pixel (zero beyond k*k*C); one thread per
+// (pixel, pair of output channels)
+__global__ void im2col_bf16_kernel(const float* __restrict__ x, unsigned* __restrict__ y, int64_t total, int H, int W, int C,
+                                   int k) {
+    const int p = (k - 1) / 2, kkc = k * k * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int j2 = (int)(i & 15);
+        const int64_t pix = i >> 4;
+        const int ox = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int oy = (int)(t % H);
+        const int64_t f = t / H;
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * j2 + e;
+            const int tap = j / C, c = j - tap * C;
+            const int iy = oy + tap / k - p, ix = ox + tap % k - p;
+            v[e] = (j < kkc && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((f * H + iy) * W + ix) * C + c] : 0.f;
+        }
+        y[i] = lu_pack2bf(v[0], v[1]);
     }
 }
 
@@ -542,6 +629,44 @@ extern "C" int lu_lstm_gates_bwd(const float* gates, const float* c_prev, const 
     const int64_t total = (int64_t)frames * ppf * F;
     LU_LAUNCH(lstm_gates_bwd_kernel, dim3(grid_for(total)), dim3(NT), stream, gates, c_prev, c_cur, dh_a, dh_a_fs,
               dh_b, dc_in, dz, dc_prev_out, total, ppf, (int)F);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_lstm_gates_bwd_bf16(void* gates_dz, const float* c_prev, const float* c_cur, const float* dh_a,
+                                      int64_t dh_a_fs, const float* dh_b, const float* dc_in, float* dc_prev_out,
+                                      int32_t frames, int64_t ppf, int32_t F, lu_stream_t stream) {
+    LU_REQUIRE(gates_dz && c_prev && c_cur && dh_a && dc_prev_out && frames > 0 && ppf > 0 && F > 0 && F % 4 == 0 &&
+                   dh_a_fs % 4 == 0,
+               "lu_lstm_gates_bwd_bf16: bad arguments (F %% 4 == 0 required)");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(c_prev) | reinterpret_cast<uintptr_t>(c_cur) |
+                         reinterpret_cast<uintptr_t>(dh_a) | reinterpret_cast<uintptr_t>(dh_b) |
+                         reinterpret_cast<uintptr_t>(dc_in) | reinterpret_cast<uintptr_t>(dc_prev_out);
+    LU_REQUIRE((al & 15) == 0 && (reinterpret_cast<uintptr_t>(gates_dz) & 7) == 0, "lu_lstm_gates_bwd_bf16: unaligned pointers");
+    const int64_t total4 = (int64_t)frames * ppf * (F / 4);
+    LU_LAUNCH(lstm_gates_bwd_bf16_kernel, dim3(grid_for(total4)), dim3(NT), stream, (unsigned short*)gates_dz, c_prev, c_cur,
+              dh_a, dh_a_fs, dh_b, dc_in, dc_prev_out, total4, ppf, (int)F);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_convert_f32_bf16(const float* x, void* y, int64_t n, lu_stream_t stream) {
+    LU_REQUIRE(x && y && n > 0, "lu_convert_f32_bf16: bad arguments");
+    LU_LAUNCH(convert_f32_bf16_kernel, dim3(grid_for(n, 4)), dim3(NT), stream, x, (unsigned short*)y, n);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_convert_bf16_f32(const void* x, float* y, int64_t n, lu_stream_t stream) {
+    LU_REQUIRE(x && y && n > 0, "lu_convert_bf16_f32: bad arguments");
+    LU_LAUNCH(convert_bf16_f32_kernel, dim3(grid_for(n, 4)), dim3(NT), stream, (const unsigned short*)x, y, n);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_im2col_bf16(const float* x, void* y, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t k,
+                              lu_stream_t stream) {
+    LU_REQUIRE(x && y && frames > 0 && H > 0 && W > 0 && C > 0 && k >= 1 && (k & 1) && k * k * C <= 32,
+               "lu_im2col_bf16: needs an odd k with k*k*C <= 32");
+    const int64_t total = (int64_t)frames * H * W * 16;
+    LU_LAUNCH(im2col_bf16_kernel, dim3(grid_for(total, 2)), dim3(NT), stream, x, (unsigned*)y, total, (int)H, (int)W, (int)C,
+              (int)k);
     return LU_CHECK_LAUNCH();
 }
 

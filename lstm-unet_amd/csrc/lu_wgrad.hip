@@ -28,6 +28,7 @@ struct WgradArgs {
     int32_t HWo, Wout, Hout, Hin, Win;
     int32_t k, kk, stride, pad_t, pad_l;
     int32_t c_tiles;
+    int32_t n_tiles, inner, splits;      // bf16 kernel-row variant: 128-column tiles, tiles per pixel slab, slabs
     float* ws;          // [splits][kk*C*N]
     int64_t slab;
     float* bias_ws;     // [splits][N] column sums of dy (bias gradient), or null; kernel-row variants only
@@ -379,36 +380,54 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// bf16-MFMA kernel-row variant (precision = 1; W % 32 == 0).  Same block tile as wgrad_row_kernel (64 c x 128 n x
-// K taps of one kernel row, 8 waves), 32-pixel runs per stage = two v_mfma_f32_32x32x16_bf16 k-steps per tap.  The
-// operands stay pixel-major in LDS ([pixel][channel] bf16, converted while staged), i.e. k runs DOWN the rows, so the
-// k-contiguous MFMA fragments are fetched with the transposing LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels
-// per 16-lane group); a tap is a row shift of the x tile, which keeps every read 8-byte aligned.  Row pitches of
-// 192 B (x) and 320 B (dy) put the 4 rows of a group on distinct 64-byte bank segments.
+// bf16-MFMA kernel-row variant (precision = 1; W % 32 == 0).  Block tile = CT (c) x 128 (n) x K taps of one kernel row,
+// 8 waves, 32-pixel runs per stage = two v_mfma_f32_32x32x16_bf16 k-steps per tap.  The operands stay pixel-major in
+// LDS ([pixel][channel] bf16), i.e. k runs DOWN the rows, so the k-contiguous MFMA fragments are fetched with the
+// transposing LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group); a tap is a row shift of the x
+// tile, which keeps every read 8-byte aligned.  Row pitches of 192 / 320 B put the 4 rows of a group on distinct
+// 64-byte bank segments.
+//   XB / YB: x / dy are ALREADY bf16 in HBM (the bf16 BPTT tape: h sequence, dz) -- half the bytes, no conversion; an
+//            fp32 operand is rounded while it is staged.
+//   At bf16 rates a stage is ~1300 cycles of MFMA per CU for 17-35 KB of operands, i.e. the loads of ONE stage in
+//   flight cannot cover L2 / HBM latency: the register staging is two stages deep (sets A / B, loop unrolled by two),
+//   so a load has two MFMA phases to land.  Stages past the end of the pixel slab read the zero block.
+//   Blocks are numbered so that all (kernel row, c-tile, n-tile) blocks of a pixel slab sit on ONE XCD (block id % 8)
+//   and run back to back there: x and dy come from HBM once per slab and from that XCD's L2 for the other tiles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 
-template <int K, int CT>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
-__global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
+template <int K, int CT, bool XB, bool YB>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+__global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     constexpr int BMw = CT, BNw = 128, XP = PRB + K - 1, NT = 512;
     constexpr int WMC = CT / 32, WNN = 8 / WMC, NFW = BNw / (32 * WNN);
     constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 per LDS row: pitch = 64 B (mod 256 B)
-    constexpr int XQ = BMw / 4, XPASS = (XP * XQ + NT - 1) / NT, YPASS = PRB * (BNw / 4) / NT;
+    constexpr int XE = XB ? 8 : 4, YE = YB ? 8 : 4;     // elements per 16-byte piece
+    constexpr int PX = BMw / XE, PY = BNw / YE;         // pieces per tile row
+    constexpr int XPASS = (XP * PX + NT - 1) / NT, YPASS = PRB * PY / NT;
+    static_assert(PRB * PY % NT == 0, "dy tile: whole passes");
     __shared__ __attribute__((aligned(16))) unsigned short Xs[2][XP * XLD];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[2][PRB * YLD];
+    __shared__ float Bred[8 * BNw];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WMC, wn = wave / WMC;
-    const int n0 = blockIdx.x * BNw;
-    const int kh = blockIdx.y / a.c_tiles;
-    const int c0 = (blockIdx.y - kh * a.c_tiles) * BMw;
-    const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+    // XCD-aware numbering: block b runs on XCD b % 8; the `inner` tiles of a pixel slab are consecutive on one XCD
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int z = (jb / a.inner) * 8 + xcd;
+    if (z >= a.splits) return;
+    int tl = jb % a.inner;
+    const int n0 = (tl % a.n_tiles) * BNw;
+    tl /= a.n_tiles;
+    const int kh = tl / a.c_tiles;
+    const int c0 = (tl - kh * a.c_tiles) * BMw;
+    const int64_t p_begin = (int64_t)z * a.chunk;
     int64_t p_end = p_begin + a.chunk;
     if (p_end > a.M) p_end = a.M;
     const int n_it = p_end > p_begin ? (int)((p_end - p_begin + PRB - 1) / PRB) : 0;
-    const float* const zp = lu_zero16;
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
 
+    // cursor of the NEXT stage to fetch: (frame, row, first column), stage index
     int64_t pf = 0;
-    int oy = 0, ox0 = 0;
+    int oy = 0, ox0 = 0, ls = 0;
     {
         const int64_t p = p_begin < a.M ? p_begin : 0;
         pf = p / a.HWo;
@@ -416,60 +435,86 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
         oy = r / a.Wout;
         ox0 = r - oy * a.Wout;
     }
-    // x tile: XP rows x XQ float4; dy tile: 32 rows x 32 float4 -- item = tid + 512 * pass
-    const int xq = tid % XQ, xr0 = tid / XQ;
-    const int yq = tid & 31, yr0 = tid >> 5;
-    float4 rx[XPASS], ry[YPASS];
-    // bias gradient (see wgrad_row_kernel): summed from the fp32 values before they are rounded to bf16
-    const bool want_bias = a.bias_ws != nullptr && blockIdx.y == 0;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto bias_acc = [&]() {
+    const bool want_bias = a.bias_ws != nullptr && kh == 0 && c0 == 0;
+    float bsum[YE];
+#pragma unroll
+    for (int e = 0; e < YE; ++e) bsum[e] = 0.f;
+
+    auto load_stage = [&](lu_u4 (&rx)[XPASS], lu_u4 (&ry)[YPASS]) {
+        const bool live = ls < n_it;
+        const int iy = oy + kh - a.pad_t;
+        const bool rowok = live && iy >= 0 && iy < a.Hin;
+        const int64_t xrow = pf * a.x_fs + ((int64_t)iy * a.Win + (ox0 - a.pad_l)) * a.x_ps + c0;
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int item = tid + NT * i;
+            const int xr = item / PX, q = item - xr * PX;
+            const int ix = ox0 - a.pad_l + xr;
+            const bool ok = rowok && xr < XP && ix >= 0 && ix < a.Win && c0 + XE * q < a.C;
+            const int64_t off = xrow + (int64_t)xr * a.x_ps + XE * q;
+            const lu_u4* pp = XB ? reinterpret_cast<const lu_u4*>(reinterpret_cast<const unsigned short*>(a.x) + off)
+                                 : reinterpret_cast<const lu_u4*>(a.x + off);
+            rx[i] = *(ok ? pp : zp);
+        }
+        const int64_t yrow = pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n0;
 #pragma unroll
         for (int i = 0; i < YPASS; ++i) {
-            bsum.x += ry[i].x;
-            bsum.y += ry[i].y;
-            bsum.z += ry[i].z;
-            bsum.w += ry[i].w;
+            const int item = tid + NT * i;
+            const int yr = item / PY, q = item - yr * PY;
+            const bool ok = live && n0 + YE * q < a.N;
+            const int64_t off = yrow + (int64_t)yr * a.dy_ps + YE * q;
+            const lu_u4* pp = YB ? reinterpret_cast<const lu_u4*>(reinterpret_cast<const unsigned short*>(a.dy) + off)
+                                 : reinterpret_cast<const lu_u4*>(a.dy + off);
+            ry[i] = *(ok ? pp : zp);
         }
-    };
-    auto load_stage = [&]() {
-        const int iy = oy + kh - a.pad_t;
-        const int c = c0 + 4 * xq;
-        const bool rowok = iy >= 0 && iy < a.Hin && c < a.C;
-        const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + (ox0 - a.pad_l)) * a.x_ps + c;
-#pragma unroll
-        for (int i = 0; i < XPASS; ++i) {
-            const int xr = xr0 + i * (NT / XQ);
-            const int ix = ox0 - a.pad_l + xr;
-            rx[i] = *reinterpret_cast<const float4*>((rowok && xr < XP && ix >= 0 && ix < a.Win) ? px + (int64_t)xr * a.x_ps : zp);
-        }
-        const int n = n0 + 4 * yq;
-        const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n;
-#pragma unroll
-        for (int i = 0; i < YPASS; ++i)
-            ry[i] = *reinterpret_cast<const float4*>(n < a.N ? py + (int64_t)(yr0 + i * (NT / 32)) * a.dy_ps : zp);
-    };
-    auto put = [&](unsigned short* dst, const float4& v) {
-        unsigned* d2 = reinterpret_cast<unsigned*>(dst);
-        d2[0] = lu_pack2bf(v.x, v.y);
-        d2[1] = lu_pack2bf(v.z, v.w);
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < XPASS; ++i) {
-            const int xr = xr0 + i * (NT / XQ);
-            if (xr < XP) put(&Xs[buf][xr * XLD + 4 * xq], rx[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < YPASS; ++i) put(&Ys[buf][(yr0 + i * (NT / 32)) * YLD + 4 * yq], ry[i]);
-    };
-    auto advance = [&]() {
+        ++ls;
         ox0 += PRB;
         if (ox0 >= a.Wout) {          // W % 32 == 0: a run never straddles two rows
             ox0 = 0;
             if (++oy == a.Hout) {
                 oy = 0;
                 ++pf;
+            }
+        }
+    };
+    auto put = [&](unsigned short* dst, const lu_u4& v, bool is_bf16) {
+        if (is_bf16) {
+            *reinterpret_cast<lu_u4*>(dst) = v;
+        } else {
+            unsigned* d2 = reinterpret_cast<unsigned*>(dst);
+            d2[0] = lu_pack2bf(lu_bits2f(v.x), lu_bits2f(v.y));
+            d2[1] = lu_pack2bf(lu_bits2f(v.z), lu_bits2f(v.w));
+        }
+    };
+    auto store_stage = [&](int buf, const lu_u4 (&rx)[XPASS], const lu_u4 (&ry)[YPASS]) {
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int item = tid + NT * i;
+            const int xr = item / PX, q = item - xr * PX;
+            if (xr < XP) put(&Xs[buf][xr * XLD + XE * q], rx[i], XB);
+        }
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) {
+            const int item = tid + NT * i;
+            const int yr = item / PY, q = item - yr * PY;
+            put(&Ys[buf][yr * YLD + YE * q], ry[i], YB);
+        }
+        if (want_bias) {          // bias gradient = column sums of dy (of the values the MFMA sees when dy is bf16)
+#pragma unroll
+            for (int i = 0; i < YPASS; ++i) {
+                if (YB) {
+                    const unsigned w4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bsum[(2 * e) % YE] += lu_bits2f(w4[e] << 16);
+                        bsum[(2 * e + 1) % YE] += lu_bits2f(w4[e] & 0xffff0000u);
+                    }
+                } else {
+                    bsum[0] += lu_bits2f(ry[i].x);
+                    bsum[1] += lu_bits2f(ry[i].y);
+                    bsum[2] += lu_bits2f(ry[i].z);
+                    bsum[3] += lu_bits2f(ry[i].w);
+                }
             }
         }
     };
@@ -482,12 +527,6 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][nf][r] = 0.f;
 
-    if (n_it > 0) {
-        load_stage();
-        store_stage(0);
-        if (want_bias) bias_acc();
-    }
-    __syncthreads();
     // this lane's address inside a 4-row x 32-column transposed fetch: row (lane & 15) >> 2 (+ 8 for the upper half-wave),
     // columns 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
     const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
@@ -500,31 +539,43 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return v;
     };
-    const int l31 = lane & 31;
-    for (int it = 0; it < n_it; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < n_it) advance();
-        load_stage();                  // the last iteration re-fetches its own run (stays in cache); keeps the loop branch-free
-        LU_SCHED_FENCE();
+    auto mma_half = [&](int buf, int j) {
+        lu_bf16x8 bv[NFW];
 #pragma unroll
-        for (int j = 0; j < PRB / 16; ++j) {
-            lu_bf16x8 bv[NFW];
+        for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf][yoff + 16 * j * YLD + 32 * nf], YLD);
 #pragma unroll
-            for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf][yoff + 16 * j * YLD + 32 * nf], YLD);
+        for (int t = 0; t < K; ++t) {
+            const lu_bf16x8 av = frag(&Xs[buf][xoff + (16 * j + t) * XLD], XLD);
 #pragma unroll
-            for (int t = 0; t < K; ++t) {
-                const lu_bf16x8 av = frag(&Xs[buf][xoff + (16 * j + t) * XLD], XLD);
-#pragma unroll
-                for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
-            }
+            for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
         }
+    };
+
+    lu_u4 rxA[XPASS], ryA[YPASS], rxB[XPASS], ryB[YPASS];
+    load_stage(rxA, ryA);              // stage 0
+    store_stage(0, rxA, ryA);
+    load_stage(rxA, ryA);              // stage 1
+    load_stage(rxB, ryB);              // stage 2
+    __syncthreads();
+    const int l31 = lane & 31;
+    for (int it = 0; it < n_it; it += 2) {
+        mma_half(0, 0);
         LU_SCHED_FENCE();
-        store_stage(buf ^ 1);
-        if (want_bias && it + 1 < n_it) bias_acc();      // (the last iteration re-fetched its own run)
+        store_stage(1, rxA, ryA);      // stage it + 1 (requested two MFMA phases ago)
+        load_stage(rxA, ryA);          // stage it + 3
+        LU_SCHED_FENCE();
+        mma_half(0, 1);
+        __syncthreads();
+        mma_half(1, 0);
+        LU_SCHED_FENCE();
+        store_stage(0, rxB, ryB);      // stage it + 2
+        load_stage(rxB, ryB);          // stage it + 4
+        LU_SCHED_FENCE();
+        mma_half(1, 1);
         __syncthreads();
     }
 
-    float* slab = a.ws + (int64_t)blockIdx.z * a.slab;
+    float* slab = a.ws + (int64_t)z * a.slab;
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         const int tap = kh * K + t;
@@ -537,15 +588,25 @@ __global__ __launch_bounds__(512, (CT == 64 ? 4 : 2)) void wgrad_row_bf16_kernel
                 if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][nf][r];
             }
     }
-    if (want_bias) {          // 16 row-threads per column group -> one sum per column (fixed order: deterministic)
-        float* red = reinterpret_cast<float*>(Ys[0]);       // 16 x 128 floats = 8 KB <= one dy tile (the loop ended with a barrier)
-        *reinterpret_cast<float4*>(&red[yr0 * BNw + 4 * yq]) = bsum;
+    if (want_bias) {          // rows of a piece column live in different lanes / waves: shuffle, then 8 wave partials (fixed order)
+        constexpr int RPW = 64 / PY;      // tile rows per wave and pass: 4 (bf16 dy) or 2 (fp32 dy)
+#pragma unroll
+        for (int e = 0; e < YE; ++e) {
+            float v = bsum[e];
+            if (RPW == 4) v += lu_shfl_xor(v, 32);
+            v += lu_shfl_xor(v, RPW == 4 ? 16 : 32);
+            bsum[e] = v;
+        }
+        if (lane < PY) {
+#pragma unroll
+            for (int e = 0; e < YE; ++e) Bred[wave * BNw + YE * lane + e] = bsum[e];
+        }
         __syncthreads();
         if (tid < BNw) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < NT / 32; ++r) s += red[r * BNw + tid];
-            if (n0 + tid < a.N) a.bias_ws[(int64_t)blockIdx.z * a.N + n0 + tid] = s;
+            for (int w = 0; w < 8; ++w) s += Bred[w * BNw + tid];
+            if (n0 + tid < a.N) a.bias_ws[(int64_t)z * a.N + n0 + tid] = s;
         }
     }
 }
@@ -739,8 +800,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     const int splits = d->splits > 0 ? d->splits : 1;
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = d->x;
-    a.dy = d->dy;
+    a.x = (const float*)d->x;
+    a.dy = (const float*)d->dy;
     a.x_fs = d->x_frame_stride;
     a.dy_fs = d->dy_frame_stride;
     a.x_ps = d->x_pix_stride;
@@ -762,8 +823,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.ws = (float*)d->workspace;
     a.slab = (int64_t)a.kk * d->C * d->N;
     a.bias_ws = d->dbias ? a.ws + (int64_t)splits * a.slab : nullptr;
-    const bool xvec = (d->C % 4 == 0) && (d->x_pix_stride % 4 == 0) && (d->x_frame_stride % 4 == 0) && aligned16(d->x);
-    const bool yvec = (d->N % 4 == 0) && (d->dy_pix_stride % 4 == 0) && (d->dy_frame_stride % 4 == 0) && aligned16(d->dy);
+    const bool xvec32 = d->x_dtype == LU_F32 && (d->C % 4 == 0) && (d->x_pix_stride % 4 == 0) && (d->x_frame_stride % 4 == 0) && aligned16(d->x);
+    const bool yvec32 = d->dy_dtype == LU_F32 && (d->N % 4 == 0) && (d->dy_pix_stride % 4 == 0) && (d->dy_frame_stride % 4 == 0) && aligned16(d->dy);
     dim3 block(256);
 #define LU_WG(MF_, NF_, WM_, WN_, THIN_, YV_, GY_)                                                          \
     do {                                                                                                    \
@@ -772,10 +833,20 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         LU_LAUNCH((wgrad_kernel<MF_, NF_, WM_, WN_, THIN_, YV_>), grid, block, stream, a);                  \
     } while (0)
     LU_REQUIRE(d->phase >= 0 && d->phase <= 2, "lu_conv2d_wgrad: phase must be 0 (all), 1 (partial sums) or 2 (reduce)");
+    const bool xb = d->x_dtype == LU_BF16, yb = d->dy_dtype == LU_BF16;
+    const bool xvec = xvec32 || (xb && d->C % 8 == 0 && d->x_pix_stride % 8 == 0 && d->x_frame_stride % 8 == 0 && aligned16(d->x));
+    const bool yvec = yvec32 || (yb && d->N % 8 == 0 && d->dy_pix_stride % 8 == 0 && d->dy_frame_stride % 8 == 0 && aligned16(d->dy));
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
-                             d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOROW");
-    const bool small3 = xvec && yvec && d->stride == 1 && d->k == 3 && d->C <= 64 && d->N <= 64 && d->Wout % 16 == 0 &&
-                        d->Wout == d->Win && d->Hout == d->Hin && !getenv("LU_WGRAD_NOSMALL");
+                             d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_ROW);
+    const bool small3 = !xb && !yb && xvec && yvec && d->stride == 1 && d->k == 3 && d->C <= 64 && d->N <= 64 &&
+                        d->Wout % 16 == 0 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_SMALL3);
+    // (a 1x1 layer with >= 32 channels also fits the bf16 kernel-row scheme: one tap, no halo -- the im2col chunk of a thin input)
+    const bool row_k1 = xvec && yvec && d->stride == 1 && d->k == 1 && d->precision == 1 && d->C >= 32 && d->Wout == d->Win &&
+                        d->Hout == d->Hin && !d->dbias && !(d->flags & LU_WGRAD_F_NO_ROW);
+    const bool row_bf16 = ((row_variant && !small3) || row_k1) && d->precision == 1 && d->Wout % PRB == 0;
+    LU_REQUIRE((!xb && !yb) || row_bf16,
+               "lu_conv2d_wgrad: bf16 operands need the bf16 kernel-row variant (precision 1, stride-1 3x3 / 5x5 with C >= 64 or 1x1 with C >= 32, "
+               "C %% 8 == 0, N %% 8 == 0, W %% 32 == 0, 16-byte aligned)");
     LU_REQUIRE(!d->dbias || row_variant || small3,
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
@@ -787,15 +858,27 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         if (tiles <= 16) LU_LAUNCH((wgrad_small3_kernel<2>), grid, dim3(512), stream, a);
         else if (tiles <= 24) LU_LAUNCH((wgrad_small3_kernel<3>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_small3_kernel<5>), grid, dim3(512), stream, a);
-    } else if (row_variant && d->precision == 1 && d->Wout % PRB == 0) {
-        const char* force = getenv("LU_WGRAD_BF16_CT");         // "64" / "128": tests and A/B runs
-        const int ct = force ? atoi(force) : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
+    } else if (row_bf16) {
+        const int ct = d->k == 1 ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
+                                                                                        : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
         a.c_tiles = (d->C + ct - 1) / ct;
-        dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
-        if (d->k == 5 && ct == 128) LU_LAUNCH((wgrad_row_bf16_kernel<5, 128>), grid, dim3(512), stream, a);
-        else if (d->k == 5) LU_LAUNCH((wgrad_row_bf16_kernel<5, 64>), grid, dim3(512), stream, a);
-        else if (ct == 128) LU_LAUNCH((wgrad_row_bf16_kernel<3, 128>), grid, dim3(512), stream, a);
-        else LU_LAUNCH((wgrad_row_bf16_kernel<3, 64>), grid, dim3(512), stream, a);
+        a.n_tiles = (d->N + 127) / 128;
+        a.inner = a.n_tiles * d->k * a.c_tiles;
+        a.splits = splits;
+        dim3 grid((unsigned)(8 * a.inner * ((splits + 7) / 8)));      // XCD-aware numbering: see the kernel
+#define LU_WGB(K_, CT_)                                                                                              \
+    do {                                                                                                             \
+        if (xb && yb) LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, true, true>), grid, dim3(512), stream, a);            \
+        else if (yb) LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, false, true>), grid, dim3(512), stream, a);            \
+        else if (xb) LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, true, false>), grid, dim3(512), stream, a);            \
+        else LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, false, false>), grid, dim3(512), stream, a);                   \
+    } while (0)
+        if (d->k == 1) LU_WGB(1, 64);
+        else if (d->k == 5 && ct == 128) LU_WGB(5, 128);
+        else if (d->k == 5) LU_WGB(5, 64);
+        else if (ct == 128) LU_WGB(3, 128);
+        else LU_WGB(3, 64);
+#undef LU_WGB
     } else if (row_variant) {
         a.c_tiles = (d->C + 63) / 64;
         dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
@@ -805,7 +888,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         const int gy = (a.kk * d->C + 31) / 32;
         if (yvec) LU_WG(1, 1, 1, 4, true, true, gy);
         else LU_WG(1, 1, 1, 4, true, false, gy);
-    } else if (d->C > 64 && d->N >= 256 && yvec && !getenv("LU_WGRAD_SMALL")) {
+    } else if (d->C > 64 && d->N >= 256 && yvec && !(d->flags & LU_WGRAD_F_SMALL_TILE)) {
         // 128 x 256 tile: 64 MFMAs per pipeline stage per wave, half the x re-reads (ConvLSTM kernels: N = 4F >= 512)
         a.c_tiles = (d->C + 127) / 128;
         LU_WG(2, 4, 2, 2, false, true, a.kk * a.c_tiles);

@@ -2,16 +2,22 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 3          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 4          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
 LU_EPI_BIAS, LU_EPI_LSTM = 0, 1
+LU_F32, LU_BF16 = 0, 1
+# lu_conv_desc.flags / lu_wgrad_desc.flags (include/lstm_unet_hip.h)
+LU_CONV_F_PATCH8, LU_CONV_F_PATCH16, LU_CONV_F_NO_HALO, LU_CONV_F_XCD_BY_N = 1, 2, 4, 8
+LU_CONV_F_LDS_DMA, LU_CONV_F_MF2, LU_CONV_F_GENERAL = 16, 32, 64
+LU_CONV_F_GATES_BF16, LU_CONV_F_SRC1_CENTER = 256, 512
+LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE = 1, 2, 4, 8, 16
 
 
 class ConvSrc(C.Structure):
     _fields_ = [('x', c_f32p), ('w', c_f32p), ('frame_stride', i64), ('w_tap_stride', i64),
-                ('pix_stride', i32), ('C', i32), ('w_row_stride', i32), ('_pad', i32)]
+                ('pix_stride', i32), ('C', i32), ('w_row_stride', i32), ('dtype', i32)]
 
 
 class ConvDesc(C.Structure):
@@ -22,7 +28,7 @@ class ConvDesc(C.Structure):
                 ('c_prev', c_f32p), ('c_out', c_f32p), ('h_out', c_f32p), ('gates_out', c_f32p),
                 ('c_prev_frame_stride', i64), ('c_out_frame_stride', i64), ('h_frame_stride', i64),
                 ('gates_frame_stride', i64), ('splits', i32), ('precision', i32), ('workspace', C.c_void_p),
-                ('out_row_stride', i64), ('k_h', i32), ('_pad_end', i32)]
+                ('out_row_stride', i64), ('k_h', i32), ('flags', i32), ('h16_out', C.c_void_p), ('h16_frame_stride', i64)]
 
 
 class WgradDesc(C.Structure):
@@ -32,7 +38,7 @@ class WgradDesc(C.Structure):
                 ('k', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
                 ('dw', c_f32p), ('dw_tap_stride', i64), ('dw_row_stride', i32), ('splits', i32),
                 ('beta', f32), ('precision', i32), ('workspace', C.c_void_p),
-                ('dbias', c_f32p), ('dbias_beta', f32), ('phase', i32)]
+                ('dbias', c_f32p), ('dbias_beta', f32), ('phase', i32), ('x_dtype', i32), ('dy_dtype', i32), ('flags', i32)]
 
 
 P = C.c_void_p
@@ -53,6 +59,10 @@ PROTOTYPES = {
     'lu_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), S]),
     'lu_lstm_gates_fwd': (C.c_int, [P, P, P, P, P, i32, i64, i32, i64, S]),
     'lu_lstm_gates_bwd': (C.c_int, [P, P, P, P, i64, P, P, P, P, i32, i64, i32, S]),
+    'lu_lstm_gates_bwd_bf16': (C.c_int, [P, P, P, P, i64, P, P, P, i32, i64, i32, S]),
+    'lu_convert_f32_bf16': (C.c_int, [P, P, i64, S]),
+    'lu_convert_bf16_f32': (C.c_int, [P, P, i64, S]),
+    'lu_im2col_bf16': (C.c_int, [P, P, i32, i32, i32, i32, i32, S]),
     'lu_colreduce_workspace_bytes': (C.c_size_t, [i64, i32]),
     'lu_colsum': (C.c_int, [P, i64, i32, i32, P, f32, P, S]),
     'lu_bn_stats': (C.c_int, [P, i64, i32, P, P, S]),

@@ -1,7 +1,6 @@
 """Thin, pointer-level call helpers over the C ABI (descriptor packing + error checks).
 Everything here works on raw addresses; ops.py feeds it torch device pointers."""
 import ctypes as C
-import os
 
 from . import cabi
 
@@ -23,11 +22,12 @@ def same_pad(n_in, k, s):
     return n_out, total // 2, total - total // 2
 
 
-def conv_src(x, frame_stride, pix_stride, Cin, w, w_tap_stride, w_row_stride):
+def conv_src(x, frame_stride, pix_stride, Cin, w, w_tap_stride, w_row_stride, dtype=cabi.LU_F32):
     s = cabi.ConvSrc()
     s.x, s.w = x, w
     s.frame_stride, s.w_tap_stride = frame_stride, w_tap_stride
     s.pix_stride, s.C, s.w_row_stride = pix_stride, Cin, w_row_stride
+    s.dtype = dtype
     return s
 
 
@@ -41,7 +41,9 @@ def conv_splits(frames, Hout, Wout, N, k, channels):
 
 
 def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,
-           out_frame_stride, out_pix_stride, lstm=None, splits=1, workspace=None, out_row_stride=0, precision=0, k_h=0):
+           out_frame_stride, out_pix_stride, lstm=None, splits=1, workspace=None, out_row_stride=0, precision=0, k_h=0,
+           flags=0, h16=None):
+    """h16 = (ptr, frame_stride): optional bf16 copy of h written by the fused ConvLSTM epilogue (precision 1)."""
     d = cabi.ConvDesc()
     d.n_src = len(srcs)
     for i, s in enumerate(srcs):
@@ -51,6 +53,9 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
     d.bias, d.out, d.out_frame_stride, d.out_pix_stride = bias, out, out_frame_stride, out_pix_stride
     d.epilogue = cabi.LU_EPI_BIAS
     d.splits, d.workspace, d.out_row_stride, d.precision, d.k_h = splits, workspace, out_row_stride, precision, k_h
+    d.flags = flags
+    if h16 is not None:
+        d.h16_out, d.h16_frame_stride = h16
     if lstm is not None:
         d.epilogue = cabi.LU_EPI_LSTM
         (d.c_prev, d.c_prev_frame_stride, d.c_out, d.c_out_frame_stride, d.h_out, d.h_frame_stride,
@@ -59,7 +64,8 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
 
 
 def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, Wout, k, stride, pad_t, pad_l,
-               dw, dw_tap_stride, dw_row_stride, splits, beta, precision=0, dbias=None, dbias_beta=0.0):
+               dw, dw_tap_stride, dw_row_stride, splits, beta, precision=0, dbias=None, dbias_beta=0.0,
+               x_dtype=cabi.LU_F32, dy_dtype=cabi.LU_F32, flags=0):
     d = cabi.WgradDesc()
     d.x, d.x_frame_stride, d.x_pix_stride, d.C = x, x_fs, x_ps, Cin
     d.dy, d.dy_frame_stride, d.dy_pix_stride, d.N = dy, dy_fs, dy_ps, N
@@ -68,7 +74,23 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     d.dw, d.dw_tap_stride, d.dw_row_stride, d.splits, d.beta = dw, dw_tap_stride, dw_row_stride, splits, beta
     d.precision = precision
     d.dbias, d.dbias_beta = dbias, dbias_beta
+    d.x_dtype, d.dy_dtype, d.flags = x_dtype, dy_dtype, flags
     return d
+
+
+def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=5, cus=256):
+    """Pixel-axis split of the bf16 kernel-row variant.  Its blocks are numbered XCD-aware (all tiles of a pixel slab on
+    one XCD), one block per CU at 128-channel tiles (two at 64), all of equal length: pick a multiple of 8 slabs so that
+    tiles x slabs is close to `rounds` full waves of the chip -- few fat slabs keep the slab write + re-read small
+    (round 1: ~3000 blocks = 38 slabs of 26 MB at level 1 = 1 GB per launch; now 16 slabs)."""
+    inner = k * -(-Cin // ct) * -(-N // 128)
+    per_round = cus * (1 if ct == 128 else 2)
+    s = max(8, int(round(rounds * per_round / float(inner) / 8.0)) * 8)
+    while s > 8 and pixels // s < 2048:
+        s -= 8
+    if pixels // s < 1024:          # tiny problems (tests): any split count will do
+        s = max(1, min(s, pixels // 512))
+    return int(s)
 
 
 def wgrad_splits(pixels, k, Cin, N, target_blocks=3072, row_variant=False, small3=False):
@@ -76,7 +98,6 @@ def wgrad_splits(pixels, k, Cin, N, target_blocks=3072, row_variant=False, small
     long-running blocks the slowest CU (4 blocks vs 3) sets the time, so aim for a few thousand shorter
     blocks (>= 2048 pixels = 128 pipeline stages each) and let the dispatcher balance them; beyond ~3000 the slab
     reduce grows faster than the balance improves (re-measured with the kernel-row variants: 3072 vs 6144 +1-2 %)."""
-    target_blocks = int(os.environ.get('LU_WGRAD_BLOCKS', target_blocks))     # tuning knob (bench A/B)
     if small3:           # all-taps kernel of the narrow layers: one block per pixel slab, ~2 blocks per CU
         return max(1, min(512, pixels // 2048))
     ct = max(1, -(-Cin // 128)) if Cin % 4 == 0 else -(-(k * k * Cin) // 32)

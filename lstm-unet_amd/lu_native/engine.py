@@ -132,7 +132,7 @@ class Engine:
     def _bf16_conv(self, k, stride, n_out):
         return self.precision == 'bf16' and stride == 1 and k in (3, 5) and n_out > 64 and n_out % 4 == 0
 
-    def _pack(self, name, role, make, co=0, cs=None):
+    def _pack(self, name, role, make, co=0, cs=None, packer=None):
         ver = self.flat_params._version       # in-place torch updates (copy_, torch optimisers) bump it; the raw-pointer
         if ver != self._packed_version:       # Adam kernel does not, hence Adam.apply_gradients -> weights_changed()
             self._packed.clear()
@@ -140,7 +140,7 @@ class Engine:
         key = (name, role, co, cs)
         pw = self._packed.get(key)
         if pw is None:
-            pw = self._packed[key] = ops.pack_bf16(make())
+            pw = self._packed[key] = (packer or ops.pack_bf16)(make())
         return pw
 
     def _bn_forward(self, prefix, y, training, rec):
@@ -217,14 +217,39 @@ class Engine:
 
     # ------------------------------------------------------------------ ConvLSTM layer
     def _lstm_forward(self, bi, li, spec, x_seq, T, B, tape):
-        """x_seq [T*B,H,W,C] time-major -> h sequence [T*B,H,W,F]; updates the carried state."""
-        _, H, W, _ = x_seq.shape
+        """x_seq [T*B,H,W,C] time-major -> h sequence [T*B,H,W,F]; updates the carried state.
+        bf16 mode, fused step: the hidden sequence is ALSO kept as bf16 (h16_all: the recurrent operand of the next step and
+        the x operand of the hoisted recurrent weight gradient) and the BPTT tape (saved gates, later dz in place) is bf16 --
+        every consumer rounds these tensors to bf16 MFMA operands anyway, so storing them rounded halves their HBM traffic
+        and changes no forward value.  fp32 mode is untouched."""
+        _, H, W, Cin = x_seq.shape
         F = spec['f']
+        k = spec['k']
         dev = x_seq.device
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
-        if self._bf16_conv(spec['k'], 1, 4 * F):
-            kernel = self._pack(pre + '.kernel', 'fwd', lambda w=kernel: w)
+        bf = self._bf16_conv(k, 1, 4 * F)
+        tape16 = bf and ops.fused_step_applies(B, H, W, F, True)
+        x_center = tape16 and Cin % 4 != 0 and k * k * Cin <= 32      # thin image: im2col chunk, one tap
+        src16 = tape16 and (x_center or Cin % 8 == 0)                 # both operands of the step as bf16 tensors
+        x5 = x_seq.view(T, B, H, W, -1)
+        x16 = None
+        if bf:
+            w_in = kernel
+            if x_center:
+                kernel = self._pack(pre + '.kernel', 'center', lambda w=w_in: w, packer=ops.pack_center_bf16)
+                x5 = ops.im2col_bf16(x_seq, k).view(T, B, H, W, 32)
+            elif src16:
+                kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w)
+                x16 = ops.to_bf16(x_seq)      # one pass per window; also the x operand of the hoisted weight gradient
+                x5 = x16.view(T, B, H, W, -1)
+            else:
+                kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w)
+                if Cin % 4 != 0:
+                    # the bf16 kernel reads 16-byte channel groups: thin inputs get zero pad channels
+                    cpad = -(-Cin // 4) * 4
+                    x5 = torch.zeros((T, B, H, W, cpad), device=dev, dtype=torch.float32)
+                    x5[..., :Cin] = x_seq.view(T, B, H, W, -1)
             rec_k = self._pack(pre + '.recurrent_kernel', 'fwd', lambda w=rec_k: w)
         h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
@@ -238,16 +263,17 @@ class Engine:
                                  (tuple(st[0].shape), (B, H, W, F)))
             h_all[0].copy_(st[0])
             c_all[0].copy_(st[1])
-        gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32) if tape is not None else None
-        x5 = x_seq.view(T, B, H, W, -1)
-        if isinstance(kernel, ops.PackedW) and x_seq.shape[3] % 4 != 0:
-            # the bf16 kernel reads 16-byte channel groups: thin inputs (the 1-channel image) get zero pad channels
-            cpad = -(-x_seq.shape[3] // 4) * 4
-            x5 = torch.zeros((T, B, H, W, cpad), device=dev, dtype=torch.float32)
-            x5[..., :x_seq.shape[3]] = x_seq.view(T, B, H, W, -1)
+        h16_all = None
+        if tape16:
+            h16_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.bfloat16)
+            ops.to_bf16(h_all[0], out=h16_all[0])
+        gates = None
+        if tape is not None:
+            gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.bfloat16 if tape16 else torch.float32)
         for t in range(T):
-            ops.convlstm_step(x5[t], h_all[t], c_all[t], kernel, rec_k, bias, h_all[t + 1], c_all[t + 1],
-                              gates[t] if gates is not None else None)
+            ops.convlstm_step(x5[t], h16_all[t] if src16 else h_all[t], c_all[t], kernel, rec_k, bias, h_all[t + 1],
+                              c_all[t + 1], gates[t] if gates is not None else None,
+                              h16_out=h16_all[t + 1] if tape16 else None, x_center=x_center)
         if st is None:
             self.states[bi][li] = [h_all[T].clone(), c_all[T].clone()]
         else:
@@ -255,7 +281,7 @@ class Engine:
             st[1].copy_(c_all[T])
         if tape is not None:
             tape.append({'kind': 'lstm', 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'h_all': h_all, 'c_all': c_all,
-                         'gates': gates, 'T': T, 'B': B})
+                         'gates': gates, 'T': T, 'B': B, 'h16_all': h16_all, 'x25': x5 if x_center else None, 'x16': x16})
         return h_all[1:].view(T * B, H, W, F)
 
     def _lstm_backward(self, rec, dh_seq, need_dx):
@@ -264,32 +290,67 @@ class Engine:
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel']
         h_all, c_all, gates, x_seq = rec['h_all'], rec['c_all'], rec['gates'], rec['x']
+        h16_all, x25, x16 = rec.get('h16_all'), rec.get('x25'), rec.get('x16')
+        tape16 = gates.dtype == torch.bfloat16
         _, _, H, W, F = h_all.shape
+        k = spec['k']
         dev = h_all.device
         dz = gates      # in place: the saved gates of step t are dead once dz_t is formed (halves the BPTT tape)
         dh5 = dh_seq.view(T, B, H, W, F)
         dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
         dh_rec = None
         rec_kt = ops.flip_transpose(rec_k) if T > 1 else None
-        if rec_kt is not None and self._bf16_conv(spec['k'], 1, F):
+        rec_bf = rec_kt is not None and self._bf16_conv(k, 1, F)
+        if rec_bf:
             rec_kt = ops.pack_bf16(rec_kt)
-        p = (spec['k'] - 1) // 2
+        p = (k - 1) // 2
         for t in reversed(range(T)):
-            ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc[(t + 1) & 1] if t < T - 1 else None,
-                               dz[t], dc[t & 1])
+            dc_in = dc[(t + 1) & 1] if t < T - 1 else None
+            if tape16:
+                ops.lstm_gates_bwd_bf16(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dc[t & 1])
+            else:
+                ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
             if t > 0:
                 if dh_rec is None:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
-                ops.conv_raw([(dz[t], rec_kt)], B, H, W, H, W, spec['k'], 1, 1, p, p, F, None, dh_rec)
+                dz_t = dz[t] if (rec_bf or not tape16) else ops.to_f32(dz[t])       # (fp32 kernels read fp32)
+                ops.conv_raw([(dz_t, rec_kt)], B, H, W, H, W, k, 1, 1, p, p, F, None, dh_rec)
         rec['gates'] = None
         dz_seq = dz.view(T * B, H, W, 4 * F)
+        dz32 = [None]
+
+        def dz_f32():      # fallback for consumers without a bf16-operand kernel (small / odd layer shapes)
+            if not tape16:
+                return dz_seq
+            if dz32[0] is None:
+                dz32[0] = ops.to_f32(dz_seq)
+            return dz32[0]
+
         # hoisted over all T: one big reduction per weight
         bf = self.precision == 'bf16'
-        ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, bf16=bf,
-                         dbias=self.G[pre + '.bias'])       # + the bias gradient = column sums of dz, on the side
-        ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1, bf16=bf)
-        dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1, bf16=self._bf16_conv(spec['k'], 1, kernel.shape[2])) if need_dx else None
-        rec['h_all'] = rec['c_all'] = rec['x'] = None
+        hp16 = h16_all[:T].view(T * B, H, W, F) if tape16 else None
+        if tape16 and ops.bf16_row_wgrad_ok(hp16, dz_seq, k, 1):
+            ops.conv2d_wgrad(hp16, dz_seq, self.G[pre + '.recurrent_kernel'], 1, bf16=True,
+                             dbias=self.G[pre + '.bias'])       # + the bias gradient = column sums of dz, on the side
+        else:
+            ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_f32(), self.G[pre + '.recurrent_kernel'], 1, bf16=bf,
+                             dbias=self.G[pre + '.bias'])
+        gk = self.G[pre + '.kernel']
+        if x25 is not None and ops.bf16_row_wgrad_ok(x25.view(T * B, H, W, 32), dz_seq, 1, 1):
+            # thin image: the weight gradient of the im2col chunk is a 1x1 problem over its 32 (tap, c) rows
+            tmp = torch.empty((1, 1, 32, 4 * F), device=dev, dtype=torch.float32)
+            ops.conv2d_wgrad(x25.view(T * B, H, W, 32), dz_seq, tmp, 1, bf16=True)
+            rows = gk.shape[0] * gk.shape[1] * gk.shape[2]
+            gk.view(rows, 4 * F).copy_(tmp.view(32, 4 * F)[:rows])
+        elif tape16 and ops.bf16_row_wgrad_ok(x16 if x16 is not None else x_seq, dz_seq, k, 1):
+            ops.conv2d_wgrad(x16 if x16 is not None else x_seq, dz_seq, gk, 1, bf16=True)
+        else:
+            ops.conv2d_wgrad(x_seq, dz_f32(), gk, 1, bf16=bf)
+        dx = None
+        if need_dx:
+            dx_bf = self._bf16_conv(k, 1, kernel.shape[2])
+            dx = ops.conv2d_dgrad(dz_seq if (dx_bf or not tape16) else dz_f32(), kernel, (H, W), 1, bf16=dx_bf)
+        rec['h_all'] = rec['c_all'] = rec['x'] = rec['h16_all'] = rec['x25'] = rec['x16'] = None
         return dx
 
     # ------------------------------------------------------------------ forward / backward

@@ -18,6 +18,8 @@ _lib = None
 FUSED_MIN_TILES = 160   # fused ConvLSTM step needs this many 256x32ch tiles to fill the chip (tests set 0)
 FUSED_MIN_TILES_BF16 = 0    # ... the bf16 kernel is better fused at every size (B = 1 streaming: 394 vs 384 frames/s)
 EVENT_LOG = None   # bench.py: list collecting (kernel class, algorithmic FLOPs, start, end) around the MFMA launches
+CONV_FLAGS = 0     # tests / A-B tools: cabi.LU_CONV_F_* kernel-variant overrides OR-ed into every lu_conv_desc
+WGRAD_FLAGS = 0    # ... cabi.LU_WGRAD_F_* into every lu_wgrad_desc (the library itself never reads the environment)
 
 
 class _timed(object):
@@ -64,7 +66,7 @@ def _chk(*tensors):
             continue
         if not t.is_cuda:
             raise NativeError('lu_native ops need device tensors (got %s); no CPU fallback exists' % t.device)
-        if t.dtype not in (torch.float32, torch.float64, torch.int16):    # int16: packed bf16 weight images
+        if t.dtype not in (torch.float32, torch.float64, torch.int16, torch.bfloat16):    # int16: packed bf16 weight images
             raise NativeError('unexpected dtype %s' % t.dtype)
 
 
@@ -123,7 +125,10 @@ def _src(x, w):
         assert x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2)
         ck = 32 if w.precision == 1 else 16
         assert x.shape[3] >= w.shape[2] and -(-x.shape[3] // ck) == -(-w.shape[2] // ck), (x.shape, w.shape)
-        return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data.data_ptr(), 0, 0)
+        assert x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and w.precision == 1)
+        return calls.conv_src(x.data_ptr(), x.stride(0), x.stride(2), x.shape[3], w.data.data_ptr(), 0, 0,
+                              dtype=cabi.LU_BF16 if x.dtype == torch.bfloat16 else cabi.LU_F32)
+    assert x.dtype == torch.float32, 'bf16 activations need packed bf16 weights'
     assert x.dim() == 4 and w.dim() == 4 and x.stride(3) == 1 and w.stride(3) == 1, (x.shape, x.stride(), w.shape)
     assert x.stride(1) == x.shape[2] * x.stride(2), 'rows of x must be dense'
     assert w.shape[2] == x.shape[3] and w.stride(0) == w.shape[1] * w.stride(1)
@@ -153,7 +158,7 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
                      pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors,
-                     precision=prec, k_h=k_h)
+                     precision=prec, k_h=k_h, flags=CONV_FLAGS)
     return out
 
 
@@ -192,6 +197,8 @@ def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None, bf16=False
     _, pt, _ = same_pad(Hin, k, stride)
     _, pl, _ = same_pad(Win, k, stride)
     bf16 = bf16 and dy.shape[3] % 4 == 0 and dy.is_contiguous()      # the bf16 kernels read 16-byte channel groups
+    assert dy.dtype == torch.float32 or (bf16 and stride == 1), 'a bf16 dy needs the bf16 halo kernel'
+    _chk(dy, w)
     if stride == 2 and c_off == 0 and (c_sub is None or c_sub == w.shape[2]) and out is None and k > 1:
         return _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16)
     wt = flip_transpose(w, c_off, c_sub)
@@ -241,34 +248,57 @@ def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16=False):
     return out
 
 
+def bf16_row_wgrad_ok(x, dy, k, stride):
+    """True when lu_conv2d_wgrad takes its bf16 kernel-row variant for these operands (mirrors its kernel choice)."""
+    frames, Hin, Win, Cin = x.shape
+    _, Hout, Wout, N = dy.shape
+
+    def vec(t, ch):
+        q = 8 if t.dtype == torch.bfloat16 else 4
+        return ch % q == 0 and t.stride(2) % q == 0 and t.stride(0) % q == 0 and t.data_ptr() % 16 == 0
+
+    small3 = k == 3 and Cin <= 64 and N <= 64 and x.dtype == torch.float32 and dy.dtype == torch.float32
+    shape_ok = (k in (3, 5) and Cin >= 64 and not small3) or (k == 1 and Cin >= 32)
+    return (stride == 1 and shape_ok and Wout % 32 == 0 and vec(x, Cin) and vec(dy, N) and
+            Hout == Hin and Wout == Win and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
+
+
 def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta=0.0):
     """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy.
     dbias (optional [N]): the layer's bias gradient = column sums of dy -- summed on the side by the kernel-row wgrad
-    kernels where they apply, by a separate lu_colsum pass elsewhere."""
+    kernels where they apply, by a separate lu_colsum pass elsewhere.
+    x / dy may be bf16 tensors (the bf16 BPTT tape) when the bf16 kernel-row variant applies (bf16_row_wgrad_ok)."""
     _chk(x, dy, dw, dbias)
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     k = dw.shape[0]
     _, pt, _ = same_pad(Hin, k, stride)
     _, pl, _ = same_pad(Win, k, stride)
-    row_variant = (stride == 1 and k in (3, 5) and Wout % 16 == 0 and Cin >= 64 and Cin % 4 == 0 and N % 4 == 0 and
-                   x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and dy.stride(0) % 4 == 0 and
-                   x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and Hout == Hin and Wout == Win and
-                   not os.environ.get('LU_WGRAD_NOROW'))     # mirrors lu_conv2d_wgrad's kernel choice
+    xb, yb = x.dtype == torch.bfloat16, dy.dtype == torch.bfloat16
     aligned = (Cin % 4 == 0 and N % 4 == 0 and x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and
                dy.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
-    small3 = (aligned and stride == 1 and k == 3 and Cin <= 64 and N <= 64 and Wout % 16 == 0 and Hout == Hin and Wout == Win and
-              not os.environ.get('LU_WGRAD_NOSMALL'))      # all-taps kernel of the narrow decoder layers (takes precedence)
+    row_variant = (aligned and stride == 1 and k in (3, 5) and Wout % 16 == 0 and Cin >= 64 and Hout == Hin and Wout == Win and
+                   not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))     # mirrors lu_conv2d_wgrad's kernel choice
+    small3 = (aligned and not xb and not yb and stride == 1 and k == 3 and Cin <= 64 and N <= 64 and Wout % 16 == 0 and
+              Hout == Hin and Wout == Win and
+              not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_SMALL3))      # all-taps kernel of the narrow decoder layers (takes precedence)
     if small3:
         row_variant = False
-    bf16_row = bf16 and row_variant and Wout % 32 == 0
-    splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
-                                target_blocks=3072)      # re-measured after the kernel-row variants: ~3000 blocks >= 6000
+    bf16_row = bf16 and bf16_row_wgrad_ok(x, dy, k, stride)
+    assert bf16_row or not (xb or yb), 'bf16 operands need the bf16 kernel-row weight gradient'
+    if bf16_row:
+        ct = 64 if (k == 1 or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
+            (128 if (Cin % 128 == 0 or Cin > 256) else 64)
+        splits = calls.wgrad_splits_bf16_row(frames * Hout * Wout, k, Cin, N, ct)
+    else:
+        splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
+                                    target_blocks=3072)      # re-measured after the kernel-row variants: ~3000 blocks >= 6000
     d = calls.wgrad_desc(x.data_ptr(), x.stride(0), x.stride(2), Cin, dy.data_ptr(), dy.stride(0), dy.stride(2), N,
                          frames, Hin, Win, Hout, Wout, k, stride, pt, pl, dw.data_ptr(), dw.stride(1), dw.stride(2),
                          splits, beta, precision=1 if bf16 else 0,
                          dbias=dbias.data_ptr() if (dbias is not None and (row_variant or small3)) else None,
-                         dbias_beta=dbias_beta)
+                         dbias_beta=dbias_beta, x_dtype=cabi.LU_BF16 if xb else cabi.LU_F32,
+                         dy_dtype=cabi.LU_BF16 if yb else cabi.LU_F32, flags=WGRAD_FLAGS)
     if dbias is not None and not (row_variant or small3):
         bias_grad(dy, dbias, dbias_beta)
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
@@ -288,34 +318,100 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     return dw
 
 
-def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out):
+def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out, h16_out=None, x_center=False):
     """One ConvLSTM2D cell step (reference Networks.py:48-50,62-63).  Fused two-source conv + gate
-    epilogue when F % 32 == 0, otherwise conv -> pre-activations -> gate kernel."""
+    epilogue when F % 32 == 0, otherwise conv -> pre-activations -> gate kernel.
+    bf16 mode extras (fused bf16 kernel only): h_prev may be the bf16 copy of the previous hidden state, h16_out receives
+    the bf16 copy of the new one, gates_out may be a bf16 tensor (the bf16 BPTT tape), and with x_center=True x_t is the
+    im2col image of a thin input (ops.im2col_bf16) whose kernel was packed as ONE tap."""
     packed = isinstance(kernel, PackedW)
     bf16 = packed and kernel.precision == 1
-    _chk(x_t, h_prev, c_prev, kernel.data if packed else kernel, rec.data if packed else rec, bias, h_out, c_out, gates_out)
+    _chk(x_t, h_prev, c_prev, kernel.data if packed else kernel, rec.data if packed else rec, bias, h_out, c_out, gates_out,
+         h16_out)
     frames, H, W, _ = x_t.shape
     F = rec.shape[2]
-    k = kernel.shape[0]
+    k = rec.shape[0]
     p = (k - 1) // 2
     # The fused epilogue cannot take a K split, so tile-starved steps (streaming inference: B = 1) run the conv with
     # a split into pre-activations and the stand-alone gate kernel instead.
     tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
     if F % 32 == 0 and tiles >= (FUSED_MIN_TILES_BF16 if bf16 else FUSED_MIN_TILES):
+        flags = CONV_FLAGS
+        if gates_out is not None and gates_out.dtype == torch.bfloat16:
+            flags |= cabi.LU_CONV_F_GATES_BF16
+        cin_flops = kernel.shape[2] * (kernel.shape[0] * kernel.shape[1]) / float(k * k)
+        if x_center:       # the hidden state goes first: the centre-tap image chunk is the last pipeline stage
+            flags |= cabi.LU_CONV_F_SRC1_CENTER
+            srcs = [_src(h_prev, rec), _src(x_t, kernel)]
+        else:
+            srcs = [_src(x_t, kernel), _src(h_prev, rec)]
         with _timed(('conv_halo_frag_kernel<%d,LU_EPI_LSTM,*,bf16> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
                     'conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
-                    2.0 * k * k * (kernel.shape[2] + F) * 4 * F * frames * H * W):
-            calls.conv2d(lib(), _stream(), [_src(x_t, kernel), _src(h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p,
+                    2.0 * k * k * (cin_flops + F) * 4 * F * frames * H * W):
+            calls.conv2d(lib(), _stream(), srcs, frames, H, W, H, W, k, 1, 1, p, p,
                          4 * F, _p(bias), None, 0, 0,
                          lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
                                h_out.stride(0), _p(gates_out), gates_out.stride(0) if gates_out is not None else 0),
-                         precision=kernel.precision if packed else 0)
+                         precision=kernel.precision if packed else 0, flags=flags,
+                         h16=None if h16_out is None else (h16_out.data_ptr(), h16_out.stride(0)))
     else:
+        assert h16_out is None and not x_center and h_prev.dtype == torch.float32 and \
+            (gates_out is None or gates_out.dtype == torch.float32), 'the bf16 tape belongs to the fused bf16 step'
         z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
         assert c_prev.is_contiguous() and c_out.is_contiguous()
         calls.check(lib(), lib().lu_lstm_gates_fwd(z.data_ptr(), c_prev.data_ptr(), c_out.data_ptr(), h_out.data_ptr(),
                                                    _p(gates_out), frames, H * W, F, h_out.stride(0), _stream()),
                     'lu_lstm_gates_fwd')
+
+
+def fused_step_applies(frames, H, W, F, bf16):
+    """True when convlstm_step takes the fused kernel for this shape."""
+    tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
+    return F % 32 == 0 and tiles >= (FUSED_MIN_TILES_BF16 if bf16 else FUSED_MIN_TILES)
+
+
+def to_bf16(x, out=None):
+    """fp32 tensor -> bf16 tensor (round to nearest even), lu_convert_f32_bf16."""
+    _chk(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    assert out.is_contiguous() and out.numel() == x.numel()
+    calls.check(lib(), lib().lu_convert_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'lu_convert_f32_bf16')
+    return out
+
+
+def to_f32(x, out=None):
+    _chk(x)
+    assert x.is_contiguous() and x.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_convert_bf16_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'lu_convert_bf16_f32')
+    return out
+
+
+def im2col_bf16(x, k):
+    """[frames,H,W,C] fp32 thin input (k*k*C <= 32) -> [frames,H,W,32] bf16 im2col image (lu_im2col_bf16)."""
+    _chk(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    frames, H, W, Cc = x.shape
+    y = torch.empty((frames, H, W, 32), device=x.device, dtype=torch.bfloat16)
+    calls.check(lib(), lib().lu_im2col_bf16(x.data_ptr(), y.data_ptr(), frames, H, W, Cc, k, _stream()), 'lu_im2col_bf16')
+    return y
+
+
+def pack_center_bf16(w):
+    """[k,k,C,N] kernel of a thin input (k*k*C <= 32) -> PackedW of ONE tap whose 'channels' are the k*k*C (tap, c) rows,
+    matching im2col_bf16's channel order."""
+    _chk(w)
+    assert w.is_contiguous()
+    k, _, Cc, N = w.shape
+    rows = k * k * Cc
+    assert rows <= 32
+    data = torch.empty(-(-N // 32) * 1024, device=w.device, dtype=torch.int16)
+    calls.check(lib(), lib().lu_pack_weights_taps_bf16(w.data_ptr(), 0, N, 1, rows, N, data.data_ptr(), _stream()),
+                'lu_pack_weights_taps_bf16')
+    return PackedW(data, (1, 1, rows, N))
 
 
 def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc_in, dz, dc_prev_out):
@@ -330,6 +426,22 @@ def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc_in, dz, dc_prev_out):
                                                    dh_a.stride(0), _p(dh_b), _p(dc_in), dz.data_ptr(),
                                                    dc_prev_out.data_ptr(), frames, H * W, F, _stream()),
                     'lu_lstm_gates_bwd')
+
+
+def lstm_gates_bwd_bf16(gates_dz, c_prev, c_cur, dh_a, dh_b, dc_in, dc_prev_out):
+    """BPTT gate backward on the bf16 tape: gates_dz holds the saved gates (bf16) and receives dz (bf16) in place."""
+    _chk(gates_dz, c_prev, c_cur, dh_a, dh_b, dc_in, dc_prev_out)
+    frames, H, W, F = c_cur.shape
+    assert gates_dz.dtype == torch.bfloat16
+    for t in (gates_dz, c_prev, c_cur, dc_prev_out):
+        assert t.is_contiguous()
+    n_in = 2 + 2 + 1 + (dh_b is not None) + (dc_in is not None)       # gates (bf16: 4 x 2 B = 2 words), c_prev, c_cur, dh ...
+    with _timed('hbm:lstm_gates_bwd_bf16_kernel (BPTT gate backward on the bf16 tape: dz in place of the saved gates, dc)',
+                4.0 * (n_in + 2 + 1) * F * frames * H * W):
+        calls.check(lib(), lib().lu_lstm_gates_bwd_bf16(gates_dz.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(),
+                                                        dh_a.data_ptr(), dh_a.stride(0), _p(dh_b), _p(dc_in),
+                                                        dc_prev_out.data_ptr(), frames, H * W, F, _stream()),
+                    'lu_lstm_gates_bwd_bf16')
 
 
 def _colws(rows, Cc, device):

@@ -26,6 +26,8 @@ class EmuBackend(object):
         return np.array(a, dtype=dtype, order="C", copy=True)
 
     def empty(self, shape, dtype=np.float32):
+        if dtype == np.int16:
+            return np.full(shape, 0x7fc0, np.int16)      # bf16 NaN pattern
         return np.full(shape, np.nan, dtype)
 
     def ptr(self, d, offset_elems=0):
@@ -49,6 +51,8 @@ class HipBackend(object):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
 
     def empty(self, shape, dtype=np.float32):
+        if dtype == np.int16:
+            return self.torch.full(shape, 0x7fc0, dtype=self.torch.int16, device='cuda')      # bf16 NaN pattern
         t = self.torch.empty(shape, dtype=self.torch.float32 if dtype == np.float32 else self.torch.float64,
                              device='cuda')
         return t.fill_(float('nan'))
@@ -81,6 +85,16 @@ def bf16_round(a):
     return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
 
 
+def bf16_bits(a):
+    """fp32 -> nearest-even bf16 bit patterns (int16 array): a bf16 tensor as the C ABI sees it."""
+    return (bf16_round(a).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)
+
+
+def bf16_values(bits):
+    """int16 bf16 bit patterns -> fp32 values."""
+    return (np.ascontiguousarray(bits).view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
 def pack_bf16(be, wd, k, Cin, N):
     nbytes = be.lib.lu_pack_weights_bf16_bytes(k, Cin, N)
     out = be.empty((nbytes // 4 + 4,))
@@ -95,8 +109,10 @@ def pack_f32(be, wd, k, Cin, N):
     return out
 
 
-def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1, precision=0):
-    """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy."""
+def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1, precision=0, flags=0,
+           bf16_src=()):
+    """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy.
+    bf16_src: indices of sources handed over as bf16 tensors (precision 1)."""
     frames, Hin, Win = srcs[0].shape[:3]
     if N is None:
         N = ws[0].shape[-1]
@@ -108,18 +124,20 @@ def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None
         Hout, Wout = out_hw
     out = be.empty((frames, Hout, Wout, N))
     keep, cs = [], []
-    for x, w in zip(srcs, ws):
+    for si, (x, w) in enumerate(zip(srcs, ws)):
         Cin = x.shape[3]
-        xd, wd = be.dev(x), be.dev(w)
+        b16 = si in bf16_src
+        xd, wd = (be.dev(bf16_bits(x), np.int16) if b16 else be.dev(x)), be.dev(w)
         keep += [xd, wd]
         if precision:
             wd = (pack_bf16 if precision == 1 else pack_f32)(be, wd, k, Cin, N)
             keep.append(wd)
-        cs.append(calls.conv_src(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(wd), Cin * N, N))
+        cs.append(calls.conv_src(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(wd), Cin * N, N,
+                                 dtype=cabi.LU_BF16 if b16 else cabi.LU_F32))
     bd = None if bias is None else be.dev(bias)
     wsb = be.empty((splits * frames * Hout * Wout * N,)) if splits > 1 else None
     calls.conv2d(be.lib, be.stream, cs, frames, Hin, Win, Hout, Wout, k, stride, dil, pt, pl, N, be.ptr(bd),
-                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb), precision=precision)
+                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb), precision=precision, flags=flags)
     return be.host(out)
 
 
@@ -178,25 +196,75 @@ def conv2d_dgrad(be, dy, w, in_hw, stride):
     return conv2d(be, [dy], [wt], None, k, 1, stride, pad=(k - 1 - pt, k - 1 - pl), out_hw=(Hin, Win))
 
 
-def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0, precision=0, dbias0=None, dbias_beta=0.0):
-    """-> dw, or (dw, dbias) when dbias0 (initial contents of the bias-gradient buffer) is given."""
+def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0, precision=0, dbias0=None, dbias_beta=0.0, flags=0,
+                 x_bf16=False, dy_bf16=False):
+    """-> dw, or (dw, dbias) when dbias0 (initial contents of the bias-gradient buffer) is given.
+    x_bf16 / dy_bf16: hand the operand over as a bf16 tensor (the bf16 BPTT tape)."""
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     _, pt, _ = calls.same_pad(Hin, k, stride)
     _, pl, _ = calls.same_pad(Win, k, stride)
     dw = be.empty((k, k, Cin, N)) if dw0 is None else be.dev(dw0)
-    xd, dyd = be.dev(x), be.dev(dy)
+    xd = be.dev(bf16_bits(x), np.int16) if x_bf16 else be.dev(x)
+    dyd = be.dev(bf16_bits(dy), np.int16) if dy_bf16 else be.dev(dy)
     db = None if dbias0 is None else be.dev(dbias0)
     d = calls.wgrad_desc(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(dyd), Hout * Wout * N, N, N, frames, Hin, Win,
                          Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta, precision=precision,
-                         dbias=be.ptr(db), dbias_beta=dbias_beta)
+                         dbias=be.ptr(db), dbias_beta=dbias_beta, x_dtype=cabi.LU_BF16 if x_bf16 else cabi.LU_F32,
+                         dy_dtype=cabi.LU_BF16 if dy_bf16 else cabi.LU_F32, flags=flags)
     ws = be.empty((be.lib.lu_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4 + 4,))
     d.workspace = be.ptr(ws)
     calls.check(be.lib, be.lib.lu_conv2d_wgrad(C.byref(d), be.stream), 'wgrad')
     return be.host(dw) if db is None else (be.host(dw), be.host(db))
 
 
-def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias, precision=0):
+def convlstm_step_tape16(be, x_t, h, c, kernel, rec, bias, center=False, flags=0):
+    """The fused bf16 ConvLSTM step as the bf16-tape engine drives it: h handed over as a bf16 tensor, h also written as
+    bf16, gates written as bf16; center=True: x_t is a thin input, passed as its im2col image (lu_im2col_bf16) with the
+    kernel packed as one tap (source order [h, image]).  -> h (fp32), c, gates (values of the bf16 tape), h16 (values)."""
+    frames, H, W, Cin = x_t.shape
+    F = rec.shape[2]
+    k = rec.shape[0]
+    c_out, h_out = be.empty((frames, H, W, F)), be.empty((frames, H, W, F))
+    gates16, h16 = be.empty((frames, H, W, 4 * F), np.int16), be.empty((frames, H, W, F), np.int16)
+    xd, cd, kd, rd, bd = [be.dev(a) for a in (x_t, c, kernel, rec, bias)]
+    hd = be.dev(bf16_bits(h), np.int16)
+    rp = pack_bf16(be, rd, k, F, 4 * F)
+    src_h = calls.conv_src(be.ptr(hd), H * W * F, F, F, be.ptr(rp), 0, 0, dtype=cabi.LU_BF16)
+    fl = flags | cabi.LU_CONV_F_GATES_BF16
+    if center:
+        x25 = be.empty((frames, H, W, 32), np.int16)
+        calls.check(be.lib, be.lib.lu_im2col_bf16(be.ptr(xd), be.ptr(x25), frames, H, W, Cin, k, be.stream), 'im2col')
+        kp = be.empty((-(-4 * F // 32) * 512 + 4,))
+        calls.check(be.lib, be.lib.lu_pack_weights_taps_bf16(be.ptr(kd), 0, 4 * F, 1, k * k * Cin, 4 * F, be.ptr(kp),
+                                                             be.stream), 'pack center')
+        srcs = [src_h, calls.conv_src(be.ptr(x25), H * W * 32, 32, 32, be.ptr(kp), 0, 0, dtype=cabi.LU_BF16)]
+        fl |= cabi.LU_CONV_F_SRC1_CENTER
+    else:
+        kp = pack_bf16(be, kd, k, Cin, 4 * F)
+        x16 = be.dev(bf16_bits(x_t), np.int16)      # all sources of a launch share the element type
+        srcs = [calls.conv_src(be.ptr(x16), H * W * Cin, Cin, Cin, be.ptr(kp), 0, 0, dtype=cabi.LU_BF16), src_h]
+    p = (k - 1) // 2
+    calls.conv2d(be.lib, be.stream, srcs, frames, H, W, H, W, k, 1, 1, p, p, 4 * F, be.ptr(bd), None, 0, 0,
+                 lstm=(be.ptr(cd), H * W * F, be.ptr(c_out), H * W * F, be.ptr(h_out), H * W * F, be.ptr(gates16),
+                       H * W * 4 * F), precision=1, flags=fl, h16=(be.ptr(h16), H * W * F))
+    return be.host(h_out), be.host(c_out), bf16_values(be.host(gates16)), bf16_values(be.host(h16))
+
+
+def lstm_gates_bwd_bf16(be, gates, c_prev, c_cur, dh_a, dh_b, dc_in):
+    """-> dz (values of the bf16 tape after the in-place update), dc_prev."""
+    frames, H, W, F = c_cur.shape
+    gd = be.dev(bf16_bits(gates), np.int16)
+    cp, cc, da = be.dev(c_prev), be.dev(c_cur), be.dev(dh_a)
+    db = None if dh_b is None else be.dev(dh_b)
+    di = None if dc_in is None else be.dev(dc_in)
+    dcp = be.empty((frames, H, W, F))
+    calls.check(be.lib, be.lib.lu_lstm_gates_bwd_bf16(be.ptr(gd), be.ptr(cp), be.ptr(cc), be.ptr(da), H * W * F, be.ptr(db),
+                                                      be.ptr(di), be.ptr(dcp), frames, H * W, F, be.stream), 'gates bwd bf16')
+    return bf16_values(be.host(gd)), be.host(dcp)
+
+
+def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias, precision=0, flags=0):
     frames, H, W, Cin = x_t.shape
     F = rec.shape[2]
     k = kernel.shape[0]
@@ -212,5 +280,5 @@ def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias, precision=0):
     p = (k - 1) // 2
     calls.conv2d(be.lib, be.stream, srcs, frames, H, W, H, W, k, 1, 1, p, p, 4 * F, be.ptr(bd), None, 0, 0,
                  lstm=(be.ptr(cd), H * W * F, be.ptr(c_out), H * W * F, be.ptr(h_out), H * W * F, be.ptr(gates),
-                       H * W * 4 * F), precision=precision)
+                       H * W * 4 * F), precision=precision, flags=flags)
     return be.host(h_out), be.host(c_out), be.host(gates)

@@ -234,7 +234,14 @@ BF16_NET = {'down_conv_kernels': [[(3, 72), (3, 72)], [(3, 8)]], 'lstm_kernels':
             'up_conv_kernels': [[(3, 72)], [(3, 72), (1, 3)]]}
 
 
-def test_bf16_precision_mode(dev, monkeypatch):
+# wide first level: F = 96 > 64 puts the recurrent gradient, the hoisted weight gradients and the gate backward on the
+# bf16-tape kernels (bf16 h sequence / dz as MFMA operands); the narrow nets above exercise the fp32 fall-backs
+BF16_NET_WIDE = {'down_conv_kernels': [[(3, 72)], [(3, 8)]], 'lstm_kernels': [[(3, 96)], [(3, 32)]],
+                 'up_conv_kernels': [[(3, 72)], [(3, 72), (1, 3)]]}
+
+
+@pytest.mark.parametrize('which', ['narrow', 'wide'])
+def test_bf16_precision_mode(dev, monkeypatch, which):
     """Engine(precision='bf16') (BASELINE config 5): the wide stride-1 convolutions run on the bf16-MFMA kernel and the
     step stays close to the fp32 step.  Stated tolerances: logits within 3e-2 * max|logit| of the fp32 engine, loss within
     2e-2 relative, label maps equal outside a 5e-2 top-2 tie band, every gradient tensor within 0.1 L2-relative."""
@@ -243,7 +250,7 @@ def test_bf16_precision_mode(dev, monkeypatch):
     seen = []
     real = calls.conv2d
     monkeypatch.setattr(calls, 'conv2d', lambda *a, **k: (seen.append(k.get('precision', 0)), real(*a, **k))[1])
-    net, cin, B, T, H, W = BF16_NET, 1, 2, 3, 16, 32
+    net, cin, B, T, H, W = (BF16_NET, 1, 2, 3, 16, 32) if which == 'narrow' else (BF16_NET_WIDE, 1, 1, 3, 8, 32)
     rng = np.random.default_rng(21)
     p = perturbed_params(net, cin, 4)
     x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)

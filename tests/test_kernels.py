@@ -17,7 +17,7 @@ from oracle import np_oracle as npo
 from oracle import torch_oracle as tho
 import kernel_harness as KH
 from kernel_harness import f32
-from lu_native import calls
+from lu_native import cabi, calls
 
 BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
 
@@ -95,12 +95,12 @@ def test_conv_halo_variant(be):
 
 
 @pytest.mark.parametrize('patch', ['8', '16'])
-def test_conv_bf16_mfma_variant(be, patch, monkeypatch):
-    monkeypatch.setenv('LU_CONV_BF16_PATCH', patch)       # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks)
-    _conv_bf16_cases(be)
+def test_conv_bf16_mfma_variant(be, patch):
+    # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks) forced through lu_conv_desc.flags
+    _conv_bf16_cases(be, cabi.LU_CONV_F_PATCH16 if patch == '16' else cabi.LU_CONV_F_PATCH8)
 
 
-def _conv_bf16_cases(be):
+def _conv_bf16_cases(be, flags=0):
     """Mixed-precision halo kernel (precision = 1): operands rounded to bf16, fp32 accumulation.  Against the oracle
     on the SAME bf16-rounded operands only the summation order differs (tolerance as for the fp32 kernels); against
     the unrounded oracle the error is the bf16 operand rounding (2^-9 relative per operand)."""
@@ -108,19 +108,19 @@ def _conv_bf16_cases(be):
     for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
                                      (1, 8, 33, 100, 96, 3, 2)]:
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
-        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1)
+        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags)
         close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
         full = npo.conv2d_same(x, w, b, 1)
         assert np.abs(got - full).max() <= 2.0 ** -7 * np.abs(full).max()
     xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources (UpBlock concat)
     wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
     ref = npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb))
-    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1), ref, 5e-5)
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=flags), ref, 5e-5)
     F = 32                                                         # fused ConvLSTM step
     x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
     ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
     h1, c1 = npo.convlstm_step(R(x), R(h), c, R(ker), R(rec), b)
-    hg, cg, _ = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1)
+    hg, cg, _ = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=flags)
     close(hg, h1, 3e-5)
     close(cg, c1, 3e-5)
     xi, xh = rnd(1, 16, 32, 1), rnd(1, 16, 32, 40)                 # 1-channel image (zero-padded to 4) + vector source
@@ -128,37 +128,65 @@ def _conv_bf16_cases(be):
     ref = npo.conv2d_same(R(xi), R(wi)) + npo.conv2d_same(R(xh), R(wh))
     xi4 = np.concatenate([xi, np.zeros((1, 16, 32, 3), np.float32)], -1)
     wi4 = np.concatenate([wi, np.zeros((5, 5, 3, 72), np.float32)], 2)
-    close(KH.conv2d(be, [xi4, xh], [wi4, wh], None, 5, 1, precision=1), ref, 5e-5)
+    close(KH.conv2d(be, [xi4, xh], [wi4, wh], None, 5, 1, precision=1, flags=flags), ref, 5e-5)
     with pytest.raises(RuntimeError):                             # thin sources must be padded by the caller
-        KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1)
+        KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, precision=1, flags=flags)
+    # bf16 TENSORS as sources (the bf16 BPTT tape: dz for the recurrent / input gradients): same arithmetic, no conversion
+    for (fr, H, W, Cc, N, k, sp) in [(2, 16, 30, 40, 128, 5, 1), (1, 9, 33, 96, 72, 3, 2)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags, bf16_src=(0,))
+        close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
+        if sp == 1:
+            assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1, precision=1, flags=flags))
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=flags, bf16_src=(0, 1)),
+          npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb)), 5e-5)
+    with pytest.raises(RuntimeError):                             # mixed element types in one launch are rejected
+        KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=flags, bf16_src=(1,))
+    # fused step on the bf16 tape: h in as bf16, h / gates out as bf16 as well; then the thin image as a centre-tap chunk
+    x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
+    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    h0, c0, g0 = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=flags)
+    hg, cg, g16, h16 = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags)
+    assert np.array_equal(hg, h0) and np.array_equal(cg, c0)
+    assert np.array_equal(g16, R(g0)) and np.array_equal(h16, R(h0))
+    for (k, cin) in [(5, 1), (3, 3)]:
+        x, h, c = rnd(2, 16, 32, cin), rnd(2, 16, 32, F, scale=0.5), rnd(2, 16, 32, F)
+        ker, rec, b = rnd(k, k, cin, 4 * F, scale=0.3), rnd(k, k, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+        h1, c1 = npo.convlstm_step(R(x), R(h), c, R(ker), R(rec), b)
+        hg, cg, g16, h16 = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=True, flags=flags)
+        close(hg, h1, 3e-5)
+        close(cg, c1, 3e-5)
+        assert np.array_equal(h16, R(hg))
+        z = npo.conv2d_same(R(x), R(ker), b) + npo.conv2d_same(R(h), R(rec))
+        assert np.abs(g16[..., 2 * F:3 * F] - np.tanh(z[..., 2 * F:3 * F])).max() <= 2.0 ** -8
 
 
 @pytest.mark.parametrize('patch', ['8', '16'])
-def test_conv_f32_fragment_weights_variant(be, patch, monkeypatch):
+def test_conv_f32_fragment_weights_variant(be, patch):
     """precision = 2: the fragment-order halo kernel on the exact fp32 MFMA (weights packed by lu_pack_weights_f32 and
     streamed from L2).  Same tap / channel order as the LDS-staged kernel, so without a K split the two agree bit for bit."""
-    monkeypatch.setenv('LU_CONV_BF16_PATCH', patch)
+    flags = cabi.LU_CONV_F_PATCH16 if patch == '16' else cabi.LU_CONV_F_PATCH8
     for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
                                      (1, 8, 60, 100, 96, 3, 2)]:
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
-        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=2)
+        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=2, flags=flags)
         close(got, npo.conv2d_same(x, w, b, 1), 5e-5)
         if sp == 1:
             assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1))
     xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources
     wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
-    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=2), npo.conv2d_same(xa, wa) + npo.conv2d_same(xb, wb), 5e-5)
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=2, flags=flags), npo.conv2d_same(xa, wa) + npo.conv2d_same(xb, wb), 5e-5)
     F = 32                                                         # fused ConvLSTM step (gates exchanged through LDS)
     x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
     ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
     h1, c1 = npo.convlstm_step(x, h, c, ker, rec, b)
-    hg, cg, gates = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=2)
+    hg, cg, gates = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=2, flags=flags)
     close(hg, h1, 2e-5)
     close(cg, c1, 2e-5)
     h0, c0, g0 = KH.convlstm_step_fused(be, x, h, c, ker, rec, b)
     assert np.array_equal(hg, h0) and np.array_equal(cg, c0) and np.array_equal(gates, g0)
     with pytest.raises(RuntimeError):
-        KH.conv2d(be, [rnd(1, 8, 8, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=2)
+        KH.conv2d(be, [rnd(1, 8, 8, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=2, flags=flags)
 
 
 def test_conv_bf16_gather_variant(be):
@@ -324,12 +352,11 @@ def test_wgrad_two_phase_call(be):
 
 
 @pytest.mark.parametrize('ct', ['64', '128'])
-def test_wgrad_bf16_mfma_variant(be, ct, monkeypatch):
-    monkeypatch.setenv('LU_WGRAD_BF16_CT', ct)         # 64- and 128-channel block tiles
-    _wgrad_bf16_cases(be)
+def test_wgrad_bf16_mfma_variant(be, ct):
+    _wgrad_bf16_cases(be, cabi.LU_WGRAD_F_CT64 if ct == '64' else cabi.LU_WGRAD_F_CT128)      # 64- / 128-channel block tiles
 
 
-def _wgrad_bf16_cases(be):
+def _wgrad_bf16_cases(be, flags=0):
     """Kernel-row weight gradient on the bf16 MFMA (precision = 1, W % 32 == 0): x and dy rounded to bf16, fp32
     accumulation -- exact up to summation order against the fp32 reference on bf16-rounded operands.  Shapes the bf16
     kernel does not cover (W % 32 != 0) silently stay on the fp32 kernels."""
@@ -337,13 +364,29 @@ def _wgrad_bf16_cases(be):
     for (fr, H, W, Cc, N, k, sp) in [(2, 5, 32, 72, 136, 3, 1), (1, 4, 64, 64, 128, 5, 3), (1, 3, 32, 132, 72, 5, 2)]:
         x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
         _, gw = _torch_conv_grads(R(x), rnd(k, k, Cc, N), R(dy), 1)
-        got = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1)
+        got = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags)
         close(got, gw, 2e-4)
         _, gfull = _torch_conv_grads(x, rnd(k, k, Cc, N), dy, 1)
         assert np.abs(got - gfull).max() > 0 and np.abs(got - gfull).max() <= 2.0 ** -6 * np.abs(gfull).max()
     x, dy = rnd(1, 4, 16, 64), rnd(1, 4, 16, 128)             # W % 32 != 0 -> fp32 kernel, full precision
     _, gw = _torch_conv_grads(x, rnd(3, 3, 64, 128), dy, 1)
     close(KH.conv2d_wgrad(be, x, dy, 3, 1, precision=1), gw, 2e-4)
+    # bf16 TENSORS as operands (h sequence / dz of the bf16 tape): identical arithmetic to rounding while staging; odd stage
+    # counts and slab counts that are not multiples of 8 exercise the zero-filled tail stages and the XCD-aware numbering
+    for (fr, H, W, Cc, N, k, sp, xb, yb) in [(2, 5, 32, 72, 136, 3, 3, True, True), (1, 4, 64, 64, 128, 5, 2, False, True),
+                                             (1, 3, 32, 136, 72, 5, 1, True, False), (3, 3, 32, 64, 64, 5, 9, True, True)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        base, db0 = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags, dbias0=np.zeros(N, np.float32))
+        got, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags, x_bf16=xb, dy_bf16=yb,
+                                  dbias0=np.zeros(N, np.float32))
+        assert np.array_equal(got, base)
+        close(db, (R(dy) if yb else dy).reshape(-1, N).sum(0), 2e-4)
+        close(db0, dy.reshape(-1, N).sum(0), 2e-4)
+    x, dy = rnd(2, 4, 32, 32), rnd(2, 4, 32, 72)              # 1x1 problem over 32 rows: the im2col chunk of a thin input
+    _, gw = _torch_conv_grads(R(x), rnd(1, 1, 32, 72), R(dy), 1)
+    close(KH.conv2d_wgrad(be, x, dy, 1, 1, splits=2, precision=1, x_bf16=True, dy_bf16=True), gw, 2e-4)
+    with pytest.raises(RuntimeError):                         # bf16 operands need the bf16 kernel-row variant
+        KH.conv2d_wgrad(be, rnd(1, 4, 16, 64), rnd(1, 4, 16, 128), 3, 1, precision=1, dy_bf16=True)
 
 
 @pytest.mark.parametrize('k,cin', [(3, 8), (5, 1)])
@@ -531,3 +574,44 @@ def test_adam_scale_transpose_add(be):
     yd, x0d = be.dev(y0), be.dev(x0)
     ck(be, be.lib.lu_add_inplace(be.ptr(yd), be.ptr(x0d), 100, be.stream), 'add')
     assert np.array_equal(be.host(yd), y0 + x0)
+
+
+def test_bf16_tape_pointwise(be):
+    """lu_lstm_gates_bwd_bf16 == the fp32 gate backward evaluated on the bf16-rounded saved gates, result rounded to bf16;
+    lu_convert_* round trip; lu_im2col_bf16 against a direct gather."""
+    R = KH.bf16_round
+    F = 8
+    sh = (2, 3, 5, F)
+    gates = np.concatenate([RNG.random(sh + ()).astype(np.float32) for _ in range(4)], -1)
+    gates[..., 2 * F:3 * F] = 2 * gates[..., 2 * F:3 * F] - 1
+    gates[0, 0, 0, :4] = [0.0, 1.0, 0.5, 1.0]                      # saturated hard-sigmoid gates: zero slope
+    c_prev, c_cur, dh_a, dh_b, dc_in = [rnd(*sh) for _ in range(5)]
+    g = R(gates).astype(np.float64)
+    gi, gf, gg, go = [g[..., i * F:(i + 1) * F] for i in range(4)]
+    hs = lambda a: np.where((a > 0) & (a < 1), 0.2, 0.0)          # noqa: E731
+    for (db, di) in [(dh_b, dc_in), (None, None)]:
+        dh = dh_a.astype(np.float64) + (0 if db is None else db)
+        tc = np.tanh(c_cur.astype(np.float64))
+        dc = dh * go * (1 - tc * tc) + (0 if di is None else di)
+        ref = np.concatenate([dc * gg * hs(gi), dc * c_prev * hs(gf), dc * gi * (1 - gg * gg), dh * tc * hs(go)], -1)
+        dz, dcp = KH.lstm_gates_bwd_bf16(be, gates, c_prev, c_cur, dh_a, db, di)
+        assert np.abs(dz - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6
+        close(dcp, dc * gf, 1e-5)
+    x = rnd(1000)
+    yb, xd = be.empty((1000,), np.int16), be.dev(x)
+    ck(be, be.lib.lu_convert_f32_bf16(be.ptr(xd), be.ptr(yb), 1000, be.stream), 'cvt')
+    assert np.array_equal(KH.bf16_values(be.host(yb)), R(x))
+    xf = be.empty((1000,))
+    ck(be, be.lib.lu_convert_bf16_f32(be.ptr(yb), be.ptr(xf), 1000, be.stream), 'cvt back')
+    assert np.array_equal(be.host(xf), R(x))
+    for (k, cin) in [(5, 1), (3, 3), (1, 2)]:
+        x = rnd(2, 6, 7, cin)
+        y, xd = be.empty((2, 6, 7, 32), np.int16), be.dev(x)
+        ck(be, be.lib.lu_im2col_bf16(be.ptr(xd), be.ptr(y), 2, 6, 7, cin, k, be.stream), 'im2col')
+        p = (k - 1) // 2
+        xp = np.pad(x, ((0, 0), (p, p), (p, p), (0, 0)))
+        ref = np.zeros((2, 6, 7, 32), np.float32)
+        for kh in range(k):
+            for kw in range(k):
+                ref[..., (kh * k + kw) * cin:(kh * k + kw + 1) * cin] = xp[:, kh:kh + 6, kw:kw + 7, :]
+        assert np.array_equal(KH.bf16_values(be.host(y)), R(ref))
