@@ -307,6 +307,12 @@ int lu_scale_frames(float* x, const float* keep, int32_t frames, int64_t per_fra
 /* [n, a, b] -> [n, b, a]  (NCHW <-> NHWC at the public boundary, losses.py:17-18, train2D.py:98-100) */
 int lu_transpose_inner(const float* x, float* y, int64_t n, int32_t a, int32_t b, lu_stream_t stream);
 
+/* HOST utility (no device work): CRC-32C of n bytes, continuing from `crc` (0 to start) -- the checksum of TensorFlow
+ * tensor bundles, i.e. of the reference's saved-model files (`model.save_weights(..., save_format='tf')`, train2D.py:235;
+ * `model.load_weights`, Inference2D.py:34) read and written by tf_bundle.py without TensorFlow.
+ * lu_crc32c("123456789", 9, 0) == 0xE3069283. */
+uint32_t lu_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* y = x + y on n elements (gradient fan-in of skip connections) */
 int lu_add_inplace(float* y, const float* x, int64_t n, lu_stream_t stream);
 

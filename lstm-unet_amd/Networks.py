@@ -65,62 +65,163 @@ def _flat_from_internal(y, T, B, nchw):
     return y.view((B * T,) + tuple(y.shape[2:]))
 
 
-class _Descr(object):
-    """Stands in for the Keras layer objects the reference keeps in its .ConvLSTM/.Conv/.BN/.LReLU lists."""
+class _Layer(object):
+    """Callable view of one Keras layer object of the reference's .ConvLSTM / .Conv / .BN / .LReLU lists
+    (Networks.py:44-58,130-139): it owns no storage -- weights are views into the owning engine's flat parameter buffer,
+    so calling a layer, a block or the whole model always uses the same tensors.  Channels-last 4-D / 5-D device tensors
+    in and out (the blocks do the NCHW <-> channels-last boundary work)."""
 
-    def __init__(self, kind, **kw):
-        self.kind = kind
+    def __init__(self, kind, owner, prefix=None, index=None, **kw):
+        self.kind, self._owner, self._prefix, self._index = kind, owner, prefix, index
         self.__dict__.update(kw)
 
     def __repr__(self):
-        return '%s(%s)' % (self.kind, ', '.join('%s=%r' % kv for kv in self.__dict__.items() if kv[0] != 'kind'))
+        skip = ('kind', '_owner', '_prefix', '_index')
+        return '%s(%s)' % (self.kind, ', '.join('%s=%r' % kv for kv in self.__dict__.items() if kv[0] not in skip))
+
+    def _engine(self):
+        e = self._owner._engine_built()
+        return e, self._owner._prefix_of(self)
+
+    @property
+    def weights(self):
+        """[kernel, (recurrent_kernel,) bias] / [gamma, beta, moving_mean, moving_variance] as device tensor views."""
+        e, pre = self._engine()
+        if self.kind == 'ConvLSTM2D':
+            names = [f'{pre}.lstm.{self._index}.{n}' for n in ('kernel', 'recurrent_kernel', 'bias')]
+        elif self.kind == 'Conv2D':
+            names = [f'{pre}.conv.{self._index}.{n}' for n in ('kernel', 'bias')]
+        elif self.kind == 'BatchNormalization':
+            names = [f'{pre}.bn.{self._index}.{n}' for n in ('gamma', 'beta', 'moving_mean', 'moving_var')]
+        else:
+            return []
+        return [e.P[n] if n in e.P else e.S[n] for n in names if n in e.P or n in e.S]
+
+    def get_weights(self):
+        return [w.detach().cpu().numpy() for w in self.weights]
+
+    def __call__(self, x, training=None):
+        e, pre = self._engine()
+        x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(device=e.device, dtype=torch.float32)
+        if self.kind == 'LeakyReLU':
+            Cc = x.shape[-1]
+            one, zero = torch.ones(Cc, device=e.device), torch.zeros(Cc, device=e.device)
+            return ops.bn_lrelu_apply(x.contiguous(), one, zero, self.alpha)
+        if self.kind == 'BatchNormalization':      # alpha = 1: the fused kernel's LeakyReLU becomes the identity
+            if f'{pre}.bn.{self._index}.gamma' not in e.P:
+                raise RuntimeError('this BatchNormalization layer is constructed but never called by the model '
+                                   '(Networks.py:138,148-149): it owns no variables')
+            gamma, beta = e.P[f'{pre}.bn.{self._index}.gamma'], e.P[f'{pre}.bn.{self._index}.beta']
+            mm, mv = e.S[f'{pre}.bn.{self._index}.moving_mean'], e.S[f'{pre}.bn.{self._index}.moving_var']
+            from lu_native.engine import BN_EPS, BN_MOMENTUM
+            y = x.contiguous()
+            if training:
+                sums = ops.bn_stats(y)
+                scale, shift, _, _ = ops.bn_finalize_train(sums, y.numel() // y.shape[-1], gamma, beta, BN_EPS, BN_MOMENTUM,
+                                                           mm, mv)
+            else:
+                scale, shift = ops.bn_finalize_infer(gamma, beta, mm, mv, BN_EPS)
+            return ops.bn_lrelu_apply(y, scale, shift, 1.0)
+        if self.kind == 'Conv2D':
+            w, b = e.P[f'{pre}.conv.{self._index}.kernel'], e.P[f'{pre}.conv.{self._index}.bias']
+            return ops.conv2d([(x.contiguous(), w)], b, self.strides)
+        if self.kind == 'ConvLSTM2D':              # [B,T,H,W,C] channels-last sequence in and out, stateful
+            if x.dim() != 5:
+                raise ValueError('ConvLSTM2D expects a 5-D [batch, time, H, W, C] tensor')
+            B, T = x.shape[0], x.shape[1]
+            seq = x.permute(1, 0, 2, 3, 4).contiguous().view((T * B,) + tuple(x.shape[2:]))
+            bi = int(pre.split('.')[1])
+            spec = e.plan['down'][bi]['lstm'][self._index]
+            h = e._lstm_forward(bi, self._index, spec, seq, T, B, None)
+            return h.view((T, B) + tuple(h.shape[1:])).permute(1, 0, 2, 3, 4).contiguous()
+        raise TypeError(self.kind)
 
 
 class DownBlock2D(object):
     """N x ConvLSTM2D (stateful, return_sequences) -> M x (Conv2D -> BN -> LeakyReLU), first conv strided."""
 
-    def __init__(self, conv_kernels: List[tuple], lstm_kernels: List[tuple], stride=2, data_format='NCHW'):
+    def __init__(self, conv_kernels: List[tuple], lstm_kernels: List[tuple], stride=2, data_format='NCHW', _parent=None):
+        """_parent = (engine, block index): this block is model.DownLayers[i] -- a view that runs on the model's own
+        parameters and recurrent state (reference Networks.py:195-199 keeps the very layer objects the model calls)."""
         self.data_format = data_format
         self._nchw = _is_nchw(data_format)
-        self.ConvLSTM = [_Descr('ConvLSTM2D', kernel_size=k, filters=f) for k, f in lstm_kernels]
+        self.ConvLSTM = [_Layer('ConvLSTM2D', self, index=i, kernel_size=k, filters=f) for i, (k, f) in enumerate(lstm_kernels)]
         self.Conv, self.BN, self.LReLU = [], [], []
         self.total_stride = 1
         for l_ind, (kxy, kout) in enumerate(conv_kernels):
             _stride = stride if l_ind == 0 else 1
             self.total_stride *= _stride
-            self.Conv.append(_Descr('Conv2D', kernel_size=kxy, filters=kout, strides=_stride))
-            self.BN.append(_Descr('BatchNormalization', momentum=0.99, epsilon=1e-3))
-            self.LReLU.append(_Descr('LeakyReLU', alpha=0.3))
+            self.Conv.append(_Layer('Conv2D', self, index=l_ind, kernel_size=kxy, filters=kout, strides=_stride))
+            self.BN.append(_Layer('BatchNormalization', self, index=l_ind, momentum=0.99, epsilon=1e-3))
+            self.LReLU.append(_Layer('LeakyReLU', self, index=l_ind, alpha=0.3))
 
         def plan_fn(cin):
             blk, c = plan_mod.down_block(conv_kernels, lstm_kernels, stride, cin)
             return {'down': [blk], 'up': [], 'total_stride': self.total_stride, 'in_channels': cin, 'last_depth': c}
 
-        self._engine = Engine(None, pad_image=False, plan_fn=plan_fn)
+        if _parent is None:
+            self._engine, self._bi = Engine(None, pad_image=False, plan_fn=plan_fn), 0
+        else:
+            self._engine, self._bi = _parent
+
+    def _engine_built(self):
+        if self._engine.plan is None:
+            raise RuntimeError('layer variables are created at the first call (Keras-style lazy build): call the block / '
+                               'the model once first')
+        return self._engine
+
+    def _prefix_of(self, layer):
+        return f'down.{self._bi}'
+
+    def _build_for(self, cin, device):
+        e = self._engine
+        if e.plan is None:
+            if e.net_params is not None and self._bi != 0:
+                raise RuntimeError('model.DownLayers[%d] shares the model\'s parameters: call the model (or DownLayers[0]) '
+                                   'once so that they exist' % self._bi)
+            e.build(cin, device)
+        return e
 
     def call(self, inputs, training=None, mask=None):
         x, T, B = _to_internal(inputs, self._nchw, _device())
-        e = self._engine
-        e.build(x.shape[-1], x.device)
-        blk = e.plan['down'][0]
+        e = self._build_for(x.shape[-1], x.device)
+        bi = self._bi
+        if e.batch is None:
+            e.batch = B
+        blk = e.plan['down'][bi]
         seq = x
         for li, l in enumerate(blk['lstm']):
-            seq = e._lstm_forward(0, li, l, seq, T, B, None)
+            seq = e._lstm_forward(bi, li, l, seq, T, B, None)
         for ci, l in enumerate(blk['conv']):
-            seq = e._conv_unit('down.0', ci, l, [(seq, 0, l['cin'])], True, bool(training), [] if training else None)
+            seq = e._conv_unit(f'down.{bi}', ci, l, [(seq, 0, l['cin'])], True, bool(training), [] if training else None)
         return _from_internal(seq, T, B, self._nchw), _flat_from_internal(seq, T, B, self._nchw)
 
     __call__ = call
 
     def reset_states_per_batch(self, is_last_batch):
-        self._engine.reset_states_per_batch(is_last_batch)
+        e = self._engine
+        if e.states is None:
+            return
+        keep = torch.as_tensor(np.asarray(is_last_batch), dtype=torch.float32).reshape(-1).to(e.device)
+        for st in e.states[self._bi]:
+            if st is not None:
+                ops.scale_frames(st[0], keep)
+                ops.scale_frames(st[1], keep)
 
     def get_states(self):
         st = self._engine.get_states()
-        return [[None, None] for _ in self.ConvLSTM] if st is None else st[0]
+        return [[None, None] for _ in self.ConvLSTM] if st is None else st[self._bi]
 
     def set_states(self, states):
-        self._engine.set_states([states])
+        e = self._engine
+        if e.states is None:
+            if e.net_params is not None:
+                raise RuntimeError('call the model once before setting the states of one of its blocks')
+            e.set_states([states])
+            return
+        full = [[None if s is None else [s[0], s[1]] for s in blk] for blk in e.states]
+        full[self._bi] = states
+        e.set_states(full)
 
     @classmethod
     def unit_test(cls):
@@ -133,7 +234,7 @@ class DownBlock2D(object):
 class UpBlock2D(object):
     """bilinear resize x up_factor -> concat [x, skip] on channels -> M x (Conv2D -> BN -> LeakyReLU)."""
 
-    def __init__(self, kernels: List[tuple], up_factor=2, data_format='NCHW', return_logits=False):
+    def __init__(self, kernels: List[tuple], up_factor=2, data_format='NCHW', return_logits=False, _parent=None):
         if up_factor not in (1, 2):
             raise ValueError('up_factor must be 1 or 2 (got %r)' % (up_factor,))
         self.data_format = data_format
@@ -141,11 +242,21 @@ class UpBlock2D(object):
         self.up_factor = up_factor
         self.channel_axis = 1 if self._nchw else -1
         self.return_logits = return_logits
-        self.Conv = [_Descr('Conv2D', kernel_size=k, filters=f, strides=1) for k, f in kernels]
-        self.BN = [_Descr('BatchNormalization', momentum=0.99, epsilon=1e-3) for _ in kernels]
-        self.LReLU = [_Descr('LeakyReLU', alpha=0.3) for _ in kernels]
+        self.Conv = [_Layer('Conv2D', self, index=i, kernel_size=k, filters=f, strides=1) for i, (k, f) in enumerate(kernels)]
+        self.BN = [_Layer('BatchNormalization', self, index=i, momentum=0.99, epsilon=1e-3) for i in range(len(kernels))]
+        self.LReLU = [_Layer('LeakyReLU', self, index=i, alpha=0.3) for i in range(len(kernels))]
         self._kernels = list(kernels)
-        self._engine = None
+        self._engine, self._bi = (None, 0) if _parent is None else _parent
+        self._shared = _parent is not None
+
+    def _engine_built(self):
+        if self._engine is None or self._engine.plan is None:
+            raise RuntimeError('layer variables are created at the first call (Keras-style lazy build): call the block / '
+                               'the model once first')
+        return self._engine
+
+    def _prefix_of(self, layer):
+        return f'up.{self._bi}'
 
     def call(self, inputs, training=None, mask=None):
         input_sequence, skip = inputs
@@ -156,7 +267,9 @@ class UpBlock2D(object):
             return (x.permute(0, 2, 3, 1) if self._nchw else x).contiguous()
 
         x, s = to4(input_sequence), to4(skip)
-        if self._engine is None:
+        if self._shared:
+            self._engine_built()
+        elif self._engine is None:
             c_up, c_skip = x.shape[-1], s.shape[-1]
 
             def plan_fn(cin):
@@ -166,14 +279,18 @@ class UpBlock2D(object):
             self._engine = Engine(None, pad_image=False, plan_fn=plan_fn)
             self._engine.build(c_skip, dev)
         e = self._engine
-        blk = e.plan['up'][0]
+        bi = self._bi
+        blk = e.plan['up'][bi]
+        if (x.shape[-1], s.shape[-1]) != (blk['c_up'], blk['c_skip']):
+            raise ValueError('UpBlock2D was built for %d + %d input channels, got %d + %d' %
+                             (blk['c_up'], blk['c_skip'], x.shape[-1], s.shape[-1]))
         u = ops.upsample2x(x) if self.up_factor == 2 else x
         n = len(blk['conv'])
         a = None
         for ci, l in enumerate(blk['conv']):
             last = self.return_logits and ci == n - 1
             srcs = [(u, 0, blk['c_up']), (s, blk['c_up'], blk['c_skip'])] if ci == 0 else [(a, 0, l['cin'])]
-            a = e._conv_unit('up.0', ci, l, srcs, not last, bool(training), [] if training else None)
+            a = e._conv_unit(f'up.{bi}', ci, l, srcs, not last, bool(training), [] if training else None)
         return (a.permute(0, 3, 1, 2) if self._nchw else a).contiguous()
 
     __call__ = call
@@ -227,17 +344,18 @@ class ULSTMnet2D(object):
             raise ValueError('Number of layers in down path ({}) do not match number of layers in up path ({})'.format(
                 len(net_params['down_conv_kernels']), len(net_params['up_conv_kernels'])))
         n = len(net_params['down_conv_kernels'])
-        for i, (cf, lf) in enumerate(zip(net_params['down_conv_kernels'], net_params['lstm_kernels'])):
-            stride = 2 if i < n - 1 else 1
-            blk = _Descr('DownBlock2D', conv_kernels=cf, lstm_kernels=lf, stride=stride, total_stride=stride)
-            self.DownLayers.append(blk)
-            self.total_stride *= stride
-        for i, cf in enumerate(net_params['up_conv_kernels']):
-            self.UpLayers.append(_Descr('UpBlock2D', kernels=cf, up_factor=2 if i > 0 else 1,
-                                        return_logits=i + 1 == n))
-            self.last_depth = cf[-1][1]
         self._engine = Engine(net_params, pad_image=bool(pad_image), seed=seed, dp=dp, sync_bn=sync_bn,
                               precision=precision)
+        # DownLayers / UpLayers are callable block views over THIS model's parameters and recurrent state
+        # (reference Networks.py:195-205 keeps the layer objects the model itself calls)
+        for i, (cf, lf) in enumerate(zip(net_params['down_conv_kernels'], net_params['lstm_kernels'])):
+            stride = 2 if i < n - 1 else 1
+            self.DownLayers.append(DownBlock2D(cf, lf, stride, data_format, _parent=(self._engine, i)))
+            self.total_stride *= stride
+        for i, cf in enumerate(net_params['up_conv_kernels']):
+            self.UpLayers.append(UpBlock2D(cf, 2 if i > 0 else 1, data_format, return_logits=i + 1 == n,
+                                           _parent=(self._engine, i)))
+            self.last_depth = cf[-1][1]
         self._flat_param = None
 
     # -- torch-style parameter access (one flat leaf: all weights live in one HBM buffer) --
@@ -251,6 +369,38 @@ class ULSTMnet2D(object):
     @property
     def engine(self):
         return self._engine
+
+    @property
+    def trainable_variables(self):
+        """Per-tensor views of the flat parameter buffer, each carrying a `.name` (k.Model.trainable_variables of the
+        reference, train2D.py:92): 12 ConvLSTM + 34 Conv2D + 32 BatchNormalization tensors for the default network."""
+        if self._engine.plan is None:
+            raise RuntimeError('variables are created at the first call (Keras-style lazy build)')
+        out = []
+        for name, t in self._engine.P.items():
+            v = t.detach()
+            v.name = name
+            out.append(v)
+        return out
+
+    @property
+    def variables(self):
+        """trainable_variables + the BatchNormalization moving statistics."""
+        out = self.trainable_variables
+        for name, t in self._engine.S.items():
+            v = t.detach()
+            v.name = name
+            out.append(v)
+        return out
+
+    def get_weights(self):
+        return [v.cpu().numpy() for v in self.variables]
+
+    def set_weights(self, weights):
+        names = [v.name for v in self.variables]
+        if len(weights) != len(names):
+            raise ValueError('expected %d arrays, got %d' % (len(names), len(weights)))
+        self._engine.load_params(dict(zip(names, weights)))
 
     def call(self, inputs, training=None, mask=None):
         x_tb, T, B = _to_internal(inputs, self._nchw, _device())
@@ -287,13 +437,27 @@ class ULSTMnet2D(object):
     def set_states(self, states):
         self._engine.set_states(states)
 
-    # weights I/O (own format; TF tensor-bundle reader is SURVEY §8f-3, out of scope this round)
-    def save_weights(self, path):
-        torch.save({k: torch.from_numpy(v) for k, v in self._engine.export_params().items()}, path)
+    # weights I/O: the reference's `save_weights(path, save_format='tf')` / `load_weights(path)` pair (train2D.py:235,
+    # Inference2D.py:34).  save_format 'tf' writes / reads a TensorFlow tensor bundle (<path>.index +
+    # <path>.data-00000-of-00001, tf_bundle.py: no TensorFlow needed) with the object-graph keys tf.keras gives this model;
+    # 'pt' (default) is a torch.save blob under exactly `path`.
+    def save_weights(self, path, save_format=None):
+        if save_format in ('tf', 'tensorflow'):
+            import tf_bundle
+            tf_bundle.save_model_weights(self, path)
+        elif save_format in (None, 'pt', 'h5'):
+            torch.save({k: torch.from_numpy(v) for k, v in self._engine.export_params().items()}, path)
+        else:
+            raise ValueError('unknown save_format %r' % (save_format,))
 
     def load_weights(self, path, in_channels=1):
-        blob = torch.load(path, map_location='cpu')
+        import os
         self._engine.build(in_channels, _device())
+        if os.path.exists(path + '.index'):
+            import tf_bundle
+            self._engine.load_params(tf_bundle.load_model_weights(self, path))
+            return
+        blob = torch.load(path, map_location='cpu')
         self._engine.load_params({k: v.numpy() for k, v in blob.items()})
 
     @classmethod

@@ -23,6 +23,40 @@ void lu_set_error(const char* fmt, ...) {
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
 extern "C" int lu_abi_version(void) { return 4; }
 
+// ---------------------------------------------------------------------------------------------
+// CRC-32C (Castagnoli), slicing-by-8, HOST code: the checksum of TensorFlow tensor bundles (tf_bundle.py reads / writes
+// the reference's `model.ckpt` files, train2D.py:235 / Inference2D.py:34) -- 300 MB of weights in a Python byte loop
+// would take minutes.
+// ---------------------------------------------------------------------------------------------
+extern "C" uint32_t lu_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^ T[3][hi & 0xFF] ^
+            T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 #ifndef LU_EMU
 int lu_check_launch() {
     hipError_t e = hipGetLastError();

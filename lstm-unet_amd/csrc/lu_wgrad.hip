@@ -539,13 +539,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return v;
     };
+    // The K taps of a kernel row read the SAME x columns shifted by one pixel (= one k) each: fetch the 8 + K - 1 rows once
+    // (NR transposing reads instead of 2 K) and cut the per-tap fragments out of the registers -- a tap-t fragment is
+    // elements t .. t + 7 of the 4 NR fetched (a 16-bit funnel shift for odd t, pure renaming for even t).  The LDS read
+    // traffic of the loop halves, and it was the busiest unit: 14 reads per 10 MFMAs at K = 5.
+    constexpr int NR = (8 + K - 1 + 3) / 4;
     auto mma_half = [&](int buf, int j) {
         lu_bf16x8 bv[NFW];
 #pragma unroll
         for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf][yoff + 16 * j * YLD + 32 * nf], YLD);
+        short xw[4 * NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf][xoff + (16 * j + 4 * r) * XLD]);
+            xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
+        }
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-            const lu_bf16x8 av = frag(&Xs[buf][xoff + (16 * j + t) * XLD], XLD);
+            lu_bf16x8 av;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
 #pragma unroll
             for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
         }

@@ -46,7 +46,13 @@ class WeightedCELoss(object):
 
     def __call__(self, gt_sequence, output_sequence):
         out = output_sequence
-        ops._chk(out)      # device tensors only: there is no CPU path
+        if not torch.is_tensor(out) or not out.is_cuda:
+            # host logits (numpy / CPU tensor, as a caller of the reference may hold them): moved to the device -- the
+            # arithmetic still runs in the HIP kernels, there is no CPU path
+            import Networks
+            out = torch.as_tensor(np.asarray(out) if not torch.is_tensor(out) else out).to(device=Networks._device(),
+                                                                                            dtype=torch.float32)
+        ops._chk(out)
         gt = torch.as_tensor(np.asarray(gt_sequence) if not torch.is_tensor(gt_sequence) else gt_sequence)
         gt = gt.to(device=out.device, dtype=torch.float32).squeeze(self.channel_axis)
         if self.channel_axis == 2:

@@ -83,6 +83,7 @@ PROTOTYPES = {
     'lu_scale_frames': (C.c_int, [P, P, i32, i64, S]),
     'lu_transpose_inner': (C.c_int, [P, P, i64, i32, i32, S]),
     'lu_add_inplace': (C.c_int, [P, P, i64, S]),
+    'lu_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),
 }
 
 

@@ -111,12 +111,13 @@ class Engine:
 
     def load_params(self, params):
         """name -> array; used by tests (oracle-initialised weights) and checkpoint restore."""
-        for k, v in params.items():
-            t = torch.as_tensor(np.asarray(v), dtype=torch.float32)
-            dst = self.P.get(k, self.S.get(k))
-            if dst is None:
-                raise KeyError(k)
-            dst.copy_(t.reshape(dst.shape))
+        with torch.no_grad():       # P[...] are views of a leaf that may require grad (Networks.parameters())
+            for k, v in params.items():
+                t = torch.as_tensor(np.asarray(v), dtype=torch.float32)
+                dst = self.P.get(k, self.S.get(k))
+                if dst is None:
+                    raise KeyError(k)
+                dst.copy_(t.reshape(dst.shape))
         self.weights_changed()
 
     def export_params(self):

@@ -103,7 +103,8 @@ class Trainer(object):
     def load_state_dict(self, sd, in_channels=1):
         e = self.engine
         e.build(in_channels, Nets._device())
-        e.flat_params.copy_(sd['params'])
+        with torch.no_grad():      # flat_params may be an autograd leaf (Networks.parameters())
+            e.flat_params.copy_(sd['params'])
         for k, v in sd['bn'].items():
             e.S[k].copy_(v)
         if sd['adam_m'] is not None:
