@@ -290,6 +290,25 @@ def main():
         infer = {'frames_per_s': round(n_inf / (time.perf_counter() - t_inf), 2), 'frames': n_inf,
                  'what': 'streaming forward, B=1 T=1, %dx%d (+reflect pad to %dx%d), softmax returned per frame' %
                          (H, W, H + 16, W + 16)}
+        # ... and the whole per-frame path of Inference2D.py:45-131: forward + post-processing to the uint16 instance map
+        # (GPU connected components / hole fill / edge absorption / relabel, label map copied to the host).  The model is
+        # random-init, so its own softmax holds almost no cells: the post-processing is timed on a synthetic softmax with
+        # ~60 cells per 256x256 frame (scaled with the area) swapped in behind the forward.
+        import Inference2D
+        from DataHandeling import SyntheticSequence2D
+        prov = SyntheticSequence2D(image_crop_size=(H, W), unroll_len=1, batch_size=1, data_format='NCHW', seed=7, rank=0)
+        seg = prov.get_batch()[1][0, 0, 0]                        # {-1,0,1,2} class map of synthetic cells
+        seg = np.where(seg < 0, 0, seg).astype(np.int64)
+        fake = torch.from_numpy(np.eye(3, dtype=np.float32)[seg].transpose(2, 0, 1) * 0.9 + 0.03).to(dev).contiguous()
+        lab = Inference2D.postprocess(fake, 2, 10, 10 ** 6)
+        torch.cuda.synchronize()
+        t_pp = time.perf_counter()
+        for i in range(n_inf):
+            _, sm_ = m(frames_in[i % 4], training=False)
+            lab = Inference2D.postprocess(fake, 2, 10, 10 ** 6)
+        torch.cuda.synchronize()
+        infer['frames_per_s_with_postprocess'] = round(n_inf / (time.perf_counter() - t_pp), 2)
+        infer['postprocess_objects'] = int(lab.max())
         del m
     total_flops, _ = step_flops(net, H, W, B, T)
     # ---- secondary: the same step in the bf16 mixed-precision mode (BASELINE config-5 arithmetic), N = 1 only ----

@@ -260,13 +260,17 @@ int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const float* scale, c
                           lu_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Bilinear x2 up-sampling, half-pixel centres, edge clamp (k.backend.resize_images, Networks.py:143)
+ * Bilinear x2 up-sampling, edge clamp (k.backend.resize_images(..., 'bilinear'), Networks.py:143).  The source coordinate
+ * depends on the TensorFlow release behind the reference:
+ *   legacy = 1: src = o / 2 -- the v1 resize_bilinear op (align_corners=False, half_pixel_centers=False) that
+ *               keras.backend.resize_images calls in TF 2.0 / 2.1, the release the reference pins (README: 2.0.0a0)
+ *   legacy = 0: src = (o + 0.5) / 2 - 0.5 -- half-pixel centres (tf.image.resize v2; later Keras releases)
  * ------------------------------------------------------------------------------------------- */
-int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32_t H, int32_t W, int32_t C,
+int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t legacy,
                       lu_stream_t stream);
 /* dx[frames,H,W,C] = transpose of the above applied to dy (pixel stride dy_pix_stride, first C channels) */
 int lu_upsample2x_bwd(const float* dy, int32_t dy_pix_stride, float* dx, int32_t frames, int32_t H, int32_t W,
-                      int32_t C, lu_stream_t stream);
+                      int32_t C, int32_t legacy, lu_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spatial window copy with REFLECT or ZERO fill:
@@ -315,6 +319,35 @@ uint32_t lu_crc32c(const void* data, size_t n, uint32_t crc);
 
 /* y = x + y on n elements (gradient fan-in of skip connections) */
 int lu_add_inplace(float* y, const float* x, int64_t n, lu_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inference post-processing on the device: softmax [3,H,W] -> instance labels (Inference2D.py:66-123, host numpy / scipy /
+ * OpenCV in the reference).  Integer work, bit-exact; the host (Inference2D.postprocess) sequences these calls and reads
+ * back the small per-label arrays.  One workspace (lu_post_workspace_bytes) serves all of them; per-label arrays hold
+ * lu_post_max_labels(H, W) entries.
+ *   lu_post_label        :66-78  edge threshold 0.2 / cell mask, binary_fill_holes, 8-connected components numbered in
+ *                                cv2.connectedComponentsWithStats' order with their areas, nearest-label absorption of edge
+ *                                pixels closer than edge_dist (scipy distance_transform_edt tie-break)
+ *   lu_post_label_stats          per-label bounding box, 4 x Euler number (8-conn) and component count: an object has
+ *                                holes iff components - Euler > 0
+ *   lu_post_fill_object  :80-91  per-object binary_fill_holes with the reference's additive label quirk
+ *   lu_post_bbox_of_label        bounding box of one label value in the current map
+ *   lu_post_present      :93-103 labels present inside the field of view
+ *   lu_post_relabel      :113-123 consecutive uint16 ids of the kept labels
+ * ------------------------------------------------------------------------------------------- */
+size_t lu_post_workspace_bytes(int32_t H, int32_t W);
+int32_t lu_post_max_labels(int32_t H, int32_t W);
+int lu_post_label(const float* softmax_chw, int32_t H, int32_t W, float edge_thresh, double edge_dist, void* workspace,
+                  int32_t* labels, int32_t* num_labels, int32_t* area, lu_stream_t stream);
+int lu_post_label_stats(const int32_t* labels, int32_t H, int32_t W, int32_t num_labels, void* workspace, int32_t* bbox,
+                        int32_t* e4, int32_t* ncomp, lu_stream_t stream);
+int lu_post_fill_object(int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                        void* workspace, int32_t* dirty, lu_stream_t stream);
+int lu_post_bbox_of_label(const int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t* box, lu_stream_t stream);
+int lu_post_present(const int32_t* labels, int32_t H, int32_t W, int32_t fov, int32_t single_column, int32_t num_labels,
+                    int32_t* present, lu_stream_t stream);
+int lu_post_relabel(const int32_t* labels, int32_t H, int32_t W, const int32_t* newid, int32_t num_labels, uint16_t* out,
+                    lu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -4,60 +4,44 @@ Per frame (Inference2D.py:45-62): reshape to [1,1,1,H,W] (NCHW) / [1,1,H,W,1], o
 training=False and pad_image=True, take the softmax [3,H,W]; the first `pre_sequence_frames` frames (a
 mirrored prefix) only warm the recurrent state.  The forward runs on the gfx950 kernels.
 
-Post-processing to instance label maps (Inference2D.py:66-131) is host code in the reference too
-(numpy / scipy / OpenCV).  OpenCV is not available here, so 8-connected labelling uses
-scipy.ndimage.label: the label PARTITION is the same, the label NUMBERING may differ from
-cv2.connectedComponentsWithStats (unpinned) -- output ids are relabelled consecutively
-after filtering in both implementations.
+Post-processing to instance label maps (Inference2D.py:66-131: host numpy / scipy / OpenCV in the reference) runs on the
+GPU here: union-find connected components numbered in cv2.connectedComponentsWithStats' order, binary_fill_holes, nearest-label
+edge absorption with scipy's distance-transform tie-break, the per-object hole fill with the reference's additive quirk, the
+FOV / size filters and the consecutive relabel (csrc/lu_postprocess.hip, lu_native/post.py).  Label maps are bit-identical to
+the reference's algorithm as restated in oracle/postprocess_oracle.py (scipy stages run through scipy itself there; the
+OpenCV label ORDER is a restatement of its block scan: OpenCV is not installed -- SURVEY §8f-1).  The reference's FOV quirk
+(`fov_im[:, FOV] = 0` masks ONE column, Inference2D.py:97) is kept by default; `--fov_fix` masks columns [0, FOV).
 """
 import argparse
 import os
 import pickle
 
 import numpy as np
-import scipy.ndimage
 
-from utils import log_print, get_model, bbox_crop, bbox_fill
-
-
-def postprocess(softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0):
-    """softmax [3,H,W] -> uint16 instance labels (0 = background)."""
-    seg_edge = np.greater_equal(softmax_chw[2], 0.2)
-    seg_cell = np.logical_and(np.equal(np.argmax(softmax_chw, 0), 1), np.logical_not(seg_edge))
-    seg_cell = scipy.ndimage.binary_fill_holes(seg_cell).astype(np.float32)
-    seg_edge = np.maximum(seg_edge.astype(np.float32) - seg_cell, 0)
-    labels, n = scipy.ndimage.label(seg_cell.astype(np.uint8), structure=np.ones((3, 3)))
-    num_cells = n + 1
-    areas = np.bincount(labels.ravel(), minlength=num_cells)
-    labels = labels.astype(np.float32)
-    dist, ind = scipy.ndimage.distance_transform_edt(1 - seg_cell, return_indices=True)
-    labels = labels[ind[0], ind[1]] * seg_edge * (dist < edge_dist) + labels
-    for lab in range(1, num_cells):
-        bw = labels == lab
-        if not np.any(bw):
-            continue
-        crop, loc = bbox_crop(bw)
-        fill = scipy.ndimage.binary_fill_holes(crop).astype(np.float32) - crop
-        labels = labels + bbox_fill(bw, fill, loc) * lab
-    remove = []
-    if fov:
-        inside = np.ones_like(labels)
-        inside[:fov, :] = 0
-        inside[-fov:, :] = 0
-        inside[:, :fov] = 0       # the reference zeroes a single column here (Inference2D.py:97, a typo)
-        inside[:, -fov:] = 0
-        remove = np.setdiff1d(np.arange(num_cells), np.unique(labels * inside))
-    out = np.zeros(labels.shape, np.uint16)
-    nxt = 0
-    for lab in range(1, num_cells):
-        if min_cell_size <= areas[lab] <= max_cell_size and lab not in remove:
-            nxt += 1
-            out[labels == lab] = nxt
-    return out
+from utils import log_print, get_model, select_gpu, write_tiff16
 
 
-def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0):
-    """Yield (t, softmax [3,H,W]) for every real frame; warm-up frames are consumed silently."""
+_POST = None
+
+
+def postprocess(softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, stages=None):
+    """softmax [3,H,W] (device tensor, or host array -- moved to the device) -> uint16 instance labels (0 = background),
+    Inference2D.py:66-123 on the GPU.  fov_fix=False reproduces the reference's single-column FOV mask (:97)."""
+    import torch
+    import Networks
+    from lu_native.post import PostProcessor
+    global _POST
+    if _POST is None:
+        _POST = PostProcessor()
+    sm = softmax_chw
+    if not torch.is_tensor(sm) or sm.device.type == 'cpu':
+        sm = torch.as_tensor(np.asarray(sm), dtype=torch.float32).to(Networks._device())
+    return _POST(sm, edge_dist, min_cell_size, max_cell_size, fov, fov_fix, stages)
+
+
+def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0, on_device=False):
+    """Yield (t, softmax [3,H,W]) for every real frame; warm-up frames are consumed silently.  on_device=True yields the
+    device tensor (what the GPU post-processing consumes) instead of a host array."""
     nchw = data_format[1] == 'C'
     for T, image in enumerate(frames):
         t = T - pre_sequence_frames
@@ -71,12 +55,12 @@ def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0):
         _, sm = model(image, training=False)
         if t < 0:
             continue
-        sm = sm.cpu().numpy()[0, 0]
-        yield t, (sm if nchw else np.transpose(sm, (2, 0, 1)))
+        sm = sm[0, 0] if nchw else sm[0, 0].permute(2, 0, 1).contiguous()
+        yield t, (sm if on_device else sm.cpu().numpy())
 
 
 def inference(params):
-    from PIL import Image
+    select_gpu(getattr(params, 'gpu_id', None))
     with open(os.path.join(params.model_path, 'model_params.pickle'), 'rb') as fobj:
         model_dict = pickle.load(fobj)
     model_cls = get_model(model_dict['name'])
@@ -86,28 +70,29 @@ def inference(params):
     log_print('Restored from {}'.format(os.path.join(params.model_path, 'model.ckpt')))
     dataset = params.data_reader(params.sequence_path, params.filename_format,
                                  pre_sequence_frames=params.pre_sequence_frames).dataset
-    # Post-processing (scipy, ~15 ms per 256x256 frame) and file output run on worker threads while the GPU computes the
-    # next frames: at bf16 rates the forward is 2.6 ms per frame and the host side would otherwise set the pace.
+    # The forward AND the post-processing run on the GPU; only the uint16 label map (and, with --save_intermediate, the
+    # softmax) comes back.  File output runs on worker threads so that TIFF encoding never stalls the device.
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=int(getattr(params, 'num_post_threads', 4)))
 
-    def finish(t, sm):
-        labels = postprocess(sm, params.edge_dist, params.min_cell_size, params.max_cell_size, params.FOV)
+    def write(t, labels, sm):
         out_fname = os.path.join(params.output_path, 'mask{time:03d}.tif'.format(time=t))
-        Image.fromarray(labels).save(out_fname)
+        if sm is not None:        # Inference2D.py:104-108: HWC softmax scaled to 16 bit; cv2.imwrite of the channel-flipped array
+            vis = np.round(np.transpose(sm, (1, 2, 0)) * (2 ** 16 - 1)).astype(np.uint16)      # stores R,G,B = bg, cell, edge
+            write_tiff16(os.path.join(params.save_intermediate_vis_path, 'softmax{time:03d}.tif'.format(time=t)), vis)
+        write_tiff16(out_fname, labels)
         log_print('Saved File: {}'.format(out_fname))
-        if params.save_intermediate:
-            vis = np.round(np.transpose(sm, (1, 2, 0)) * (2 ** 16 - 1)).astype(np.uint16)
-            np.save(os.path.join(params.save_intermediate_vis_path, 'softmax{time:03d}.npy'.format(time=t)), vis)
-            Image.fromarray(labels).save(os.path.join(params.save_intermediate_label_path,
-                                                      'mask{time:03d}.tif'.format(time=t)))
+        if sm is not None:
+            write_tiff16(os.path.join(params.save_intermediate_label_path, 'mask{time:03d}.tif'.format(time=t)), labels)
 
     pending = []
     try:
-        for t, sm in stream_softmax(model, dataset, params.data_format, params.pre_sequence_frames):
+        for t, sm in stream_softmax(model, dataset, params.data_format, params.pre_sequence_frames, on_device=True):
             if params.dry_run:
                 continue
-            pending.append(pool.submit(finish, t, sm))
+            labels = postprocess(sm, params.edge_dist, params.min_cell_size, params.max_cell_size, params.FOV,
+                                 bool(getattr(params, 'fov_fix', False)))
+            pending.append(pool.submit(write, t, labels, sm.cpu().numpy() if params.save_intermediate else None))
             while len(pending) > 16:          # bounded backlog
                 pending.pop(0).result()
         for job in pending:
@@ -140,6 +125,8 @@ FLAGS = [
     (('--dry_run',), dict(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
     (('--precision',), dict(dest='precision', choices=['fp32', 'bf16'],
                             help='[MI355X] fp32 (default) or bf16 MFMA operands for the wide convolutions')),
+    (('--fov_fix',), dict(dest='fov_fix', action='store_const', const=True,
+                          help='[MI355X] mask columns [0, FOV) instead of the reference\'s single column FOV (Inference2D.py:97)')),
 ]
 
 

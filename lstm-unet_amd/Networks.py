@@ -9,6 +9,11 @@ hand-written gfx950 kernels through lu_native (no TensorFlow, no MIOpen, no CPU 
 
 Documented deviation: the reference's Softmax axis is wrong for NHWC
 (`Softmax(self.channel_axis + 1)` = batch axis); here softmax is always over the class axis.
+
+TensorFlow-version dependence: `k.backend.resize_images(x, f, f, fmt, interpolation='bilinear')` (Networks.py:143) samples
+at src = o / f in TF 2.0 / 2.1 (the v1 resize_bilinear op without half-pixel centres -- the release the reference's README
+pins, 2.0.0a0, and the one its pretrained models come from) and at half-pixel centres in later releases.  `resize='tf2.0'`
+(default) / `resize='half_pixel'` on ULSTMnet2D / UpBlock2D select the convention.
 """
 from typing import List
 
@@ -234,7 +239,8 @@ class DownBlock2D(object):
 class UpBlock2D(object):
     """bilinear resize x up_factor -> concat [x, skip] on channels -> M x (Conv2D -> BN -> LeakyReLU)."""
 
-    def __init__(self, kernels: List[tuple], up_factor=2, data_format='NCHW', return_logits=False, _parent=None):
+    def __init__(self, kernels: List[tuple], up_factor=2, data_format='NCHW', return_logits=False, _parent=None,
+                 resize='tf2.0'):
         if up_factor not in (1, 2):
             raise ValueError('up_factor must be 1 or 2 (got %r)' % (up_factor,))
         self.data_format = data_format
@@ -246,6 +252,7 @@ class UpBlock2D(object):
         self.BN = [_Layer('BatchNormalization', self, index=i, momentum=0.99, epsilon=1e-3) for i in range(len(kernels))]
         self.LReLU = [_Layer('LeakyReLU', self, index=i, alpha=0.3) for i in range(len(kernels))]
         self._kernels = list(kernels)
+        self._resize = resize
         self._engine, self._bi = (None, 0) if _parent is None else _parent
         self._shared = _parent is not None
 
@@ -276,7 +283,7 @@ class UpBlock2D(object):
                 blk, c = plan_mod.up_block(self._kernels, self.up_factor, self.return_logits, c_up, c_skip)
                 return {'down': [], 'up': [blk], 'total_stride': 1, 'in_channels': cin, 'last_depth': c}
 
-            self._engine = Engine(None, pad_image=False, plan_fn=plan_fn)
+            self._engine = Engine(None, pad_image=False, plan_fn=plan_fn, resize=self._resize)
             self._engine.build(c_skip, dev)
         e = self._engine
         bi = self._bi
@@ -284,7 +291,7 @@ class UpBlock2D(object):
         if (x.shape[-1], s.shape[-1]) != (blk['c_up'], blk['c_skip']):
             raise ValueError('UpBlock2D was built for %d + %d input channels, got %d + %d' %
                              (blk['c_up'], blk['c_skip'], x.shape[-1], s.shape[-1]))
-        u = ops.upsample2x(x) if self.up_factor == 2 else x
+        u = ops.upsample2x(x, e.resize) if self.up_factor == 2 else x
         n = len(blk['conv'])
         a = None
         for ci, l in enumerate(blk['conv']):
@@ -328,7 +335,7 @@ class ULSTMnet2D(object):
     """ConvLSTM encoder / conv decoder U-Net (reference Networks.py:178-291)."""
 
     def __init__(self, net_params=DEFAULT_NET_DOWN_PARAMS, data_format='NCHW', pad_image=True, seed=0, dp=None,
-                 sync_bn=False, precision='fp32'):
+                 sync_bn=False, precision='fp32', resize='tf2.0'):
         self.data_format = data_format
         self._nchw = _is_nchw(data_format)
         self.data_format_keras = 'channels_first' if self._nchw else 'channels_last'
@@ -345,7 +352,7 @@ class ULSTMnet2D(object):
                 len(net_params['down_conv_kernels']), len(net_params['up_conv_kernels'])))
         n = len(net_params['down_conv_kernels'])
         self._engine = Engine(net_params, pad_image=bool(pad_image), seed=seed, dp=dp, sync_bn=sync_bn,
-                              precision=precision)
+                              precision=precision, resize=resize)
         # DownLayers / UpLayers are callable block views over THIS model's parameters and recurrent state
         # (reference Networks.py:195-205 keeps the layer objects the model itself calls)
         for i, (cf, lf) in enumerate(zip(net_params['down_conv_kernels'], net_params['lstm_kernels'])):

@@ -66,6 +66,7 @@ _INFER_DEFAULTS = dict(
     FOV=0, min_cell_size=10, max_cell_size=100, edge_dist=2, pre_sequence_frames=4,
     dry_run=False, save_intermediate=True, save_intermediate_path='./tmp/output/PhC-C2DL-PSC/01',
     precision='fp32',      # MI355X option: 'bf16' = bf16 MFMA operands
+    fov_fix=False,         # MI355X option: True masks columns [0, FOV) instead of the reference's single column (Inference2D.py:97)
 )
 
 

@@ -421,10 +421,15 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// bilinear x2 (half-pixel centres, edge clamp)
+// bilinear x2, edge clamp.  Two source-coordinate conventions (k.backend.resize_images(..., 'bilinear'), Networks.py:143,
+// depends on the TensorFlow release):
+//   legacy = 1  src = o / 2          (out[2i] = in[i], out[2i+1] = (in[i] + in[i+1]) / 2): the v1 resize_bilinear op with
+//               align_corners=False, half_pixel_centers=False -- what keras.backend.resize_images calls in TF 2.0 / 2.1,
+//               i.e. in the release the reference pins (README: tensorflow 2.0.0a0)
+//   legacy = 0  src = (o + 0.5) / 2 - 0.5   half-pixel centres: tf.image.resize (v2), used by later Keras releases
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void up2_taps(int o, int n_in, int& lo, int& hi, float& frac) {
-    const float src = (o + 0.5f) * 0.5f - 0.5f;
+__device__ __forceinline__ void up2_taps(int o, int n_in, int legacy, int& lo, int& hi, float& frac) {
+    const float src = legacy ? o * 0.5f : (o + 0.5f) * 0.5f - 0.5f;
     const float fl = floorf(src);
     frac = src - fl;
     const int i0 = (int)fl;
@@ -433,7 +438,7 @@ __device__ __forceinline__ void up2_taps(int o, int n_in, int& lo, int& hi, floa
 }
 
 __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int frames, int H, int W,
-                                      int C) {
+                                      int C, int legacy) {
     const int64_t total = (int64_t)frames * 4 * H * W * C;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
         const int c = (int)(i % C);
@@ -444,8 +449,8 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
         const int64_t f = t / (2 * H);
         int ylo, yhi, xlo, xhi;
         float fy, fx;
-        up2_taps(oy, H, ylo, yhi, fy);
-        up2_taps(ox, W, xlo, xhi, fx);
+        up2_taps(oy, H, legacy, ylo, yhi, fy);
+        up2_taps(ox, W, legacy, xlo, xhi, fx);
         const float* xf = x + f * (int64_t)H * W * C + c;
         const float v00 = xf[((int64_t)ylo * W + xlo) * C], v01 = xf[((int64_t)ylo * W + xhi) * C];
         const float v10 = xf[((int64_t)yhi * W + xlo) * C], v11 = xf[((int64_t)yhi * W + xhi) * C];
@@ -455,7 +460,7 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
 }
 
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, int dy_ps, float* __restrict__ dx, int frames,
-                                      int H, int W, int C) {
+                                      int H, int W, int C, int legacy) {
     const int64_t total = (int64_t)frames * H * W * C;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
         const int c = (int)(i % C);
@@ -470,14 +475,14 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, int dy_ps, f
             if (oy < 0 || oy >= 2 * H) continue;
             int ylo, yhi;
             float fy;
-            up2_taps(oy, H, ylo, yhi, fy);
+            up2_taps(oy, H, legacy, ylo, yhi, fy);
             const float wy = (ylo == iy ? 1.f - fy : 0.f) + (yhi == iy ? fy : 0.f);
             if (wy == 0.f) continue;
             for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
                 if (ox < 0 || ox >= 2 * W) continue;
                 int xlo, xhi;
                 float fx;
-                up2_taps(ox, W, xlo, xhi, fx);
+                up2_taps(ox, W, legacy, xlo, xhi, fx);
                 const float wx = (xlo == ix ? 1.f - fx : 0.f) + (xhi == ix ? fx : 0.f);
                 if (wx == 0.f) continue;
                 acc += wy * wx * df[((int64_t)oy * 2 * W + ox) * dy_ps];
@@ -777,18 +782,19 @@ extern "C" int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const floa
 }
 
 extern "C" int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32_t H, int32_t W, int32_t C,
-                                 lu_stream_t stream) {
-    LU_REQUIRE(x && y && frames > 0 && H > 0 && W > 0 && C > 0, "lu_upsample2x_fwd: bad arguments");
+                                 int32_t legacy, lu_stream_t stream) {
+    LU_REQUIRE(x && y && frames > 0 && H > 0 && W > 0 && C > 0 && (legacy == 0 || legacy == 1), "lu_upsample2x_fwd: bad arguments");
     LU_LAUNCH(upsample2x_fwd_kernel, dim3(grid_for((int64_t)frames * 4 * H * W * C)), dim3(NT), stream, x, y,
-              (int)frames, (int)H, (int)W, (int)C);
+              (int)frames, (int)H, (int)W, (int)C, (int)legacy);
     return LU_CHECK_LAUNCH();
 }
 
 extern "C" int lu_upsample2x_bwd(const float* dy, int32_t dy_ps, float* dx, int32_t frames, int32_t H, int32_t W,
-                                 int32_t C, lu_stream_t stream) {
-    LU_REQUIRE(dy && dx && frames > 0 && H > 0 && W > 0 && C > 0 && dy_ps >= C, "lu_upsample2x_bwd: bad arguments");
+                                 int32_t C, int32_t legacy, lu_stream_t stream) {
+    LU_REQUIRE(dy && dx && frames > 0 && H > 0 && W > 0 && C > 0 && dy_ps >= C && (legacy == 0 || legacy == 1),
+               "lu_upsample2x_bwd: bad arguments");
     LU_LAUNCH(upsample2x_bwd_kernel, dim3(grid_for((int64_t)frames * H * W * C)), dim3(NT), stream, dy, (int)dy_ps,
-              dx, (int)frames, (int)H, (int)W, (int)C);
+              dx, (int)frames, (int)H, (int)W, (int)C, (int)legacy);
     return LU_CHECK_LAUNCH();
 }
 

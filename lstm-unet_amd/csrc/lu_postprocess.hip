@@ -1,0 +1,464 @@
+// lu_postprocess.hip -- inference post-processing on the GPU: softmax [3,H,W] -> instance label map, the device side of
+// Inference2D.postprocess (reference Inference2D.py:66-123, host numpy / scipy / OpenCV there).
+//
+// Integer / index work, bit-exact by construction; everything is HBM- or latency-bound (one 832 x 992 frame is 0.8 M pixels),
+// nothing here wants the matrix pipe.  Building blocks:
+//   classify            edge = softmax[2] >= 0.2, cell = (argmax == 1) & !edge                                   (:66-68)
+//   union-find CCL      one kernel family for all four labelling problems (connectivity and the "same set" predicate are
+//                       mode parameters): background 4-conn (binary_fill_holes :69), foreground 8-conn
+//                       (cv2.connectedComponentsWithStats :72), equal-label 8-conn (component count per label), and
+//                       "everything but label n" 4-conn inside a crop (the per-object binary_fill_holes :86).
+//                       parent[p] = p; every pixel merges with its already-scanned neighbours through atomicMin on the
+//                       roots (the smaller linear index wins, so a component's root is its first pixel in raster order and
+//                       the result does not depend on scheduling); a last pass flattens the trees.
+//   OpenCV label order  components are numbered by the block-raster position of their first 2 x 2 block (why: see
+//                       oracle/postprocess_oracle.py): atomicMin of the block index per root, a 0/1 mark per block, an
+//                       exclusive scan over the block grid = label - 1.  Areas by atomicAdd (integers: order-free).
+//   edge absorption     an edge pixel closer than edge_dist to a cell pixel takes the label of the NEAREST cell pixel with
+//                       scipy's distance_transform_edt tie-break (smallest column, then smallest row: pinned against scipy
+//                       in the tests) -- a window search, embarrassingly parallel                                (:77-78)
+//   per-label statistics bounding boxes, component counts and the bit-quad Euler number E8 = (Q1 - Q3 - 2 QD) / 4 of every
+//                       label at once: holes(n) = components(n) - E8(n) tells the host which objects have holes at all
+//   object hole fill    CCL of "not n" inside the object's bounding box (+1 pixel), components that do not reach the box
+//                       border are the holes; L += n there -- the reference's additive quirk included; a `dirty` flag
+//                       reports a hole that contained another label (the host then falls back to the strictly sequential
+//                       order of the reference for the remaining labels)                                          (:80-91)
+//   FOV presence / relabel   which labels survive the field-of-view mask (single-column quirk of :97 selectable), final
+//                       consecutive ids as uint16                                                              (:93-123)
+#include <stdint.h>
+#include <string.h>
+#include "lu_device.h"
+
+namespace {
+
+constexpr int PT = 256;
+enum { MODE_BG4 = 0, MODE_FG8 = 1, MODE_EQ8 = 2, MODE_NE4 = 3 };
+
+inline unsigned pgrid(int64_t n) {
+    int64_t b = (n + PT - 1) / PT;
+    if (b < 1) b = 1;
+    if (b > 65535) b = 65535;
+    return (unsigned)b;
+}
+
+struct Rect {
+    int x0, y0, w, h;      // crop inside the H x W image (row stride W)
+};
+
+__global__ void classify_kernel(const float* __restrict__ sm, int64_t hw, float thresh, int32_t* __restrict__ cell,
+                                int32_t* __restrict__ edge) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        const float a = sm[i], b = sm[hw + i], c = sm[2 * hw + i];
+        const int e = c >= thresh;
+        edge[i] = e;
+        cell[i] = (b > a && b >= c && !e) ? 1 : 0;      // np.argmax: the FIRST maximum wins
+    }
+}
+
+__device__ __forceinline__ bool ccl_active(int v, int mode, int n, int nl) {
+    switch (mode) {
+        case MODE_BG4: return v == 0;
+        case MODE_FG8: return v != 0;
+        case MODE_EQ8: return v > 0 && v < nl;
+        default: return v != n;
+    }
+}
+
+__device__ __forceinline__ int ccl_find(const int32_t* parent, int i) {
+    int p = parent[i];
+    while (p != i) {
+        i = p;
+        p = parent[i];
+    }
+    return i;
+}
+
+__device__ __forceinline__ void ccl_union(int32_t* parent, int a, int b) {
+    while (true) {
+        a = ccl_find(parent, a);
+        b = ccl_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&parent[a], b);      // a was a root: hang it under the smaller root
+        if (old == a) return;
+        a = old;                                       // somebody re-parented a meanwhile: continue from there
+    }
+}
+
+__global__ void ccl_init_kernel(const int32_t* __restrict__ val, int32_t* __restrict__ parent, int W, Rect r, int mode, int n,
+                                int nl) {
+    const int64_t total = (int64_t)r.w * r.h;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        const int y = r.y0 + (int)(i / r.w), x = r.x0 + (int)(i % r.w);
+        const int p = y * W + x;
+        parent[p] = ccl_active(val[p], mode, n, nl) ? p : -1;
+    }
+}
+
+__global__ void ccl_merge_kernel(const int32_t* __restrict__ val, int32_t* parent, int W, Rect r, int mode, int n, int nl) {
+    const int64_t total = (int64_t)r.w * r.h;
+    const bool eight = mode == MODE_FG8 || mode == MODE_EQ8;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        const int ly = (int)(i / r.w), lx = (int)(i % r.w);
+        const int p = (r.y0 + ly) * W + r.x0 + lx;
+        const int v = val[p];
+        if (!ccl_active(v, mode, n, nl)) continue;
+        // already-scanned neighbours: left, up (+ up-left, up-right for 8-connectivity), inside the crop
+        const int dxs[4] = {-1, 0, -1, 1}, dys[4] = {0, -1, -1, -1};
+        for (int k = 0; k < (eight ? 4 : 2); ++k) {
+            const int qx = lx + dxs[k], qy = ly + dys[k];
+            if (qx < 0 || qx >= r.w || qy < 0) continue;
+            const int q = (r.y0 + qy) * W + r.x0 + qx;
+            const int u = val[q];
+            if (!ccl_active(u, mode, n, nl) || (mode == MODE_EQ8 && u != v)) continue;
+            ccl_union(parent, p, q);
+        }
+    }
+}
+
+__global__ void ccl_flatten_kernel(int32_t* parent, int W, Rect r) {
+    const int64_t total = (int64_t)r.w * r.h;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        const int p = (r.y0 + (int)(i / r.w)) * W + r.x0 + (int)(i % r.w);
+        if (parent[p] >= 0) parent[p] = ccl_find(parent, p);
+    }
+}
+
+// flag[root] = 1 for components touching the border of the crop
+__global__ void border_flag_kernel(const int32_t* __restrict__ parent, int32_t* __restrict__ flag, int W, Rect r) {
+    const int64_t total = 2 * (int64_t)(r.w + r.h);
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        int lx, ly;
+        if (i < r.w) { lx = (int)i; ly = 0; }
+        else if (i < 2 * r.w) { lx = (int)(i - r.w); ly = r.h - 1; }
+        else if (i < 2 * r.w + r.h) { lx = 0; ly = (int)(i - 2 * r.w); }
+        else { lx = r.w - 1; ly = (int)(i - 2 * r.w - r.h); }
+        const int p = (r.y0 + ly) * W + r.x0 + lx;
+        const int root = parent[p];
+        if (root >= 0) flag[root] = 1;
+    }
+}
+
+__global__ void fill_bg_kernel(int32_t* __restrict__ cell, const int32_t* __restrict__ parent, const int32_t* __restrict__ flag,
+                               int32_t* __restrict__ edge, int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        const int root = parent[i];
+        if (root >= 0 && !flag[root]) cell[i] = 1;      // a background component that never reaches the frame border
+        if (cell[i]) edge[i] = 0;                       // seg_edge = max(seg_edge - seg_cell, 0)
+    }
+}
+
+__global__ void bbox_init_kernel(int32_t* __restrict__ bbox, int64_t n) {      // min fields INT_MAX, max fields -1
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT) {
+        bbox[4 * i] = bbox[4 * i + 1] = 0x7fffffff;
+        bbox[4 * i + 2] = bbox[4 * i + 3] = -1;
+    }
+}
+
+__global__ void fill32_kernel(int32_t* __restrict__ a, int32_t v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT) a[i] = v;
+}
+
+__global__ void fg_key_kernel(const int32_t* __restrict__ parent, int32_t* __restrict__ key, int H, int W) {
+    const int64_t hw = (int64_t)H * W;
+    const int bw = (W + 1) / 2;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        const int root = parent[i];
+        if (root < 0) continue;
+        const int y = (int)(i / W), x = (int)(i % W);
+        atomicMin(&key[root], (y >> 1) * bw + (x >> 1));
+    }
+}
+
+__global__ void key_mark_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ key, int32_t* __restrict__ mark,
+                                int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT)
+        if (parent[i] == i) mark[key[i]] = 1;
+}
+
+// exclusive prefix sum of `in` (n entries) by ONE block of 1024 threads; total -> *total_out
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n,
+                                                    int32_t* total_out) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = t * per, hi = lo + per < n ? lo + per : n;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t ? part[t - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        const int v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (t == 1023) *total_out = part[1023] + 1;      // number of labels INCLUDING the background
+}
+
+__global__ void fg_assign_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ key,
+                                 const int32_t* __restrict__ scanv, int32_t* __restrict__ lab, int32_t* __restrict__ area,
+                                 int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        const int root = parent[i];
+        const int l = root >= 0 ? scanv[key[root]] + 1 : 0;
+        lab[i] = l;
+        atomicAdd(&area[l], 1);
+    }
+}
+
+__global__ void absorb_kernel(const int32_t* __restrict__ cc, const int32_t* __restrict__ edge, int32_t* __restrict__ lab,
+                              int H, int W, double edge_dist, int radius) {
+    const int64_t hw = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        int l = cc[i];
+        if (l == 0 && edge[i]) {
+            const int y = (int)(i / W), x = (int)(i % W);
+            int bd = 0x7fffffff, bx = 0, by = 0, bl = 0;
+            for (int dy = -radius; dy <= radius; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -radius; dx <= radius; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    const int v = cc[(int64_t)yy * W + xx];
+                    if (!v) continue;
+                    const int d2 = dy * dy + dx * dx;
+                    // nearest; ties: smallest column, then smallest row (scipy's feature transform)
+                    if (d2 < bd || (d2 == bd && (xx < bx || (xx == bx && yy < by)))) {
+                        bd = d2; bx = xx; by = yy; bl = v;
+                    }
+                }
+            }
+            if (bl && sqrt((double)bd) < edge_dist) l = bl;
+        }
+        lab[i] = l;
+    }
+}
+
+// per-label bounding boxes and 4 * Euler number (bit quads over the zero-padded frame); labels outside [1, nl) are ignored
+__global__ void label_stats_kernel(const int32_t* __restrict__ lab, int H, int W, int nl, int32_t* __restrict__ bbox,
+                                   int32_t* __restrict__ e4) {
+    const int64_t total = (int64_t)(H + 1) * (W + 1);
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        const int y = (int)(i / (W + 1)), x = (int)(i % (W + 1));      // quad = pixels (y-1..y, x-1..x)
+        int q[4];
+        q[0] = (y > 0 && x > 0) ? lab[(int64_t)(y - 1) * W + x - 1] : 0;
+        q[1] = (y > 0 && x < W) ? lab[(int64_t)(y - 1) * W + x] : 0;
+        q[2] = (y < H && x > 0) ? lab[(int64_t)y * W + x - 1] : 0;
+        q[3] = (y < H && x < W) ? lab[(int64_t)y * W + x] : 0;
+        if (y < H && x < W) {
+            const int v = q[3];
+            if (v > 0 && v < nl) {
+                atomicMin(&bbox[4 * v], x);
+                atomicMin(&bbox[4 * v + 1], y);
+                atomicMax(&bbox[4 * v + 2], x);
+                atomicMax(&bbox[4 * v + 3], y);
+            }
+        }
+        for (int a = 0; a < 4; ++a) {
+            const int v = q[a];
+            if (v <= 0 || v >= nl) continue;
+            bool seen = false;
+            for (int b = 0; b < a; ++b) seen = seen || q[b] == v;
+            if (seen) continue;
+            const int m = (q[0] == v) | ((q[1] == v) << 1) | ((q[2] == v) << 2) | ((q[3] == v) << 3);
+            const int cnt = __popc(m);
+            int d = 0;
+            if (cnt == 1) d = 1;
+            else if (cnt == 3) d = -1;
+            else if (m == 0x9 || m == 0x6) d = -2;      // the two diagonal quads
+            if (d) atomicAdd(&e4[v], d);
+        }
+    }
+}
+
+__global__ void count_roots_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ lab, int32_t* __restrict__ ncomp,
+                                   int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT)
+        if (parent[i] == i) atomicAdd(&ncomp[lab[i]], 1);
+}
+
+__global__ void clear_flag_kernel(const int32_t* __restrict__ parent, int32_t* __restrict__ flag, int W, Rect r) {
+    const int64_t total = (int64_t)r.w * r.h;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        const int p = (r.y0 + (int)(i / r.w)) * W + r.x0 + (int)(i % r.w);
+        flag[p] = 0;
+    }
+}
+
+// holes of object n inside the crop: "not n" components without a border flag get += n
+__global__ void object_fill_kernel(int32_t* lab, const int32_t* __restrict__ parent, const int32_t* __restrict__ flag, int W,
+                                   Rect r, int n, int32_t* dirty) {
+    const int64_t total = (int64_t)r.w * r.h;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < total; i += (int64_t)gridDim.x * PT) {
+        const int p = (r.y0 + (int)(i / r.w)) * W + r.x0 + (int)(i % r.w);
+        const int root = parent[p];
+        if (root >= 0 && !flag[root]) {
+            const int v = lab[p];
+            if (v != 0) *dirty = 1;      // the hole held another label: later objects may see changed sets
+            lab[p] = v + n;
+        }
+    }
+}
+
+__global__ void bbox_of_label_kernel(const int32_t* __restrict__ lab, int H, int W, int n, int32_t* __restrict__ box) {
+    const int64_t hw = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        if (lab[i] != n) continue;
+        const int y = (int)(i / W), x = (int)(i % W);
+        atomicMin(&box[0], x);
+        atomicMin(&box[1], y);
+        atomicMax(&box[2], x);
+        atomicMax(&box[3], y);
+    }
+}
+
+__global__ void present_kernel(const int32_t* __restrict__ lab, int H, int W, int fov, int single_column, int nl,
+                               int32_t* __restrict__ present) {
+    const int64_t hw = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        // fov_im[:fov, :] = 0; fov_im[-fov:, :] = 0; fov_im[:, fov] = 0 (reference quirk) or [:, :fov]; fov_im[:, -fov:] = 0
+        const bool out = y < fov || y >= H - fov || (single_column ? x == fov : x < fov) || x >= W - fov;
+        const int v = out ? 0 : lab[i];
+        if (v >= 0 && v < nl) present[v] = 1;
+    }
+}
+
+__global__ void relabel_kernel(const int32_t* __restrict__ lab, const int32_t* __restrict__ newid, int nl,
+                               unsigned short* __restrict__ out, int64_t hw) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
+        const int v = lab[i];
+        out[i] = (v > 0 && v < nl) ? (unsigned short)newid[v] : (unsigned short)0;
+    }
+}
+
+int run_ccl(const int32_t* val, int32_t* parent, int W, Rect r, int mode, int n, int nl, lu_stream_t stream) {
+    const int64_t total = (int64_t)r.w * r.h;
+    LU_LAUNCH(ccl_init_kernel, dim3(pgrid(total)), dim3(PT), stream, val, parent, W, r, mode, n, nl);
+    LU_LAUNCH(ccl_merge_kernel, dim3(pgrid(total)), dim3(PT), stream, val, parent, W, r, mode, n, nl);
+    LU_LAUNCH(ccl_flatten_kernel, dim3(pgrid(total)), dim3(PT), stream, parent, W, r);
+    return LU_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// Workspace layout (int32 words): cell | edge | parent | flag | key | cc   (H*W each)   mark | scanv (NB each)
+extern "C" size_t lu_post_workspace_bytes(int32_t H, int32_t W) {
+    const size_t hw = (size_t)H * W, nb = (size_t)((H + 1) / 2) * ((W + 1) / 2);
+    return (6 * hw + 2 * nb + 16) * sizeof(int32_t);
+}
+
+extern "C" int32_t lu_post_max_labels(int32_t H, int32_t W) { return ((H + 1) / 2) * ((W + 1) / 2) + 2; }
+
+extern "C" int lu_post_label(const float* softmax_chw, int32_t H, int32_t W, float edge_thresh, double edge_dist,
+                             void* workspace, int32_t* labels, int32_t* num_labels, int32_t* area, lu_stream_t stream) {
+    LU_REQUIRE(softmax_chw && workspace && labels && num_labels && area && H > 0 && W > 0 && edge_dist >= 0,
+               "lu_post_label: bad arguments");
+    LU_REQUIRE((int64_t)H * W < ((int64_t)1 << 30), "lu_post_label: frame too large");
+    const int64_t hw = (int64_t)H * W;
+    const int nb = ((H + 1) / 2) * ((W + 1) / 2);
+    int32_t* ws = (int32_t*)workspace;
+    int32_t *cell = ws, *edge = ws + hw, *parent = ws + 2 * hw, *flag = ws + 3 * hw, *key = ws + 4 * hw, *cc = ws + 5 * hw;
+    int32_t *mark = ws + 6 * hw, *scanv = mark + nb;
+    const Rect full{0, 0, W, H};
+    const dim3 g(pgrid(hw)), b(PT);
+    LU_LAUNCH(classify_kernel, g, b, stream, softmax_chw, hw, edge_thresh, cell, edge);
+    // binary_fill_holes: background components (4-conn) that do not reach the frame border become cell
+    if (run_ccl(cell, parent, W, full, MODE_BG4, 0, 0, stream)) return 1;
+    LU_LAUNCH(fill32_kernel, g, b, stream, flag, 0, hw);
+    LU_LAUNCH(border_flag_kernel, dim3(pgrid(2 * (int64_t)(W + H))), b, stream, (const int32_t*)parent, flag, W, full);
+    LU_LAUNCH(fill_bg_kernel, g, b, stream, cell, (const int32_t*)parent, (const int32_t*)flag, edge, hw);
+    // 8-connected components, numbered in OpenCV's order
+    if (run_ccl(cell, parent, W, full, MODE_FG8, 0, 0, stream)) return 1;
+    LU_LAUNCH(fill32_kernel, g, b, stream, key, 0x7fffffff, hw);
+    LU_LAUNCH(fg_key_kernel, g, b, stream, (const int32_t*)parent, key, H, W);
+    LU_LAUNCH(fill32_kernel, dim3(pgrid(nb)), b, stream, mark, 0, (int64_t)nb);
+    LU_LAUNCH(key_mark_kernel, g, b, stream, (const int32_t*)parent, (const int32_t*)key, mark, hw);
+    LU_LAUNCH(scan_kernel, dim3(1), dim3(1024), stream, (const int32_t*)mark, scanv, nb, num_labels);
+    LU_LAUNCH(fill32_kernel, dim3(pgrid(nb + 2)), b, stream, area, 0, (int64_t)nb + 2);
+    LU_LAUNCH(fg_assign_kernel, g, b, stream, (const int32_t*)parent, (const int32_t*)key, (const int32_t*)scanv, cc, area, hw);
+    // edge pixels within edge_dist of a cell take the nearest cell's label
+    int radius = 0;      // smallest window that holds every offset with sqrt(dy^2 + dx^2) < edge_dist
+    while ((double)(radius + 1) < edge_dist) ++radius;
+    LU_LAUNCH(absorb_kernel, g, b, stream, (const int32_t*)cc, (const int32_t*)edge, labels, H, W, edge_dist, radius);
+    return LU_CHECK_LAUNCH();
+}
+
+/* bbox[4*v .. 4*v+3] = xmin, ymin, xmax, ymax; e4[v] = 4 * Euler number (8-connectivity); ncomp[v] = 8-connected components
+ * of label v; for 1 <= v < num_labels (host value).  workspace as above. */
+extern "C" int lu_post_label_stats(const int32_t* labels, int32_t H, int32_t W, int32_t num_labels, void* workspace,
+                                   int32_t* bbox, int32_t* e4, int32_t* ncomp, lu_stream_t stream) {
+    LU_REQUIRE(labels && workspace && bbox && e4 && ncomp && H > 0 && W > 0 && num_labels >= 1, "lu_post_label_stats: bad arguments");
+    const int64_t hw = (int64_t)H * W;
+    int32_t* parent = (int32_t*)workspace + 2 * hw;
+    const Rect full{0, 0, W, H};
+    const dim3 b(PT);
+    LU_LAUNCH(fill32_kernel, dim3(pgrid(num_labels)), b, stream, e4, 0, (int64_t)num_labels);
+    LU_LAUNCH(fill32_kernel, dim3(pgrid(num_labels)), b, stream, ncomp, 0, (int64_t)num_labels);
+    LU_LAUNCH(bbox_init_kernel, dim3(pgrid(num_labels)), b, stream, bbox, (int64_t)num_labels);
+    LU_LAUNCH(label_stats_kernel, dim3(pgrid((int64_t)(H + 1) * (W + 1))), b, stream, labels, H, W, num_labels, bbox, e4);
+    if (run_ccl(labels, parent, W, full, MODE_EQ8, 0, num_labels, stream)) return 1;
+    LU_LAUNCH(count_roots_kernel, dim3(pgrid(hw)), b, stream, (const int32_t*)parent, labels, ncomp, hw);
+    return LU_CHECK_LAUNCH();
+}
+
+/* Holes of object n (labels == n) inside the crop [x0, x0+w) x [y0, y0+h) -- its bounding box grown by one pixel, clipped to
+ * the frame: 4-connected components of "labels != n" that do not touch the crop border get labels += n (reference
+ * Inference2D.py:80-91 through bbox_crop / binary_fill_holes / bbox_fill, additive quirk included).  *dirty (device int,
+ * never cleared here) is set when such a hole held a non-zero label. */
+extern "C" int lu_post_fill_object(int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                   void* workspace, int32_t* dirty, lu_stream_t stream) {
+    LU_REQUIRE(labels && workspace && dirty && n > 0 && x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 + w <= W && y0 + h <= H,
+               "lu_post_fill_object: bad arguments");
+    const int64_t hw = (int64_t)H * W;
+    int32_t *parent = (int32_t*)workspace + 2 * hw, *flag = (int32_t*)workspace + 3 * hw;
+    const Rect r{x0, y0, w, h};
+    const dim3 b(PT), g(pgrid((int64_t)w * h));
+    if (run_ccl(labels, parent, W, r, MODE_NE4, n, 0, stream)) return 1;
+    LU_LAUNCH(clear_flag_kernel, g, b, stream, (const int32_t*)parent, flag, W, r);
+    LU_LAUNCH(border_flag_kernel, dim3(pgrid(2 * (int64_t)(w + h))), b, stream, (const int32_t*)parent, flag, W, r);
+    LU_LAUNCH(object_fill_kernel, g, b, stream, labels, (const int32_t*)parent, (const int32_t*)flag, W, r, n, dirty);
+    return LU_CHECK_LAUNCH();
+}
+
+/* box[0..3] = xmin, ymin, xmax, ymax of labels == n (xmin = INT_MAX when the label is absent); the strictly sequential
+ * fall-back of the hole filling needs the box of the CURRENT label set */
+extern "C" int lu_post_bbox_of_label(const int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t* box, lu_stream_t stream) {
+    LU_REQUIRE(labels && box && H > 0 && W > 0, "lu_post_bbox_of_label: bad arguments");
+    LU_LAUNCH(bbox_init_kernel, dim3(1), dim3(PT), stream, box, (int64_t)1);
+    LU_LAUNCH(bbox_of_label_kernel, dim3(pgrid((int64_t)H * W)), dim3(PT), stream, labels, H, W, n, box);
+    return LU_CHECK_LAUNCH();
+}
+
+/* present[v] = 1 for every label value v in [0, num_labels) that occurs inside the field of view (rows [fov, H-fov),
+ * columns [.., W-fov); left side: single_column = 1 masks only column `fov` -- the reference's `fov_im[:, FOV] = 0`,
+ * Inference2D.py:97 -- 0 masks columns [0, fov)); masked pixels count as label 0, as `labels * fov_im` does. */
+extern "C" int lu_post_present(const int32_t* labels, int32_t H, int32_t W, int32_t fov, int32_t single_column, int32_t num_labels,
+                               int32_t* present, lu_stream_t stream) {
+    LU_REQUIRE(labels && present && H > 0 && W > 0 && fov >= 0 && num_labels >= 1, "lu_post_present: bad arguments");
+    LU_LAUNCH(fill32_kernel, dim3(pgrid(num_labels)), dim3(PT), stream, present, 0, (int64_t)num_labels);
+    LU_LAUNCH(present_kernel, dim3(pgrid((int64_t)H * W)), dim3(PT), stream, labels, H, W, fov, single_column, num_labels, present);
+    return LU_CHECK_LAUNCH();
+}
+
+/* out[p] = newid[labels[p]] for 0 < labels[p] < num_labels, else 0 (uint16): the consecutive relabelling of
+ * Inference2D.py:113-123 with newid = 0 for filtered labels */
+extern "C" int lu_post_relabel(const int32_t* labels, int32_t H, int32_t W, const int32_t* newid, int32_t num_labels, uint16_t* out,
+                               lu_stream_t stream) {
+    LU_REQUIRE(labels && newid && out && H > 0 && W > 0 && num_labels >= 1, "lu_post_relabel: bad arguments");
+    LU_LAUNCH(relabel_kernel, dim3(pgrid((int64_t)H * W)), dim3(PT), stream, labels, newid, num_labels, (unsigned short*)out,
+              (int64_t)H * W);
+    return LU_CHECK_LAUNCH();
+}

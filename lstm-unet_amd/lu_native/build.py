@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
-SOURCES = ['lu_conv.hip', 'lu_wgrad.hip', 'lu_pointwise.hip']
+SOURCES = ['lu_conv.hip', 'lu_wgrad.hip', 'lu_pointwise.hip', 'lu_postprocess.hip']
 LIB = os.path.join(CSRC, 'liblstmunet_hip.so')
 
 

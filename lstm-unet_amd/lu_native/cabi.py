@@ -71,8 +71,8 @@ PROTOTYPES = {
     'lu_bn_lrelu_apply': (C.c_int, [P, P, P, P, f32, i64, i32, S]),
     'lu_bn_lrelu_bwd_reduce': (C.c_int, [P, P, P, P, P, P, f32, i64, i32, P, P, S]),
     'lu_bn_lrelu_bwd_apply': (C.c_int, [P, P, P, P, P, P, f32, P, f64, P, P, P, i64, i32, S]),
-    'lu_upsample2x_fwd': (C.c_int, [P, P, i32, i32, i32, i32, S]),
-    'lu_upsample2x_bwd': (C.c_int, [P, i32, P, i32, i32, i32, i32, S]),
+    'lu_upsample2x_fwd': (C.c_int, [P, P, i32, i32, i32, i32, i32, S]),
+    'lu_upsample2x_bwd': (C.c_int, [P, i32, P, i32, i32, i32, i32, i32, S]),
     'lu_window_copy': (C.c_int, [P, i32, P, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, S]),
     'lu_wce_workspace_bytes': (C.c_size_t, [i64]),
     'lu_softmax_wce_fwd': (C.c_int, [P, P, P, P, P, i64, P, S]),
@@ -84,6 +84,14 @@ PROTOTYPES = {
     'lu_transpose_inner': (C.c_int, [P, P, i64, i32, i32, S]),
     'lu_add_inplace': (C.c_int, [P, P, i64, S]),
     'lu_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),
+    'lu_post_workspace_bytes': (C.c_size_t, [i32, i32]),
+    'lu_post_max_labels': (i32, [i32, i32]),
+    'lu_post_label': (C.c_int, [P, i32, i32, f32, f64, P, P, P, P, S]),
+    'lu_post_label_stats': (C.c_int, [P, i32, i32, i32, P, P, P, P, S]),
+    'lu_post_fill_object': (C.c_int, [P, i32, i32, i32, i32, i32, i32, i32, P, P, S]),
+    'lu_post_bbox_of_label': (C.c_int, [P, i32, i32, i32, P, S]),
+    'lu_post_present': (C.c_int, [P, i32, i32, i32, i32, i32, P, S]),
+    'lu_post_relabel': (C.c_int, [P, i32, i32, P, i32, P, S]),
 }
 
 

@@ -35,7 +35,8 @@ def model_pads(h, w, total_stride, pad_image):
 
 
 class Engine:
-    def __init__(self, net_params, pad_image=True, seed=0, dp=None, sync_bn=False, plan_fn=None, precision='fp32'):
+    def __init__(self, net_params, pad_image=True, seed=0, dp=None, sync_bn=False, plan_fn=None, precision='fp32',
+                 resize='tf2.0'):
         """precision: 'fp32' (default; v_mfma_f32_32x32x2_f32 everywhere -- the parity configuration) or 'bf16'
         (BASELINE config 5: stride-1 3x3 / 5x5 convolutions with more than 64 output channels -- ConvLSTM steps, their
         recurrent / input gradients, the wide encoder / decoder convs -- feed bf16-rounded operands to
@@ -43,6 +44,10 @@ class Engine:
         if precision not in ('fp32', 'bf16'):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
+        # bilinear source-coordinate convention of UpBlock2D (Networks.py:143): 'tf2.0' = the legacy v1 op that
+        # keras.backend.resize_images calls in the TensorFlow release the reference pins; 'half_pixel' = tf.image.resize v2
+        ops._legacy(resize)
+        self.resize = resize
         self._packed_version = -1
         self._packed = {}    # (param name, role, c_off, c_sub) -> ops.PackedW; dropped whenever the weights change
         self.net_params = net_params
@@ -383,7 +388,7 @@ class Engine:
         up_in = act
         for bi, (blk, skip) in enumerate(zip(plan['up'], skips[::-1])):
             if blk['up_factor'] == 2:
-                u = ops.upsample2x(up_in)
+                u = ops.upsample2x(up_in, self.resize)
                 if tape is not None:
                     tape.append({'kind': 'up', 'in_hw': (up_in.shape[1], up_in.shape[2])})
             else:
@@ -433,7 +438,7 @@ class Engine:
                     if blk['up_factor'] == 2:
                         urec = tape.pop()
                         assert urec['kind'] == 'up'
-                        d = ops.upsample2x_bwd(d_u, urec['in_hw'])
+                        d = ops.upsample2x_bwd(d_u, urec['in_hw'], self.resize)
                     else:
                         d = d_u
             self._bucket_done(seg)

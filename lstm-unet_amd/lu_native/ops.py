@@ -529,22 +529,31 @@ def bn_lrelu_bwd_apply(y, dz, scale, shift, mean, invstd, alpha, sums, count, dg
     return out
 
 
-def upsample2x(x):
+RESIZE_CONVENTIONS = ('tf2.0', 'half_pixel')     # legacy src = o/2 (TF 2.0 / 2.1 keras.backend.resize_images) | tf.image.resize v2
+
+
+def _legacy(resize):
+    if resize not in RESIZE_CONVENTIONS:
+        raise ValueError('resize convention must be one of %s' % (RESIZE_CONVENTIONS,))
+    return 1 if resize == 'tf2.0' else 0
+
+
+def upsample2x(x, resize='tf2.0'):
     _chk(x)
     frames, H, W, Cc = x.shape
     y = torch.empty((frames, 2 * H, 2 * W, Cc), device=x.device, dtype=torch.float32)
-    calls.check(lib(), lib().lu_upsample2x_fwd(x.data_ptr(), y.data_ptr(), frames, H, W, Cc, _stream()),
+    calls.check(lib(), lib().lu_upsample2x_fwd(x.data_ptr(), y.data_ptr(), frames, H, W, Cc, _legacy(resize), _stream()),
                 'lu_upsample2x_fwd')
     return y
 
 
-def upsample2x_bwd(dy, in_hw):
+def upsample2x_bwd(dy, in_hw, resize='tf2.0'):
     """dy: [frames,2H,2W,C] (channel-slice view allowed) -> [frames,H,W,C]."""
     _chk(dy)
     frames, _, _, Cc = dy.shape
     H, W = in_hw
     dx = torch.empty((frames, H, W, Cc), device=dy.device, dtype=torch.float32)
-    calls.check(lib(), lib().lu_upsample2x_bwd(dy.data_ptr(), dy.stride(2), dx.data_ptr(), frames, H, W, Cc, _stream()),
+    calls.check(lib(), lib().lu_upsample2x_bwd(dy.data_ptr(), dy.stride(2), dx.data_ptr(), frames, H, W, Cc, _legacy(resize), _stream()),
                 'lu_upsample2x_bwd')
     return dx
 

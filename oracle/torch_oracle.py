@@ -60,11 +60,21 @@ def bn_infer(x, gamma, beta, mm, mv, eps=1e-3):
     return (x - mm) * torch.rsqrt(mv + eps) * gamma + beta
 
 
-def resize_bilinear(x, f):
+def resize_bilinear(x, f, resize='tf2.0'):
+    """'half_pixel' = torch's align_corners=False; 'tf2.0' = the legacy v1 op (src = o / f): for f = 2,
+    out[2i] = in[i], out[2i+1] = (in[i] + in[min(i+1, n-1)]) / 2 along each axis (see np_oracle.resize_bilinear)."""
     if f == 1:
         return x
-    y = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=f, mode='bilinear', align_corners=False)
-    return y.permute(0, 2, 3, 1)
+    if resize == 'half_pixel':
+        y = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=f, mode='bilinear', align_corners=False)
+        return y.permute(0, 2, 3, 1)
+    assert resize == 'tf2.0' and f == 2
+
+    def axis(t, dim):
+        n = t.shape[dim]
+        nxt = torch.index_select(t, dim, torch.clamp(torch.arange(n) + 1, max=n - 1))
+        return torch.stack([t, 0.5 * (t + nxt)], dim + 1).reshape(t.shape[:dim] + (2 * n,) + t.shape[dim + 1:])
+    return axis(axis(x, 1), 2)
 
 
 def convlstm_seq(x, kernel, rec_kernel, bias, h0, c0, rounded=False):
@@ -102,11 +112,12 @@ class TorchULSTM:
     """Functional model over a name->tensor parameter dict (names as np_oracle.init_params)."""
 
     def __init__(self, net_params, in_channels, params, dtype=torch.float64, pad_image=False,
-                 bn_eps=1e-3, bn_momentum=0.99, bf16_operands=False):
+                 bn_eps=1e-3, bn_momentum=0.99, bf16_operands=False, resize='tf2.0'):
         """bf16_operands: restate Engine(precision='bf16') -- the convolutions that mode runs on the bf16 MFMA
         (ConvLSTM gate convolutions with 3x3 / 5x5 kernels and 4F > 64 columns; Conv2D layers with >= 64 output
         channels whose sources all have C % 4 == 0) see bf16-rounded operands, everything else stays in `dtype`."""
         self.bf16_operands = bool(bf16_operands)
+        self.resize = resize
         self.net_params = net_params
         self.plan = npo.net_plan(net_params, in_channels)
         self.dtype = dtype
@@ -185,7 +196,7 @@ class TorchULSTM:
             out_down = act.reshape((b, t) + tuple(act.shape[1:]))
         up_in = out_skip
         for bi, (blk, skip) in enumerate(zip(self.plan['up'], skips[::-1])):
-            act = torch.cat([resize_bilinear(up_in, blk['up_factor']), skip], dim=-1)
+            act = torch.cat([resize_bilinear(up_in, blk['up_factor'], self.resize), skip], dim=-1)
             n = len(blk['conv'])
             for ci, l in enumerate(blk['conv']):
                 last = blk['return_logits'] and ci == n - 1

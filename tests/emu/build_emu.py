@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'lstm-unet_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'liblstmunet_emu.so')
-SOURCES = ['lu_conv.hip', 'lu_wgrad.hip', 'lu_pointwise.hip']
+SOURCES = ['lu_conv.hip', 'lu_wgrad.hip', 'lu_pointwise.hip', 'lu_postprocess.hip']
 
 
 def build():

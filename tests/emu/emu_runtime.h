@@ -258,4 +258,11 @@ inline float shfl_down(float v, int d) {
 #define gridDim (lu_emu::g_rt.gridDim_)
 #define __syncthreads() lu_emu::block_barrier()
 
+// integer atomics / bit ops of the post-processing kernels: fibers of one block run interleaved on ONE OS thread and only
+// switch at barriers, so plain read-modify-write is atomic here
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+
 typedef void* hipStream_t;

@@ -144,18 +144,14 @@ def test_edge_rule_bbox_and_data_contract(golden_dir):
     assert nhwc.get_batch()[0].shape == (1, 2, 16, 16, 1)
 
 
-def test_inference_postprocess_partition():
+def test_inference_postprocess_needs_the_device():
+    """The post-processing runs on the GPU (tests/test_postprocess.py); without a device it fails loudly, no CPU path."""
     import Inference2D
-    sm = np.zeros((3, 40, 40), np.float32)
-    sm[0] = 1.0
-    for (y, x) in ((5, 5), (5, 25), (25, 10)):
-        sm[1, y:y + 8, x:x + 8] = 2.0
-        sm[2, y - 1:y + 9, x - 1:x + 9] = np.maximum(sm[2, y - 1:y + 9, x - 1:x + 9], 0.0)
-    sm[2, 4, 4:14] = 0.5        # an edge line on top of the first cell
-    lab = Inference2D.postprocess(sm, edge_dist=2, min_cell_size=10, max_cell_size=100)
-    assert lab.dtype == np.uint16 and set(np.unique(lab)) == {0, 1, 2, 3}
-    assert lab[8, 8] != lab[8, 28] != lab[28, 13]
-    assert Inference2D.postprocess(sm, min_cell_size=100, max_cell_size=200).max() == 0
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    with pytest.raises(Exception, match='no HIP device|no CPU'):
+        Inference2D.postprocess(np.zeros((3, 8, 8), np.float32))
 
 
 DP_WORKER = r'''

@@ -490,19 +490,27 @@ def test_colsum(be):
     close(be.host(out), 1 + x[:, 2:8].astype(np.float64).sum(0), 1e-4)
 
 
-def test_upsample_fwd_bwd(be):
+@pytest.mark.parametrize('resize', ['tf2.0', 'half_pixel'])
+def test_upsample_fwd_bwd(be, resize):
+    """Both bilinear source-coordinate conventions of k.backend.resize_images (Networks.py:143): the legacy v1 op of
+    TF 2.0 / 2.1 (src = o / 2) and half-pixel centres (tf.image.resize v2)."""
+    legacy = 1 if resize == 'tf2.0' else 0
     fr, H, W, Cc = 2, 5, 4, 3
     x = rnd(fr, H, W, Cc)
     xd = be.dev(x)
     y = be.empty((fr, 2 * H, 2 * W, Cc))
-    ck(be, be.lib.lu_upsample2x_fwd(be.ptr(xd), be.ptr(y), fr, H, W, Cc, be.stream), 'up')
-    close(be.host(y), npo.resize_bilinear(x, 2), 1e-6)
+    ck(be, be.lib.lu_upsample2x_fwd(be.ptr(xd), be.ptr(y), fr, H, W, Cc, legacy, be.stream), 'up')
+    close(be.host(y), npo.resize_bilinear(x, 2, resize), 1e-6)
+    if legacy:          # out[2i] = in[i], out[2i+1] = mean of in[i], in[i+1] (edge clamp)
+        assert np.array_equal(be.host(y)[:, ::2, ::2], x)
     dyw = rnd(fr, 2 * H, 2 * W, Cc + 2)    # gradient arrives as a channel slice of a wider tensor
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    (gx,) = torch.autograd.grad(tho.resize_bilinear(xt, 2), [xt], torch.tensor(dyw[..., :Cc], dtype=torch.float64))
+    up = tho.resize_bilinear(xt, 2, resize)
+    assert np.abs(up.detach().numpy() - npo.resize_bilinear(x, 2, resize)).max() <= 1e-12      # the two oracles agree
+    (gx,) = torch.autograd.grad(up, [xt], torch.tensor(dyw[..., :Cc], dtype=torch.float64))
     dx = be.empty(x.shape)
     dywd = be.dev(dyw)
-    ck(be, be.lib.lu_upsample2x_bwd(be.ptr(dywd), Cc + 2, be.ptr(dx), fr, H, W, Cc, be.stream), 'upb')
+    ck(be, be.lib.lu_upsample2x_bwd(be.ptr(dywd), Cc + 2, be.ptr(dx), fr, H, W, Cc, legacy, be.stream), 'upb')
     close(be.host(dx), gx.numpy(), 1e-5)
 
 

@@ -54,8 +54,10 @@ def test_hard_sigmoid_breakpoints():
 
 def test_bilinear_2x2_kat():
     x = np.array([[0., 1.], [0., 1.]]).reshape(1, 2, 2, 1)
-    y = npo.resize_bilinear(x, 2)[0, 0, :, 0]
-    assert np.allclose(y, [0, .25, .75, 1])
+    y = npo.resize_bilinear(x, 2, 'half_pixel')[0, 0, :, 0]
+    assert np.allclose(y, [0, .25, .75, 1])                      # tf.image.resize v2: half-pixel centres
+    y = npo.resize_bilinear(x, 2, 'tf2.0')[0, 0, :, 0]
+    assert np.allclose(y, [0, .5, 1, 1])                         # legacy v1 op (TF 2.0 / 2.1 Keras): src = o / 2, edge clamp
     assert np.allclose(npo.resize_bilinear(x, 1), x)
 
 
