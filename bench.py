@@ -27,9 +27,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-PEAK_HBM_GBS = 8000.0             # same guide: HBM3E spec (about 6.3 TB/s achievable)
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
+from lu_native.profile import PEAK_FP32_MFMA_TFLOPS, PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS  # noqa: E402,F401
 
 
 def conv_flops(k, cin, cout, h, w):
@@ -218,12 +216,6 @@ def main():
     torch.cuda.synchronize()
     if dp.rank == 0:
         ev, ops.EVENT_LOG = ops.EVENT_LOG, None
-        classes = {}
-        for kind, fl, e0, e1 in ev:
-            c = classes.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'n': 0})
-            c['flops'] += fl
-            c['ms'] += e0.elapsed_time(e1)
-            c['n'] += 1
         traffic_db, traffic_src = {}, None
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only): a STATIC table
             if (H, W, T, B) == (256, 256, 8, 4):      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
@@ -250,29 +242,16 @@ def main():
             n = sum(v['launches'] for v in hit)
             return round(sum(v['traffic_bytes_per_launch'] * v['launches'] for v in hit) / n) if n else None
 
-        rows, hbm_rows = [], []
-        for kind, c in classes.items():
-            if c['ms'] <= 0:
-                continue
-            if kind.startswith('hbm:'):       # bandwidth-bound kernels: algorithmic bytes / time against the 8 TB/s spec
-                gbs = c['flops'] / (c['ms'] * 1e-3) / 1e9
-                hbm_rows.append({'kernel': kind[4:], 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                 'frac': round(gbs / PEAK_HBM_GBS, 4), 'launches_per_step': c['n'],
-                                 'avg_launch_ms': round(c['ms'] / c['n'], 4), 'ms_per_step': round(c['ms'], 2)})
-                continue
-            ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in kind else PEAK_FP32_MFMA_TFLOPS
-            rows.append({'kernel': kind, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic_of(kind),
-                         'launches_per_step': c['n'], 'avg_launch_ms': round(c['ms'] / c['n'], 4),
-                         'ms_per_step': round(c['ms'], 2), 'flops_per_launch_avg': c['flops'] / c['n']})
-        rows.sort(key=lambda r_: -r_['ms_per_step'])
+        from lu_native.profile import summarize_events
+        rows, hbm_rows = summarize_events(ev)
+        for r_ in rows:
+            r_['traffic'] = traffic_of(r_['kernel'])
         if rows:
             roofline = dict(rows[0])            # the dominant kernel class = largest share of the step
             roofline['traffic_unit'] = 'bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE'
             roofline['traffic_source'] = traffic_src
             roofline['all_mfma_kernels'] = rows
-            roofline['hbm_kernels'] = sorted(hbm_rows, key=lambda r_: -r_['ms_per_step'])
+            roofline['hbm_kernels'] = hbm_rows
     # ---- secondary metric: streaming inference (Inference2D.py:45-62: B=1, T=1, pad_image=True, stateful) ----
     infer = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_infer:

@@ -259,6 +259,7 @@ class CTCRAMReaderSequence2D(object):
         rng = np.random.default_rng([self._seed[0], self._seed[1], slot])
         keys = list(self.sequence_data.keys())
         T = self.unroll_len
+        empty_draws = 0
         while True:
             data = self.sequence_data[keys[int(rng.integers(0, len(keys)))]]
             aug = ClipAugmenter(rng, data['images'].shape[1:], self.sub_seq_size, self.randomize, self.elastic_augmentation)
@@ -274,6 +275,13 @@ class CTCRAMReaderSequence2D(object):
                     idx += idx[-2:-T + rem - 2:-1]
                 else:
                     idx += idx[-1:] * (T - rem)
+            if not idx:      # deal_with_end == 0 and fewer than unroll_len (sub-sampled) frames: nothing to yield from this draw
+                empty_draws += 1
+                if empty_draws > 100 * len(keys):      # ... and from no other sequence either: fail instead of spinning
+                    raise ValueError('no sequence holds unroll_len = %d frames after temporal sub-sampling '
+                                     '(deal_with_end = 0 trims clips to whole windows)' % T)
+                continue
+            empty_draws = 0
             for j, t in enumerate(idx):
                 img, seg = aug.frame(data['images'][t], data['segs'][t], data['max'])
                 if not (np.isfinite(img).all() and np.isfinite(seg).all()):
@@ -289,13 +297,28 @@ class CTCRAMReaderSequence2D(object):
             self._queues = [queue.Queue(maxsize=self.queue_capacity) for _ in range(self.batch_size)]
 
             def work(slots):
-                while not self._stop:
+                # An exception in a producer (non-finite frame, unreadable file ...) must reach the training loop: the
+                # reference stops its coordinator (DataHandeling.py:425-428).  It travels through the queue as the item.
+                try:
+                    while not self._stop:
+                        for b in slots:
+                            if self._queues[b].full():
+                                continue
+                            self._queues[b].put(next(self._slots[b]))
+                        if all(self._queues[b].full() for b in slots):
+                            threading.Event().wait(0.005)
+                except BaseException as exc:      # noqa: B902 -- re-raised by get_batch in the consumer thread
+                    self._stop = True
                     for b in slots:
-                        if self._queues[b].full():
-                            continue
-                        self._queues[b].put(next(self._slots[b]))
-                    if all(self._queues[b].full() for b in slots):
-                        threading.Event().wait(0.005)
+                        while True:
+                            try:
+                                self._queues[b].put_nowait(exc)
+                                break
+                            except queue.Full:
+                                try:
+                                    self._queues[b].get_nowait()
+                                except queue.Empty:
+                                    pass
 
             n = min(self.num_threads, self.batch_size)
             for i in range(n):
@@ -320,6 +343,8 @@ class CTCRAMReaderSequence2D(object):
         for b in range(B):
             for t in range(T):
                 item = self._queues[b].get() if self._queues is not None else next(self._slots[b])
+                if isinstance(item, BaseException):      # a producer thread died: surface its error here
+                    raise item
                 image[b, t], seg[b, t], full[b, t], keep[b] = item      # keep: the flag of the window's last frame
         axis = 2 if self.data_format[1] == 'C' else 4
         return np.expand_dims(image, axis), np.expand_dims(seg, axis), full, keep

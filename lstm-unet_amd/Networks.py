@@ -24,7 +24,7 @@ from lu_native import ops
 from lu_native import plan as plan_mod
 from lu_native.engine import Engine
 
-__all__ = ['DEFAULT_NET_DOWN_PARAMS', 'DownBlock2D', 'UpBlock2D', 'ULSTMnet2D']
+__all__ = ['DEFAULT_NET_DOWN_PARAMS', 'DownBlock2D', 'UpBlock2D', 'ULSTMnet2D', 'Variable']
 
 _W = (128, 256, 256, 512)
 DEFAULT_NET_DOWN_PARAMS = {
@@ -68,6 +68,35 @@ def _flat_from_internal(y, T, B, nchw):
     """[T*B,H,W,C] -> the reference's 4-D [B*T, ...] skip layout."""
     y = _from_internal(y, T, B, nchw)
     return y.view((B * T,) + tuple(y.shape[2:]))
+
+
+class Variable(object):
+    """One named tensor of the model, tf.Variable-style: .name, .shape, .numpy(), .assign(value); `.tensor` is the device
+    view into the engine's flat buffer (no copy -- assigning through it changes the model)."""
+
+    def __init__(self, name, tensor, on_assign=None):
+        self.name, self.tensor, self._on_assign = name, tensor, on_assign
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    def numpy(self):
+        return self.tensor.detach().cpu().numpy()
+
+    def __array__(self, dtype=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def assign(self, value):
+        with torch.no_grad():
+            self.tensor.copy_(torch.as_tensor(np.asarray(value), dtype=torch.float32).reshape(self.tensor.shape))
+        if self._on_assign is not None:
+            self._on_assign()
+        return self
+
+    def __repr__(self):
+        return '<Variable %s shape=%s>' % (self.name, self.shape)
 
 
 class _Layer(object):
@@ -383,25 +412,17 @@ class ULSTMnet2D(object):
         reference, train2D.py:92): 12 ConvLSTM + 34 Conv2D + 32 BatchNormalization tensors for the default network."""
         if self._engine.plan is None:
             raise RuntimeError('variables are created at the first call (Keras-style lazy build)')
-        out = []
-        for name, t in self._engine.P.items():
-            v = t.detach()
-            v.name = name
-            out.append(v)
-        return out
+        e = self._engine
+        return [Variable(name, t.detach(), e.weights_changed) for name, t in e.P.items()]
 
     @property
     def variables(self):
         """trainable_variables + the BatchNormalization moving statistics."""
-        out = self.trainable_variables
-        for name, t in self._engine.S.items():
-            v = t.detach()
-            v.name = name
-            out.append(v)
-        return out
+        e = self._engine
+        return self.trainable_variables + [Variable(name, t.detach(), e.weights_changed) for name, t in e.S.items()]
 
     def get_weights(self):
-        return [v.cpu().numpy() for v in self.variables]
+        return [v.numpy() for v in self.variables]
 
     def set_weights(self, weights):
         names = [v.name for v in self.variables]

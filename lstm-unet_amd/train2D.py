@@ -24,7 +24,7 @@ import losses
 from lu_native import ops
 from lu_native.dp import DataParallel
 from lu_native.engine import Adam
-from utils import log_print
+from utils import log_print, select_gpu
 
 
 class AWSError(Exception):
@@ -133,6 +133,7 @@ class _RunningMean(object):
 
 
 def train(params):
+    select_gpu(getattr(params, 'gpu_id', None))
     dp = DataParallel()
     is_main = dp.rank == 0
     trainer = Trainer(params.net_model, params.net_kernel_params, params.data_format, params.class_weights,
@@ -148,8 +149,22 @@ def train(params):
     ckpt_dir = os.path.join(params.experiment_save_dir, 'tf_ckpts')
     saved = []
 
+    def sync_bn_stats():
+        """Rank-local BatchNorm (the default under DP) lets every rank drift its own moving statistics; what is saved
+        (and what every rank continues from) is their mean over the ranks (SURVEY §8e semantics decision 3)."""
+        if dp.world_size > 1 and not trainer.engine.sync_bn and trainer.engine.plan is not None:
+            for t in trainer.engine.S.values():
+                dp.all_reduce_(t)
+                t.mul_(1.0 / dp.world_size)
+
     def save_ckpt():
-        if params.dry_run or not is_main:
+        if params.dry_run:
+            return None
+        sync_bn_stats()                      # (collective: every rank takes part)
+        if dp.world_size > 1:                # recurrent states are rank-local clip streams: one small file per rank
+            os.makedirs(ckpt_dir, exist_ok=True)
+            torch.save(trainer.state_dict()['states'], os.path.join(ckpt_dir, 'states-%d.rank%d.pt' % (trainer.step, dp.rank)))
+        if not is_main:
             return None
         os.makedirs(ckpt_dir, exist_ok=True)
         path = os.path.join(ckpt_dir, 'ckpt-%d.pt' % trainer.step)
@@ -169,7 +184,11 @@ def train(params):
             path = os.path.join(path, cands[-1]) if cands else ''
         if path:
             try:
-                trainer.load_state_dict(torch.load(path, map_location='cpu'))
+                sd = torch.load(path, map_location='cpu')
+                if dp.world_size > 1:            # this rank's own clip-stream states, or none (zeros) if it has no file
+                    own = os.path.join(os.path.dirname(path), 'states-%d.rank%d.pt' % (sd['step'], dp.rank))
+                    sd['states'] = torch.load(own, map_location='cpu') if os.path.exists(own) else None
+                trainer.load_state_dict(sd)
                 log_print('Restored from {}'.format(path))
             except FileNotFoundError:
                 raise ValueError('Could not load checkpoint: {}'.format(path))
@@ -216,8 +235,38 @@ def train(params):
                 r = requests.get('http://169.254.169.254/latest/meta-data/spot/instance-action')
                 if not r.status_code == 404:
                     raise AWSError('Quitting Spot Instance Gracefully')
-            image_sequence, seg_sequence, _, is_last_batch = train_data_provider.get_batch()
+            batch_err = None
+            try:
+                image_sequence, seg_sequence, _, is_last_batch = train_data_provider.get_batch()
+            except ValueError as exc:
+                batch_err = exc
+            if dp.world_size > 1:                # a rank that fails must take the others with it, not leave them in an all-reduce
+                flag = torch.tensor([1.0 if batch_err is not None else 0.0], device=Nets._device())
+                dp.all_reduce_(flag)
+                if float(flag.item()) > 0 and batch_err is None:
+                    batch_err = ValueError('another data-parallel rank reported a data error')
+            if batch_err is not None:
+                raise batch_err
+            profiling = bool(params.profile) and is_main and not params.dry_run and \
+                (trainer.step + 1) % params.write_to_tb_interval == 0
+            if profiling:                        # --profile (train2D.py:152-160): this step under per-kernel HIP events
+                ops.EVENT_LOG = []
             softmax, predictions, loss_value = trainer.train_step(image_sequence, seg_sequence)
+            if profiling:
+                import json
+                from lu_native.profile import summarize_events
+                torch.cuda.synchronize()
+                ev, ops.EVENT_LOG = ops.EVENT_LOG, None
+                mfma_rows, hbm_rows = summarize_events(ev)
+                prof_dir = os.path.join(params.experiment_log_dir, 'profile')
+                os.makedirs(prof_dir, exist_ok=True)
+                with open(os.path.join(prof_dir, 'step_%d.json' % trainer.step), 'w') as fh:
+                    json.dump({'step': trainer.step, 'mfma_kernels': mfma_rows, 'hbm_kernels': hbm_rows,
+                               'counters': 'run the same command under `rocprofv3 --kernel-trace --stats` / `--pmc '
+                                           'FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` '
+                                           'for HBM bytes and MFMA utilisation (tools/gpu/pmc_traffic.sh)'}, fh, indent=1)
+                log_print('Profiled step {}: {}'.format(trainer.step, ', '.join(
+                    '%s %.0f %s' % (r['kernel'].split(' ')[0], r['achieved'], r['unit']) for r in (mfma_rows + hbm_rows)[:4])))
             model.reset_states_per_batch(is_last_batch)
             train_loss(loss_value)
             pred_pub = predictions.permute(0, 1, 4, 2, 3) if params.channel_axis == 1 else predictions
@@ -254,9 +303,14 @@ def train(params):
             log_print('Saving Model Before closing due to error: {}'.format(str(err)))
             save_ckpt()
     finally:
+        if not params.dry_run and trainer.engine.plan is not None:
+            try:
+                sync_bn_stats()
+            except Exception:      # noqa: BLE001 -- a dead peer must not keep rank 0 from writing its model
+                pass
         if not params.dry_run and is_main and trainer.engine.plan is not None:
             model_fname = os.path.join(params.experiment_save_dir, 'model.ckpt')
-            model.save_weights(model_fname)
+            model.save_weights(model_fname, save_format=getattr(params, 'save_format', None))
             with open(os.path.join(params.experiment_save_dir, 'model_params.pickle'), 'wb') as fobj:
                 pickle.dump({'name': model.__class__.__name__, 'params': (params.net_kernel_params,)}, fobj,
                             protocol=pickle.HIGHEST_PROTOCOL)
@@ -296,7 +350,8 @@ FLAGS = [
     (('-n', '--experiment_name'), _FLAG(dest='experiment_name', type=str, help='Name of experiment')),
     (('--gpu_id',), _FLAG(dest='gpu_id', type=str, help="Visible GPUs: example, '0,2,3'")),
     (('--dry_run',), _FLAG(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
-    (('--profile',), _FLAG(dest='profile', type=bool, help='Write profiling data (use rocprofv3 around the run)')),
+    (('--profile',), _FLAG(dest='profile', type=bool,
+                           help='Write per-kernel timing / roofline tables of one step every write_to_tb_interval steps to <log_dir>/profile')),
     (('--root_data_dir',), _FLAG(dest='root_data_dir', type=str, help='Root folder containing training data')),
     (('--data_provider_class',), _FLAG(dest='data_provider_class', type=str, action=_AddReader,
                                        help='Type of data provider')),

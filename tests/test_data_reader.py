@@ -117,3 +117,25 @@ def test_reader_feeds_training_shapes(tmp_path):
                           'crop_size': (32, 32), 'batch_size': 2, 'unroll_len': 2, 'num_train_threads': 1, 'num_val_threads': 1})
     img, seg, full, keep = p.train_data_provider.get_batch()
     assert img.shape == (2, 2, 1, 32, 32) and seg.shape == img.shape
+
+
+def test_short_clips_and_producer_errors_surface(tmp_path):
+    """Two failure modes that used to hang get_batch: (1) deal_with_end = 0 with every clip shorter than unroll_len trims
+    each draw to nothing -- now a ValueError instead of an endless loop; (2) an exception in a producer thread travels
+    through the slot queue and is re-raised in the consumer (the reference stops its coordinator, DataHandeling.py:425-428)."""
+    root = str(tmp_path)
+    _make_ctc(root, n_frames=4)
+    r = _reader(root, unroll_len=5, deal_with_end=0)
+    with pytest.raises(ValueError, match='unroll_len'):
+        r.get_batch()
+    ok = _reader(root, unroll_len=5, deal_with_end=2)            # padding modes still serve such clips
+    assert ok.get_batch()[0].shape == (2, 5, 1, 32, 32)
+    r2 = _reader(root, unroll_len=2, num_threads=2)
+    r2._read_sequence_to_ram_()
+    key = next(iter(r2.sequence_data))
+    r2.sequence_data[key]['images'][1][:] = np.nan               # a non-finite frame -> ValueError inside the worker thread
+    r2._read_sequence_to_ram_ = lambda: None                     # (start_queues would re-read the files)
+    with pytest.raises(ValueError, match='non-finite'):
+        for _ in range(200):
+            r2.get_batch()
+    r2.stop()

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import tiny_net
@@ -73,3 +74,62 @@ def test_dp2_equals_single_process(tmp_path):
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= 2e-3, (diff.max(), (diff > 1e-4).mean())
     # rank-local BN is a different (documented) model: it must NOT coincide with the pooled statistics
     assert np.abs(local['loss'] - ref_loss).max() > 1e-6
+
+
+GPU_WORKER = r'''
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from conftest import tiny_net
+import train2D, Networks
+from lu_native.dp import DataParallel
+dp = DataParallel()                     # LU_DP_BACKEND=gloo: both ranks on the ONE GPU of the box, HIP kernels underneath
+assert dp.world_size == 2 and torch.cuda.is_available()
+d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
+net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3)
+sl = slice(dp.rank, dp.rank + 1)
+_, _, loss = tr.train_step(d['x'][sl], d['gt'][sl])
+tr.model.reset_states_per_batch(np.ones(1, np.float32))
+_, _, loss2 = tr.train_step(d['x'][sl, ::-1].copy(), d['gt'][sl, ::-1].copy())
+torch.cuda.synchronize()
+if dp.rank == 0:
+    np.savez(os.path.join(%(tmp)r, 'dp_gpu_out.npz'), params=tr.engine.flat_params.cpu().numpy(),
+             loss=np.array([float(loss), float(loss2)]))
+dp.barrier()
+'''
+
+
+@pytest.mark.gpu
+def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path):
+    """The N > 1 path on the REAL kernels: two ranks (gloo, sharing the one GPU of the test box -- RCCL needs one device
+    per rank) x 1 slot with SyncBN == one process on the 2-slot batch.  What runs: rank-sharded slots, loss-sum all-reduce
+    before the gradient, bucketed gradient all-reduce fired from the engine's backward, pooled BN statistics."""
+    import train2D
+    import Networks
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 1, 24, 32)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(2, 3, 1, 24, 32)).astype(np.float32)
+    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
+    script = tmp_path / 'worker_gpu.py'
+    script.write_text(GPU_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    port = 29600 + os.getpid() % 1500
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', LU_DP_BACKEND='gloo',
+                                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+    tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, seed=3)
+    _, _, l1 = tr.train_step(x, gt)
+    tr.model.reset_states_per_batch(np.ones(2, np.float32))
+    _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
+    ref = tr.engine.flat_params.cpu().numpy()
+    got = np.load(tmp_path / 'dp_gpu_out.npz')
+    assert np.abs(got['loss'] - np.array([float(l1), float(l2)])).max() <= 1e-5
+    diff = np.abs(got['params'] - ref)
+    assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= 2e-3, (diff.max(), (diff > 1e-4).mean())

@@ -464,3 +464,55 @@ def test_lstm_bptt_backward_consistency(case):
         print('lstm bptt consistency (%s): %s' % (case, report))
         for row in report:
             assert max(row[1:]) <= 1e-5, row
+
+
+def test_block_and_layer_views_share_the_model_parameters(dev):
+    """model.DownLayers[i] / model.UpLayers[i] are callable DownBlock2D / UpBlock2D views over the model's own flat
+    parameter buffer and recurrent state (reference Networks.py:195-205 holds the very layer objects the model calls), their
+    .ConvLSTM / .Conv / .BN / .LReLU entries are callable layer views; trainable_variables lists every tensor by name;
+    WeightedCELoss accepts host logits."""
+    import Networks
+    import losses
+    net = tiny_net(3)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 2, 16, 16, 1)).astype(np.float32)
+    m = Networks.ULSTMnet2D(net, 'NHWC', False, seed=6)
+    with pytest.raises(RuntimeError):
+        m.DownLayers[1](x, False)                                   # the shared variables do not exist yet
+    logits, _ = m(x, False)
+    assert isinstance(m.DownLayers[0], Networks.DownBlock2D) and isinstance(m.UpLayers[0], Networks.UpBlock2D)
+    names = [v.name for v in m.trainable_variables]
+    assert len(names) == len(m.engine.P) and 'down.0.lstm.0.recurrent_kernel' in names and 'up.3.conv.2.bias' in names
+    assert len(m.variables) == len(names) + len(m.engine.S)
+    # the blocks, chained by hand on a twin model, reproduce the model bit for bit (same kernels, same weights, same state)
+    m2 = Networks.ULSTMnet2D(net, 'NHWC', False, seed=6)
+    m2.engine.build(1, dev)
+    skips, seq = [], torch.from_numpy(x).to(dev)
+    flat = seq.reshape((4,) + tuple(seq.shape[2:]))
+    for blk in m2.DownLayers:
+        skips.append(flat)
+        seq, flat = blk(seq, False)
+    up = flat
+    for blk, skip in zip(m2.UpLayers, skips[::-1]):
+        up = blk((up, skip), False)
+    got = up.reshape((2, 2) + tuple(up.shape[1:]))
+    assert torch.equal(got, logits)
+    assert m2.DownLayers[2].get_states()[0][0].shape == m2.get_states()[2][0][0].shape
+    # layer views alias the flat buffer
+    w = m.DownLayers[0].Conv[0].weights[0]
+    assert w.data_ptr() == m.engine.P['down.0.conv.0.kernel'].data_ptr()
+    assert [tuple(t.shape) for t in m.DownLayers[0].ConvLSTM[0].weights] == [(3, 3, 1, 32), (3, 3, 8, 32), (32,)]
+    assert len(m.UpLayers[3].BN[2].weights) == 0                     # constructed, never called: owns no variables
+    y = m.DownLayers[0].Conv[1](torch.from_numpy(rng.standard_normal((1, 8, 8, 8)).astype(np.float32)).to(dev))
+    assert tuple(y.shape) == (1, 8, 8, 8)
+    z = m.DownLayers[0].LReLU[0](torch.tensor([[[[-1.0, 2.0]]]]))
+    assert np.allclose(z.cpu().numpy().ravel(), [-0.3, 2.0])
+    # get_weights / set_weights round trip
+    ws = m.get_weights()
+    m2.set_weights(ws)
+    assert torch.equal(m2.engine.flat_params, m.engine.flat_params)
+    # host logits are accepted by the loss (moved to the device; the arithmetic stays in the HIP kernels)
+    gt = rng.integers(-1, 3, size=(2, 2, 16, 16, 1)).astype(np.float32)
+    ce = losses.WeightedCELoss(4, [0.15, 0.25, 0.6])
+    host = logits.detach().cpu().numpy()
+    assert abs(float(ce(gt, host)) - float(ce(gt, logits))) <= 1e-7

@@ -170,6 +170,6 @@ def test_postprocess_full_frame_832x992():
     """Fluo-C2DL-MSC frame size (BASELINE config-4): hundreds of objects, noisy edges."""
     import torch
     for seed, nested in ((1, False), (2, True)):
-        sm = po.synthetic_softmax(832, 992, seed=seed, n_cells=400, nested=nested, noise=0.4, rmax=16)
+        sm = po.synthetic_softmax(832, 992, seed=seed, n_cells=400, nested=nested, noise=0.25, rmax=16)
         ref, st = _check(torch.device('cuda', 0), sm, edge_dist=2, min_cell_size=10, max_cell_size=5000, fov=0)
         assert ref.max() > 50
