@@ -54,7 +54,8 @@ def _to_internal(x, nchw, device):
         raise ValueError('expected a 5-D [batch, time, ...] tensor, got shape %s' % (tuple(x.shape),))
     x = x.permute(1, 0, 3, 4, 2) if nchw else x.permute(1, 0, 2, 3, 4)
     T, B = x.shape[0], x.shape[1]
-    return x.contiguous().view(T * B, x.shape[2], x.shape[3], x.shape[4]), T, B
+    # (through a flat view: size-1 dimensions keep arbitrary strides under .contiguous(), the kernels want canonical ones)
+    return x.contiguous().reshape(-1).view(T * B, x.shape[2], x.shape[3], x.shape[4]), T, B
 
 
 def _from_internal(y, T, B, nchw):

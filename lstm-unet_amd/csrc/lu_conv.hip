@@ -993,6 +993,13 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
             return;
         }
         const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
+        if (LU_DBG(a, 2)) {      // ablation: no A-fragment LDS reads
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv1, bv0, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv0, bv1, acc[i]);
+            return;
+        }
         // k-step 0 for every row, then k-step 1 (back-to-back MFMAs never depend on each other); all k-step-0 fragments
         // are requested up front and every k-step-1 read hides behind a k-step-0 MFMA
         lu_bf16x8 a0[RW], a1[RW];
@@ -1074,20 +1081,20 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
             // conditional step: the number of loads in flight is then the same on every path and the compiler's vmcnt
             // waits stay exact (a path-dependent count makes it wait for the youngest load, i.e. HBM latency per stage).
             if (pend[s & 1] >= 0) {
-                piece_store(pend[s & 1], hb ^ 1, rp[s & 1]);
+                if (!LU_DBG(a, 4)) piece_store(pend[s & 1], hb ^ 1, rp[s & 1]);
                 pend[s & 1] = -1;
             }
 #ifndef LU_ABL_MFMA_ONLY
-            piece_load(fetch ? sc.tap : 0, fetch ? nc : sc, rp[s & 1], fetch);
+            if (!LU_DBG(a, 4)) piece_load(fetch ? sc.tap : 0, fetch ? nc : sc, rp[s & 1], fetch);
 #endif
             if (fetch) pend[s & 1] = sc.tap;
             sc = sS[(s + D - 1) % D];            // state of stage it + D - 1 ...
             if (it + D < it1) tap_advance(sc);      // ... + 1 (past the end: re-reads the last fragments, unused)
 #ifndef LU_ABL_MFMA_ONLY
-            load_b(sc, rb0[s], rb1[s]);
+            if (!LU_DBG(a, 1)) load_b(sc, rb0[s], rb1[s]);
 #endif
             if (last_tap && it + 1 < it1) {      // (HPASS + 2 <= K*K: the staged pieces have been retired by now)
-                __syncthreads();          // the next halo is complete and every wave is done with the old one
+                if (!LU_DBG(a, 16)) __syncthreads();          // the next halo is complete and every wave is done with the old one
                 hb ^= 1;
                 next_chunk(nc);
             }
@@ -1110,6 +1117,15 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         if (D == 4 && it + 2 < it1) step(it + 2, S2());
     }
 
+    if (LU_DBG(a, 8)) {      // ablation: no epilogue (one store keeps the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][r];
+        if (t == 12345.678f) a.out[0] = t;
+        return;
+    }
     if (EPI == LU_EPI_LSTM) {
         // exchange: wave (wm, wn) holds gate wn of rows RW wm .. RW wm + RW - 1; the gate epilogue wants the four gates of
         // a (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
@@ -1579,7 +1595,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
-    a.dbg = (d->flags >> 16) & 7;      // (only -DLU_ABLATION tool builds look at it)
+    a.dbg = (d->flags >> 16) & 0xff;      // (only -DLU_ABLATION tool builds look at it)
     dim3 block(256);
     // LDS-DMA tile staging measured 4-5 % SLOWER than VGPR staging here (123.5 vs 129.9 TFLOP/s on the recurrent
     // dgrads): opt-in only, kept as a measured negative result.

@@ -31,5 +31,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_ablation(verbose=True):
+    """TOOLS ONLY (tools/kbench.py): the same sources with -DLU_ABLATION, which lets lu_conv_desc.flags >> 16 switch parts of
+    the fragment kernel's loop off (weight loads, LDS reads, halo prefetch, epilogue, barrier) to see what bounds it.  A
+    separate file: the product library never contains these switches."""
+    out = os.path.join(CSRC, 'liblstmunet_abl.so')
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DLU_ABLATION', '-x', 'hip'] + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--ablation' in sys.argv:
+        build_ablation()
+    else:
+        build(force='--force' in sys.argv)

@@ -165,8 +165,11 @@ def test_train_step_parity(dev):
             fl = grad_floor({k: v.numpy() for k, v in grads_ref.items()})
             worst = max((rel_err(e.G[k].cpu().numpy(), grads_ref[k].numpy(), fl), k) for k in grads_ref)
             assert worst[0] <= GRAD_TOL.get(name, 2e-3), (name, step, worst)
+            # (a conv bias in front of BatchNorm has an exactly-zero true gradient -- the mean subtraction cancels it -- so the
+            # product's value there is pure fp32 rounding noise: its floor is wider)
             l2 = max((float(np.linalg.norm(e.G[k].cpu().numpy().astype(np.float64) - grads_ref[k].numpy()) /
-                            max(np.linalg.norm(grads_ref[k].numpy()), fl)), k) for k in grads_ref)
+                            max(np.linalg.norm(grads_ref[k].numpy()), fl * (3.0 if '.conv.' in k and k.endswith('.bias') else 1.0))),
+                      k) for k in grads_ref)
             assert l2[0] <= GRAD_L2_TOL.get(name, 2e-3), (name, step, l2)
             print('train_step_parity %s step %d: worst max-rel %.3e (%s), worst L2-rel %.3e (%s)' %
                   (name, step, worst[0], worst[1], l2[0], l2[1]))

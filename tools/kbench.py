@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'lstm-unet_amd'))
 import torch
 from lu_native import ops
+if os.environ.get('KB_LIB'):           # e.g. lstm-unet_amd/csrc/liblstmunet_abl.so (python -m lu_native.build --ablation)
+    ops.LIB_PATH = os.path.abspath(os.environ['KB_LIB'])
+ops.CONV_FLAGS = int(os.environ.get('KB_DBG', '0')) << 16      # ablation bits (ablation build only)
 
 dev = torch.device('cuda', 0)
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
@@ -71,6 +74,32 @@ for name, hw, cin, F in levels:
             timeit(lambda: ops.conv2d_wgrad(xs, dy, dw2, 1, bf16=True), fl, 'rec_wgrad_bf16 ' + name, reps=2)
             print('   max |dw_bf16 - dw_f32| / max|dw| = %.3e' % ((dw2 - dw).abs().max().item() / dw.abs().max().item()))
         del xs, dy
+
+if 'tape16' in which:    # the bf16-tape kernels exactly as the engine drives them (bf16 sources, bf16 gates / h copies)
+    for name, hw, cin, F in levels:
+        if os.environ.get('KB_LEVEL') and name not in os.environ['KB_LEVEL'].split(','):
+            continue
+        xs = r(B, hw, hw, cin)
+        h, c = r(B, hw, hw, F, scale=0.5), r(B, hw, hw, F)
+        kx, kh, b = r(k, k, cin, 4 * F, scale=0.05), r(k, k, F, 4 * F, scale=0.02), r(4 * F)
+        ph = ops.pack_bf16(kh)
+        if cin % 8:
+            x16, pk, ctr = ops.im2col_bf16(xs, k), ops.pack_center_bf16(kx), True
+        else:
+            x16, pk, ctr = ops.to_bf16(xs), ops.pack_bf16(kx), False
+        h16 = ops.to_bf16(h)
+        ho, co = torch.empty_like(h), torch.empty_like(c)
+        g16 = torch.empty(B, hw, hw, 4 * F, device=dev, dtype=torch.bfloat16)
+        h16o = torch.empty_like(h16)
+        fl = 2.0 * k * k * (cin + F) * 4 * F * hw * hw * B
+        timeit(lambda: ops.convlstm_step(x16, h16, c, pk, ph, b, ho, co, g16, h16_out=h16o, x_center=ctr), fl,
+               'step_tape16 ' + name, reps=10)
+        wt = ops.pack_bf16(ops.flip_transpose(kh))
+        out = torch.empty(B, hw, hw, F, device=dev)
+        p = (k - 1) // 2
+        fl = 2.0 * k * k * F * 4 * F * hw * hw * B
+        timeit(lambda: ops.conv_raw([(g16, wt)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad_tape16 ' + name,
+               reps=10)
 
 if 'misc' in which:     # the layers outside the halo kernels' domain (config-2 shapes, all 32 frames at once)
     FR = 32
