@@ -66,6 +66,8 @@ enum {
     LU_CONV_F_LDS_DMA = 16,      /* general fp32 kernel: global_load_lds staging (measured slower) */
     LU_CONV_F_MF2 = 32,          /* general fp32 kernel: 4-wave variant of the wide tiles */
     LU_CONV_F_GENERAL = 64,      /* general fp32 kernel: the fully general (dilation-capable) instantiation */
+    LU_CONV_F_LOOP_GEN1 = 128,   /* bf16 halo kernel: the first loop generation (run-time tap state machine) instead of the
+                                  * compile-time unrolled tap sequence -- A/B and regression tests */
     LU_CONV_F_GATES_BF16 = 256,  /* LU_EPI_LSTM, precision 1: gates_out is a bf16 tensor (the bf16 BPTT tape) */
     LU_CONV_F_SRC1_CENTER = 512  /* precision 1 halo kernel, two sources: src[1] contributes its CENTRE tap only (k*k = 1):
                                   * the im2col image of a thin input (lu_im2col_bf16) as one 32-channel chunk, weights
@@ -183,7 +185,8 @@ enum {
     LU_WGRAD_F_NO_SMALL3 = 2,    /* do not take the all-taps kernel of the narrow 3x3 layers */
     LU_WGRAD_F_CT64 = 4,         /* bf16 kernel-row variant: force 64-channel tiles */
     LU_WGRAD_F_CT128 = 8,        /* ... force 128-channel tiles */
-    LU_WGRAD_F_SMALL_TILE = 16   /* general kernel: 128 x 128 instead of 128 x 256 tiles */
+    LU_WGRAD_F_SMALL_TILE = 16,  /* general kernel: 128 x 128 instead of 128 x 256 tiles */
+    LU_WGRAD_F_PRB32 = 32        /* bf16 kernel-row variant: 32-pixel stages where 64-pixel ones would be taken (A/B, tests) */
 };
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

@@ -31,6 +31,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <type_traits>
+#include <utility>
 #include "lu_device.h"
 
 namespace {
@@ -81,8 +82,8 @@ struct ConvArgs {
     int64_t c_prev_fs, c_out_fs, h_fs, gates_fs;
 };
 
-#ifdef LU_ABLATION      // tools-only build: loop ablations selected by lu_conv_desc.flags >> 16
-#define LU_DBG(a, bit) ((a).dbg & (bit))
+#ifdef LU_ABLATION      // tools-only builds (-DLU_ABLATION=<bits>): loop ablations as COMPILE-TIME constants -- a run-time
+#define LU_DBG(a, bit) ((LU_ABLATION) & (bit))      // switch between accumulator updates costs 5x by itself (measured)
 #else
 #define LU_DBG(a, bit) 0
 #endif
@@ -834,6 +835,111 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap
 // F32 = false: bf16 operands, 32-channel chunks.  F32 = true: the same structure on the exact fp32 MFMA
 // (v_mfma_f32_32x32x2_f32), 16-channel chunks, weights packed by pack_weights_f32_kernel -- both halo images have an
 // 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
+// Epilogue of the fragment kernels (both loop generations): bias / K-split stores, or the fused ConvLSTM gate block with
+// its exchange of the four gate fragments through the (dead) halo LDS.
+template <int EPI, int RW>
+__device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[RW], unsigned char* Ah, int f, int y0, int x0,
+                                              int nt, int n0, int ks) {
+    constexpr int BN = 128, TW = 32, EX_LD = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    if (LU_DBG(a, 8)) {      // ablation: no epilogue (one store keeps the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][r];
+        if (t == 12345.678f) a.out[0] = t;
+        return;
+    }
+    if (EPI == LU_EPI_LSTM) {
+        // exchange: wave (wm, wn) holds gate wn of rows RW wm .. RW wm + RW - 1; the gate epilogue wants the four gates of
+        // a (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
+        float* Ex = reinterpret_cast<float*>(Ah);      // [2 row groups][32 px][EX_LD]
+        // One (pixel, channel quad) per thread and pass: 64 pixels x 8 quads = 512 threads; 16-byte loads / stores
+        // (8-byte for the bf16 tape) instead of one scalar per gate plane.
+        const int F = a.F;
+        const int pr = tid >> 3, cq = tid & 7;
+        const int g = pr >> 5, px = pr & 31;
+        const int ch = nt * 32 + 4 * cq;                // F % 32 == 0 is enforced by the host
+        float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), bf = bi, bg = bi, bo = bi;
+        if (a.bias) {
+            bi = *reinterpret_cast<const float4*>(a.bias + ch);
+            bf = *reinterpret_cast<const float4*>(a.bias + F + ch);
+            bg = *reinterpret_cast<const float4*>(a.bias + 2 * F + ch);
+            bo = *reinterpret_cast<const float4*>(a.bias + 3 * F + ch);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            __syncthreads();                            // pass 0: all halo reads finished; later: previous pass consumed
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pxr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Ex[(wm * TW + pxr) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
+            }
+            __syncthreads();
+            const int oy = y0 + RW * g + i, ox = x0 + px;
+            if (oy >= a.Hin || ox >= a.Win) continue;
+            const int64_t pix = (int64_t)oy * a.Win + ox;
+            const float* ex = &Ex[(g * TW + px) * EX_LD + 4 * cq];
+            const float4 zi = *reinterpret_cast<const float4*>(ex), zf = *reinterpret_cast<const float4*>(ex + 32),
+                         zg = *reinterpret_cast<const float4*>(ex + 64), zo = *reinterpret_cast<const float4*>(ex + 96);
+            const float4 cp = *reinterpret_cast<const float4*>(a.c_prev + (int64_t)f * a.c_prev_fs + pix * F + ch);
+            float4 gi, gf, gg, go, cn, hn;
+#define LU_GATE(m)                                      \
+    gi.m = hard_sigmoid(zi.m + bi.m);                   \
+    gf.m = hard_sigmoid(zf.m + bf.m);                   \
+    gg.m = tanhf(zg.m + bg.m);                          \
+    go.m = hard_sigmoid(zo.m + bo.m);                   \
+    cn.m = fmaf(gf.m, cp.m, gi.m * gg.m);               \
+    hn.m = go.m * tanhf(cn.m);
+            LU_GATE(x) LU_GATE(y) LU_GATE(z) LU_GATE(w)
+#undef LU_GATE
+            *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
+            *reinterpret_cast<float4*>(a.h_out + (int64_t)f * a.h_fs + pix * F + ch) = hn;
+            if (a.h16_out) {
+                lu_u2 hv;
+                hv.x = lu_pack2bf(hn.x, hn.y);
+                hv.y = lu_pack2bf(hn.z, hn.w);
+                *reinterpret_cast<lu_u2*>(a.h16_out + (int64_t)f * a.h16_fs + pix * F + ch) = hv;
+            }
+            if (a.gates_out) {
+                if (a.gates_bf16) {
+                    unsigned short* gp = reinterpret_cast<unsigned short*>(a.gates_out) + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
+                    lu_u2 v;
+                    v.x = lu_pack2bf(gi.x, gi.y); v.y = lu_pack2bf(gi.z, gi.w);
+                    *reinterpret_cast<lu_u2*>(gp) = v;
+                    v.x = lu_pack2bf(gf.x, gf.y); v.y = lu_pack2bf(gf.z, gf.w);
+                    *reinterpret_cast<lu_u2*>(gp + F) = v;
+                    v.x = lu_pack2bf(gg.x, gg.y); v.y = lu_pack2bf(gg.z, gg.w);
+                    *reinterpret_cast<lu_u2*>(gp + 2 * F) = v;
+                    v.x = lu_pack2bf(go.x, go.y); v.y = lu_pack2bf(go.z, go.w);
+                    *reinterpret_cast<lu_u2*>(gp + 3 * F) = v;
+                } else {
+                    float* gp = a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
+                    *reinterpret_cast<float4*>(gp) = gi;
+                    *reinterpret_cast<float4*>(gp + F) = gf;
+                    *reinterpret_cast<float4*>(gp + 2 * F) = gg;
+                    *reinterpret_cast<float4*>(gp + 3 * F) = go;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int oy = y0 + RW * wm + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (oy >= a.Hin || ox >= a.Win) continue;
+            const int64_t pix = (int64_t)oy * a.Win + ox;
+            float v[1] = {acc[i][r]};
+            conv_epilogue_row<1, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0 + 32 * wn, ks, lane & 31);
+        }
+    }
+}
+
 // B16 = true (bf16 MFMA only): every source is ALREADY a bf16 tensor (the bf16 BPTT tape: h sequence, dz; the bf16 copy of a
 // block input; the im2col image of the thin first input) -- a piece is then 8 channels = 16 raw bytes, half as many
 // loads, no conversion.  The element type is a compile-time property of the launch: a run-time (even uniform) branch
@@ -1117,101 +1223,201 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         if (D == 4 && it + 2 < it1) step(it + 2, S2());
     }
 
-    if (LU_DBG(a, 8)) {      // ablation: no epilogue (one store keeps the accumulators alive)
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < RW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t += acc[i][r];
-        if (t == 12345.678f) a.out[0] = t;
-        return;
+    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Second loop generation of the bf16 fragment kernel (what precision = 1 launches).  Same tile, same LDS images, same
+// fragment streams and the same epilogue as conv_halo_frag_kernel -- what changes is WHO does the bookkeeping.  The first
+// generation advanced a run-time (source, chunk, tap) state machine per pipeline stage: ~200 scalar / vector instructions
+// between two groups of 16 MFMAs, i.e. as many issue cycles as the MFMAs themselves take at bf16 rates (an in-order wave
+// cannot hide its own bookkeeping behind its own MFMAs; the compile-time ablations of tools/gpu/r02_ablate.sh put the
+// MFMA-only loop at 1.5 PFLOP/s against 0.96-1.13 for the real one).  Here the K*K taps of a channel chunk are a
+// compile-time unrolled sequence: tap offsets into the halo, the ring slot of every weight fragment, the tap at which
+// each piece of the next halo is requested and stored are all constants of the instruction stream, and only the chunk
+// (source pointer, weight base) is run-time state, updated once per K*K stages.  The weight-fragment ring is K deep so
+// that slot = tap % K stays static across chunks (K*K % K == 0).
+// ---------------------------------------------------------------------------------------------------------
+template <class Fn, int... T>
+__device__ __forceinline__ void lu_static_for_impl(Fn&& fn, std::integer_sequence<int, T...>) {
+    (fn(std::integral_constant<int, T>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void lu_static_for(Fn&& fn) {
+    lu_static_for_impl(fn, std::make_integer_sequence<int, N>{});
+}
+
+struct ChunkDesc {
+    const unsigned char* x;      // source activations of this block's frame (byte pointer)
+    const unsigned char* w;      // this lane's fragment bytes of (tap 0, chunk)
+    int64_t wts;                 // bytes between taps
+    int ps, C, c0;               // pixel stride (elements), channels of the source, first channel of the chunk
+    int single;                  // 1: the centre-tap-only chunk (its packed image holds ONE tap)
+};
+
+template <int K, int EPI, int RW, bool B16>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
+__global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
+    constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32, KK = K * K;
+    constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
+    constexpr int CKS = CKB;                            // channels per stage
+    constexpr int PC = B16 ? 8 : 4;                     // channels per 16-byte piece
+    constexpr int G = CKS / PC;                         // 16-byte global channel groups per halo pixel
+    constexpr int ESZ = B16 ? 2 : 4;                    // bytes per source element
+    constexpr int HPASS = (HP * G + NT - 1) / NT;       // halo pieces per thread and chunk
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int EX_LD = BN + 4;
+    constexpr int PITCH = 80;                           // bytes per halo pixel: (32 + 8) bf16
+    constexpr int AH_BYTES = HP * PITCH;
+    constexpr int D = K;                                // weight-fragment ring depth (stages)
+    static_assert(HPASS + 2 <= KK, "the next halo is fetched one piece per tap and stored two taps later");
+    static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
+    LU_DYN_LDS(unsigned char, Ah);                      // [2][AH_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int bid = blockIdx.x;
+    const int slot = bid >> 3;
+    const int nt = slot % a.n_tiles;
+    const int tile = (slot / a.n_tiles) * 8 + (bid & 7);
+    if (tile >= a.m_tiles) return;
+    const int f = tile / a.tiles_pf;
+    const int t2 = tile - f * a.tiles_pf;
+    const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
+    const int n0 = nt * BN;
+    const int ks = blockIdx.y;
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const int q = tid % G;
+    const int nfr = (a.N + 31) >> 5;
+    const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
+    const bool frag_ok = frag < nfr;
+    const int wl = frag * 2048 + lane * 16;             // this lane's bytes inside a (tap, chunk) block of the packed weights
+
+    // chunks with K*K taps: source 0, then source 1 unless that one is the centre-tap image (handled after the loop)
+    const int nch0 = a.src[0].nchunk, nch1 = a.n_src > 1 ? a.src[1].nchunk : 0;
+    const bool ctr1 = a.src1_center != 0;
+    const int n_full = nch0 + (ctr1 ? 0 : nch1);
+    auto describe = [&](int ci) {
+        ChunkDesc d;
+        const int s = (ci >= nch0) ? 1 : 0;                  // (ci == n_full with ctr1: the centre chunk = source 1, chunk 0)
+        const int ch = ci - (s ? nch0 : 0);
+        const int nch = s ? a.src[1].nchunk : nch0;
+        d.x = reinterpret_cast<const unsigned char*>(a.src[s].x) + (int64_t)f * a.src[s].frame_stride * ESZ;
+        d.w = reinterpret_cast<const unsigned char*>(a.src[s].w) + (int64_t)ch * nfr * 2048 + wl;
+        d.wts = (int64_t)nch * nfr * 2048;
+        d.ps = a.src[s].pix_stride;
+        d.C = a.src[s].C;
+        d.c0 = ch * CKS;
+        d.single = (s && ctr1) ? 1 : 0;
+        return d;
+    };
+    // K split: whole chunks per slice
+    int cb = 0, ce = n_full;
+    if (a.ksplit > 1) {
+        const int per = (n_full + a.ksplit - 1) / a.ksplit;
+        cb = ks * per < n_full ? ks * per : n_full;
+        ce = cb + per < n_full ? cb + per : n_full;
     }
-    if (EPI == LU_EPI_LSTM) {
-        // exchange: wave (wm, wn) holds gate wn of rows RW wm .. RW wm + RW - 1; the gate epilogue wants the four gates of
-        // a (pixel, channel) in one lane.  Per pass one patch row of each row group goes through LDS.
-        float* Ex = reinterpret_cast<float*>(Ah);      // [2 row groups][32 px][EX_LD]
-        // One (pixel, channel quad) per thread and pass: 64 pixels x 8 quads = 512 threads; 16-byte loads / stores
-        // (8-byte for the bf16 tape) instead of one scalar per gate plane.
-        const int F = a.F;
-        const int pr = tid >> 3, cq = tid & 7;
-        const int g = pr >> 5, px = pr & 31;
-        const int ch = nt * 32 + 4 * cq;                // F % 32 == 0 is enforced by the host
-        float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), bf = bi, bg = bi, bo = bi;
-        if (a.bias) {
-            bi = *reinterpret_cast<const float4*>(a.bias + ch);
-            bf = *reinterpret_cast<const float4*>(a.bias + F + ch);
-            bg = *reinterpret_cast<const float4*>(a.bias + 2 * F + ch);
-            bo = *reinterpret_cast<const float4*>(a.bias + 3 * F + ch);
+
+    auto piece_load = [&](int p, const ChunkDesc& d, lu_u4& r, bool want) {
+        const int hp = (tid + NT * p) / G;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        const bool ok = want && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int c = d.c0 + PC * q;
+        const int64_t off = ((int64_t)(iy * a.Win + ix) * d.ps + c) * ESZ;
+        r = *((ok && c < d.C) ? reinterpret_cast<const lu_u4*>(d.x + off) : zp);
+    };
+    auto piece_store = [&](int p, int hb, const lu_u4& r) {
+        const int hp = (tid + NT * p) / G;
+        if (hp < HP) {
+            if (B16) {
+                *reinterpret_cast<lu_u4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
+            } else {
+                lu_u2 v;
+                v.x = lu_pack2bf(lu_bits2f(r.x), lu_bits2f(r.y));
+                v.y = lu_pack2bf(lu_bits2f(r.z), lu_bits2f(r.w));
+                *reinterpret_cast<lu_u2*>(&Ah[hb * AH_BYTES + hp * PITCH + 8 * q]) = v;
+            }
         }
+    };
+    auto load_b = [&](const ChunkDesc& d, int tap, float4& b0, float4& b1) {
+        const unsigned char* wp = d.w + (d.single ? 0 : tap) * d.wts;
+        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : lu_zero16);
+        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_zero16);
+    };
+
+    f32x16 acc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // this lane's A-fragment address for (row 0 of its row group, tap (0, 0)); a tap adds a compile-time constant
+    const int abase = (RW * wm * HWD + (lane & 31)) * PITCH + 16 * (lane >> 5);
+    auto mma_stage = [&](int hb, int tapoff, const float4& b0, const float4& b1) {
+        const unsigned char* ab = &Ah[hb * AH_BYTES + abase + tapoff];
+        const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
+        lu_bf16x8 a0[RW], a1[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            __syncthreads();                            // pass 0: all halo reads finished; later: previous pass consumed
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pxr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ex[(wm * TW + pxr) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
-            }
-            __syncthreads();
-            const int oy = y0 + RW * g + i, ox = x0 + px;
-            if (oy >= a.Hin || ox >= a.Win) continue;
-            const int64_t pix = (int64_t)oy * a.Win + ox;
-            const float* ex = &Ex[(g * TW + px) * EX_LD + 4 * cq];
-            const float4 zi = *reinterpret_cast<const float4*>(ex), zf = *reinterpret_cast<const float4*>(ex + 32),
-                         zg = *reinterpret_cast<const float4*>(ex + 64), zo = *reinterpret_cast<const float4*>(ex + 96);
-            const float4 cp = *reinterpret_cast<const float4*>(a.c_prev + (int64_t)f * a.c_prev_fs + pix * F + ch);
-            float4 gi, gf, gg, go, cn, hn;
-#define LU_GATE(m)                                      \
-    gi.m = hard_sigmoid(zi.m + bi.m);                   \
-    gf.m = hard_sigmoid(zf.m + bf.m);                   \
-    gg.m = tanhf(zg.m + bg.m);                          \
-    go.m = hard_sigmoid(zo.m + bo.m);                   \
-    cn.m = fmaf(gf.m, cp.m, gi.m * gg.m);               \
-    hn.m = go.m * tanhf(cn.m);
-            LU_GATE(x) LU_GATE(y) LU_GATE(z) LU_GATE(w)
-#undef LU_GATE
-            *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
-            *reinterpret_cast<float4*>(a.h_out + (int64_t)f * a.h_fs + pix * F + ch) = hn;
-            if (a.h16_out) {
-                lu_u2 hv;
-                hv.x = lu_pack2bf(hn.x, hn.y);
-                hv.y = lu_pack2bf(hn.z, hn.w);
-                *reinterpret_cast<lu_u2*>(a.h16_out + (int64_t)f * a.h16_fs + pix * F + ch) = hv;
-            }
-            if (a.gates_out) {
-                if (a.gates_bf16) {
-                    unsigned short* gp = reinterpret_cast<unsigned short*>(a.gates_out) + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
-                    lu_u2 v;
-                    v.x = lu_pack2bf(gi.x, gi.y); v.y = lu_pack2bf(gi.z, gi.w);
-                    *reinterpret_cast<lu_u2*>(gp) = v;
-                    v.x = lu_pack2bf(gf.x, gf.y); v.y = lu_pack2bf(gf.z, gf.w);
-                    *reinterpret_cast<lu_u2*>(gp + F) = v;
-                    v.x = lu_pack2bf(gg.x, gg.y); v.y = lu_pack2bf(gg.z, gg.w);
-                    *reinterpret_cast<lu_u2*>(gp + 2 * F) = v;
-                    v.x = lu_pack2bf(go.x, go.y); v.y = lu_pack2bf(go.z, go.w);
-                    *reinterpret_cast<lu_u2*>(gp + 3 * F) = v;
-                } else {
-                    float* gp = a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch;
-                    *reinterpret_cast<float4*>(gp) = gi;
-                    *reinterpret_cast<float4*>(gp + F) = gf;
-                    *reinterpret_cast<float4*>(gp + 2 * F) = gg;
-                    *reinterpret_cast<float4*>(gp + 3 * F) = go;
-                }
-            }
+            acc[i] = lu_mfma_bf16(a0[i], bv0, acc[i]);
+            a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH + 32);
         }
-        return;
-    }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int oy = y0 + RW * wm + i;
+        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
+        LU_SCHED_GROUP(0x100, RW);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (oy >= a.Hin || ox >= a.Win) continue;
-            const int64_t pix = (int64_t)oy * a.Win + ox;
-            float v[1] = {acc[i][r]};
-            conv_epilogue_row<1, EPI>(a, v, f, pix, (int64_t)f * a.HWo + pix, nt, n0 + 32 * wn, ks, lane & 31);
+        for (int i = 0; i < RW; ++i) {
+            LU_SCHED_GROUP(0x008, 1);
+            LU_SCHED_GROUP(0x100, 1);
+        }
+        LU_SCHED_GROUP(0x008, RW);
+    };
+
+    const bool have_center = ctr1 && ce == n_full;           // this slice ends with the centre-tap stage
+    if (ce > cb || have_center) {
+        ChunkDesc cur = describe(cb < ce ? cb : n_full);
+        float4 rb0[D], rb1[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) load_b(cur, j, rb0[j], rb1[j]);
+        {
+            lu_u4 rh[HPASS];                     // first halo: all pieces at once
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_load(p, cur, rh[p], true);
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_store(p, 0, rh[p]);
+        }
+        __syncthreads();
+        int hb = 0;
+        lu_u4 rp0 = lu_u4{0u, 0u, 0u, 0u}, rp1 = lu_u4{0u, 0u, 0u, 0u};
+        for (int ci = cb; ci < ce; ++ci) {
+            const bool has_next = ci + 1 < ce || have_center;
+            const ChunkDesc nxt = describe(has_next ? ci + 1 : ci);      // (no next chunk: harmless re-reads of this one)
+            lu_static_for<KK>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                constexpr int sl = tap % D;
+                LU_SCHED_FENCE();
+                mma_stage(hb, ((tap / K) * HWD + (tap % K)) * PITCH, rb0[sl], rb1[sl]);
+                LU_SCHED_FENCE();
+                // the piece requested two taps ago is older than the fragments the MFMAs above waited for: it has landed
+                if (tap >= 2 && tap - 2 < HPASS) piece_store(tap - 2, hb ^ 1, ((tap - 2) & 1) ? rp1 : rp0);
+                if (tap < HPASS) piece_load(tap, nxt, (tap & 1) ? rp1 : rp0, has_next);
+                if (tap + D < KK) load_b(cur, tap + D, rb0[sl], rb1[sl]);
+                else load_b(nxt, tap + D - KK, rb0[sl], rb1[sl]);
+            });
+            __syncthreads();                     // the next halo is complete and every wave is done with the old one
+            hb ^= 1;
+            cur = nxt;
+        }
+        if (have_center) {                       // one more stage: the centre tap of the im2col chunk (ring slot 0 holds its fragments)
+            LU_SCHED_FENCE();
+            mma_stage(hb, (PAD * HWD + PAD) * PITCH, rb0[0], rb1[0]);
+            LU_SCHED_FENCE();
         }
     }
+    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1575,6 +1781,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
     }
     const bool want_xcd_n = (d->flags & LU_CONV_F_XCD_BY_N) != 0;
+    const bool gen1 = (d->flags & LU_CONV_F_LOOP_GEN1) != 0;      // A/B: the first loop generation of the bf16 fragment kernel
     bool src16 = false;      // all sources bf16 tensors (a property of the launch: mixed element types are rejected)
     for (int s2 = 0; s2 < a.n_src; ++s2) {
         LU_REQUIRE(!a.src[s2].bf16 || (halo && d->precision == 1),
@@ -1628,7 +1835,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
         dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
         LU_REQUIRE(d->dil == 1 && d->stride == 1 && k_h == d->k, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1, a square kernel");
-        if (d->precision == 1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        // (3x3: the first loop generation -- its 8-row-patch instance fits 4 waves per SIMD, the unrolled one does not: measured)
+        if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 1 && !gen1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 1 && !gen1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (d->precision == 1 && !gen1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (d->precision == 1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->precision == 1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (d->precision == 1 && src16) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
@@ -1673,7 +1885,15 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
         a.n_tiles = (d->N + 127) / 128;
         dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
-        if (halo && src16 && d->k == 5 && th == 16)
+        if (halo && !gen1 && src16 && d->k == 5 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (halo && !gen1 && src16 && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (halo && !gen1 && d->k == 5 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        else if (halo && !gen1 && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (halo && src16 && d->k == 5 && th == 16)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && src16 && d->k == 5)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);

@@ -396,18 +396,26 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 
-template <int K, int CT, bool XB, bool YB>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+//   S = 2: the stride-2 3x3 layers (first convolution of a down block).  A stage is still 32 OUTPUT pixels of one output
+//   row; the x tile holds the 2 * 31 + K input pixels under them and a tap-t fragment reads every second tile row
+//   (the transposing read takes one address per lane, so a row stride costs nothing).
+//   PRBT = 64 (W % 64 == 0): 64-pixel stages.  All eight waves meet at a barrier per stage, so whatever a stage spends on
+//   loads, LDS stores and cursor arithmetic (about as many issue cycles as 20 MFMAs take) is exposed once per stage;
+//   twice the MFMAs per stage halves that share.  One register set then suffices (a load has a whole 2600-cycle stage to land).
+template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
 __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
-    constexpr int BMw = CT, BNw = 128, XP = PRB + K - 1, NT = 512;
+    constexpr int PRB = PRBT;      // (shadows the file-level default inside this kernel)
+    constexpr int BMw = CT, BNw = 128, XP = S * (PRB - 1) + K, NT = 512;
     constexpr int WMC = CT / 32, WNN = 8 / WMC, NFW = BNw / (32 * WNN);
     constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 per LDS row: pitch = 64 B (mod 256 B)
     constexpr int XE = XB ? 8 : 4, YE = YB ? 8 : 4;     // elements per 16-byte piece
     constexpr int PX = BMw / XE, PY = BNw / YE;         // pieces per tile row
     constexpr int XPASS = (XP * PX + NT - 1) / NT, YPASS = PRB * PY / NT;
     static_assert(PRB * PY % NT == 0, "dy tile: whole passes");
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[2][XP * XLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Ys[2][PRB * YLD];
-    __shared__ float Bred[8 * BNw];
+    LU_DYN_LDS(unsigned short, smem);      // Xs[2][XP * XLD] | Ys[2][PRB * YLD] | Bred[8 * 128] floats (wgrad_row_bf16_lds)
+    unsigned short* const Xs = smem;
+    unsigned short* const Ys = smem + 2 * XP * XLD;
+    float* const Bred = reinterpret_cast<float*>(Ys + 2 * PRB * YLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WMC, wn = wave / WMC;
     // XCD-aware numbering: block b runs on XCD b % 8; the `inner` tiles of a pixel slab are consecutive on one XCD
@@ -442,14 +450,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
 
     auto load_stage = [&](lu_u4 (&rx)[XPASS], lu_u4 (&ry)[YPASS]) {
         const bool live = ls < n_it;
-        const int iy = oy + kh - a.pad_t;
+        const int iy = S * oy + kh - a.pad_t;
         const bool rowok = live && iy >= 0 && iy < a.Hin;
-        const int64_t xrow = pf * a.x_fs + ((int64_t)iy * a.Win + (ox0 - a.pad_l)) * a.x_ps + c0;
+        const int64_t xrow = pf * a.x_fs + ((int64_t)iy * a.Win + (S * ox0 - a.pad_l)) * a.x_ps + c0;
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) {
             const int item = tid + NT * i;
             const int xr = item / PX, q = item - xr * PX;
-            const int ix = ox0 - a.pad_l + xr;
+            const int ix = S * ox0 - a.pad_l + xr;
             const bool ok = rowok && xr < XP && ix >= 0 && ix < a.Win && c0 + XE * q < a.C;
             const int64_t off = xrow + (int64_t)xr * a.x_ps + XE * q;
             const lu_u4* pp = XB ? reinterpret_cast<const lu_u4*>(reinterpret_cast<const unsigned short*>(a.x) + off)
@@ -491,13 +499,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         for (int i = 0; i < XPASS; ++i) {
             const int item = tid + NT * i;
             const int xr = item / PX, q = item - xr * PX;
-            if (xr < XP) put(&Xs[buf][xr * XLD + XE * q], rx[i], XB);
+            if (xr < XP) put(&Xs[buf * (XP * XLD) + xr * XLD + XE * q], rx[i], XB);
         }
 #pragma unroll
         for (int i = 0; i < YPASS; ++i) {
             const int item = tid + NT * i;
             const int yr = item / PY, q = item - yr * PY;
-            put(&Ys[buf][yr * YLD + YE * q], ry[i], YB);
+            put(&Ys[buf * (PRB * YLD) + yr * YLD + YE * q], ry[i], YB);
         }
         if (want_bias) {          // bias gradient = column sums of dy (of the values the MFMA sees when dy is bf16)
 #pragma unroll
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     // columns 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
     const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const int xoff = frow * XLD + wm * 32 + fcol, yoff = frow * YLD + wn * 32 * NFW + fcol;
+    const int xoff = S * frow * XLD + wm * 32 + fcol, yoff = frow * YLD + wn * 32 * NFW + fcol;
     auto frag = [&](const unsigned short* base, int ld) {      // 8 consecutive k (rows) of this lane's column
         const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + 4 * ld);
         lu_bf16x8 v;
@@ -547,45 +555,77 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     auto mma_half = [&](int buf, int j) {
         lu_bf16x8 bv[NFW];
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf][yoff + 16 * j * YLD + 32 * nf], YLD);
-        short xw[4 * NR];
+        for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf * (PRB * YLD) + yoff + 16 * j * YLD + 32 * nf], YLD);
+        if constexpr (S == 1) {
+            short xw[4 * NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf][xoff + (16 * j + 4 * r) * XLD]);
-            xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
-        }
+            for (int r = 0; r < NR; ++r) {
+                const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf * (XP * XLD) + xoff + (16 * j + 4 * r) * XLD]);
+                xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
+            }
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
-            lu_bf16x8 av;
+            for (int t = 0; t < K; ++t) {
+                lu_bf16x8 av;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
+                for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
 #pragma unroll
-            for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
+                for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
+            }
+        } else {      // strided rows: consecutive k are S tile rows apart -- one pair of reads per tap
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const unsigned short* base = &Xs[buf * (XP * XLD) + xoff + (S * 16 * j + t) * XLD];
+                const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + S * 4 * XLD);
+                lu_bf16x8 av;
+                av[0] = lo[0]; av[1] = lo[1]; av[2] = lo[2]; av[3] = lo[3];
+                av[4] = hi[0]; av[5] = hi[1]; av[6] = hi[2]; av[7] = hi[3];
+#pragma unroll
+                for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
+            }
         }
     };
 
-    lu_u4 rxA[XPASS], ryA[YPASS], rxB[XPASS], ryB[YPASS];
-    load_stage(rxA, ryA);              // stage 0
-    store_stage(0, rxA, ryA);
-    load_stage(rxA, ryA);              // stage 1
-    load_stage(rxB, ryB);              // stage 2
-    __syncthreads();
     const int l31 = lane & 31;
-    for (int it = 0; it < n_it; it += 2) {
-        mma_half(0, 0);
-        LU_SCHED_FENCE();
-        store_stage(1, rxA, ryA);      // stage it + 1 (requested two MFMA phases ago)
-        load_stage(rxA, ryA);          // stage it + 3
-        LU_SCHED_FENCE();
-        mma_half(0, 1);
+    if constexpr (PRB == 32) {
+        lu_u4 rxA[XPASS], ryA[YPASS], rxB[XPASS], ryB[YPASS];
+        load_stage(rxA, ryA);              // stage 0
+        store_stage(0, rxA, ryA);
+        load_stage(rxA, ryA);              // stage 1
+        load_stage(rxB, ryB);              // stage 2
         __syncthreads();
-        mma_half(1, 0);
-        LU_SCHED_FENCE();
-        store_stage(0, rxB, ryB);      // stage it + 2
-        load_stage(rxB, ryB);          // stage it + 4
-        LU_SCHED_FENCE();
-        mma_half(1, 1);
+        for (int it = 0; it < n_it; it += 2) {
+            mma_half(0, 0);
+            LU_SCHED_FENCE();
+            store_stage(1, rxA, ryA);      // stage it + 1 (requested two MFMA phases ago)
+            load_stage(rxA, ryA);          // stage it + 3
+            LU_SCHED_FENCE();
+            mma_half(0, 1);
+            __syncthreads();
+            mma_half(1, 0);
+            LU_SCHED_FENCE();
+            store_stage(0, rxB, ryB);      // stage it + 2
+            load_stage(rxB, ryB);          // stage it + 4
+            LU_SCHED_FENCE();
+            mma_half(1, 1);
+            __syncthreads();
+        }
+    } else {
+        lu_u4 rxA[XPASS], ryA[YPASS];
+        load_stage(rxA, ryA);              // stage 0
+        store_stage(0, rxA, ryA);
+        load_stage(rxA, ryA);              // stage 1
         __syncthreads();
+        for (int it = 0; it < n_it; ++it) {
+            const int buf = it & 1;
+            mma_half(buf, 0);
+            LU_SCHED_FENCE();
+            store_stage(buf ^ 1, rxA, ryA);      // stage it + 1 (requested one whole stage ago)
+            load_stage(rxA, ryA);                // stage it + 2
+            LU_SCHED_FENCE();
+#pragma unroll
+            for (int j = 1; j < PRB / 16; ++j) mma_half(buf, j);
+            __syncthreads();
+        }
     }
 
     float* slab = a.ws + (int64_t)z * a.slab;
@@ -798,6 +838,12 @@ __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ ws, int N, in
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// dynamic LDS of wgrad_row_bf16_kernel<K, CT, *, *, S, PRBT>
+size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb) {
+    const int XP = S * (prb - 1) + K, XLD = CT + 32, YLD = 128 + 32;
+    return (size_t)(2 * XP * XLD + 2 * prb * YLD) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
+}
+
 }  // namespace
 
 extern "C" size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d) {
@@ -822,7 +868,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.C = d->C;
     a.N = d->N;
     a.M = (int64_t)d->frames * d->Hout * d->Wout;
-    a.chunk = ((a.M + splits - 1) / splits + PRB - 1) / PRB * PRB;     // multiple of both kernels' pixel runs (16 / 32)
+    a.chunk = ((a.M + splits - 1) / splits + 63) / 64 * 64;     // multiple of every kernel's pixel run (16 / 32 / 64)
     a.HWo = d->Hout * d->Wout;
     a.Wout = d->Wout;
     a.Hout = d->Hout;
@@ -856,11 +902,14 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     // (a 1x1 layer with >= 32 channels also fits the bf16 kernel-row scheme: one tap, no halo -- the im2col chunk of a thin input)
     const bool row_k1 = xvec && yvec && d->stride == 1 && d->k == 1 && d->precision == 1 && d->C >= 32 && d->Wout == d->Win &&
                         d->Hout == d->Hin && !d->dbias && !(d->flags & LU_WGRAD_F_NO_ROW);
-    const bool row_bf16 = ((row_variant && !small3) || row_k1) && d->precision == 1 && d->Wout % PRB == 0;
+    // ... and the stride-2 3x3 layers (x rows read with a stride; the general fp32 kernel ran them at 73 TFLOP/s in bf16 mode)
+    const bool row_s2 = xvec && yvec && d->stride == 2 && d->k == 3 && d->precision == 1 && d->C >= 64 &&
+                        d->Hout == (d->Hin + 1) / 2 && d->Wout == (d->Win + 1) / 2 && !(d->flags & LU_WGRAD_F_NO_ROW);
+    const bool row_bf16 = ((row_variant && !small3) || row_k1 || row_s2) && d->precision == 1 && d->Wout % PRB == 0;
     LU_REQUIRE((!xb && !yb) || row_bf16,
                "lu_conv2d_wgrad: bf16 operands need the bf16 kernel-row variant (precision 1, stride-1 3x3 / 5x5 with C >= 64 or 1x1 with C >= 32, "
                "C %% 8 == 0, N %% 8 == 0, W %% 32 == 0, 16-byte aligned)");
-    LU_REQUIRE(!d->dbias || row_variant || small3,
+    LU_REQUIRE(!d->dbias || row_variant || small3 || (row_s2 && row_bf16),
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
     if (d->phase == 2) {
@@ -881,17 +930,36 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         dim3 grid((unsigned)(8 * a.inner * ((splits + 7) / 8)));      // XCD-aware numbering: see the kernel
 #define LU_WGB(K_, CT_)                                                                                              \
     do {                                                                                                             \
-        if (xb && yb) LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, true, true>), grid, dim3(512), stream, a);            \
-        else if (yb) LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, false, true>), grid, dim3(512), stream, a);            \
-        else if (xb) LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, true, false>), grid, dim3(512), stream, a);            \
-        else LU_LAUNCH((wgrad_row_bf16_kernel<K_, CT_, false, false>), grid, dim3(512), stream, a);                   \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, true>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);            \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, true>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);            \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, false>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);            \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, false>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);                   \
     } while (0)
-        if (d->k == 1) LU_WGB(1, 64);
+#define LU_WGB64(K_)      /* 64-pixel stages: 128-channel tiles of the 5x5 ConvLSTM kernels (the bulk of the step) */    \
+    do {                                                                                                             \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, true, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);     \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, true, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);     \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);     \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);            \
+    } while (0)
+#define LU_WGB2(CT_)                                                                                                  \
+    do {                                                                                                             \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);          \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);          \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);          \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);                 \
+    } while (0)
+        if (d->stride == 2 && ct == 128) LU_WGB2(128);
+        else if (d->stride == 2) LU_WGB2(64);
+        else if (d->k == 1) LU_WGB(1, 64);
+        else if (d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32)) LU_WGB64(5);
         else if (d->k == 5 && ct == 128) LU_WGB(5, 128);
         else if (d->k == 5) LU_WGB(5, 64);
         else if (ct == 128) LU_WGB(3, 128);
         else LU_WGB(3, 64);
 #undef LU_WGB
+#undef LU_WGB64
+#undef LU_WGB2
     } else if (row_variant) {
         a.c_tiles = (d->C + 63) / 64;
         dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);

@@ -67,6 +67,7 @@ class Engine:
         self.segments = []   # [(name, start, end)] gradient buckets in backward-completion order
         self.on_bucket_ready = None  # callback(start, end) fired as each bucket's gradient completes
         self.debug = None            # tests/diag/diag_gpu.py: dict collecting clones of intermediate gradients
+        self._h16_seq = None         # bf16 copy of the last ConvLSTM output of the current down block (bf16 tape)
 
     # ------------------------------------------------------------------ build
     def build(self, in_channels, device):
@@ -165,8 +166,10 @@ class Engine:
             scale, shift = ops.bn_finalize_infer(gamma, beta, mm, mv, BN_EPS)
         return ops.bn_lrelu_apply(y, scale, shift, LRELU_ALPHA)
 
-    def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape):
-        """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151)."""
+    def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape, alt16=None):
+        """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151).
+        alt16: a bf16 copy of the (single) source, if one exists (the ConvLSTM output of a down block): the x operand of the
+        layer's weight gradient in bf16 mode."""
         wname = f'{prefix}.conv.{ci}.kernel'
         w = self.P[wname]
         vec = all(x.shape[3] % 4 == 0 and x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -180,7 +183,7 @@ class Engine:
         y = ops.conv2d(pairs, self.P[f'{prefix}.conv.{ci}.bias'], spec['stride'])
         rec = None
         if tape is not None:
-            rec = {'kind': 'conv', 'prefix': prefix, 'ci': ci, 'spec': spec, 'srcs': srcs, 'bn': with_bn}
+            rec = {'kind': 'conv', 'prefix': prefix, 'ci': ci, 'spec': spec, 'srcs': srcs, 'bn': with_bn, 'alt16': alt16}
             tape.append(rec)
         if not with_bn:
             return y
@@ -214,11 +217,14 @@ class Engine:
         dxs = []
         for si, ((x, co, cs), need) in enumerate(zip(rec['srcs'], need_dx)):
             # the bias gradient (column sums of dy) rides on the first source's weight-gradient launch
+            a16 = rec.get('alt16')
+            if a16 is not None and self.precision == 'bf16' and ops.bf16_row_wgrad_ok(a16, dy, gw.shape[0], spec['stride']):
+                x = a16
             ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
                              dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
                                         bf16=self.precision == 'bf16' and cs >= 64) if need else None)
-        rec['srcs'] = None
+        rec['srcs'] = rec['alt16'] = None
         return dxs
 
     # ------------------------------------------------------------------ ConvLSTM layer
@@ -288,6 +294,7 @@ class Engine:
         if tape is not None:
             tape.append({'kind': 'lstm', 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'h_all': h_all, 'c_all': c_all,
                          'gates': gates, 'T': T, 'B': B, 'h16_all': h16_all, 'x25': x5 if x_center else None, 'x16': x16})
+        self._h16_seq = h16_all[1:].view(T * B, H, W, F) if (h16_all is not None and tape is not None) else None
         return h_all[1:].view(T * B, H, W, F)
 
     def _lstm_backward(self, rec, dh_seq, need_dx):
@@ -380,10 +387,13 @@ class Engine:
         for bi, blk in enumerate(plan['down']):
             skips.append(act)
             seq = act
+            self._h16_seq = None
             for li, l in enumerate(blk['lstm']):
                 seq = self._lstm_forward(bi, li, l, seq, T, B, tape)
             for ci, l in enumerate(blk['conv']):
-                seq = self._conv_unit(f'down.{bi}', ci, l, [(seq, 0, l['cin'])], True, training, tape)
+                seq = self._conv_unit(f'down.{bi}', ci, l, [(seq, 0, l['cin'])], True, training, tape,
+                                      alt16=self._h16_seq if ci == 0 else None)
+            self._h16_seq = None
             act = seq
         up_in = act
         for bi, (blk, skip) in enumerate(zip(plan['up'], skips[::-1])):

@@ -110,6 +110,8 @@ def _conv_bf16_cases(be, flags=0):
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
         got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags)
         close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
+        # the two loop generations of the kernel walk the same (chunk, tap) order: bit-identical
+        assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_CONV_F_LOOP_GEN1))
         full = npo.conv2d_same(x, w, b, 1)
         assert np.abs(got - full).max() <= 2.0 ** -7 * np.abs(full).max()
     xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources (UpBlock concat)
@@ -148,6 +150,8 @@ def _conv_bf16_cases(be, flags=0):
     h0, c0, g0 = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=flags)
     hg, cg, g16, h16 = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags)
     assert np.array_equal(hg, h0) and np.array_equal(cg, c0)
+    hg1, cg1, g161, _ = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags | cabi.LU_CONV_F_LOOP_GEN1)
+    assert np.array_equal(hg1, hg) and np.array_equal(cg1, cg) and np.array_equal(g161, g16)
     assert np.array_equal(g16, R(g0)) and np.array_equal(h16, R(h0))
     for (k, cin) in [(5, 1), (3, 3)]:
         x, h, c = rnd(2, 16, 32, cin), rnd(2, 16, 32, F, scale=0.5), rnd(2, 16, 32, F)
@@ -382,6 +386,14 @@ def _wgrad_bf16_cases(be, flags=0):
         assert np.array_equal(got, base)
         close(db, (R(dy) if yb else dy).reshape(-1, N).sum(0), 2e-4)
         close(db0, dy.reshape(-1, N).sum(0), 2e-4)
+    for (fr, H, W, Cc, N, sp, xb, yb) in [(2, 6, 64, 72, 136, 2, True, False), (1, 5, 64, 64, 64, 1, False, False),
+                                          (1, 8, 128, 128, 72, 3, True, True)]:      # stride-2 3x3 (TF-SAME: odd H too)
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, (H + 1) // 2, W // 2, N)
+        _, gw = _torch_conv_grads(R(x), rnd(3, 3, Cc, N), R(dy), 2)
+        got, db = KH.conv2d_wgrad(be, x, dy, 3, 2, splits=sp, precision=1, flags=flags, x_bf16=xb, dy_bf16=yb,
+                                  dbias0=np.zeros(N, np.float32))
+        close(got, gw, 2e-4)
+        close(db, (R(dy) if yb else dy).reshape(-1, N).sum(0), 2e-4)
     x, dy = rnd(2, 4, 32, 32), rnd(2, 4, 32, 72)              # 1x1 problem over 32 rows: the im2col chunk of a thin input
     _, gw = _torch_conv_grads(R(x), rnd(1, 1, 32, 72), R(dy), 1)
     close(KH.conv2d_wgrad(be, x, dy, 1, 1, splits=2, precision=1, x_bf16=True, dy_bf16=True), gw, 2e-4)

@@ -7,7 +7,6 @@ import torch
 from lu_native import ops
 if os.environ.get('KB_LIB'):           # e.g. lstm-unet_amd/csrc/liblstmunet_abl.so (python -m lu_native.build --ablation)
     ops.LIB_PATH = os.path.abspath(os.environ['KB_LIB'])
-ops.CONV_FLAGS = int(os.environ.get('KB_DBG', '0')) << 16      # ablation bits (ablation build only)
 
 dev = torch.device('cuda', 0)
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
