@@ -231,13 +231,19 @@ def main():
             traffic_db = {}
 
         def traffic_of(kind):
-            """launch-weighted mean over the rocprof kernel names of this class, e.g. the event-log class
-            conv_halo_frag_kernel<5,LU_EPI_LSTM,*,bf16> covers rocprof's conv_halo_frag_kernel<5, 1, 8, false> and <5, 1, 4, false>."""
+            """launch-weighted mean over the rocprof kernel names of this event class, e.g. the class
+            conv_halo_frag_kernel<5,LU_EPI_LSTM,*,bf16> covers rocprof's conv_halo_frag2_kernel<5, 1, 8, true> and <5, 1, 4, true>
+            (and the first-generation conv_halo_frag_kernel<5, 1, 8, false, ...> of older tables)."""
             name = kind.split(' ')[0]
-            name = name.replace(',LU_EPI_LSTM', ', 1').replace(',LU_EPI_BIAS', ', 0').replace(',*,bf16>', ', [0-9], false>')
-            pat = re.escape(name).replace(re.escape('[0-9]'), '[0-9]')
-            if name.startswith('wgrad_row_bf16_kernel<'):      # rocprof: wgrad_row_bf16_kernel<5, 128>
-                pat = re.escape(name[:-1]) + r', \d+>'
+            m = re.match(r'(\w+)<(\d)(?:,LU_EPI_(LSTM|BIAS))?', name)
+            if name.startswith('conv_halo_frag_kernel<') and m:
+                pat = r'conv_halo_frag2?_kernel<%s, %d, ' % (m.group(2), 1 if m.group(3) == 'LSTM' else 0)
+            elif name.startswith('wgrad_row_bf16_kernel<') and m:      # rocprof: wgrad_row_bf16_kernel<5, 128, true, true, 1, 64>
+                pat = r'wgrad_row_bf16_kernel<%s, ' % m.group(2)
+            elif m and m.group(3):                                     # conv_halo_kernel<5,LU_EPI_LSTM> -> <5, 1>
+                pat = re.escape('%s<%s, %d>' % (m.group(1), m.group(2), 1 if m.group(3) == 'LSTM' else 0))
+            else:
+                pat = re.escape(name) + (r'[<(]' if '<' not in name else '')
             hit = [v for k_, v in traffic_db.items() if re.search(pat, k_)]
             n = sum(v['launches'] for v in hit)
             return round(sum(v['traffic_bytes_per_launch'] * v['launches'] for v in hit) / n) if n else None

@@ -412,9 +412,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     constexpr int PX = BMw / XE, PY = BNw / YE;         // pieces per tile row
     constexpr int XPASS = (XP * PX + NT - 1) / NT, YPASS = PRB * PY / NT;
     static_assert(PRB * PY % NT == 0, "dy tile: whole passes");
-    LU_DYN_LDS(unsigned short, smem);      // Xs[2][XP * XLD] | Ys[2][PRB * YLD] | Bred[8 * 128] floats (wgrad_row_bf16_lds)
+    constexpr int XPA = XPASS * NT / PX;   // x-tile rows ALLOCATED: every (thread, pass) owns a slot, so the stores need no guard
+    LU_DYN_LDS(unsigned short, smem);      // Xs[2][XPA * XLD] | Ys[2][PRB * YLD] | Bred[8 * 128] floats (wgrad_row_bf16_lds)
     unsigned short* const Xs = smem;
-    unsigned short* const Ys = smem + 2 * XP * XLD;
+    unsigned short* const Ys = smem + 2 * XPA * XLD;
     float* const Bred = reinterpret_cast<float*>(Ys + 2 * PRB * YLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WMC, wn = wave / WMC;
@@ -422,9 +423,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int z = (jb / a.inner) * 8 + xcd;
     if (z >= a.splits) return;
+    // inside a slab: (kernel row, c-tile) fastest, n-tile slowest.  An XCD holds 32 blocks at a time; with more tiles than
+    // that per slab (L1: 5 x 2 x 8 = 80) the concurrent set should share dy columns -- every "round" then reads all of x
+    // (the small operand) but a DISJOINT part of dy, instead of all of dy every round (PMC: 3.3x -> see profiles/)
     int tl = jb % a.inner;
-    const int n0 = (tl % a.n_tiles) * BNw;
-    tl /= a.n_tiles;
+    const int rc = a.inner / a.n_tiles;          // K * c_tiles
+    const int n0 = (tl / rc) * BNw;
+    tl -= (tl / rc) * rc;
     const int kh = tl / a.c_tiles;
     const int c0 = (tl - kh * a.c_tiles) * BMw;
     const int64_t p_begin = (int64_t)z * a.chunk;
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         for (int i = 0; i < XPASS; ++i) {
             const int item = tid + NT * i;
             const int xr = item / PX, q = item - xr * PX;
-            if (xr < XP) put(&Xs[buf * (XP * XLD) + xr * XLD + XE * q], rx[i], XB);
+            put(&Xs[buf * (XPA * XLD) + xr * XLD + XE * q], rx[i], XB);      // (rows >= XP: zeros into slots nobody reads)
         }
 #pragma unroll
         for (int i = 0; i < YPASS; ++i) {
@@ -507,6 +512,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
             const int yr = item / PY, q = item - yr * PY;
             put(&Ys[buf * (PRB * YLD) + yr * YLD + YE * q], ry[i], YB);
         }
+    };
+    auto bias_stage = [&](const lu_u4 (&ry)[YPASS]) {
         if (want_bias) {          // bias gradient = column sums of dy (of the values the MFMA sees when dy is bf16)
 #pragma unroll
             for (int i = 0; i < YPASS; ++i) {
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
             short xw[4 * NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf * (XP * XLD) + xoff + (16 * j + 4 * r) * XLD]);
+                const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf * (XPA * XLD) + xoff + (16 * j + 4 * r) * XLD]);
                 xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
             }
 #pragma unroll
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         } else {      // strided rows: consecutive k are S tile rows apart -- one pair of reads per tap
 #pragma unroll
             for (int t = 0; t < K; ++t) {
-                const unsigned short* base = &Xs[buf * (XP * XLD) + xoff + (S * 16 * j + t) * XLD];
+                const unsigned short* base = &Xs[buf * (XPA * XLD) + xoff + (S * 16 * j + t) * XLD];
                 const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + S * 4 * XLD);
                 lu_bf16x8 av;
                 av[0] = lo[0]; av[1] = lo[1]; av[2] = lo[2]; av[3] = lo[3];
@@ -589,6 +596,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     if constexpr (PRB == 32) {
         lu_u4 rxA[XPASS], ryA[YPASS], rxB[XPASS], ryB[YPASS];
         load_stage(rxA, ryA);              // stage 0
+        bias_stage(ryA);
         store_stage(0, rxA, ryA);
         load_stage(rxA, ryA);              // stage 1
         load_stage(rxB, ryB);              // stage 2
@@ -596,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         for (int it = 0; it < n_it; it += 2) {
             mma_half(0, 0);
             LU_SCHED_FENCE();
+            bias_stage(ryA);
             store_stage(1, rxA, ryA);      // stage it + 1 (requested two MFMA phases ago)
             load_stage(rxA, ryA);          // stage it + 3
             LU_SCHED_FENCE();
@@ -603,6 +612,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
             __syncthreads();
             mma_half(1, 0);
             LU_SCHED_FENCE();
+            bias_stage(ryB);
             store_stage(0, rxB, ryB);      // stage it + 2
             load_stage(rxB, ryB);          // stage it + 4
             LU_SCHED_FENCE();
@@ -612,18 +622,28 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     } else {
         lu_u4 rxA[XPASS], ryA[YPASS];
         load_stage(rxA, ryA);              // stage 0
+        bias_stage(ryA);
         store_stage(0, rxA, ryA);
         load_stage(rxA, ryA);              // stage 1
         __syncthreads();
         for (int it = 0; it < n_it; ++it) {
             const int buf = it & 1;
             mma_half(buf, 0);
+            bias_stage(ryA);
             LU_SCHED_FENCE();
+            // One branch-free scheduling region: the LDS stores of stage it + 1, the loads of stage it + 2 and the remaining
+            // MFMAs of this stage are independent of each other -- spread the bookkeeping BETWEEN the MFMAs (an in-order
+            // wave cannot hide it behind its own MFMAs otherwise, and the barrier keeps all waves in the same phase)
             store_stage(buf ^ 1, rxA, ryA);      // stage it + 1 (requested one whole stage ago)
             load_stage(rxA, ryA);                // stage it + 2
-            LU_SCHED_FENCE();
 #pragma unroll
             for (int j = 1; j < PRB / 16; ++j) mma_half(buf, j);
+#pragma unroll
+            for (int g = 0; g < (PRB / 16 - 1) * K * NFW; ++g) {
+                LU_SCHED_GROUP(0x008, 1);        // one MFMA ...
+                LU_SCHED_GROUP(0x366, 8);        // ... then up to 8 non-MFMA instructions (VALU / SALU / VMEM / DS)
+            }
+            LU_SCHED_FENCE();
             __syncthreads();
         }
     }
@@ -813,10 +833,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_small3_kernel(WgradArgs a) {
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ dw,
-                                    int C, int N, int64_t tap_stride, int row_stride, float beta) {
-    const int64_t total = slab;
+                                    int C, int N, int64_t tap_stride, int row_stride, float beta,
+                                    const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta) {
+    // elements [0, slab): the weight gradient; [slab, slab + N): the bias gradient riding on the same launch (its own
+    // 40-microsecond launch per layer added up to 0.7 ms per step)
+    const int64_t total = slab + (bias_ws ? N : 0);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
+        if (i >= slab) {
+            const int n = (int)(i - slab);
+            for (int z = 0; z < splits; ++z) s += bias_ws[(int64_t)z * N + n];
+            dbias[n] = (dbias_beta != 0.f ? dbias_beta * dbias[n] : 0.f) + s;
+            continue;
+        }
         for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * slab + i];
         const int64_t row = i / N;
         const int n = (int)(i - row * N);
@@ -827,21 +856,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
     }
 }
 
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ ws, int N, int splits, float* __restrict__ dbias,
-                                         float beta) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * N + n];
-    dbias[n] = (beta != 0.f ? beta * dbias[n] : 0.f) + s;
-}
-
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // dynamic LDS of wgrad_row_bf16_kernel<K, CT, *, *, S, PRBT>
-size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb) {
-    const int XP = S * (prb - 1) + K, XLD = CT + 32, YLD = 128 + 32;
-    return (size_t)(2 * XP * XLD + 2 * prb * YLD) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
+size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb, bool xb) {
+    const int XP = S * (prb - 1) + K, XLD = CT + 32, YLD = 128 + 32, PX = CT / (xb ? 8 : 4);
+    const int XPA = (XP * PX + 511) / 512 * 512 / PX;      // rows allocated = pass coverage (see the kernel)
+    return (size_t)(2 * XPA * XLD + 2 * prb * YLD) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
 }
 
 }  // namespace
@@ -930,24 +951,24 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         dim3 grid((unsigned)(8 * a.inner * ((splits + 7) / 8)));      // XCD-aware numbering: see the kernel
 #define LU_WGB(K_, CT_)                                                                                              \
     do {                                                                                                             \
-        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, true>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);            \
-        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, true>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);            \
-        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, false>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);            \
-        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, false>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32), stream, a);                   \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, true>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32, true), stream, a);            \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, true>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32, false), stream, a);            \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, false>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32, true), stream, a);            \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, false>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 1, 32, false), stream, a);                   \
     } while (0)
 #define LU_WGB64(K_)      /* 64-pixel stages: 128-channel tiles of the 5x5 ConvLSTM kernels (the bulk of the step) */    \
     do {                                                                                                             \
-        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, true, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);     \
-        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, true, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);     \
-        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);     \
-        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64), stream, a);            \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, true, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64, true), stream, a);     \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, true, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64, false), stream, a);     \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64, true), stream, a);     \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64, false), stream, a);            \
     } while (0)
 #define LU_WGB2(CT_)                                                                                                  \
     do {                                                                                                             \
-        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);          \
-        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);          \
-        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);          \
-        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32), stream, a);                 \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, true), stream, a);          \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, false), stream, a);          \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, true), stream, a);          \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, false), stream, a);                 \
     } while (0)
         if (d->stride == 2 && ct == 128) LU_WGB2(128);
         else if (d->stride == 2) LU_WGB2(64);
@@ -989,13 +1010,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
 #undef LU_WG
     int rc = LU_CHECK_LAUNCH();
     if (rc || d->phase == 1) return rc;
-    int64_t total = a.slab;
+    int64_t total = a.slab + (d->dbias ? d->N : 0);
     unsigned rgrid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,
-              d->N, d->dw_tap_stride, d->dw_row_stride, d->beta);
-    rc = LU_CHECK_LAUNCH();
-    if (rc || !d->dbias) return rc;
-    LU_LAUNCH(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), stream, (const float*)a.bias_ws,
-              d->N, splits, d->dbias, d->dbias_beta);
+              d->N, d->dw_tap_stride, d->dw_row_stride, d->beta, (const float*)(d->dbias ? a.bias_ws : nullptr), d->dbias,
+              d->dbias_beta);
     return LU_CHECK_LAUNCH();
 }

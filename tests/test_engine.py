@@ -6,7 +6,7 @@ as few as 1024 pixels), so its gradient is ill-conditioned: perturbing the WEIGH
 relative 1e-6 / 1e-5 moves its own gradients by up to 8e-3 / 4e-2 of a tensor's max at config-1 size
 (measured with tests/diag/, notes in DESIGN.md §9).  fp32 arithmetic therefore cannot agree with fp64 better than
 that on the big case (and the second step starts from fp32-drifted weights/state); the small cases (few kink
-crossings) are held to 2e-3, config-1 to 0.15 max-relative / 0.05 L2-relative per tensor, and
+crossings) are held to 2e-3, config-1 to 2x its measured error (0.055 max-relative / 0.013 L2-relative per tensor), and
 `test_layerwise_backward_consistency` checks every backward kernel of the big case against an fp64
 evaluation FROM THE SAME DEVICE INPUTS to 1e-6 (no chaos in that comparison).  'hip' = real gfx950 library (`-m gpu`); 'emu' = same
 host code on the host-emulated kernels (CPU, small shapes) to validate tape/backward plumbing.
@@ -84,8 +84,13 @@ GPU_CASES = [
     ('c1', c1_net(), 1, 1, 4, 128, 128, False),
     ('k5-odd', tiny_net(5, (32, 64, 32, 64), (32, 16, 16, 8)), 3, 2, 3, 35, 35, True),
 ]
-GRAD_TOL = {'c1': 0.15}      # max-abs / tensor-max; kink-flip outliers dominate it (see module docstring)
-GRAD_L2_TOL = {'c1': 0.05}   # ||g - g_ref||_2 / ||g_ref||_2 per tensor, robust to a handful of flips
+# config-1 end-to-end against the fp64 oracle, MEASURED on the MI355X (gpurun_out/r02h_gpu_tests.log): worst max-abs /
+# tensor-max 2.71e-2 (down.2.conv.1.kernel, step 0; 1.2e-3 at step 1), worst L2-relative 6.3e-3 (down.2.lstm.0.recurrent_kernel;
+# 1.2e-3 at step 1).  Tolerances = 2x the measured values; the kink-flip conditioning that puts them above the small-net
+# 2e-3 is quantified in DESIGN.md §9, and every backward kernel of this case is held to 1e-5 from the same device inputs
+# (test_layerwise_backward_consistency, test_lstm_bptt_backward_consistency).
+GRAD_TOL = {'c1': 0.055}     # max-abs / tensor-max
+GRAD_L2_TOL = {'c1': 0.013}  # ||g - g_ref||_2 / ||g_ref||_2 per tensor
 
 
 def _all_cases(request_dev):

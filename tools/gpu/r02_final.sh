@@ -1,0 +1,23 @@
+# full measurement set of a round (usage: bash tools/gpu/r02_final.sh <tag>); everything lands in gpurun_out/<tag>_*
+tag=${1:-r02}
+R=$GRAFT_REPO_ROOT
+python -m pytest tests -q -m gpu -s > gpurun_out/${tag}_gpu_tests.log 2>&1; tail -3 gpurun_out/${tag}_gpu_tests.log; grep "train_step_parity c1\|lstm bptt\|config-" gpurun_out/${tag}_gpu_tests.log | cut -c1-400
+python bench.py --steps 8 --warmup 3 > gpurun_out/${tag}_f32_bench_line.json 2> gpurun_out/${tag}_f32_bench.err; tail -2 gpurun_out/${tag}_f32_bench.err
+python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bf16_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
+python bench.py --precision bf16 --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bf16_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
+python bench.py --hw 832 992 --batch 2 --unroll 16 --steps 2 --warmup 1 --no-bf16 --no-infer --no-cpu-baseline > gpurun_out/${tag}_f32_c4_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
+python - <<PY
+import json
+for n in ('f32_bench_line','bf16_bench_line','bf16_c5shape_bench_line','f32_c4_bench_line'):
+    try:
+        d=json.load(open('gpurun_out/${tag}_%s.json' % n))
+        print(n, d['value'], d['ms_per_step'], d['step_tflops_achieved_per_gpu'], d['peak_hbm_gb'], d.get('inference'), (d.get('bf16_mode') or {}).get('frames_per_s'))
+    except Exception as e: print(n, 'FAILED', e)
+PY
+cd /tmp && export TMPDIR=/tmp
+for mode in fp32 bf16; do
+  short=f32; [ $mode = bf16 ] && short=bf16
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_$mode -- python $R/bench.py --precision $mode --steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 > /dev/null 2>&1
+  (cd $R && python tools/prof_summary.py gpurun_out/${tag}_prof_$mode gpurun_out/${tag}_${short}_kernel_stats | head -2; rm -rf gpurun_out/${tag}_prof_$mode)
+done
+cd $R && bash tools/gpu/pmc_traffic.sh $tag
