@@ -69,9 +69,11 @@ enum {
     LU_CONV_F_LOOP_GEN1 = 128,   /* bf16 halo kernel: the first loop generation (run-time tap state machine) instead of the
                                   * compile-time unrolled tap sequence -- A/B and regression tests */
     LU_CONV_F_GATES_BF16 = 256,  /* LU_EPI_LSTM, precision 1: gates_out is a bf16 tensor (the bf16 BPTT tape) */
-    LU_CONV_F_SRC1_CENTER = 512  /* precision 1 halo kernel, two sources: src[1] contributes its CENTRE tap only (k*k = 1):
+    LU_CONV_F_SRC1_CENTER = 512, /* precision 1 halo kernel, two sources: src[1] contributes its CENTRE tap only (k*k = 1):
                                   * the im2col image of a thin input (lu_im2col_bf16) as one 32-channel chunk, weights
                                   * packed as ONE tap by lu_pack_weights_taps_bf16 */
+    LU_CONV_F_NO_BALANCE = 1024  /* few-tile launches (<= 2048 tile x split work items): keep the m-tile-per-XCD block
+                                  * numbering instead of the balanced one (equal runs of work items per XCD) -- A/B */
 };
 
 typedef struct lu_conv_desc {

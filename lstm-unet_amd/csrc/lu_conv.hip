@@ -61,6 +61,9 @@ struct ConvArgs {
     int32_t N, n_tiles, m_tiles;
     int32_t tiles_x, tiles_pf;   // halo kernel: 8x32-pixel tiles per row / per frame
     int32_t xcd_by_n;            // halo kernel: give each XCD its own n-tiles (weights stay L2-resident per XCD)
+    int32_t balanced;            // > 0: few-tile launch, 1-D grid: the m_tiles x n_tiles x ksplit work items cut into 8 equal
+                                 // runs of `balanced` items, one run per XCD (lu_block_tile) ...
+    int32_t balanced_by_m;       // ... in (m, split, n) order (activations outweigh weights) instead of (n, split, m)
     int32_t src1_center;   // fragment kernel: source 1 contributes its centre tap only (im2col image of a thin input)
     int32_t gates_bf16;    // LSTM epilogue of the fragment kernel: gates_out is bf16
     unsigned short* h16_out;   // ... optional bf16 copy of h
@@ -87,6 +90,39 @@ struct ConvArgs {
 #else
 #define LU_DBG(a, bit) 0
 #endif
+
+// blockIdx -> (m-tile, n-tile, K split).  Workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).
+//  default:  all n-tiles of one m-tile get consecutive slots of the SAME XCD, so the activation slab they share is fetched
+//            into one L2; the grid is padded to a multiple of 8 m-tiles; blockIdx.y is the K split.
+//  balanced: launches with few tiles (streaming inference, the coarse levels: 5 m-tiles would leave 3 XCDs idle and put 96
+//            blocks on the 64 slots of the others).  1-D grid; the work items in (n-tile, split, m-tile) order are cut into
+//            8 equal runs, one per XCD: every XCD streams its own 1/8 of the weights once, the (small) input is shared.
+//            balanced_by_m: (m-tile, split, n-tile) order instead -- layers whose activations outweigh their weights.
+// false: padding block (uniform per block, taken before any barrier).
+__device__ __forceinline__ bool lu_block_tile(const ConvArgs& a, int& mt, int& nt, int& ks) {
+    const int bid = blockIdx.x;
+    if (a.balanced) {
+        const int w = (bid & 7) * a.balanced + (bid >> 3);
+        if ((bid >> 3) >= a.balanced || w >= a.m_tiles * a.n_tiles * a.ksplit) return false;
+        if (a.balanced_by_m) {
+            const int r = w / a.n_tiles;
+            nt = w - r * a.n_tiles;
+            mt = r / a.ksplit;
+            ks = r - mt * a.ksplit;
+        } else {
+            const int r = w / a.m_tiles;
+            mt = w - r * a.m_tiles;
+            nt = r / a.ksplit;
+            ks = r - nt * a.ksplit;
+        }
+        return true;
+    }
+    const int slot = bid >> 3;
+    nt = slot % a.n_tiles;
+    mt = (slot / a.n_tiles) * 8 + (bid & 7);
+    ks = blockIdx.y;
+    return mt < a.m_tiles;
+}
 
 struct IterState {
     int s, chunk, tap, kh, kw;
@@ -205,16 +241,10 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).  All n-tiles of
-    // one m-tile get consecutive slots of the SAME XCD so the activation slab they share is fetched into one L2.
-    const int bid = blockIdx.x;
-    const int slot = bid >> 3;
-    const int nt = slot % a.n_tiles;
-    const int mt = (slot / a.n_tiles) * 8 + (bid & 7);
-    if (mt >= a.m_tiles) return;     // grid is padded to a multiple of 8 m-tiles; uniform per block, before any barrier
+    int mt, nt, ks;
+    if (!lu_block_tile(a, mt, nt, ks)) return;     // XCD-aware tile order
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
-    const int ks = blockIdx.y;
 
     // ---- A gather bookkeeping: RA pixel rows per thread, one 16-byte column group ----
     const int q = tid & 3;
@@ -548,8 +578,8 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = blockIdx.x;
     const int slot = bid >> 3;
-    int nt = slot % a.n_tiles;
-    int tile = (slot / a.n_tiles) * 8 + (bid & 7);     // XCD-aware order, see conv_fwd_kernel
+    int tile, nt, ks;
+    const bool live = lu_block_tile(a, tile, nt, ks);     // XCD-aware order
     if (a.xcd_by_n) {
         // n_tiles % 8 == 0: XCD x (= bid % 8) owns n-tiles [x*g, (x+1)*g): the 64 blocks resident on an XCD stream the
         // SAME 16x128 weight tiles (a few MB per XCD, L2-resident) instead of every n-tile's; the patch halo, fetched
@@ -557,13 +587,14 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         const int g = a.n_tiles >> 3;
         nt = (bid & 7) * g + (slot % g);
         tile = slot / g;
+        if (tile >= a.m_tiles) return;
+    } else if (!live) {
+        return;
     }
-    if (tile >= a.m_tiles) return;
     const int f = tile / a.tiles_pf;
     const int t2 = tile - f * a.tiles_pf;
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
-    const int ks = blockIdx.y;
     const float* const zp = lu_zero16;
     // Per-source fields live in registers and are picked with selects: indexing a.src[st.s] inside the tap loop costs a
     // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
@@ -964,16 +995,12 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int bid = blockIdx.x;
-    const int slot = bid >> 3;
-    const int nt = slot % a.n_tiles;
-    const int tile = (slot / a.n_tiles) * 8 + (bid & 7);
-    if (tile >= a.m_tiles) return;
+    int tile, nt, ks;
+    if (!lu_block_tile(a, tile, nt, ks)) return;
     const int f = tile / a.tiles_pf;
     const int t2 = tile - f * a.tiles_pf;
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
-    const int ks = blockIdx.y;
     const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
     const int q = tid % G;                 // channel group inside the chunk
     // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
@@ -1275,16 +1302,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int bid = blockIdx.x;
-    const int slot = bid >> 3;
-    const int nt = slot % a.n_tiles;
-    const int tile = (slot / a.n_tiles) * 8 + (bid & 7);
-    if (tile >= a.m_tiles) return;
+    int tile, nt, ks;
+    if (!lu_block_tile(a, tile, nt, ks)) return;
     const int f = tile / a.tiles_pf;
     const int t2 = tile - f * a.tiles_pf;
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
-    const int ks = blockIdx.y;
     const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
     const int q = tid % G;
     const int nfr = (a.N + 31) >> 5;
@@ -1432,14 +1455,10 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int bid = blockIdx.x;
-    const int slot = bid >> 3;
-    const int nt = slot % a.n_tiles;
-    const int mt = (slot / a.n_tiles) * 8 + (bid & 7);
-    if (mt >= a.m_tiles) return;
+    int mt, nt, ks;
+    if (!lu_block_tile(a, mt, nt, ks)) return;
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * 128;
-    const int ks = blockIdx.y;
     const float* const zp = lu_zero16;
     const int nfr = (a.N + 31) >> 5;
     const int frag = nt * 4 + wn;
@@ -1802,7 +1821,19 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
+    a.balanced = a.balanced_by_m = 0;
     a.dbg = (d->flags >> 16) & 0xff;      // (only -DLU_ABLATION tool builds look at it)
+    // grid of a tile kernel: few-tile launches take the balanced numbering of lu_block_tile (a.n_tiles / a.ksplit set before)
+    const bool no_balance = (d->flags & LU_CONV_F_NO_BALANCE) != 0;
+    auto tile_grid = [&]() {
+        const int64_t work = m_tiles * a.n_tiles * a.ksplit;
+        if (!no_balance && !a.xcd_by_n && work <= 2048 && (a.ksplit > 1 || m_tiles < 64)) {
+            a.balanced = (int32_t)((work + 7) / 8);
+            a.balanced_by_m = (int64_t)a.kk * a.N < a.M;      // weight bytes / input bytes = k*k*N / M
+            return dim3((unsigned)(a.balanced * 8));
+        }
+        return dim3((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles), (unsigned)a.ksplit);
+    };
     dim3 block(256);
     // LDS-DMA tile staging measured 4-5 % SLOWER than VGPR staging here (123.5 vs 129.9 TFLOP/s on the recurrent
     // dgrads): opt-in only, kept as a measured negative result.
@@ -1833,7 +1864,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
                        "lu_conv2d_fwd: the fragment kernel's ConvLSTM epilogue needs 16-byte aligned state / bias pointers");
         a.n_tiles = a.F / 32;
         a.xcd_by_n = (halo && want_xcd_n && a.n_tiles % 8 == 0) ? 1 : 0;
-        dim3 grid((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles));
+        const dim3 grid = tile_grid();
         LU_REQUIRE(d->dil == 1 && d->stride == 1 && k_h == d->k, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1, a square kernel");
         // (3x3: the first loop generation -- its 8-row-patch instance fits 4 waves per SIMD, the unrolled one does not: measured)
         if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
@@ -1867,7 +1898,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     }
     if (d->precision == 2) {     // fp32 MFMA, fragment-packed weights (halo shapes only, checked above)
         a.n_tiles = (d->N + 127) / 128;
-        dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
+        const dim3 gridb = tile_grid();
         if (d->k == 5 && th == 16)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, true, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->k == 5)
@@ -1884,7 +1915,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     }
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
         a.n_tiles = (d->N + 127) / 128;
-        dim3 gridb((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
+        const dim3 gridb = tile_grid();
         if (halo && !gen1 && src16 && d->k == 5 && th == 16)
             LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && !gen1 && src16 && d->k == 5)
@@ -1915,7 +1946,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
                   a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);
         return LU_CHECK_LAUNCH();
     }
-    dim3 grid((unsigned)(m_tiles8 * a.n_tiles), (unsigned)a.ksplit);
+    const dim3 grid = tile_grid();
     const bool gen = d->dil != 1 || (d->flags & LU_CONV_F_GENERAL) != 0;   // A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \

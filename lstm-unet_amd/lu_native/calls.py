@@ -31,13 +31,56 @@ def conv_src(x, frame_stride, pix_stride, Cin, w, w_tap_stride, w_row_stride, dt
     return s
 
 
-def conv_splits(frames, Hout, Wout, N, k, channels):
-    """K-axis split for problems with too few 256x128 output tiles to occupy 256 CUs twice over."""
-    tiles = -(-(frames * Hout * Wout) // 256) * -(-N // 128)
+SPLIT_CAP, SPLIT_MIN_IT = 32, 12      # most K splits / fewest k-steps per block conv_splits considers
+IT_US = 1.89     # one k-step (16 channels of one tap) of a 256 x 128 fp32 tile, per block of a resident PAIR, microseconds
+                 # (measured: 2048-block fused step, 620 k-steps, 9.39 ms = 8 block-times; a lone block needs 2.28)
+
+
+def launch_rounds(blocks):
+    """Block-times a launch of `blocks` equal tile blocks costs: 8 XCDs x 32 CUs x 2 resident blocks sharing one MFMA pipe.
+    A partial round of <= 32 blocks per XCD runs one block per CU (a lone block reaches ~83 % of a pair's rate).  Fitted to
+    tools/step_sweep.py on the B = 1 streaming shapes: 57 / 60 blocks per XCD ~2.0-2.3, 88 ~3.1, 95 ~3.1, 255 ~8.0."""
+    per = -(-blocks // 8)
+    full, rem = divmod(per, 64)
+    if full == 0:
+        return 1.2 if rem <= 32 else 2.0
+    return 2.0 * full + (0.0 if rem == 0 else 1.1 if rem <= 32 else 2.0)
+
+
+def conv_tiles(frames, Hout, Wout, N, k, halo=True):
+    """256-pixel x 128-column tiles of a launch: 8 x 32-pixel patches where the halo kernel applies (stride-1 3x3 / 5x5,
+    N > 64, <= 25 % of the patches wasted -- mirrors lu_conv2d_fwd), flattened pixel rows otherwise."""
+    patches = frames * -(-Hout // 8) * -(-Wout // 32)
+    if halo and k in (3, 5) and N > 64 and patches * 256 * 4 <= frames * Hout * Wout * 5:
+        return patches * -(-N // 128)
+    return -(-(frames * Hout * Wout) // 256) * -(-N // 128)
+
+
+def conv_cost_us(frames, Hout, Wout, N, k, channels, splits, halo=True):
+    """Modelled duration of the fp32 conv kernels with a K split (+ the slab reduce), microseconds."""
+    M = frames * Hout * Wout
     n_it = k * k * -(-channels // 16)
-    if tiles >= 384 or n_it < 64:
+    t = launch_rounds(conv_tiles(frames, Hout, Wout, N, k, halo) * splits) * (n_it / float(splits) + 12) * IT_US
+    if splits > 1:
+        t += (2 * splits + 1) * M * N * 4 / 4e6 + 5        # slabs written + read, result written, at ~4 TB/s
+    return t
+
+
+def conv_splits(frames, Hout, Wout, N, k, channels, halo=True):
+    """K-axis split for launches with too few 256x128 output tiles to fill 256 CUs: the split count with the smallest
+    modelled duration (whole rounds of resident blocks matter more than the count itself: 152 tiles x 3 = 456 blocks is one
+    round, x 4 = 608 is two)."""
+    n_it = k * k * -(-channels // 16)
+    if conv_tiles(frames, Hout, Wout, N, k, halo) > 2048 or n_it < 64:
         return 1
-    return int(max(1, min(512 // tiles, n_it // 32, 16)))
+    cands = [s for s in range(1, SPLIT_CAP + 1) if n_it // s >= SPLIT_MIN_IT] or [1]
+    return min(cands, key=lambda s: (conv_cost_us(frames, Hout, Wout, N, k, channels, s, halo), s))
+
+
+def fused_step_cost_us(frames, H, W, F, k, channels):
+    """Modelled duration of the fused fp32 ConvLSTM step (8 x 32-pixel patches x 32 hidden channels x 4 gates per block)."""
+    blocks = conv_tiles(frames, H, W, 4 * F, k)
+    return launch_rounds(blocks) * (k * k * -(-channels // 16) + 20) * IT_US
 
 
 def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,

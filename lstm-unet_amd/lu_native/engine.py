@@ -68,6 +68,11 @@ class Engine:
         self.on_bucket_ready = None  # callback(start, end) fired as each bucket's gradient completes
         self.debug = None            # tests/diag/diag_gpu.py: dict collecting clones of intermediate gradients
         self._h16_seq = None         # bf16 copy of the last ConvLSTM output of the current down block (bf16 tape)
+        self._bn_infer = {}          # BN prefix -> (validity token, (scale, shift)) of the inference-mode affine
+        self._bn_epoch = 0
+        self._state16 = {}           # (block, layer) -> (h state tensor, its bf16 copy) left by the last inference step
+        self.persistent_states = False   # True (lu_native.graph): inference copies the new state INTO the existing state
+                                         # tensors instead of adopting the step's output tensors as the state
 
     # ------------------------------------------------------------------ build
     def build(self, in_channels, device):
@@ -162,8 +167,14 @@ class Engine:
             scale, shift, mean, invstd = ops.bn_finalize_train(sums, count, gamma, beta, BN_EPS, BN_MOMENTUM, mm, mv)
             if rec is not None:
                 rec.update(scale=scale, shift=shift, mean=mean, invstd=invstd, count=count)
+            self._bn_epoch += 1      # the raw-pointer kernel moved mm / mv without bumping their torch versions
         else:
-            scale, shift = ops.bn_finalize_infer(gamma, beta, mm, mv, BN_EPS)
+            # inference scale / shift depend on the weights and moving statistics only: computed once, not per frame
+            token = (self.flat_params._version, mm._version, mv._version, self._bn_epoch)
+            hit = self._bn_infer.get(prefix)
+            if hit is None or hit[0] != token:
+                hit = self._bn_infer[prefix] = (token, ops.bn_finalize_infer(gamma, beta, mm, mv, BN_EPS))
+            scale, shift = hit[1]
         return ops.bn_lrelu_apply(y, scale, shift, LRELU_ALPHA)
 
     def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape, alt16=None):
@@ -263,34 +274,59 @@ class Engine:
                     x5 = torch.zeros((T, B, H, W, cpad), device=dev, dtype=torch.float32)
                     x5[..., :Cin] = x_seq.view(T, B, H, W, -1)
             rec_k = self._pack(pre + '.recurrent_kernel', 'fwd', lambda w=rec_k: w)
+        st = self.states[bi][li]
+        if st is not None and tuple(st[0].shape) != (B, H, W, F):
+            raise ValueError('stateful ConvLSTM: batch/shape changed from %s to %s' % (tuple(st[0].shape), (B, H, W, F)))
+        if tape is None:
+            # inference: the carried state is read in place and the last step's outputs BECOME the state (no copies in or out)
+            h_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.float32)
+            c_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.float32)
+            h16_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.bfloat16) if tape16 else None
+            if st is None:
+                h_prev, c_prev = h_seq.new_zeros((B, H, W, F)), h_seq.new_zeros((B, H, W, F))
+            else:
+                h_prev, c_prev = st
+            h16_prev = None
+            if src16:
+                hit = self._state16.get((bi, li))
+                h16_prev = hit[1] if (hit is not None and hit[0] is h_prev) else ops.to_bf16(h_prev)
+            for t in range(T):
+                ops.convlstm_step(x5[t], h16_prev if src16 else h_prev, c_prev, kernel, rec_k, bias, h_seq[t], c_seq[t], None,
+                                  h16_out=h16_seq[t] if tape16 else None, x_center=x_center)
+                h_prev, c_prev = h_seq[t], c_seq[t]
+                h16_prev = h16_seq[t] if tape16 else None
+            if self.persistent_states and st is not None:      # hipGraph replay: the state buffers keep their addresses
+                st[0].copy_(h_prev)
+                st[1].copy_(c_prev)
+            elif self.persistent_states:
+                self.states[bi][li] = [h_prev.clone(), c_prev.clone()]
+            else:
+                self.states[bi][li] = [h_prev, c_prev]
+                self._state16[(bi, li)] = (h_prev, h16_prev)
+            self._h16_seq = None
+            return h_seq.view(T * B, H, W, F)
         h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
-        st = self.states[bi][li]
         if st is None:
             h_all[0].zero_()
             c_all[0].zero_()
         else:
-            if tuple(st[0].shape) != (B, H, W, F):
-                raise ValueError('stateful ConvLSTM: batch/shape changed from %s to %s' %
-                                 (tuple(st[0].shape), (B, H, W, F)))
             h_all[0].copy_(st[0])
             c_all[0].copy_(st[1])
         h16_all = None
         if tape16:
             h16_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.bfloat16)
             ops.to_bf16(h_all[0], out=h16_all[0])
-        gates = None
-        if tape is not None:
-            gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.bfloat16 if tape16 else torch.float32)
+        gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.bfloat16 if tape16 else torch.float32)
         for t in range(T):
             ops.convlstm_step(x5[t], h16_all[t] if src16 else h_all[t], c_all[t], kernel, rec_k, bias, h_all[t + 1],
-                              c_all[t + 1], gates[t] if gates is not None else None,
-                              h16_out=h16_all[t + 1] if tape16 else None, x_center=x_center)
+                              c_all[t + 1], gates[t], h16_out=h16_all[t + 1] if tape16 else None, x_center=x_center)
         if st is None:
             self.states[bi][li] = [h_all[T].clone(), c_all[T].clone()]
         else:
             st[0].copy_(h_all[T])
             st[1].copy_(c_all[T])
+        self._state16.pop((bi, li), None)
         if tape is not None:
             tape.append({'kind': 'lstm', 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'h_all': h_all, 'c_all': c_all,
                          'gates': gates, 'T': T, 'B': B, 'h16_all': h16_all, 'x25': x5 if x_center else None, 'x16': x16})
@@ -490,6 +526,7 @@ class Engine:
         if self.states is None:
             return
         keep = torch.as_tensor(keep, dtype=torch.float32).reshape(-1).to(self.device)
+        self._state16.clear()
         for blk in self.states:
             for st in blk:
                 if st is not None:
@@ -508,6 +545,7 @@ class Engine:
         if self.states is None:     # not built yet: apply at first call
             self._pending_states = states
             return
+        self._state16.clear()
         for bi, blk in enumerate(states):
             for li, st in enumerate(blk):
                 if st is None or st[0] is None:

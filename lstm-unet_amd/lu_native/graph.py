@@ -13,6 +13,7 @@ class GraphedFrame(object):
     def __init__(self, model, example, warmup=2):
         dev = torch.device('cuda', torch.cuda.current_device())
         self.model = model
+        model.engine.persistent_states = True      # replayed launches address fixed buffers: no state-tensor swapping
         self.x = torch.as_tensor(example, dtype=torch.float32).to(dev).contiguous().clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

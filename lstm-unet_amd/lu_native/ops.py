@@ -15,7 +15,8 @@ from .calls import NativeError, same_pad
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblstmunet_hip.so')
 _lib = None
-FUSED_MIN_TILES = 160   # fused ConvLSTM step needs this many 256x32ch tiles to fill the chip (tests set 0)
+FUSED_MIN_TILES = None  # None: fp32 steps pick fused / K-split + gate kernel by modelled duration (calls.fused_step_cost_us);
+                        # an integer: fused from that many 256x32ch tiles on (tests set 0 = always fused)
 FUSED_MIN_TILES_BF16 = 0    # ... the bf16 kernel is better fused at every size (B = 1 streaming: 394 vs 384 frames/s)
 EVENT_LOG = None   # bench.py: list collecting (kernel class, algorithmic FLOPs, start, end) around the MFMA launches
 CONV_FLAGS = 0     # tests / A-B tools: cabi.LU_CONV_F_* kernel-variant overrides OR-ed into every lu_conv_desc
@@ -140,13 +141,13 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     """One lu_conv2d_fwd launch (bias epilogue); picks a K-split + workspace for tile-starved problems.
     out_view = (ptr, frame_stride, pix_stride, row_stride) overrides the dense addressing of `out`."""
     channels = sum(x.shape[3] for x, _ in pairs)
-    splits = calls.conv_splits(frames, Hout, Wout, N, k, channels) if not k_h else 1
+    halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
+    splits = calls.conv_splits(frames, Hout, Wout, N, k, channels, halo and out_view is None) if not k_h else 1
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
     prec = max([w.precision for _, w in pairs if isinstance(w, PackedW)] + [0])
     bf16 = prec == 1
-    halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
     if bf16:
@@ -339,8 +340,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     p = (k - 1) // 2
     # The fused epilogue cannot take a K split, so tile-starved steps (streaming inference: B = 1) run the conv with
     # a split into pre-activations and the stand-alone gate kernel instead.
-    tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
-    if F % 32 == 0 and tiles >= (FUSED_MIN_TILES_BF16 if bf16 else FUSED_MIN_TILES):
+    if fused_step_applies(frames, H, W, F, bf16, k, x_t.shape[3] + h_prev.shape[3]):
         flags = CONV_FLAGS
         if gates_out is not None and gates_out.dtype == torch.bfloat16:
             flags |= cabi.LU_CONV_F_GATES_BF16
@@ -369,10 +369,21 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
                     'lu_lstm_gates_fwd')
 
 
-def fused_step_applies(frames, H, W, F, bf16):
-    """True when convlstm_step takes the fused kernel for this shape."""
-    tiles = -(-(frames * H * W) // 256) * (F // 32 if F % 32 == 0 else 1)
-    return F % 32 == 0 and tiles >= (FUSED_MIN_TILES_BF16 if bf16 else FUSED_MIN_TILES)
+def fused_step_applies(frames, H, W, F, bf16, k=5, channels=None):
+    """True when convlstm_step takes the fused kernel for this shape.  The fused epilogue cannot take a K split, so
+    tile-starved fp32 steps (streaming inference: B = 1) may be faster as K-split conv + slab reduce + gate kernel."""
+    if F % 32:
+        return False
+    tiles = -(-(frames * H * W) // 256) * (F // 32)
+    if bf16:
+        return tiles >= FUSED_MIN_TILES_BF16
+    if FUSED_MIN_TILES is not None:
+        return tiles >= FUSED_MIN_TILES
+    if channels is None or tiles > 2048:
+        return True
+    s = calls.conv_splits(frames, H, W, 4 * F, k, channels)
+    unfused = calls.conv_cost_us(frames, H, W, 4 * F, k, channels, s) + frames * H * W * F * 4 * 8 / 4e6 + 5
+    return 0.95 * calls.fused_step_cost_us(frames, H, W, F, k, channels) <= unfused      # (margin: model error)
 
 
 def to_bf16(x, out=None):

@@ -71,6 +71,26 @@ def test_conv_ksplit_and_many_mtiles(be):
     close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, splits=4), ref, 5e-5)
 
 
+def test_conv_block_numbering_variants_are_bitwise_equal(be):
+    """Few-tile launches number their blocks in equal runs of (tile, split) work items per XCD (weights-major or
+    activations-major order, lu_block_tile); LU_CONV_F_NO_BALANCE keeps the m-tile-per-XCD numbering.  The numbering moves
+    blocks between XCDs and nothing else: results must be bit-identical, with and without a K split, in the general
+    and the halo kernel, with 5 / 11 / 3 m-tiles (not multiples of 8) and for both orders (k*k*N above / below M)."""
+    nb = cabi.LU_CONV_F_NO_BALANCE
+    for (fr, H, W, Cc, N, k, sp) in [(1, 34, 34, 32, 160, 5, 3), (3, 30, 31, 16, 24, 3, 1), (1, 20, 30, 32, 136, 3, 4),
+                                     (2, 16, 30, 36, 128, 5, 2), (1, 17, 40, 16, 72, 5, 1)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        a = KH.conv2d(be, [x], [w], b, k, 1, splits=sp)
+        close(a, npo.conv2d_same(x, w, b, 1), 5e-5)
+        assert np.array_equal(a, KH.conv2d(be, [x], [w], b, k, 1, splits=sp, flags=nb)), (fr, H, W, Cc, N, k, sp)
+    F = 32
+    x, h, c = rnd(1, 16, 40, 8), rnd(1, 16, 40, F, scale=0.5), rnd(1, 16, 40, F)
+    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    fused = KH.convlstm_step_fused(be, x, h, c, ker, rec, b)
+    for u, v in zip(fused, KH.convlstm_step_fused(be, x, h, c, ker, rec, b, flags=nb)):
+        assert np.array_equal(u, v)
+
+
 def test_conv_halo_variant(be):
     """8x32-patch halo-reuse kernel (stride-1 3x3 / 5x5, N > 64): ragged patches, two sources incl. a thin one,
     K split, and the fused ConvLSTM epilogue on it."""

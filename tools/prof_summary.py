@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(src, dst):
+def main(src, dst, ngrid=40):
     db = sorted(glob.glob(src + '/**/*.db', recursive=True))[0]
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
@@ -16,7 +16,7 @@ def main(src, dst):
         for n, c, t, a, lo, hi in rows:
             f.write('"%s",%d,%d,%.1f,%d,%d,%.4f\n' % (n, c, t, a, lo, hi, 100.0 * t / total))
     grid = cur.execute("select name, grid_x/workgroup_x, grid_y, grid_z, count(*), avg(end-start), sum(end-start) from kernels "
-                       "group by name, grid_x, grid_y, grid_z order by sum(end-start) desc limit 40").fetchall()
+                       "group by name, grid_x, grid_y, grid_z order by sum(end-start) desc limit %d" % int(ngrid)).fetchall()
     with open(dst + '_by_grid.csv', 'w') as f:
         f.write('Name,BlocksX,BlocksY,BlocksZ,Calls,AverageNs,TotalNs\n')
         for r in grid:
@@ -27,4 +27,4 @@ def main(src, dst):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
