@@ -72,8 +72,10 @@ enum {
     LU_CONV_F_SRC1_CENTER = 512, /* precision 1 halo kernel, two sources: src[1] contributes its CENTRE tap only (k*k = 1):
                                   * the im2col image of a thin input (lu_im2col_bf16) as one 32-channel chunk, weights
                                   * packed as ONE tap by lu_pack_weights_taps_bf16 */
-    LU_CONV_F_NO_BALANCE = 1024  /* few-tile launches (<= 2048 tile x split work items): keep the m-tile-per-XCD block
+    LU_CONV_F_NO_BALANCE = 1024, /* few-tile launches (<= 2048 tile x split work items): keep the m-tile-per-XCD block
                                   * numbering instead of the balanced one (equal runs of work items per XCD) -- A/B */
+    LU_CONV_F_SLABS_ONLY = 2048  /* LU_EPI_BIAS, splits > 1: stop after the partial slabs -- workspace[s][frames*Hout*Wout][N],
+                                  * bias NOT added, `out` unused; the consumer sums them (lu_lstm_gates_fwd_slabs) */
 };
 
 typedef struct lu_conv_desc {
@@ -117,6 +119,15 @@ typedef struct lu_conv_desc {
                                      * the recurrent operand of the next step and the x operand of the hoisted weight
                                      * gradient, so neither re-reads / re-rounds the fp32 sequence */
     int64_t h16_frame_stride;
+    /* LU_EPI_BIAS, optional (both or neither): the stored value becomes
+     *     lrelu(post_scale[n] * (acc + bias[n]) + post_shift[n], post_alpha)
+     * i.e. the inference-mode BatchNormalization (lu_bn_finalize_infer) + LeakyReLU of a conv unit (reference
+     * Networks.py:69-72,146-151 with training=False) in the same call: with splits > 1 the slab reduce applies it (no extra
+     * pass: the tile-starved streaming case), otherwise a short in-place pass over `out` follows the tile kernel.  `out`
+     * must be dense.  Same arithmetic as lu_bn_lrelu_apply on the plain conv output (bit-identical). */
+    const float* post_scale;        /* [N] */
+    const float* post_shift;        /* [N] */
+    float post_alpha;
 } lu_conv_desc;
 
 /* bf16 weight image for precision == 1: [tap][ceil(C/32)][N][32] bf16 (zero-filled beyond C), built from a
@@ -203,6 +214,12 @@ int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream);
 int lu_lstm_gates_fwd(const float* z, const float* c_prev, float* c_out, float* h_out, float* gates_out,
                       int32_t frames, int64_t pix_per_frame, int32_t F,
                       int64_t h_frame_stride, lu_stream_t stream);
+/* The same gate block fed by the partial slabs of a K-split convolution (LU_CONV_F_SLABS_ONLY):
+ *   z = bias + slabs[0] + slabs[1] + ... + slabs[splits-1]   (this order: the sum lu_conv2d_fwd's own reduce forms),
+ * slabs = [splits][rows][4F].  Tile-starved steps (streaming inference, B = 1) skip one pass over z this way. */
+int lu_lstm_gates_fwd_slabs(const float* slabs, int32_t splits, const float* bias, const float* c_prev, float* c_out,
+                            float* h_out, float* gates_out, int32_t frames, int64_t pix_per_frame, int32_t F,
+                            int64_t h_frame_stride, lu_stream_t stream);
 
 /* backward of the gate block for one timestep:
  *   dh = dh_a (+ dh_b if non-NULL); dc = dh*o*(1-tanh(c)^2) + dc_in(if non-NULL)

@@ -76,6 +76,9 @@ struct ConvArgs {
     float* out;
     int64_t out_frame_stride;
     int64_t out_row_stride;   // elements between output rows (0: dense = Wout * out_pix_stride)
+    const float* post_scale;  // LU_EPI_BIAS, optional: out = lrelu(post_scale[n] * (acc + bias[n]) + post_shift[n]) -- inference
+    const float* post_shift;  // BatchNorm + LeakyReLU of a conv unit: applied by the slab reduce of a K-split launch, by a short
+    float post_alpha;         // in-place pass otherwise (the tile kernels' epilogues stay as they are: measured, see DESIGN)
     // lstm epilogue
     int32_t F;
     const float* c_prev;
@@ -1633,16 +1636,21 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
     }
 }
 
-// out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic)
+// out[m, n] = bias[n] + sum_s ws[s][m][n]   (fixed order: deterministic), optionally through the post affine + LeakyReLU
 __global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t M, int N, int HWo,
                                      const float* __restrict__ bias, float* __restrict__ out, int64_t out_fs,
-                                     int out_ps, int Wout, int64_t out_rs) {
+                                     int out_ps, int Wout, int64_t out_rs, const float* __restrict__ post_scale,
+                                     const float* __restrict__ post_shift, float post_alpha) {
     const int64_t total = M * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / N;
         const int n = (int)(i - m * N);
         float s = bias ? bias[n] : 0.f;
         for (int k = 0; k < ksplit; ++k) s += ws[(int64_t)k * total + i];
+        if (post_scale) {
+            s = fmaf(s, post_scale[n], post_shift[n]);
+            s = s > 0.f ? s : post_alpha * s;
+        }
         const int64_t f = m / HWo;
         const int64_t pix = m - f * HWo;
         if (out_rs) {
@@ -1651,6 +1659,16 @@ __global__ void ksplit_reduce_kernel(const float* __restrict__ ws, int ksplit, i
         } else {
             out[f * out_fs + pix * out_ps + n] = s;
         }
+    }
+}
+
+// out[m, n] = lrelu(scale[n] * out[m, n] + shift[n]) in place on a dense [M, N] output (post affine of an unsplit launch)
+__global__ void post_affine_kernel(float* __restrict__ out, int64_t total, int N, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const float t = fmaf(out[i], scale[n], shift[n]);
+        out[i] = t > 0.f ? t : alpha * t;
     }
 }
 
@@ -1776,6 +1794,24 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.out = d->out;
     a.out_frame_stride = d->out_frame_stride;
     a.out_row_stride = d->out_row_stride;
+    a.post_scale = d->post_scale;
+    a.post_shift = d->post_shift;
+    a.post_alpha = d->post_alpha;
+    LU_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr) && (!d->post_scale || d->epilogue == LU_EPI_BIAS),
+               "lu_conv2d_fwd: post_scale / post_shift come as a pair and belong to LU_EPI_BIAS");
+    LU_REQUIRE(!d->post_scale || (d->out_row_stride == 0 && d->out_pix_stride == d->N &&
+                                  d->out_frame_stride == (int64_t)d->Hout * d->Wout * d->N),
+               "lu_conv2d_fwd: the post affine needs a dense [frames, Hout, Wout, N] output");
+    auto post_pass = [&]() -> int {      // unsplit launch with a post affine: short in-place pass over the dense output
+        if (!a.post_scale) return 0;
+        const int64_t tot = a.M * a.N;
+        const unsigned g = (unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+        LU_LAUNCH(post_affine_kernel, dim3(g), dim3(256), stream, a.out, tot, a.N, a.post_scale, a.post_shift, a.post_alpha);
+        return LU_CHECK_LAUNCH();
+    };
+    const bool slabs_only = (d->flags & LU_CONV_F_SLABS_ONLY) != 0;
+    LU_REQUIRE(!slabs_only || (d->epilogue == LU_EPI_BIAS && d->splits > 1 && !d->post_scale),
+               "lu_conv2d_fwd: LU_CONV_F_SLABS_ONLY needs LU_EPI_BIAS with splits > 1 (and no post affine)");
     int64_t m_tiles = (a.M + BM - 1) / BM;
     // halo-reuse kernel: stride-1 SAME 3x3 / 5x5, wide 16-byte-aligned outputs, <= 25 % of the 8x32 patches wasted
     const int64_t tiles_x = (d->Wout + 31) / 32;
@@ -1888,7 +1924,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         return LU_CHECK_LAUNCH();
     }
     LU_REQUIRE(d->epilogue == LU_EPI_BIAS, "lu_conv2d_fwd: unknown epilogue %d", d->epilogue);
-    LU_REQUIRE(d->out, "lu_conv2d_fwd: out is null");
+    LU_REQUIRE(d->out || slabs_only, "lu_conv2d_fwd: out is null");
     const int nf = d->N > 64 ? 4 : (d->N > 32 ? 2 : 1);
     a.n_tiles = (d->N + 32 * nf - 1) / (32 * nf);
     if (d->splits > 1 && a.n_it >= 2 * d->splits) {
@@ -1896,6 +1932,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.ksplit = d->splits;
         a.ws = (float*)d->workspace;
     }
+    LU_REQUIRE(!slabs_only || a.ksplit > 1, "lu_conv2d_fwd: LU_CONV_F_SLABS_ONLY with more splits than half the k-steps (%d)", a.n_it);
     if (d->precision == 2) {     // fp32 MFMA, fragment-packed weights (halo shapes only, checked above)
         a.n_tiles = (d->N + 127) / 128;
         const dim3 gridb = tile_grid();
@@ -1906,11 +1943,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         else
             LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, true, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         int rcb = LU_CHECK_LAUNCH();
-        if (rcb || a.ksplit == 1) return rcb;
+        if (rcb || slabs_only) return rcb;
+        if (a.ksplit == 1) return post_pass();
         const int64_t totb = a.M * a.N;
         const unsigned rgb = (unsigned)((totb + 255) / 256 < 8192 ? (totb + 255) / 256 : 8192);
         LU_LAUNCH(ksplit_reduce_kernel, dim3(rgb), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N, a.HWo, a.bias,
-                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);
+                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride, a.post_scale, a.post_shift, a.post_alpha);
         return LU_CHECK_LAUNCH();
     }
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
@@ -1939,11 +1977,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         else
             LU_LAUNCH(conv_gather_bf16_kernel, gridb, dim3(512), stream, a);
         int rcb = LU_CHECK_LAUNCH();
-        if (rcb || a.ksplit == 1) return rcb;
+        if (rcb || slabs_only) return rcb;
+        if (a.ksplit == 1) return post_pass();
         const int64_t totb = a.M * a.N;
         const unsigned rgb = (unsigned)((totb + 255) / 256 < 8192 ? (totb + 255) / 256 : 8192);
         LU_LAUNCH(ksplit_reduce_kernel, dim3(rgb), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N, a.HWo, a.bias,
-                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);
+                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride, a.post_scale, a.post_shift, a.post_alpha);
         return LU_CHECK_LAUNCH();
     }
     const dim3 grid = tile_grid();
@@ -1959,11 +1998,13 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
             LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1, false>), grid, dim3(512), stream, a);    \
         else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false, 2, false>), grid, block, stream, a);      \
         int rc_ = LU_CHECK_LAUNCH();                                                            \
-        if (rc_ || a.ksplit == 1) return rc_;                                                   \
+        if (rc_ || slabs_only) return rc_;                                                      \
+        if (a.ksplit == 1) return post_pass();                                                  \
         const int64_t tot_ = a.M * a.N;                                                         \
         const unsigned rg_ = (unsigned)((tot_ + 255) / 256 < 8192 ? (tot_ + 255) / 256 : 8192); \
         LU_LAUNCH(ksplit_reduce_kernel, dim3(rg_), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N,   \
-                  a.HWo, a.bias, a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride);        \
+                  a.HWo, a.bias, a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride, a.post_scale,  \
+                  a.post_shift, a.post_alpha);                                                                   \
         return LU_CHECK_LAUNCH();                                                               \
     }
     LU_CONV_CASE(4, true)

@@ -21,7 +21,7 @@ void lu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
-extern "C" int lu_abi_version(void) { return 4; }
+extern "C" int lu_abi_version(void) { return 5; }
 
 // ---------------------------------------------------------------------------------------------
 // CRC-32C (Castagnoli), slicing-by-8, HOST code: the checksum of TensorFlow tensor bundles (tf_bundle.py reads / writes
@@ -94,6 +94,44 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ z, const float* 
         const float* zp = z + row * 4 * F + ch;
         const float gi = hsig(zp[0]), gf = hsig(zp[F]), gg = tanhf(zp[2 * F]), go = hsig(zp[3 * F]);
         const float cn = fmaf(gf, c_prev[i], gi * gg);      // (same contraction as the fused epilogues in lu_conv.hip)
+        c_out[i] = cn;
+        const int64_t f = row / ppf;
+        h_out[f * h_fs + (row - f * ppf) * F + ch] = go * tanhf(cn);
+        if (gates_out) {
+            float* gp = gates_out + row * 4 * F + ch;
+            gp[0] = gi;
+            gp[F] = gf;
+            gp[2 * F] = gg;
+            gp[3 * F] = go;
+        }
+    }
+}
+
+// The same gate block on the partial slabs of a K-split convolution: z = bias + slab 0 + slab 1 + ... (the order of
+// ksplit_reduce_kernel, so both routes produce the same bits).
+__global__ void lstm_gates_fwd_slabs_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
+                                            const float* __restrict__ bias, const float* __restrict__ c_prev,
+                                            float* __restrict__ c_out, float* __restrict__ h_out,
+                                            float* __restrict__ gates_out, int64_t total, int64_t ppf, int F, int64_t h_fs) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t row = i / F;
+        const int ch = (int)(i - row * F);
+        const float* zp = slabs + row * 4 * F + ch;
+        float zi = 0.f, zf = 0.f, zg = 0.f, zo = 0.f;
+        if (bias) {
+            zi = bias[ch];
+            zf = bias[F + ch];
+            zg = bias[2 * F + ch];
+            zo = bias[3 * F + ch];
+        }
+        for (int k = 0; k < splits; ++k, zp += slab_stride) {
+            zi += zp[0];
+            zf += zp[F];
+            zg += zp[2 * F];
+            zo += zp[3 * F];
+        }
+        const float gi = hsig(zi), gf = hsig(zf), gg = tanhf(zg), go = hsig(zo);
+        const float cn = fmaf(gf, c_prev[i], gi * gg);
         c_out[i] = cn;
         const int64_t f = row / ppf;
         h_out[f * h_fs + (row - f * ppf) * F + ch] = go * tanhf(cn);
@@ -379,20 +417,20 @@ __global__ void bn_lrelu_apply_kernel(const float* __restrict__ x, float* __rest
             float4 v = reinterpret_cast<const float4*>(x)[i];
             float4 o;
             float t;
-            t = v.x * scale[c] + shift[c];
+            t = fmaf(v.x, scale[c], shift[c]);
             o.x = t > 0.f ? t : alpha * t;
-            t = v.y * scale[c + 1] + shift[c + 1];
+            t = fmaf(v.y, scale[c + 1], shift[c + 1]);
             o.y = t > 0.f ? t : alpha * t;
-            t = v.z * scale[c + 2] + shift[c + 2];
+            t = fmaf(v.z, scale[c + 2], shift[c + 2]);
             o.z = t > 0.f ? t : alpha * t;
-            t = v.w * scale[c + 3] + shift[c + 3];
+            t = fmaf(v.w, scale[c + 3], shift[c + 3]);
             o.w = t > 0.f ? t : alpha * t;
             reinterpret_cast<float4*>(y)[i] = o;
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
             const int c = (int)(i % C);
-            const float t = x[i] * scale[c] + shift[c];
+            const float t = fmaf(x[i], scale[c], shift[c]);
             y[i] = t > 0.f ? t : alpha * t;
         }
     }
@@ -657,6 +695,17 @@ extern "C" int lu_lstm_gates_fwd(const float* z, const float* c_prev, float* c_o
     const int64_t total = (int64_t)frames * ppf * F;
     LU_LAUNCH(lstm_gates_fwd_kernel, dim3(grid_for(total)), dim3(NT), stream, z, c_prev, c_out, h_out, gates_out,
               total, ppf, (int)F, h_fs);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_lstm_gates_fwd_slabs(const float* slabs, int32_t splits, const float* bias, const float* c_prev,
+                                       float* c_out, float* h_out, float* gates_out, int32_t frames, int64_t ppf, int32_t F,
+                                       int64_t h_fs, lu_stream_t stream) {
+    LU_REQUIRE(slabs && splits > 0 && c_prev && c_out && h_out && frames > 0 && ppf > 0 && F > 0,
+               "lu_lstm_gates_fwd_slabs: bad arguments");
+    const int64_t total = (int64_t)frames * ppf * F;
+    LU_LAUNCH(lstm_gates_fwd_slabs_kernel, dim3(grid_for(total)), dim3(NT), stream, slabs, (int)splits, total * 4, bias, c_prev,
+              c_out, h_out, gates_out, total, ppf, (int)F, h_fs);
     return LU_CHECK_LAUNCH();
 }
 

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 4          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 5          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -12,6 +12,7 @@ LU_F32, LU_BF16 = 0, 1
 LU_CONV_F_PATCH8, LU_CONV_F_PATCH16, LU_CONV_F_NO_HALO, LU_CONV_F_XCD_BY_N = 1, 2, 4, 8
 LU_CONV_F_LDS_DMA, LU_CONV_F_MF2, LU_CONV_F_GENERAL = 16, 32, 64
 LU_CONV_F_LOOP_GEN1, LU_CONV_F_GATES_BF16, LU_CONV_F_SRC1_CENTER, LU_CONV_F_NO_BALANCE = 128, 256, 512, 1024
+LU_CONV_F_SLABS_ONLY = 2048
 LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE, LU_WGRAD_F_PRB32 = 1, 2, 4, 8, 16, 32
 
 
@@ -28,7 +29,8 @@ class ConvDesc(C.Structure):
                 ('c_prev', c_f32p), ('c_out', c_f32p), ('h_out', c_f32p), ('gates_out', c_f32p),
                 ('c_prev_frame_stride', i64), ('c_out_frame_stride', i64), ('h_frame_stride', i64),
                 ('gates_frame_stride', i64), ('splits', i32), ('precision', i32), ('workspace', C.c_void_p),
-                ('out_row_stride', i64), ('k_h', i32), ('flags', i32), ('h16_out', C.c_void_p), ('h16_frame_stride', i64)]
+                ('out_row_stride', i64), ('k_h', i32), ('flags', i32), ('h16_out', C.c_void_p), ('h16_frame_stride', i64),
+                ('post_scale', c_f32p), ('post_shift', c_f32p), ('post_alpha', f32)]
 
 
 class WgradDesc(C.Structure):
@@ -58,6 +60,7 @@ PROTOTYPES = {
     'lu_conv2d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'lu_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), S]),
     'lu_lstm_gates_fwd': (C.c_int, [P, P, P, P, P, i32, i64, i32, i64, S]),
+    'lu_lstm_gates_fwd_slabs': (C.c_int, [P, i32, P, P, P, P, P, i32, i64, i32, i64, S]),
     'lu_lstm_gates_bwd': (C.c_int, [P, P, P, P, i64, P, P, P, P, i32, i64, i32, S]),
     'lu_lstm_gates_bwd_bf16': (C.c_int, [P, P, P, P, i64, P, P, P, i32, i64, i32, S]),
     'lu_convert_f32_bf16': (C.c_int, [P, P, i64, S]),

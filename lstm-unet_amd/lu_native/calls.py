@@ -85,8 +85,9 @@ def fused_step_cost_us(frames, H, W, F, k, channels):
 
 def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,
            out_frame_stride, out_pix_stride, lstm=None, splits=1, workspace=None, out_row_stride=0, precision=0, k_h=0,
-           flags=0, h16=None):
-    """h16 = (ptr, frame_stride): optional bf16 copy of h written by the fused ConvLSTM epilogue (precision 1)."""
+           flags=0, h16=None, post=None):
+    """h16 = (ptr, frame_stride): optional bf16 copy of h written by the fused ConvLSTM epilogue (precision 1).
+    post = (scale_ptr, shift_ptr, alpha): inference BN affine + LeakyReLU folded into the store (LU_EPI_BIAS)."""
     d = cabi.ConvDesc()
     d.n_src = len(srcs)
     for i, s in enumerate(srcs):
@@ -97,6 +98,8 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
     d.epilogue = cabi.LU_EPI_BIAS
     d.splits, d.workspace, d.out_row_stride, d.precision, d.k_h = splits, workspace, out_row_stride, precision, k_h
     d.flags = flags
+    if post is not None:
+        d.post_scale, d.post_shift, d.post_alpha = post
     if h16 is not None:
         d.h16_out, d.h16_frame_stride = h16
     if lstm is not None:

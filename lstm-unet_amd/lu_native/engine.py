@@ -138,8 +138,9 @@ class Engine:
 
     # ------------------------------------------------------------------ helpers
     def weights_changed(self):
-        """Optimiser step / checkpoint load: the cached bf16 weight images are stale."""
+        """Optimiser step / checkpoint load: the cached bf16 weight images and inference BN affines are stale."""
         self._packed.clear()
+        self._bn_epoch += 1
 
     def _bf16_conv(self, k, stride, n_out):
         return self.precision == 'bf16' and stride == 1 and k in (3, 5) and n_out > 64 and n_out % 4 == 0
@@ -169,13 +170,19 @@ class Engine:
                 rec.update(scale=scale, shift=shift, mean=mean, invstd=invstd, count=count)
             self._bn_epoch += 1      # the raw-pointer kernel moved mm / mv without bumping their torch versions
         else:
-            # inference scale / shift depend on the weights and moving statistics only: computed once, not per frame
-            token = (self.flat_params._version, mm._version, mv._version, self._bn_epoch)
-            hit = self._bn_infer.get(prefix)
-            if hit is None or hit[0] != token:
-                hit = self._bn_infer[prefix] = (token, ops.bn_finalize_infer(gamma, beta, mm, mv, BN_EPS))
-            scale, shift = hit[1]
+            scale, shift = self._bn_affine_infer(prefix)
         return ops.bn_lrelu_apply(y, scale, shift, LRELU_ALPHA)
+
+    def _bn_affine_infer(self, prefix):
+        """Inference-mode scale / shift of one BatchNorm: functions of the weights and moving statistics only, computed once
+        per change of those, not per frame."""
+        mm, mv = self.S[prefix + '.moving_mean'], self.S[prefix + '.moving_var']
+        token = (self.flat_params._version, mm._version, mv._version, self._bn_epoch)
+        hit = self._bn_infer.get(prefix)
+        if hit is None or hit[0] != token:
+            hit = self._bn_infer[prefix] = (token, ops.bn_finalize_infer(self.P[prefix + '.gamma'], self.P[prefix + '.beta'],
+                                                                         mm, mv, BN_EPS))
+        return hit[1]
 
     def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape, alt16=None):
         """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151).
@@ -191,6 +198,10 @@ class Engine:
             pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs: w[:, :, co:co + cs, :], co, cs)) for (x, co, cs) in srcs]
         else:
             pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
+        if with_bn and tape is None and not training:
+            # inference: BatchNorm is a per-channel affine -- it and the LeakyReLU ride on the conv's store / slab reduce
+            scale, shift = self._bn_affine_infer(f'{prefix}.bn.{ci}')
+            return ops.conv2d(pairs, self.P[f'{prefix}.conv.{ci}.bias'], spec['stride'], post=(scale, shift, LRELU_ALPHA))
         y = ops.conv2d(pairs, self.P[f'{prefix}.conv.{ci}.bias'], spec['stride'])
         rec = None
         if tape is not None:

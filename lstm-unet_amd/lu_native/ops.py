@@ -137,15 +137,19 @@ def _src(x, w):
 
 
 def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out, out_view=None, flops=None,
-             k_h=0):
+             k_h=0, post=None, slabs_only=False):
     """One lu_conv2d_fwd launch (bias epilogue); picks a K-split + workspace for tile-starved problems.
-    out_view = (ptr, frame_stride, pix_stride, row_stride) overrides the dense addressing of `out`."""
+    out_view = (ptr, frame_stride, pix_stride, row_stride) overrides the dense addressing of `out`.
+    post = (scale, shift, alpha): inference BatchNorm affine + LeakyReLU folded into the store / the slab reduce.
+    slabs_only: return (workspace, splits) with the partial slabs instead of reducing them (None when no split applies)."""
     channels = sum(x.shape[3] for x, _ in pairs)
     halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     splits = calls.conv_splits(frames, Hout, Wout, N, k, channels, halo and out_view is None) if not k_h else 1
     ws = None
     if splits > 1:
-        ws = torch.empty(splits * frames * Hout * Wout * N, device=out.device, dtype=torch.float32)
+        ws = torch.empty(splits * frames * Hout * Wout * N, device=pairs[0][0].device, dtype=torch.float32)
+    if slabs_only and splits <= 1:
+        return None
     prec = max([w.precision for _, w in pairs if isinstance(w, PackedW)] + [0])
     bf16 = prec == 1
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
@@ -153,27 +157,35 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     if bf16:
         kind = ('conv_halo_frag_kernel<%d,LU_EPI_BIAS,*,bf16> (bf16-MFMA recurrent / input dgrads, plain convs)' % k) \
             if (halo and out_view is None) else 'conv_gather_bf16_kernel (bf16-MFMA strided / narrow / parity-plane convs)'
-    optr, ofs, ops_, ors = out_view if out_view is not None else (out.data_ptr(), out.stride(0), out.stride(2), 0)
+    if slabs_only:
+        optr, ofs, ops_, ors = None, Hout * Wout * N, N, 0
+    else:
+        optr, ofs, ops_, ors = out_view if out_view is not None else (out.data_ptr(), out.stride(0), out.stride(2), 0)
     if out_view is not None and not bf16:
         kind = 'conv_fwd_kernel (strided / dilated / narrow convs)'
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
                      pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors,
-                     precision=prec, k_h=k_h, flags=CONV_FLAGS)
-    return out
+                     precision=prec, k_h=k_h, flags=CONV_FLAGS | (cabi.LU_CONV_F_SLABS_ONLY if slabs_only else 0),
+                     post=None if post is None else (post[0].data_ptr(), post[1].data_ptr(), float(post[2])))
+    return (ws, splits) if slabs_only else out
 
 
-def conv2d(pairs, bias, stride=1, out=None):
-    """SAME convolution summed over (activation, weight) pairs -> [frames,Ho,Wo,N]."""
+def conv2d(pairs, bias, stride=1, out=None, post=None):
+    """SAME convolution summed over (activation, weight) pairs -> [frames,Ho,Wo,N].
+    post = (scale, shift, alpha): -> lrelu(scale * conv + shift), the inference BN + LeakyReLU of the conv unit in the same pass."""
     x0, w0 = pairs[0]
     _chk(bias, out, *[t.data if isinstance(t, PackedW) else t for p in pairs for t in p])
+    if post is not None:
+        _chk(post[0], post[1])
+        assert post[0].numel() == w0.shape[3] == post[1].numel() and post[0].dtype == post[1].dtype == torch.float32
     frames, Hin, Win = x0.shape[:3]
     k, N = w0.shape[0], w0.shape[3]
     Hout, pt, _ = same_pad(Hin, k, stride)
     Wout, pl, _ = same_pad(Win, k, stride)
     if out is None:
         out = torch.empty((frames, Hout, Wout, N), device=x0.device, dtype=torch.float32)
-    return conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, 1, pt, pl, N, bias, out)
+    return conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, 1, pt, pl, N, bias, out, post=post)
 
 
 def flip_transpose(w, c_off=0, c_sub=None):
@@ -362,8 +374,15 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     else:
         assert h16_out is None and not x_center and h_prev.dtype == torch.float32 and \
             (gates_out is None or gates_out.dtype == torch.float32), 'the bf16 tape belongs to the fused bf16 step'
-        z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
         assert c_prev.is_contiguous() and c_out.is_contiguous()
+        # K-split steps hand their partial slabs straight to the gate kernel (one pass over z less than reduce + gates)
+        slabs = conv_raw([(x_t, kernel), (h_prev, rec)], frames, H, W, H, W, k, 1, 1, p, p, 4 * F, None, None, slabs_only=True)
+        if slabs is not None:
+            calls.check(lib(), lib().lu_lstm_gates_fwd_slabs(slabs[0].data_ptr(), slabs[1], _p(bias), c_prev.data_ptr(),
+                                                             c_out.data_ptr(), h_out.data_ptr(), _p(gates_out), frames,
+                                                             H * W, F, h_out.stride(0), _stream()), 'lu_lstm_gates_fwd_slabs')
+            return
+        z = conv2d([(x_t, kernel), (h_prev, rec)], bias, 1)
         calls.check(lib(), lib().lu_lstm_gates_fwd(z.data_ptr(), c_prev.data_ptr(), c_out.data_ptr(), h_out.data_ptr(),
                                                    _p(gates_out), frames, H * W, F, h_out.stride(0), _stream()),
                     'lu_lstm_gates_fwd')

@@ -110,9 +110,10 @@ def pack_f32(be, wd, k, Cin, N):
 
 
 def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1, precision=0, flags=0,
-           bf16_src=()):
+           bf16_src=(), post=None, slabs=False):
     """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy.
-    bf16_src: indices of sources handed over as bf16 tensors (precision 1)."""
+    bf16_src: indices of sources handed over as bf16 tensors (precision 1).  post = (scale, shift, alpha) numpy / float.
+    slabs=True: LU_CONV_F_SLABS_ONLY -> the [splits, frames*Hout*Wout, N] partial slabs."""
     frames, Hin, Win = srcs[0].shape[:3]
     if N is None:
         N = ws[0].shape[-1]
@@ -136,8 +137,15 @@ def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None
                                  dtype=cabi.LU_BF16 if b16 else cabi.LU_F32))
     bd = None if bias is None else be.dev(bias)
     wsb = be.empty((splits * frames * Hout * Wout * N,)) if splits > 1 else None
+    pd = None
+    if post is not None:
+        keep += [be.dev(post[0]), be.dev(post[1])]
+        pd = (be.ptr(keep[-2]), be.ptr(keep[-1]), float(post[2]))
     calls.conv2d(be.lib, be.stream, cs, frames, Hin, Win, Hout, Wout, k, stride, dil, pt, pl, N, be.ptr(bd),
-                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb), precision=precision, flags=flags)
+                 be.ptr(out), Hout * Wout * N, N, splits=splits, workspace=be.ptr(wsb), precision=precision,
+                 flags=flags | (cabi.LU_CONV_F_SLABS_ONLY if slabs else 0), post=pd)
+    if slabs:
+        return be.host(wsb).reshape(splits, frames * Hout * Wout, N)
     return be.host(out)
 
 

@@ -91,6 +91,50 @@ def test_conv_block_numbering_variants_are_bitwise_equal(be):
         assert np.array_equal(u, v)
 
 
+def test_conv_post_affine_lrelu_and_slab_gates(be):
+    """ABI v5: (a) the inference BatchNorm affine + LeakyReLU folded into the conv's store or its slab reduce is the same
+    arithmetic as lu_bn_lrelu_apply on the plain conv output (bit-identical), in the general, halo and bf16 kernels, with and
+    without a K split; (b) LU_CONV_F_SLABS_ONLY + lu_lstm_gates_fwd_slabs == K-split conv + reduce + lu_lstm_gates_fwd."""
+    for (fr, H, W, Cc, N, k, st, sp, prec) in [(1, 12, 14, 32, 24, 3, 1, 1, 0), (1, 12, 14, 32, 24, 3, 2, 3, 0),
+                                               (1, 16, 32, 20, 136, 3, 1, 1, 0), (1, 16, 32, 20, 136, 5, 1, 4, 0),
+                                               (1, 16, 32, 32, 136, 3, 1, 2, 1), (1, 12, 14, 32, 72, 3, 2, 1, 1)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        scale, shift = (1.0 + 0.3 * rnd(N)).astype(np.float32), rnd(N)
+        plain = KH.conv2d(be, [x], [w], b, k, st, splits=sp, precision=prec)
+        got = KH.conv2d(be, [x], [w], b, k, st, splits=sp, precision=prec, post=(scale, shift, 0.3))
+        yd, sd, hd = be.dev(plain), be.dev(scale), be.dev(shift)
+        want = be.empty(plain.shape)
+        ck(be, be.lib.lu_bn_lrelu_apply(be.ptr(yd), be.ptr(want), be.ptr(sd), be.ptr(hd), 0.3, plain.size // N, N, be.stream),
+           'bn_lrelu_apply')
+        assert np.array_equal(got, be.host(want)), (fr, H, W, Cc, N, k, st, sp, prec)
+        t = plain.astype(np.float64) * scale + shift
+        close(got, np.where(t > 0, t, 0.3 * t), 1e-5)
+    F = 8
+    fr, H, W = 2, 6, 7
+    xi, xh, c0 = rnd(fr, H, W, 4), rnd(fr, H, W, 32, scale=0.5), rnd(fr, H, W, F)
+    wi, wh, b = rnd(5, 5, 4, 4 * F, scale=0.3), rnd(5, 5, 32, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    z = KH.conv2d(be, [xi, xh], [wi, wh], b, 5, 1, splits=3)
+    slabs = KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, splits=3, slabs=True)
+    close(slabs.sum(0).reshape(z.shape) + b, z, 1e-5)
+    outs = []
+    for route in ('z', 'slabs'):
+        zd, sl, bd, c0d = be.dev(z), be.dev(slabs), be.dev(b), be.dev(c0)
+        c1, h1, g1 = be.empty(c0.shape), be.empty(c0.shape), be.empty(z.shape)
+        if route == 'z':
+            ck(be, be.lib.lu_lstm_gates_fwd(be.ptr(zd), be.ptr(c0d), be.ptr(c1), be.ptr(h1), be.ptr(g1), fr, H * W, F,
+                                            H * W * F, be.stream), 'gates_fwd')
+        else:
+            ck(be, be.lib.lu_lstm_gates_fwd_slabs(be.ptr(sl), 3, be.ptr(bd), be.ptr(c0d), be.ptr(c1), be.ptr(h1), be.ptr(g1),
+                                                  fr, H * W, F, H * W * F, be.stream), 'gates_fwd_slabs')
+        outs.append((be.host(c1), be.host(h1), be.host(g1)))
+    for u, v in zip(*outs):
+        assert np.array_equal(u, v)
+    h_ref, c_ref = npo.convlstm_step(np.concatenate([xi, xh], -1), np.zeros_like(c0), c0,
+                                     np.concatenate([wi, wh], 2), np.zeros((5, 5, F, 4 * F), np.float32), b)
+    close(outs[1][0], c_ref, 2e-5)
+    close(outs[1][1], h_ref, 2e-5)
+
+
 def test_conv_halo_variant(be):
     """8x32-patch halo-reuse kernel (stride-1 3x3 / 5x5, N > 64): ragged patches, two sources incl. a thin one,
     K split, and the fused ConvLSTM epilogue on it."""
