@@ -39,10 +39,53 @@ def postprocess(softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, f
     return _POST(sm, edge_dist, min_cell_size, max_cell_size, fov, fov_fix, stages)
 
 
-def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0, on_device=False):
+class PostPipeline(object):
+    """Software pipeline of the per-frame path: the post-processing of frame t (a chain of small kernels with two or three
+    device -> host reads, lu_native/post.py) runs on its OWN HIP stream while the forward of frame t + 1 -- already enqueued
+    on the main stream when push() is called -- keeps the chip busy.  push(t, softmax) returns the frames finished by then
+    as [(t, labels, softmax)] (one frame late), flush() the last one.  Results are those of postprocess(): same kernels,
+    same order per frame."""
+
+    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False):
+        self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
+        self.stream = None
+        self.pending = None
+
+    def _finish(self):
+        import torch
+        t, sm, ready = self.pending
+        self.pending = None
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            labels = postprocess(sm, *self.args)      # host-blocking reads synchronise this stream only
+        return [(t, labels, sm)]
+
+    def push(self, t, softmax_chw):
+        import torch
+        if softmax_chw.device.type != 'cuda':        # the host emulator of the test-suite: nothing to overlap
+            return [(t, postprocess(softmax_chw, *self.args), softmax_chw)]
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        done = self._finish() if self.pending is not None else []
+        ready = torch.cuda.Event()
+        ready.record()                                # after the forward that produced softmax_chw (current stream)
+        softmax_chw.record_stream(self.stream)
+        self.pending = (t, softmax_chw, ready)
+        return done
+
+    def flush(self):
+        return self._finish() if self.pending is not None else []
+
+
+def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0, on_device=False, graph=False):
     """Yield (t, softmax [3,H,W]) for every real frame; warm-up frames are consumed silently.  on_device=True yields the
-    device tensor (what the GPU post-processing consumes) instead of a host array."""
+    device tensor (what the GPU post-processing consumes) instead of a host array.
+    graph=True (GPU only; the model must be at the start of a sequence): the per-frame launch sequence is captured once
+    into a hipGraph (lu_native.graph.GraphedFrame, bit-identical to the eager forward) and replayed per frame, which takes
+    the ~70 host-side launches per frame off the host.  Measured (MI355X, B = 1, 256x256): no gain in fp32 (GPU-bound) and
+    530 vs 551 frames/s in bf16 mode (the fixed state buffers cost eight small copies per frame) -- an option, off by default."""
     nchw = data_format[1] == 'C'
+    replay = None
     for T, image in enumerate(frames):
         t = T - pre_sequence_frames
         image = np.asarray(image, np.float32)
@@ -52,7 +95,14 @@ def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0, on_
             image = image.reshape((1, 1) + image.shape)
         else:
             raise ValueError()
-        _, sm = model(image, training=False)
+        if graph and replay is None:
+            from lu_native.graph import GraphedFrame
+            replay = GraphedFrame(model, image)
+            replay.reset_states()                 # the capture's warm-up frames are not history
+        if replay is not None and tuple(replay.x.shape) == image.shape:
+            sm = replay(image)[1].clone()         # the graph owns its output buffer: the next replay overwrites it
+        else:
+            _, sm = model(image, training=False)
         if t < 0:
             continue
         sm = sm[0, 0] if nchw else sm[0, 0].permute(2, 0, 1).contiguous()
@@ -86,15 +136,24 @@ def inference(params):
             write_tiff16(os.path.join(params.save_intermediate_label_path, 'mask{time:03d}.tif'.format(time=t)), labels)
 
     pending = []
-    try:
-        for t, sm in stream_softmax(model, dataset, params.data_format, params.pre_sequence_frames, on_device=True):
-            if params.dry_run:
-                continue
-            labels = postprocess(sm, params.edge_dist, params.min_cell_size, params.max_cell_size, params.FOV,
-                                 bool(getattr(params, 'fov_fix', False)))
-            pending.append(pool.submit(write, t, labels, sm.cpu().numpy() if params.save_intermediate else None))
+    pipe = PostPipeline(params.edge_dist, params.min_cell_size, params.max_cell_size, params.FOV,
+                        bool(getattr(params, 'fov_fix', False)))
+
+    def emit(done):
+        for (t_done, labels, sm_done) in done:
+            pending.append(pool.submit(write, t_done, labels, sm_done.cpu().numpy() if params.save_intermediate else None))
             while len(pending) > 16:          # bounded backlog
                 pending.pop(0).result()
+
+    try:
+        import Networks
+        use_graph = Networks._device().type == 'cuda' and bool(getattr(params, 'graph', False))
+        for t, sm in stream_softmax(model, dataset, params.data_format, params.pre_sequence_frames, on_device=True,
+                                    graph=use_graph):
+            if params.dry_run:
+                continue
+            emit(pipe.push(t, sm))            # labels of frame t - 1, computed while frame t's forward runs
+        emit(pipe.flush())
         for job in pending:
             job.result()
     except (KeyboardInterrupt, ValueError) as err:
@@ -125,6 +184,9 @@ FLAGS = [
     (('--dry_run',), dict(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
     (('--precision',), dict(dest='precision', choices=['fp32', 'bf16'],
                             help='[MI355X] fp32 (default) or bf16 MFMA operands for the wide convolutions')),
+    (('--graph',), dict(dest='graph', action='store_const', const=True,
+                        help='[MI355X] replay the per-frame launch sequence from a captured hipGraph (bit-identical; measured '
+                             'neutral to slightly slower: the frame is bound by the GPU, not by the host launches)')),
     (('--fov_fix',), dict(dest='fov_fix', action='store_const', const=True,
                           help='[MI355X] mask columns [0, FOV) instead of the reference\'s single column FOV (Inference2D.py:97)')),
 ]

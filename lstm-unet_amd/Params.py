@@ -67,6 +67,7 @@ _INFER_DEFAULTS = dict(
     dry_run=False, save_intermediate=True, save_intermediate_path='./tmp/output/PhC-C2DL-PSC/01',
     precision='fp32',      # MI355X option: 'bf16' = bf16 MFMA operands
     fov_fix=False,         # MI355X option: True masks columns [0, FOV) instead of the reference's single column (Inference2D.py:97)
+    graph=False,           # MI355X option: True replays the per-frame launch sequence from a captured hipGraph
 )
 
 

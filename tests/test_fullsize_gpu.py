@@ -280,6 +280,12 @@ def test_streaming_inference_contract():
         assert np.abs(s - ref).max() <= 1e-6
     labels = Inference2D.postprocess(outs[-1][1], min_cell_size=1, max_cell_size=10 ** 6)
     assert labels.shape == (37, 45) and labels.dtype == np.uint16
+    # the driver's path: hipGraph replay of the frame (warm-up frames of the capture are not history) == eager, bit for bit
+    m3 = Networks.ULSTMnet2D(net, 'NCHW', True, seed=4)
+    outs_g = list(Inference2D.stream_softmax(m3, frames[:2][::-1] + frames, 'NCHW', pre_sequence_frames=2, graph=True))
+    assert [t for t, _ in outs_g] == [0, 1, 2, 3, 4]
+    for (_, a), (_, b) in zip(outs, outs_g):
+        assert np.array_equal(a, b)
 
 
 def test_reference_smoke_shape_contracts():

@@ -173,3 +173,26 @@ def test_postprocess_full_frame_832x992():
         sm = po.synthetic_softmax(832, 992, seed=seed, n_cells=400, nested=nested, noise=0.25, rmax=16)
         ref, st = _check(torch.device('cuda', 0), sm, edge_dist=2, min_cell_size=10, max_cell_size=5000, fov=0)
         assert ref.max() > 50
+
+
+def test_post_pipeline_returns_the_same_label_maps(dev):
+    """Inference2D.PostPipeline (post-processing of frame t on a side stream while frame t + 1's forward is in flight)
+    delivers, one frame late and in order, exactly the label maps of the synchronous postprocess() -- also when a busy
+    main stream keeps producing work between the pushes."""
+    import Inference2D
+    import torch
+    kw = dict(edge_dist=2, min_cell_size=4, max_cell_size=10 ** 6, fov=3)
+    sms = [po.synthetic_softmax(64, 80, seed, n_cells=9, nested=(seed % 2 == 0)) for seed in range(6)]
+    want = [po.postprocess(sm, **kw) for sm in sms]
+    pipe = Inference2D.PostPipeline(kw['edge_dist'], kw['min_cell_size'], kw['max_cell_size'], kw['fov'])
+    got = []
+    busy = torch.randn(512, 512, device=dev)
+    for t, sm in enumerate(sms):
+        d = torch.from_numpy(sm).to(dev)
+        for _ in range(4):
+            busy = torch.tanh(busy @ busy * 1e-3)         # main-stream work standing in for the next forward
+        got += pipe.push(t, d)
+    got += pipe.flush()
+    assert [t for t, _, _ in got] == list(range(len(sms)))
+    for (t, labels, _), ref in zip(got, want):
+        assert np.array_equal(labels, ref), t
