@@ -448,7 +448,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         oy = r / a.Wout;
         ox0 = r - oy * a.Wout;
     }
-    const bool want_bias = a.bias_ws != nullptr && kh == 0 && c0 == 0;
+    // The bias gradient (column sums of the dy tile) is shared out over the K * c_tiles blocks that stream the SAME dy tile:
+    // block `bslot` takes the stages s with s % brc == bslot.  (One block doing all of it runs a few percent behind its
+    // siblings, the group stops sharing dy / x in L2 and the launch's fabric traffic doubles: 3.2 -> 5.3 GB measured.)
+    const bool want_bias = a.bias_ws != nullptr;
+    const int brc = a.inner / a.n_tiles, bslot = kh * a.c_tiles + c0 / BMw;
+    int bphase = 0;
     float bsum[YE];
 #pragma unroll
     for (int e = 0; e < YE; ++e) bsum[e] = 0.f;
@@ -514,7 +519,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         }
     };
     auto bias_stage = [&](const lu_u4 (&ry)[YPASS]) {
-        if (want_bias) {          // bias gradient = column sums of dy (of the values the MFMA sees when dy is bf16)
+        const bool mine = want_bias && bphase == bslot;      // (uniform)
+        bphase = bphase + 1 == brc ? 0 : bphase + 1;
+        if (mine) {               // bias gradient = column sums of dy (of the values the MFMA sees when dy is bf16)
 #pragma unroll
             for (int i = 0; i < YPASS; ++i) {
                 if (YB) {
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += Bred[w * BNw + tid];
-            if (n0 + tid < a.N) a.bias_ws[(int64_t)z * a.N + n0 + tid] = s;
+            if (n0 + tid < a.N) a.bias_ws[((int64_t)z * brc + bslot) * a.N + n0 + tid] = s;
         }
     }
 }
@@ -834,18 +841,30 @@ __global__ __launch_bounds__(512, 2) void wgrad_small3_kernel(WgradArgs a) {
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ dw,
                                     int C, int N, int64_t tap_stride, int row_stride, float beta,
-                                    const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta) {
-    // elements [0, slab): the weight gradient; [slab, slab + N): the bias gradient riding on the same launch (its own
-    // 40-microsecond launch per layer added up to 0.7 ms per step)
-    const int64_t total = slab + (bias_ws ? N : 0);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+                                    const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta,
+                                    int bias_rows, int dw_blocks) {
+    // blocks [0, dw_blocks): the weight gradient.  Blocks beyond: the bias gradient riding on the same launch (its own
+    // 40-microsecond launch per layer added up to 0.7 ms per step) -- 16 columns x 16 row lanes per block over the
+    // [bias_rows][N] partial column sums (a few hundred rows: one thread per column would be one long dependent chain).
+    if ((int)blockIdx.x >= dw_blocks) {
+        __shared__ float red[16][17];
+        const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const int n = ((int)blockIdx.x - dw_blocks) * 16 + cl;
         float s = 0.f;
-        if (i >= slab) {
-            const int n = (int)(i - slab);
-            for (int z = 0; z < splits; ++z) s += bias_ws[(int64_t)z * N + n];
-            dbias[n] = (dbias_beta != 0.f ? dbias_beta * dbias[n] : 0.f) + s;
-            continue;
+        if (n < N)
+            for (int z = rl; z < bias_rows; z += 16) s += bias_ws[(int64_t)z * N + n];
+        red[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0 && n < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) t += (red[j][cl] + red[j + 1][cl]) + (red[j + 2][cl] + red[j + 3][cl]);
+            dbias[n] = (dbias_beta != 0.f ? dbias_beta * dbias[n] : 0.f) + t;
         }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += (int64_t)dw_blocks * blockDim.x) {
+        float s = 0.f;
         for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * slab + i];
         const int64_t row = i / N;
         const int n = (int)(i - row * N);
@@ -870,7 +889,9 @@ size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb, bool xb) {
 extern "C" size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d) {
     if (!d) return 0;
     int splits = d->splits > 0 ? d->splits : 1;
-    return (size_t)splits * (d->k * d->k * (size_t)d->C + (d->dbias ? 1 : 0)) * d->N * sizeof(float);
+    // slabs + the bias rows: up to k * ceil(C / 64) partial column sums per split (the bf16 kernel-row variant shares the
+    // bias work out over the blocks of a dy tile), one for the other variants
+    return (size_t)splits * (d->k * d->k * (size_t)d->C + (d->dbias ? (size_t)d->k * ((d->C + 63) / 64) : 0)) * d->N * sizeof(float);
 }
 
 extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
@@ -933,6 +954,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     LU_REQUIRE(!d->dbias || row_variant || small3 || (row_s2 && row_bf16),
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
+    // bf16 kernel-row variant: channel tile, and the bias rows per split that go with it (also needed by a phase-2 call)
+    const int ct_bf16 = d->k == 1 ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
+                                                                                          : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
+    const int bias_rows_per_split = (row_bf16 && !small3) ? d->k * ((d->C + ct_bf16 - 1) / ct_bf16) : 1;
     if (d->phase == 2) {
         // reduce only: the slabs were produced by an earlier phase-1 call with the same descriptor
     } else if (small3) {
@@ -942,8 +967,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         else if (tiles <= 24) LU_LAUNCH((wgrad_small3_kernel<3>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_small3_kernel<5>), grid, dim3(512), stream, a);
     } else if (row_bf16) {
-        const int ct = d->k == 1 ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
-                                                                                        : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
+        const int ct = ct_bf16;
         a.c_tiles = (d->C + ct - 1) / ct;
         a.n_tiles = (d->N + 127) / 128;
         a.inner = a.n_tiles * d->k * a.c_tiles;
@@ -1010,10 +1034,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
 #undef LU_WG
     int rc = LU_CHECK_LAUNCH();
     if (rc || d->phase == 1) return rc;
-    int64_t total = a.slab + (d->dbias ? d->N : 0);
-    unsigned rgrid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,
+    const unsigned rgrid = (unsigned)((a.slab + 255) / 256 < 4096 ? (a.slab + 255) / 256 : 4096);
+    const unsigned bgrid = d->dbias ? (unsigned)((d->N + 15) / 16) : 0;
+    LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid + bgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,
               d->N, d->dw_tap_stride, d->dw_row_stride, d->beta, (const float*)(d->dbias ? a.bias_ws : nullptr), d->dbias,
-              d->dbias_beta);
+              d->dbias_beta, splits * bias_rows_per_split, (int)rgrid);
     return LU_CHECK_LAUNCH();
 }
