@@ -14,6 +14,7 @@ Reference behaviour reproduced (file:line into arbellea/LSTM-UNet):
   UpBlock2D.call    Networks.py:141-153     state API        Networks.py:77-98,279-291
   truncated BPTT: carried (h, c) are constants of the next window (stateful=True, Networks.py:48-50)
 """
+import contextlib
 import math
 
 import numpy as np
@@ -71,6 +72,9 @@ class Engine:
         self._bn_infer = {}          # BN prefix -> (validity token, (scale, shift)) of the inference-mode affine
         self._bn_epoch = 0
         self._state16 = {}           # (block, layer) -> (h state tensor, its bf16 copy) left by the last inference step
+        self.overlap_wgrad = True    # GPU: weight gradients go to a side HIP stream (see _wgrad_side); bench.py's per-kernel
+                                     # timing pass and the host emulator run them in line
+        self._side_stream = None
         self.persistent_states = False   # True (lu_native.graph): inference copies the new state INTO the existing state
                                          # tensors instead of adopting the step's output tensors as the state
 
@@ -242,8 +246,9 @@ class Engine:
             a16 = rec.get('alt16')
             if a16 is not None and self.precision == 'bf16' and ops.bf16_row_wgrad_ok(a16, dy, gw.shape[0], spec['stride']):
                 x = a16
-            ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
-                             dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
+            with self._wgrad_side(x, dy):
+                ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
+                                 dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
                                         bf16=self.precision == 'bf16' and cs >= 64) if need else None)
         rec['srcs'] = rec['alt16'] = None
@@ -386,29 +391,35 @@ class Engine:
                 dz32[0] = ops.to_f32(dz_seq)
             return dz32[0]
 
-        # hoisted over all T: one big reduction per weight
+        # hoisted over all T: one big reduction per weight, on the side stream (_wgrad_side)
         bf = self.precision == 'bf16'
         hp16 = h16_all[:T].view(T * B, H, W, F) if tape16 else None
-        if tape16 and ops.bf16_row_wgrad_ok(hp16, dz_seq, k, 1):
-            ops.conv2d_wgrad(hp16, dz_seq, self.G[pre + '.recurrent_kernel'], 1, bf16=True,
-                             dbias=self.G[pre + '.bias'])       # + the bias gradient = column sums of dz, on the side
-        else:
-            ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_f32(), self.G[pre + '.recurrent_kernel'], 1, bf16=bf,
-                             dbias=self.G[pre + '.bias'])
+        rec_16 = tape16 and ops.bf16_row_wgrad_ok(hp16, dz_seq, k, 1)
+        ker_25 = x25 is not None and ops.bf16_row_wgrad_ok(x25.view(T * B, H, W, 32), dz_seq, 1, 1)
+        ker_16 = (not ker_25) and tape16 and ops.bf16_row_wgrad_ok(x16 if x16 is not None else x_seq, dz_seq, k, 1)
+        dx_bf = self._bf16_conv(k, 1, kernel.shape[2])
+        if tape16 and (not rec_16 or not (ker_25 or ker_16) or (need_dx and not dx_bf)):
+            dz_f32()      # a consumer without a bf16-operand kernel: the fp32 copy is made on the main stream, before the fork
         gk = self.G[pre + '.kernel']
-        if x25 is not None and ops.bf16_row_wgrad_ok(x25.view(T * B, H, W, 32), dz_seq, 1, 1):
-            # thin image: the weight gradient of the im2col chunk is a 1x1 problem over its 32 (tap, c) rows
-            tmp = torch.empty((1, 1, 32, 4 * F), device=dev, dtype=torch.float32)
-            ops.conv2d_wgrad(x25.view(T * B, H, W, 32), dz_seq, tmp, 1, bf16=True)
-            rows = gk.shape[0] * gk.shape[1] * gk.shape[2]
-            gk.view(rows, 4 * F).copy_(tmp.view(32, 4 * F)[:rows])
-        elif tape16 and ops.bf16_row_wgrad_ok(x16 if x16 is not None else x_seq, dz_seq, k, 1):
-            ops.conv2d_wgrad(x16 if x16 is not None else x_seq, dz_seq, gk, 1, bf16=True)
-        else:
-            ops.conv2d_wgrad(x_seq, dz_f32(), gk, 1, bf16=bf)
+        with self._wgrad_side(dz_seq, dz32[0], hp16, h_all, x25, x16, x_seq):
+            if rec_16:
+                ops.conv2d_wgrad(hp16, dz_seq, self.G[pre + '.recurrent_kernel'], 1, bf16=True,
+                                 dbias=self.G[pre + '.bias'])       # + the bias gradient = column sums of dz, on the side
+            else:
+                ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_f32(), self.G[pre + '.recurrent_kernel'], 1, bf16=bf,
+                                 dbias=self.G[pre + '.bias'])
+            if ker_25:
+                # thin image: the weight gradient of the im2col chunk is a 1x1 problem over its 32 (tap, c) rows
+                tmp = torch.empty((1, 1, 32, 4 * F), device=dev, dtype=torch.float32)
+                ops.conv2d_wgrad(x25.view(T * B, H, W, 32), dz_seq, tmp, 1, bf16=True)
+                rows = gk.shape[0] * gk.shape[1] * gk.shape[2]
+                gk.view(rows, 4 * F).copy_(tmp.view(32, 4 * F)[:rows])
+            elif ker_16:
+                ops.conv2d_wgrad(x16 if x16 is not None else x_seq, dz_seq, gk, 1, bf16=True)
+            else:
+                ops.conv2d_wgrad(x_seq, dz_f32(), gk, 1, bf16=bf)
         dx = None
         if need_dx:
-            dx_bf = self._bf16_conv(k, 1, kernel.shape[2])
             dx = ops.conv2d_dgrad(dz_seq if (dx_bf or not tape16) else dz_f32(), kernel, (H, W), 1, bf16=dx_bf)
         rec['h_all'] = rec['c_all'] = rec['x'] = rec['h16_all'] = rec['x25'] = rec['x16'] = None
         return dx
@@ -463,6 +474,27 @@ class Engine:
         if training:
             self.tape = {'ops': tape, 'pads': (py, px), 'hw': (H, W), 'T': T, 'B': B}
         return logits
+
+    def _wgrad_side(self, *tensors):
+        """Context for the weight-gradient launches of backward.  Nothing in backward consumes a weight gradient -- only the
+        optimiser (and the DP buckets) do -- so they run on a second HIP stream: the MFMA-bound gradient GEMMs then overlap
+        with the HBM-bound chain the main stream continues with (BatchNorm backward passes, gate backward, slab reduces,
+        resizes) and fill the tails of the dgrad launches.  Same kernels on the same data: results are unchanged.
+        `tensors`: main-stream tensors the side-stream launches read (kept from the allocator until those launches ran)."""
+        dev = self.flat_params.device
+        if not self.overlap_wgrad or dev.type != 'cuda' or ops.EVENT_LOG is not None:
+            return contextlib.nullcontext()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        self._side_stream.wait_stream(torch.cuda.current_stream(dev))      # operands produced so far are ready
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self._side_stream)
+        return torch.cuda.stream(self._side_stream)
+
+    def _join_side(self):
+        if self._side_stream is not None:
+            torch.cuda.current_stream(self.flat_params.device).wait_stream(self._side_stream)
 
     def backward(self, dlogits):
         """dlogits [T*B,H,W,last_depth] -> fills flat_grads (all trainable tensors)."""
@@ -525,9 +557,11 @@ class Engine:
             self._bucket_done(seg)
             seg += 1
         assert not tape
+        self._join_side()      # the optimiser step follows on the main stream
 
     def _bucket_done(self, seg):
         if self.on_bucket_ready is not None:
+            self._join_side()      # the bucket's weight gradients ran on the side stream
             _, s, e = self.segments[seg]
             self.on_bucket_ready(s, e)
 
