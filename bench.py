@@ -161,6 +161,7 @@ def main():
     ap.add_argument('--no-infer', action='store_true', help='skip the secondary streaming-inference measurement')
     ap.add_argument('--no-bf16', action='store_true', help='skip the secondary bf16-mode measurement of the same step')
     ap.add_argument('--sync-bn', action='store_true')
+    ap.add_argument('--no-wgrad-overlap', action='store_true', help='A/B: weight gradients in line instead of on the side stream')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else)")
     args = ap.parse_args()
@@ -185,6 +186,8 @@ def main():
                               Params.CTCParams.learning_rate, dp=dp, sync_bn=args.sync_bn, seed=0,
                               precision=args.precision)
     batches = synthetic_batches(4, B, T, H, W, dp.rank, dev)
+    if args.no_wgrad_overlap:
+        trainer.engine.overlap_wgrad = False
 
     def one_step(i):
         img, seg, keep = batches[i % len(batches)]

@@ -35,6 +35,28 @@ def model_pads(h, w, total_stride, pad_image):
             (mp, mp + (total_stride - w % total_stride) % total_stride))
 
 
+class _SideLaunch(object):
+    """with-block of Engine._wgrad_side: the launches inside go to the engine's side stream, after everything the main
+    stream has enqueued so far; the operands stay referenced until the side stream has passed them."""
+
+    def __init__(self, eng, tensors):
+        self.eng, self.tensors, self.ctx = eng, tensors, None
+
+    def __enter__(self):
+        eng = self.eng
+        eng._side_release()
+        eng._side_stream.wait_stream(torch.cuda.current_stream(eng.flat_params.device))
+        self.ctx = torch.cuda.stream(eng._side_stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        ev = torch.cuda.Event()
+        ev.record(self.eng._side_stream)
+        self.eng._side_keep.append((ev, self.tensors))
+        return self.ctx.__exit__(*exc)
+
+
 class Engine:
     def __init__(self, net_params, pad_image=True, seed=0, dp=None, sync_bn=False, plan_fn=None, precision='fp32',
                  resize='tf2.0'):
@@ -72,9 +94,11 @@ class Engine:
         self._bn_infer = {}          # BN prefix -> (validity token, (scale, shift)) of the inference-mode affine
         self._bn_epoch = 0
         self._state16 = {}           # (block, layer) -> (h state tensor, its bf16 copy) left by the last inference step
-        self.overlap_wgrad = True    # GPU: weight gradients go to a side HIP stream (see _wgrad_side); bench.py's per-kernel
-                                     # timing pass and the host emulator run them in line
+        # GPU, bf16 mode: weight gradients go to a side HIP stream (see _wgrad_side: +0.6 % measured; neutral in fp32, where
+        # the HBM-bound share of backward is 8x smaller); bench.py's per-kernel timing pass and the host emulator run in line
+        self.overlap_wgrad = precision == 'bf16'
         self._side_stream = None
+        self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
         self.persistent_states = False   # True (lu_native.graph): inference copies the new state INTO the existing state
                                          # tensors instead of adopting the step's output tensors as the state
 
@@ -480,21 +504,25 @@ class Engine:
         optimiser (and the DP buckets) do -- so they run on a second HIP stream: the MFMA-bound gradient GEMMs then overlap
         with the HBM-bound chain the main stream continues with (BatchNorm backward passes, gate backward, slab reduces,
         resizes) and fill the tails of the dgrad launches.  Same kernels on the same data: results are unchanged.
-        `tensors`: main-stream tensors the side-stream launches read (kept from the allocator until those launches ran)."""
+        `tensors`: main-stream tensors the side-stream launches read.  They are HELD (a reference each) until an event
+        recorded behind those launches has completed -- tensor.record_stream() would do the same inside the caching
+        allocator, but its deferred frees made config-4 (832x992, 194 GB resident) 50 % slower: measured, tools/c4_try.py."""
         dev = self.flat_params.device
         if not self.overlap_wgrad or dev.type != 'cuda' or ops.EVENT_LOG is not None:
             return contextlib.nullcontext()
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=dev)
-        self._side_stream.wait_stream(torch.cuda.current_stream(dev))      # operands produced so far are ready
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self._side_stream)
-        return torch.cuda.stream(self._side_stream)
+        return _SideLaunch(self, tensors)
+
+    def _side_release(self, everything=False):
+        keep = self._side_keep
+        while keep and (everything or keep[0][0].query()):
+            keep.pop(0)
 
     def _join_side(self):
         if self._side_stream is not None:
             torch.cuda.current_stream(self.flat_params.device).wait_stream(self._side_stream)
+            self._side_keep.clear()      # whatever reuses that memory is main-stream work enqueued behind the join
 
     def backward(self, dlogits):
         """dlogits [T*B,H,W,last_depth] -> fills flat_grads (all trainable tensors)."""
