@@ -1,7 +1,19 @@
 # full measurement set of a round (usage: bash tools/gpu/r02_final.sh <tag>); everything lands in gpurun_out/<tag>_*
+# order: GPU tests, PMC passes (their traffic tables are what the bench lines below quote as roofline.traffic), bench lines,
+# kernel-trace profiles
 tag=${1:-r02}
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -q -m gpu -s > gpurun_out/${tag}_gpu_tests.log 2>&1; tail -3 gpurun_out/${tag}_gpu_tests.log; grep "train_step_parity c1\|lstm bptt\|config-" gpurun_out/${tag}_gpu_tests.log | cut -c1-400
+python -m pytest tests -q -m gpu -s > gpurun_out/${tag}_gpu_tests.log 2>&1; tail -3 gpurun_out/${tag}_gpu_tests.log; grep "train_step_parity c1\|config-" gpurun_out/${tag}_gpu_tests.log | cut -c1-300
+bash tools/gpu/pmc_traffic.sh $tag | tail -14
+python - <<PY
+import json, time
+for sfx in ('', '_bf16'):
+    p = 'gpurun_out/${tag}_pmc_traffic%s.json' % sfx
+    d = json.load(open(p))
+    d['collected'] = 'round 2 final binary, $tag'
+    json.dump(d, open(p, 'w'), indent=1)
+    json.dump(d, open('profiles/r02_pmc_traffic%s.json' % sfx, 'w'), indent=1)      # (the box's copy: read by bench.py below)
+PY
 python bench.py --steps 8 --warmup 3 > gpurun_out/${tag}_f32_bench_line.json 2> gpurun_out/${tag}_f32_bench.err; tail -2 gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bf16_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16 --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bf16_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
@@ -20,4 +32,4 @@ for mode in fp32 bf16; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_$mode -- python $R/bench.py --precision $mode --steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 > /dev/null 2>&1
   (cd $R && python tools/prof_summary.py gpurun_out/${tag}_prof_$mode gpurun_out/${tag}_${short}_kernel_stats | head -2; rm -rf gpurun_out/${tag}_prof_$mode)
 done
-cd $R && bash tools/gpu/pmc_traffic.sh $tag
+cd $R && bash tools/gpu/r02_inf_prof.sh ${tag}_inf 2>&1 | grep "launches/frame"
