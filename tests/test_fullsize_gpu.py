@@ -123,6 +123,31 @@ def test_full_width_net_vs_oracle_small_crop(full_engine):
     assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-3
 
 
+def test_full_width_streaming_inference_vs_oracle(full_engine):
+    """Params.py widths, B = 1 streaming (the tile-starved regime of DESIGN 3.1a: balanced block numbering, K-split ConvLSTM
+    steps through LU_CONV_F_SLABS_ONLY + lu_lstm_gates_fwd_slabs, BatchNorm affine + LeakyReLU applied by the slab
+    reduce, step outputs adopted as the recurrent state): three frames fed one at a time == one call over the clip
+    (re-associated K splits: 1e-5 * max|logit|) == the fp64 oracle in inference mode (1e-3 * max|logit|)."""
+    dev = full_engine.device
+    net = _params_net()
+    rng = np.random.default_rng(12)
+    B, T, H, W = 1, 3, 72, 88
+    x = rng.standard_normal((B, T, H, W, 1)).astype(np.float32)
+    p = {k: v for k, v in full_engine.export_params().items()}
+    e1 = _clone_engine(full_engine)
+    whole = e1.forward(torch.from_numpy(_to_tb(x)).to(dev), T, B, False).view(T, H, W, 3).cpu().numpy()
+    e2 = _clone_engine(full_engine)
+    frames = [e2.forward(torch.from_numpy(_to_tb(x[:, t:t + 1])).to(dev), 1, B, False).view(H, W, 3).cpu().numpy() for t in range(T)]
+    scale = max(1.0, float(np.abs(whole).max()))
+    assert max(np.abs(f - w).max() for f, w in zip(frames, whole)) <= 1e-5 * scale
+    for (s1, s2) in zip(e1.states, e2.states):
+        for (a, b) in zip(s1, s2):
+            assert float((a[0] - b[0]).abs().max()) <= 1e-5 and float((a[1] - b[1]).abs().max()) <= 1e-5
+    tm = tho.TorchULSTM(net, 1, p, dtype=torch.float64)
+    ref = tm.forward(torch.tensor(x, dtype=torch.float64), training=False).detach().numpy()[0]
+    assert np.abs(whole - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+
+
 def _train_step(e, x, gt, cw, T, B, opt=None):
     from lu_native import ops
     lg = e.forward(x, T, B, True)
