@@ -89,7 +89,10 @@ dp = DataParallel()                     # LU_DP_BACKEND=gloo: both ranks on the 
 assert dp.world_size == 2 and torch.cuda.is_available()
 d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
 net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
-tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3)
+tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3,
+                     precision=sys.argv[1])
+if os.environ.get('LU_TEST_NO_OVERLAP'):
+    tr.engine.overlap_wgrad = False
 sl = slice(dp.rank, dp.rank + 1)
 _, _, loss = tr.train_step(d['x'][sl], d['gt'][sl])
 tr.model.reset_states_per_batch(np.ones(1, np.float32))
@@ -103,10 +106,13 @@ dp.barrier()
 
 
 @pytest.mark.gpu
-def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision):
     """The N > 1 path on the REAL kernels: two ranks (gloo, sharing the one GPU of the test box -- RCCL needs one device
     per rank) x 1 slot with SyncBN == one process on the 2-slot batch.  What runs: rank-sharded slots, loss-sum all-reduce
-    before the gradient, bucketed gradient all-reduce fired from the engine's backward, pooled BN statistics."""
+    before the gradient, bucketed gradient all-reduce fired from the engine's backward, pooled BN statistics.
+    precision='bf16': the engine then runs its weight gradients on the side stream, so every bucket hand-over has to join
+    it first (LU_TEST_NO_OVERLAP=1 runs the same comparison with the side stream off)."""
     import train2D
     import Networks
     rng = np.random.default_rng(0)
@@ -116,7 +122,7 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path):
     script = tmp_path / 'worker_gpu.py'
     script.write_text(GPU_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
     port = 29600 + os.getpid() % 1500
-    procs = [subprocess.Popen([sys.executable, str(script)],
+    procs = [subprocess.Popen([sys.executable, str(script), precision],
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', LU_DP_BACKEND='gloo',
                                        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
@@ -124,7 +130,9 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
-    tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, seed=3)
+    tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, seed=3, precision=precision)
+    if os.environ.get('LU_TEST_NO_OVERLAP'):
+        tr.engine.overlap_wgrad = False
     _, _, l1 = tr.train_step(x, gt)
     tr.model.reset_states_per_batch(np.ones(2, np.float32))
     _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
@@ -132,4 +140,9 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path):
     got = np.load(tmp_path / 'dp_gpu_out.npz')
     assert np.abs(got['loss'] - np.array([float(l1), float(l2)])).max() <= 1e-5
     diff = np.abs(got['params'] - ref)
-    assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= 2e-3, (diff.max(), (diff > 1e-4).mean())
+    print('dp2 vs single (%s): max %.3e, fraction > 1e-4: %.3e' % (precision, diff.max(), (diff > 1e-4).mean()))
+    # bf16: the two wide ConvLSTM layers of this net (4F = 128 columns) do run on the bf16 MFMA kernels; pooled-vs-whole-batch
+    # BN statistics differ in the last fp64 bits, a few activations then round to the other bf16 neighbour, and Adam turns
+    # that into 1e-4-sized steps on ~0.5 % of the weights (measured 1.06e-3 / 5.2e-3, identical with the side stream off)
+    frac = 2e-3 if precision == 'fp32' else 1e-2
+    assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= frac, (diff.max(), (diff > 1e-4).mean())
