@@ -77,6 +77,22 @@ def conv_splits(frames, Hout, Wout, N, k, channels, halo=True):
     return min(cands, key=lambda s: (conv_cost_us(frames, Hout, Wout, N, k, channels, s, halo), s))
 
 
+def conv_plan(frames, Hout, Wout, N, k, channels, halo_ok=True):
+    """(splits, use_halo, modelled microseconds) of an fp32 LU_EPI_BIAS launch.  Where the halo kernel applies, its 8 x 32
+    patches may hang over the image (136-pixel rows: 15 %); the general kernel tiles flattened pixel rows without waste
+    and wins such launches when they are K-split anyway (B = 1 L1 step: 3.20 -> 2.93 ms measured).  The halo kernel is the
+    faster one per k-step (134 vs 128 TFLOP/s in training), hence the 5 % margin."""
+    s_g = conv_splits(frames, Hout, Wout, N, k, channels, False)
+    c_g = conv_cost_us(frames, Hout, Wout, N, k, channels, s_g, False)
+    if not halo_ok or conv_tiles(frames, Hout, Wout, N, k, True) == conv_tiles(frames, Hout, Wout, N, k, False):
+        return s_g, halo_ok, c_g
+    s_h = conv_splits(frames, Hout, Wout, N, k, channels, True)
+    c_h = conv_cost_us(frames, Hout, Wout, N, k, channels, s_h, True)
+    if c_g < 0.95 * c_h:
+        return s_g, False, c_g
+    return s_h, True, c_h
+
+
 def fused_step_cost_us(frames, H, W, F, k, channels):
     """Modelled duration of the fused fp32 ConvLSTM step (8 x 32-pixel patches x 32 hidden channels x 4 gates per block)."""
     blocks = conv_tiles(frames, H, W, 4 * F, k)

@@ -144,13 +144,23 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     slabs_only: return (workspace, splits) with the partial slabs instead of reducing them (None when no split applies)."""
     channels = sum(x.shape[3] for x, _ in pairs)
     halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
-    splits = calls.conv_splits(frames, Hout, Wout, N, k, channels, halo and out_view is None) if not k_h else 1
+    prec = max([w.precision for _, w in pairs if isinstance(w, PackedW)] + [0])
+    extra_flags = 0
+    if k_h:
+        splits = 1
+    elif prec == 0:
+        # fp32: split count AND kernel (halo patches vs flattened pixel rows) by modelled duration
+        splits, use_halo, _ = calls.conv_plan(frames, Hout, Wout, N, k, channels, halo and out_view is None)
+        if halo and out_view is None and not use_halo:
+            extra_flags = cabi.LU_CONV_F_NO_HALO
+            halo = False
+    else:
+        splits = calls.conv_splits(frames, Hout, Wout, N, k, channels, halo and out_view is None)
     ws = None
     if splits > 1:
         ws = torch.empty(splits * frames * Hout * Wout * N, device=pairs[0][0].device, dtype=torch.float32)
     if slabs_only and splits <= 1:
         return None
-    prec = max([w.precision for _, w in pairs if isinstance(w, PackedW)] + [0])
     bf16 = prec == 1
     kind = ('conv_halo_kernel<%d,LU_EPI_BIAS> (recurrent / input dgrads, plain convs)' % k) if halo else \
         'conv_fwd_kernel (strided / dilated / narrow convs)'
@@ -166,7 +176,7 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     with _timed(kind, flops if flops is not None else 2.0 * k * k * channels * N * frames * Hout * Wout / (dil * dil)):
         calls.conv2d(lib(), _stream(), [_src(x, w) for x, w in pairs], frames, Hin, Win, Hout, Wout, k, stride, dil,
                      pad_t, pad_l, N, _p(bias), optr, ofs, ops_, splits=splits, workspace=_p(ws), out_row_stride=ors,
-                     precision=prec, k_h=k_h, flags=CONV_FLAGS | (cabi.LU_CONV_F_SLABS_ONLY if slabs_only else 0),
+                     precision=prec, k_h=k_h, flags=CONV_FLAGS | extra_flags | (cabi.LU_CONV_F_SLABS_ONLY if slabs_only else 0),
                      post=None if post is None else (post[0].data_ptr(), post[1].data_ptr(), float(post[2])))
     return (ws, splits) if slabs_only else out
 
@@ -400,8 +410,7 @@ def fused_step_applies(frames, H, W, F, bf16, k=5, channels=None):
         return tiles >= FUSED_MIN_TILES
     if channels is None or tiles > 2048:
         return True
-    s = calls.conv_splits(frames, H, W, 4 * F, k, channels)
-    unfused = calls.conv_cost_us(frames, H, W, 4 * F, k, channels, s) + frames * H * W * F * 4 * 8 / 4e6 + 5
+    unfused = calls.conv_plan(frames, H, W, 4 * F, k, channels)[2] + frames * H * W * F * 4 * 8 / 4e6 + 5
     return 0.95 * calls.fused_step_cost_us(frames, H, W, F, k, channels) <= unfused      # (margin: model error)
 
 

@@ -44,7 +44,7 @@ def main(prec):
         flops = 2.0 * 25 * (cin + F) * 4 * F * fr * H * W
         res = []
         for label, fmt, flags in (('fused', 0, 0), ('fused/nobal', 0, cabi.LU_CONV_F_NO_BALANCE), ('split', 10 ** 9, 0),
-                                  ('split/nobal', 10 ** 9, cabi.LU_CONV_F_NO_BALANCE)):
+                                  ('split/nobal', 10 ** 9, cabi.LU_CONV_F_NO_BALANCE), ('split/nohalo', 10 ** 9, cabi.LU_CONV_F_NO_HALO)):
             ops.FUSED_MIN_TILES = ops.FUSED_MIN_TILES_BF16 = fmt
             ops.CONV_FLAGS = flags
             try:
