@@ -32,6 +32,7 @@ struct WgradArgs {
     float* ws;          // [splits][kk*C*N]
     int64_t slab;
     float* bias_ws;     // [splits][N] column sums of dy (bias gradient), or null; kernel-row variants only
+    int32_t xfold;      // fp32 kernel-row variant: pixel slabs folded into grid.x (8 / column tiles; 0 / 1 = none)
 };
 
 template <int MF, int NF, int WM, int WN, bool THIN, bool YVEC>
@@ -255,10 +256,17 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float Bsum[KP * BNw];     // bias-gradient partial sums (kernel row 0 blocks only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int n0 = blockIdx.x * BNw;
+    // Workgroup id % 8 picks the XCD and x is the fastest grid index: with 8 (16, ...) column tiles the K * c_tiles blocks
+    // that stream the same dy tile sit 8 ids apart, i.e. on ONE XCD, and share it in that L2.  Layers with 1 / 2 / 4 column
+    // tiles fold 8 / n_tiles pixel slabs into grid.x to keep that property (a.xfold; L0: 28.7 GB fetched per launch without).
+    const int nxt = a.xfold > 1 ? (int)gridDim.x / a.xfold : (int)gridDim.x;
+    const int bx = a.xfold > 1 ? (int)blockIdx.x % nxt : (int)blockIdx.x;
+    const int bz = a.xfold > 1 ? (int)blockIdx.z * a.xfold + (int)blockIdx.x / nxt : (int)blockIdx.z;
+    if (bz >= a.splits) return;
+    const int n0 = bx * BNw;
     const int kh = blockIdx.y / a.c_tiles;
     const int c0 = (blockIdx.y - kh * a.c_tiles) * BMw;
-    const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+    const int64_t p_begin = (int64_t)bz * a.chunk;
     int64_t p_end = p_begin + a.chunk;
     if (p_end > a.M) p_end = a.M;
     const int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
@@ -280,7 +288,11 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     // bias gradient = column sums of dy: the blocks of kernel row 0 / channel tile 0 see every dy element of their
     // (column tile, pixel slab) exactly once in `ry`, so they add it up on the side (exact fp32, no extra HBM pass).
     // The running sums live in LDS, one float4 slot per loader thread: nothing is held in registers across the MFMAs.
-    const bool want_bias = a.bias_ws != nullptr && blockIdx.y == 0;
+    // ... shared out over the gridDim.y = K * c_tiles blocks that stream this dy tile: block y takes the stages s = y mod
+    // gridDim.y (one block doing all of it lags its siblings, which then stop sharing dy / x in L2: see the bf16 variant)
+    const bool want_bias = a.bias_ws != nullptr;
+    const int brc = gridDim.y, bme = blockIdx.y;
+    int bphase = brc > 1 ? 1 : 0;      // (stage it + 1) mod brc, the stage the loop body accumulates
     float4* const bslot = reinterpret_cast<float4*>(&Bsum[yrow * BNw + 4 * yq]);
     if (want_bias) *bslot = make_float4(0.f, 0.f, 0.f, 0.f);
     auto bias_acc = [&]() {
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     if (n_it > 0) {
         load_stage(0);
         store_stage(0);
-        if (want_bias) bias_acc();
+        if (want_bias && bme == 0) bias_acc();
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -350,13 +362,14 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
         LU_SCHED_FENCE();
         store_stage(buf ^ 1);
-        if (want_bias && it + 1 < n_it) bias_acc();      // (the last iteration re-fetched its own run: not counted twice)
+        if (want_bias && it + 1 < n_it && bphase == bme) bias_acc();      // (the last iteration re-fetched its own run: not counted twice)
+        bphase = bphase + 1 == brc ? 0 : bphase + 1;
         LU_SCHED_FENCE();
         mma_pair(buf, KP - 2);
         __syncthreads();
     }
 
-    float* slab = a.ws + (int64_t)blockIdx.z * a.slab;
+    float* slab = a.ws + (int64_t)bz * a.slab;
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         const int tap = kh * K + t;
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < KP; ++r) s += red[r * BNw + tid];
-            if (n0 + tid < a.N) a.bias_ws[(int64_t)blockIdx.z * a.N + n0 + tid] = s;
+            if (n0 + tid < a.N) a.bias_ws[((int64_t)bz * brc + bme) * a.N + n0 + tid] = s;
         }
     }
 }
@@ -957,7 +970,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     // bf16 kernel-row variant: channel tile, and the bias rows per split that go with it (also needed by a phase-2 call)
     const int ct_bf16 = d->k == 1 ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
                                                                                           : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
-    const int bias_rows_per_split = (row_bf16 && !small3) ? d->k * ((d->C + ct_bf16 - 1) / ct_bf16) : 1;
+    const int bias_rows_per_split = small3 ? 1 : row_bf16 ? d->k * ((d->C + ct_bf16 - 1) / ct_bf16)
+                                                : row_variant ? d->k * ((d->C + 63) / 64) : 1;      // (blocks sharing a dy tile)
     if (d->phase == 2) {
         // reduce only: the slabs were produced by an earlier phase-1 call with the same descriptor
     } else if (small3) {
@@ -1007,7 +1021,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
 #undef LU_WGB2
     } else if (row_variant) {
         a.c_tiles = (d->C + 63) / 64;
-        dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)(d->k * a.c_tiles), (unsigned)splits);
+        const int nxt = (d->N + 127) / 128;
+        a.splits = splits;
+        a.xfold = (nxt == 1 || nxt == 2 || nxt == 4) ? 8 / nxt : 1;
+        dim3 grid((unsigned)(nxt * a.xfold), (unsigned)(d->k * a.c_tiles), (unsigned)((splits + a.xfold - 1) / a.xfold));
         if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_row_kernel<3>), grid, dim3(512), stream, a);
     } else if (!xvec) {
