@@ -19,6 +19,7 @@ class DataParallel(object):
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.bucket_bytes = bucket_bytes
         self._pending = []
+        self.launched = 0    # collectives issued so far (tests / logs)
         self._carry = None   # (start, end) range waiting to reach bucket size
         self.flat = None
         if self.world_size > 1 and not dist.is_initialized():
@@ -54,8 +55,12 @@ class DataParallel(object):
         """Called by the engine as soon as flat[start:end] holds final local gradients."""
         if self.world_size == 1:
             return
+        # adjacent ranges grow one bucket, whichever way backward walks the flat buffer (the engine finishes the decoder
+        # blocks, then the encoder blocks, from the END of the buffer towards its start): fewer, larger collectives
         if self._carry is not None and self._carry[1] == start:
             start = self._carry[0]
+        elif self._carry is not None and self._carry[0] == end:
+            end = self._carry[1]
         elif self._carry is not None:
             self._launch(*self._carry)
         self._carry = (start, end)
@@ -64,6 +69,7 @@ class DataParallel(object):
             self._carry = None
 
     def _launch(self, start, end):
+        self.launched += 1
         self._pending.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

@@ -169,6 +169,15 @@ for s, e in segs:
 dp.finish()
 exp = torch.arange(1000, dtype=torch.float32) * 3
 assert torch.equal(flat, exp), (flat[:5], exp[:5])
+assert dp.launched == 2, dp.launched          # (0,400) | (400,1000): the 16-byte piece joined its neighbour
+# the engine's order: from the END of the flat buffer towards its start -- adjacent ranges still merge
+flat2 = torch.arange(1000, dtype=torch.float32) * (dp.rank + 1)
+dp.attach(flat2)
+n0 = dp.launched
+for s, e in [(990, 1000), (900, 990), (600, 900), (500, 600), (0, 500)]:
+    dp.bucket_ready(s, e)
+dp.finish()
+assert torch.equal(flat2, exp) and dp.launched - n0 == 2, dp.launched - n0     # (600,1000) | (0,600)
 sums = torch.tensor([1.0 + dp.rank, 10.0], dtype=torch.float64)
 dp.all_reduce_(sums)
 assert sums.tolist() == [3.0, 20.0]
