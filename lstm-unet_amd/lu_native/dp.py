@@ -55,8 +55,8 @@ class DataParallel(object):
         """Called by the engine as soon as flat[start:end] holds final local gradients."""
         if self.world_size == 1:
             return
-        # adjacent ranges grow one bucket, whichever way backward walks the flat buffer (the engine finishes the decoder
-        # blocks, then the encoder blocks, from the END of the buffer towards its start): fewer, larger collectives
+        # adjacent ranges grow one bucket, whichever way the caller walks the flat buffer (the engine lays its parameters out
+        # in backward-completion order, i.e. ascending): fewer, larger collectives -- 3 per step at Params.py widths
         if self._carry is not None and self._carry[1] == start:
             start = self._carry[0]
         elif self._carry is not None and self._carry[0] == end:

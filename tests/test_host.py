@@ -170,7 +170,7 @@ dp.finish()
 exp = torch.arange(1000, dtype=torch.float32) * 3
 assert torch.equal(flat, exp), (flat[:5], exp[:5])
 assert dp.launched == 2, dp.launched          # (0,400) | (400,1000): the 16-byte piece joined its neighbour
-# the engine's order: from the END of the flat buffer towards its start -- adjacent ranges still merge
+# the opposite direction (a caller walking the flat buffer from its end): adjacent ranges still merge
 flat2 = torch.arange(1000, dtype=torch.float32) * (dp.rank + 1)
 dp.attach(flat2)
 n0 = dp.launched
