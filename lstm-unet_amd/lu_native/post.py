@@ -1,8 +1,8 @@
 """Host sequencing of the device post-processing (include/lstm_unet_hip.h `lu_post_*`, csrc/lu_postprocess.hip):
 softmax [3,H,W] on the device -> uint16 instance labels, reference Inference2D.py:66-123.
 
-Two small device -> host reads per frame (the per-label statistics and the FOV presence flags; the label map itself has to
-come back for the TIFF anyway).  Objects with holes are found for ALL labels at once from the bit-quad Euler numbers
+Two small device -> host reads per frame (label count + per-label statistics in one, and the FOV presence flags; the label
+map itself has to come back for the TIFF anyway).  Objects with holes are found for ALL labels at once from the bit-quad Euler numbers
 (holes = components - Euler number); the reference's per-object loop (`for n in range(1, num_cells)`, :80-91) is then run
 only over those, in label order.  Its additive quirk (a hole pixel that already carries label m becomes m + n) can change
 which pixels later labels own; the fill kernel reports that (`dirty`) and the remaining labels are then processed strictly
@@ -50,16 +50,18 @@ class PostProcessor(object):
         self.small[:2].zero_()
         ck(lib, lib.lu_post_label(sm.data_ptr(), H, W, 0.2, float(edge_dist), ws, L, self._p('num'), self._p('area'), st),
            'lu_post_label')
-        num = int(self.small[0].item())                     # sync 1a: the label count sizes the statistics pass
+        # the statistics pass is sized by the BOUND on the label count (a few thousand idle table entries), so that the
+        # count itself and the statistics come back in ONE device -> host read
+        ck(lib, lib.lu_post_label_stats(L, H, W, self.nmax, ws, self._p('bbox'), self._p('e4'), self._p('ncomp'), st),
+           'lu_post_label_stats')
+        host = self.small.cpu().numpy()                     # sync 1
+        num = int(host[0])
         if num > self.nmax:
             raise calls.NativeError('label count %d exceeds the bound %d' % (num, self.nmax))
         if stages is not None:
             stages['absorbed'] = self.labels.cpu().numpy().copy()
         areas = None
         if num > 1:
-            ck(lib, lib.lu_post_label_stats(L, H, W, num, ws, self._p('bbox'), self._p('e4'), self._p('ncomp'), st),
-               'lu_post_label_stats')
-            host = self.small.cpu().numpy()                 # sync 1b
             o, n = self.off, self.nmax
             areas = host[o['area']:o['area'] + num].astype(np.int64)
             bbox = host[o['bbox']:o['bbox'] + 4 * num].reshape(num, 4)
