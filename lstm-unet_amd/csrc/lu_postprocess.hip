@@ -209,12 +209,37 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
 __global__ void fg_assign_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ key,
                                  const int32_t* __restrict__ scanv, int32_t* __restrict__ lab, int32_t* __restrict__ area,
                                  int64_t hw) {
-    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) {
-        const int root = parent[i];
-        const int l = root >= 0 ? scanv[key[root]] + 1 : 0;
-        lab[i] = l;
-        atomicAdd(&area[l], 1);
+    // area[0] (the background: most of the frame) is counted per block in LDS and added once -- one global atomic per PIXEL
+    // on that single address serialised the whole kernel (0.72 ms of a 1.2 ms post-processing chain at 256 x 256)
+    __shared__ int32_t bg;
+    if (threadIdx.x == 0) bg = 0;
+    __syncthreads();
+    // a thread walks 8 consecutive pixels and adds RUNS of equal labels (the pixels of an object are row-contiguous)
+    const int64_t runs = (hw + 7) / 8;
+    for (int64_t t = (int64_t)blockIdx.x * PT + threadIdx.x; t < runs; t += (int64_t)gridDim.x * PT) {
+        int cur = -1, cnt = 0;
+        const int64_t hi = (t + 1) * 8 < hw ? (t + 1) * 8 : hw;
+        for (int64_t i = t * 8; i < hi; ++i) {
+            const int root = parent[i];
+            const int l = root >= 0 ? scanv[key[root]] + 1 : 0;
+            lab[i] = l;
+            if (l != cur) {
+                if (cnt) {
+                    if (cur) atomicAdd(&area[cur], cnt);
+                    else atomicAdd(&bg, cnt);
+                }
+                cur = l;
+                cnt = 0;
+            }
+            ++cnt;
+        }
+        if (cnt) {
+            if (cur) atomicAdd(&area[cur], cnt);
+            else atomicAdd(&bg, cnt);
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && bg) atomicAdd(&area[0], bg);
 }
 
 __global__ void absorb_kernel(const int32_t* __restrict__ cc, const int32_t* __restrict__ edge, int32_t* __restrict__ lab,
@@ -259,11 +284,11 @@ __global__ void label_stats_kernel(const int32_t* __restrict__ lab, int H, int W
         q[3] = (y < H && x < W) ? lab[(int64_t)y * W + x] : 0;
         if (y < H && x < W) {
             const int v = q[3];
-            if (v > 0 && v < nl) {
-                atomicMin(&bbox[4 * v], x);
-                atomicMin(&bbox[4 * v + 1], y);
-                atomicMax(&bbox[4 * v + 2], x);
-                atomicMax(&bbox[4 * v + 3], y);
+            if (v > 0 && v < nl) {      // only a pixel whose neighbour on that side is NOT v can be the extreme on that side
+                if (q[2] != v) atomicMin(&bbox[4 * v], x);
+                if (q[1] != v) atomicMin(&bbox[4 * v + 1], y);
+                if (x + 1 >= W || lab[(int64_t)y * W + x + 1] != v) atomicMax(&bbox[4 * v + 2], x);
+                if (y + 1 >= H || lab[(int64_t)(y + 1) * W + x] != v) atomicMax(&bbox[4 * v + 3], y);
             }
         }
         for (int a = 0; a < 4; ++a) {
@@ -388,7 +413,8 @@ extern "C" int lu_post_label(const float* softmax_chw, int32_t H, int32_t W, flo
     LU_LAUNCH(key_mark_kernel, g, b, stream, (const int32_t*)parent, (const int32_t*)key, mark, hw);
     LU_LAUNCH(scan_kernel, dim3(1), dim3(1024), stream, (const int32_t*)mark, scanv, nb, num_labels);
     LU_LAUNCH(fill32_kernel, dim3(pgrid(nb + 2)), b, stream, area, 0, (int64_t)nb + 2);
-    LU_LAUNCH(fg_assign_kernel, g, b, stream, (const int32_t*)parent, (const int32_t*)key, (const int32_t*)scanv, cc, area, hw);
+    LU_LAUNCH(fg_assign_kernel, dim3(pgrid((hw + 7) / 8)), b, stream, (const int32_t*)parent, (const int32_t*)key, (const int32_t*)scanv, cc,
+              area, hw);
     // edge pixels within edge_dist of a cell take the nearest cell's label
     int radius = 0;      // smallest window that holds every offset with sqrt(dy^2 + dx^2) < edge_dist
     while ((double)(radius + 1) < edge_dist) ++radius;
