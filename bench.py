@@ -243,6 +243,8 @@ def main():
                 pat = r'conv_halo_frag2?_kernel<%s, %d, ' % (m.group(2), 1 if m.group(3) == 'LSTM' else 0)
             elif name.startswith('wgrad_row_bf16_kernel<') and m:      # rocprof: wgrad_row_bf16_kernel<5, 128, true, true, 1, 64>
                 pat = r'wgrad_row_bf16_kernel<%s, ' % m.group(2)
+            elif name.startswith('wgrad_row_kernel<') and m:           # rocprof: wgrad_row_kernel<5> (older tables) or <5, false>
+                pat = r'wgrad_row_kernel<%s[,>]' % m.group(2)
             elif m and m.group(3):                                     # conv_halo_kernel<5,LU_EPI_LSTM> -> <5, 1>
                 pat = re.escape('%s<%s, %d>' % (m.group(1), m.group(2), 1 if m.group(3) == 'LSTM' else 0))
             else:

@@ -33,6 +33,7 @@ struct WgradArgs {
     int64_t slab;
     float* bias_ws;     // [splits][N] column sums of dy (bias gradient), or null; kernel-row variants only
     int32_t xfold;      // fp32 kernel-row variant: pixel slabs folded into grid.x (8 / column tiles; 0 / 1 = none)
+    int32_t ragged, wst, rows_per;      // fp32 kernel-row variant, W % 16 != 0: slabs of whole rows, ceil(W / 16) runs per row
 };
 
 template <int MF, int NF, int WM, int WN, bool THIN, bool YVEC>
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // same run widened by K-1 pixels ([16+K-1][64]); tap kw simply reads it shifted by kw rows.  Load bytes per FLOP
 // drop 2.3x versus one-tap-per-block; 8 waves (2 x 4), K accumulators each -> 4 waves/SIMD.
 // ---------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool RG>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
 __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     constexpr int BMw = 64, BNw = 128, XP = KP + K - 1, NT = 512;
     __shared__ __attribute__((aligned(16))) float Xs[2][XP * BMw];
@@ -266,16 +267,25 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     const int n0 = bx * BNw;
     const int kh = blockIdx.y / a.c_tiles;
     const int c0 = (blockIdx.y - kh * a.c_tiles) * BMw;
-    const int64_t p_begin = (int64_t)bz * a.chunk;
+    // pixel slab of this block: a.chunk consecutive pixels (W % 16 == 0: every 16-pixel run lies inside one image row) -- or,
+    // a.ragged (any other width): a.rows_per whole image rows, each walked in a.wst = ceil(W / 16) runs whose last one is
+    // masked beyond the row end (the dy loads return zeros there, so the x pixels under them do not matter)
+    const int64_t p_begin = RG ? 0 : (int64_t)bz * a.chunk;
     int64_t p_end = p_begin + a.chunk;
     if (p_end > a.M) p_end = a.M;
-    const int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
+    int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
     const float* const zp = lu_zero16;
 
     // the pixel run of a stage is uniform over the block: (frame, row, first column) advance by 16 pixels per stage
     int64_t pf = 0;          // frame index
     int oy = 0, ox0 = 0;
-    {
+    if (RG) {
+        const int64_t rows = a.M / a.Wout, r0 = (int64_t)bz * a.rows_per;
+        const int64_t r1 = r0 + a.rows_per < rows ? r0 + a.rows_per : rows;
+        n_it = r1 > r0 ? (int)(r1 - r0) * a.wst : 0;
+        pf = r0 / a.Hout;
+        oy = (int)(r0 - pf * a.Hout);
+    } else {
         const int64_t p = p_begin < a.M ? p_begin : 0;
         pf = p / a.HWo;
         const int r = (int)(p - pf * a.HWo);
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
         rx = *reinterpret_cast<const float4*>(okx ? px : zp);
         const int n = n0 + 4 * yq;
-        const bool oky = p_begin + (int64_t)it * KP + yrow < p_end && n < a.N;
+        const bool oky = (RG ? ox0 + yrow < a.Wout : p_begin + (int64_t)it * KP + yrow < p_end) && n < a.N;
         const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0 + yrow) * a.dy_ps + n;
         ry = *reinterpret_cast<const float4*>(oky ? py : zp);
     };
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     };
     auto advance = [&]() {
         ox0 += KP;
-        if (ox0 >= a.Wout) {          // W % 16 == 0: a run never straddles two rows
+        if (ox0 >= a.Wout) {          // (W % 16 == 0, or ragged rows with a masked last run): a run never straddles two rows
             ox0 = 0;
             if (++oy == a.Hout) {
                 oy = 0;
@@ -950,7 +960,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     const bool xb = d->x_dtype == LU_BF16, yb = d->dy_dtype == LU_BF16;
     const bool xvec = xvec32 || (xb && d->C % 8 == 0 && d->x_pix_stride % 8 == 0 && d->x_frame_stride % 8 == 0 && aligned16(d->x));
     const bool yvec = yvec32 || (yb && d->N % 8 == 0 && d->dy_pix_stride % 8 == 0 && d->dy_frame_stride % 8 == 0 && aligned16(d->dy));
-    const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && d->Wout % 16 == 0 &&
+    // (ragged: W % 16 != 0 -- fp32 kernel only, rows walked in ceil(W / 16) runs with a masked tail; from 40 pixels on, where the
+    // masked share is <= 17 %: config-4's 248- and 124-pixel levels ran the one-tap-per-block kernel at 113 TFLOP/s without it)
+    const bool ragged_w = d->Wout % 16 != 0 && d->Wout >= 40 && !xb && !yb && !(d->flags & LU_WGRAD_F_NO_RAGGED);
+    const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && (d->Wout % 16 == 0 || ragged_w) &&
                              d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_ROW);
     const bool small3 = !xb && !yb && xvec && yvec && d->stride == 1 && d->k == 3 && d->C <= 64 && d->N <= 64 &&
                         d->Wout % 16 == 0 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_SMALL3);
@@ -1023,10 +1036,18 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         a.c_tiles = (d->C + 63) / 64;
         const int nxt = (d->N + 127) / 128;
         a.splits = splits;
+        if (d->Wout % 16 != 0) {
+            a.ragged = 1;
+            a.wst = (d->Wout + 15) / 16;
+            const int64_t rows = (int64_t)d->frames * d->Hout;
+            a.rows_per = (int32_t)((rows + splits - 1) / splits);
+        }
         a.xfold = (nxt == 1 || nxt == 2 || nxt == 4) ? 8 / nxt : 1;
         dim3 grid((unsigned)(nxt * a.xfold), (unsigned)(d->k * a.c_tiles), (unsigned)((splits + a.xfold - 1) / a.xfold));
-        if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5>), grid, dim3(512), stream, a);
-        else LU_LAUNCH((wgrad_row_kernel<3>), grid, dim3(512), stream, a);
+        if (d->k == 5 && a.ragged) LU_LAUNCH((wgrad_row_kernel<5, true>), grid, dim3(512), stream, a);
+        else if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5, false>), grid, dim3(512), stream, a);
+        else if (a.ragged) LU_LAUNCH((wgrad_row_kernel<3, true>), grid, dim3(512), stream, a);
+        else LU_LAUNCH((wgrad_row_kernel<3, false>), grid, dim3(512), stream, a);
     } else if (!xvec) {
         const int gy = (a.kk * d->C + 31) / 32;
         if (yvec) LU_WG(1, 1, 1, 4, true, true, gy);

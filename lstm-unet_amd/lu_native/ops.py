@@ -303,8 +303,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     xb, yb = x.dtype == torch.bfloat16, dy.dtype == torch.bfloat16
     aligned = (Cin % 4 == 0 and N % 4 == 0 and x.stride(2) % 4 == 0 and dy.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and
                dy.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
-    row_variant = (aligned and stride == 1 and k in (3, 5) and Wout % 16 == 0 and Cin >= 64 and Hout == Hin and Wout == Win and
-                   not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))     # mirrors lu_conv2d_wgrad's kernel choice
+    ragged_w = (Wout % 16 != 0 and Wout >= 40 and not xb and not yb and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_RAGGED))
+    row_variant = (aligned and stride == 1 and k in (3, 5) and (Wout % 16 == 0 or ragged_w) and Cin >= 64 and Hout == Hin and
+                   Wout == Win and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))     # mirrors lu_conv2d_wgrad's kernel choice
     small3 = (aligned and not xb and not yb and stride == 1 and k == 3 and Cin <= 64 and N <= 64 and Wout % 16 == 0 and
               Hout == Hin and Wout == Win and
               not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_SMALL3))      # all-taps kernel of the narrow decoder layers (takes precedence)

@@ -387,6 +387,27 @@ def test_wgrad_fused_bias_gradient(be, precision):
         KH.conv2d_wgrad(be, rnd(1, 6, 6, 8), rnd(1, 6, 6, 8), 3, 1, dbias0=rnd(8))
 
 
+def test_wgrad_kernel_row_ragged_widths(be):
+    """fp32 kernel-row weight gradient on widths that are NOT multiples of 16 (config-4's 248- / 124-pixel levels; real CTC
+    crops): pixel slabs of whole rows, ceil(W / 16) runs per row with a masked tail.  Against the fp64 reference, against
+    the one-tap-per-block kernel (LU_WGRAD_F_NO_RAGGED) and with the bias gradient on the side; slab counts that do / do not
+    divide the row count, more slabs than rows."""
+    nr = cabi.LU_WGRAD_F_NO_RAGGED
+    for (fr, H, W, Cc, N, k, sp) in [(2, 5, 40, 72, 136, 3, 3), (1, 7, 44, 64, 128, 5, 2), (3, 3, 56, 128, 72, 5, 4),
+                                     (1, 2, 124, 64, 40, 3, 5)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        _, ref = _torch_conv_grads(x, rnd(k, k, Cc, N), dy, 1)
+        db0 = rnd(N)
+        dw, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
+        close(dw, ref, 2e-4)
+        close(db, dy.reshape(-1, N).astype(np.float64).sum(0) + db0, 2e-4)
+        close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, flags=nr), ref, 2e-4)
+        dw0 = rnd(k, k, Cc, N)
+        close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, dw0=dw0, beta=1.0), ref + dw0, 2e-4)
+    with pytest.raises(RuntimeError):      # the one-tap-per-block kernel has no bias gradient on the side
+        KH.conv2d_wgrad(be, rnd(1, 4, 40, 64), rnd(1, 4, 40, 64), 3, 1, dbias0=rnd(64), flags=nr)
+
+
 def test_wgrad_all_taps_narrow_layers(be):
     """wgrad_small3_kernel: stride-1 3x3 layers with C <= 64 and N <= 64 (W % 16 == 0) -- all nine taps per block, ragged
     channel counts, pixel splits, fused bias gradient."""
