@@ -110,12 +110,57 @@ def warp_affine(image, matrix, order, mode, cval=0.0):
     return ndimage.map_coordinates(image, [sy, sx], order=order, mode=mode, cval=cval)
 
 
+def adjust_contrast(image, factor):
+    """(image - mean) * factor + mean, mean over the whole crop (DataHandeling.py:250-260)."""
+    m = image.mean()
+    return (image - m) * factor + m
+
+
+def adjust_brightness(image, delta):
+    """image + delta (DataHandeling.py:239-248)."""
+    return image + delta
+
+
+def elastic_affine_points(shape_size, alpha_affine, random_state):
+    """The three control-point pairs of the clip's random affine (DataHandeling.py:152-173), float32 like the reference's.
+    Kept quirk: `center_square = float32(shape_size) // 2` is (h // 2, w // 2) but is handed to OpenCV as an (x, y) point,
+    so on a non-square crop the control triangle is centred at (x = h // 2, y = w // 2)."""
+    centre = np.float32(shape_size) // 2
+    sq = min(shape_size) // 3
+    pts1 = np.float32([centre + sq, [centre[0] + sq, centre[1] - sq], centre - sq])
+    pts2 = pts1 + random_state.uniform(-alpha_affine, alpha_affine, size=pts1.shape).astype(np.float32)
+    return pts1, pts2
+
+
+def elastic_indices(shape, alpha, sigma, random_state):
+    """Sampling coordinates (rows, cols) of the smooth random displacement field, in the reference's draw order
+    (DataHandeling.py:188-197): the x displacement is drawn first, then y; both are uniform(-1, 1) fields smoothed with a
+    Gaussian of `sigma` (scipy default boundary 'reflect') and scaled by `alpha`.  Column vectors like the reference's."""
+    dx = ndimage.gaussian_filter(random_state.rand(*shape) * 2 - 1, sigma) * alpha
+    dy = ndimage.gaussian_filter(random_state.rand(*shape) * 2 - 1, sigma) * alpha
+    x, y = np.meshgrid(np.arange(shape[1]), np.arange(shape[0]))
+    return np.reshape(y + dy, (-1, 1)), np.reshape(x + dx, (-1, 1))
+
+
+def transformed_image(image, affine_matrix, indices, seg=False):
+    """Affine warp, then the elastic resampling (DataHandeling.py:175-186): labels nearest-neighbour with -1 outside,
+    images bilinear with mirrored (warp: BORDER_REFLECT_101) / reflected (resampling) borders."""
+    shape = image.shape
+    if seg:
+        moved = warp_affine(image, affine_matrix, 0, 'constant', -1.0)
+        return ndimage.map_coordinates(moved, indices, order=0, mode='constant', cval=-1).reshape(shape)
+    moved = warp_affine(image, affine_matrix, 1, 'mirror')
+    return ndimage.map_coordinates(moved, indices, order=1, mode='reflect').reshape(shape)
+
+
 class ClipAugmenter(object):
     """One clip's geometric / photometric augmentation, drawn once per clip and applied to every frame
-    (DataHandeling.py:262-300): crop offset, flips, 90-degree rotations, temporal reverse / sub-sampling, and -- when
-    `elastic` -- a random affine (three control points jittered by 8 % of the crop) followed by a smooth random
-    displacement field (sigma = 15 % of the crop, amplitude = 2 crops before smoothing).  Labels go through the same
-    maps with nearest-neighbour sampling and -1 outside, and are then turned into {0,1,2} by the edge rule."""
+    (DataHandeling.py:262-300): temporal sub-sampling / reverse, crop offset, flips, 90-degree rotations, and -- when
+    `elastic` -- a random affine (three control points jittered by 8 % of the crop width) followed by a smooth random
+    displacement field (sigma = 15 % of the crop width, amplitude = 2 crop widths before smoothing), both drawn from ONE
+    `numpy.random.RandomState` in the reference's order (affine jitter, x field, y field) so that the helpers are pinned
+    by the reference's own (`tests/golden/elastic.npz`).  Labels go through the same maps with nearest-neighbour sampling
+    and -1 outside, and are then turned into {0,1,2} by the edge rule."""
 
     def __init__(self, rng, frame_shape, crop, randomize, elastic):
         H, W = frame_shape
@@ -131,25 +176,15 @@ class ClipAugmenter(object):
         self.rng = rng
         self.matrix = self.field = None
         if elastic:
-            centre = np.array([w // 2, h // 2], np.float64)       # (x, y)
-            sq = min(h, w) // 3
-            src = np.array([centre + sq, [centre[0] + sq, centre[1] - sq], centre - sq])
-            dst = src + rng.uniform(-0.08 * w, 0.08 * w, size=src.shape)
-            self.matrix = affine_from_points(src, dst)
-            sigma, alpha = 0.15 * w, 2.0 * w
-            dx = ndimage.gaussian_filter(rng.random((h, w)) * 2 - 1, sigma) * alpha
-            dy = ndimage.gaussian_filter(rng.random((h, w)) * 2 - 1, sigma) * alpha
-            yy, xx = np.mgrid[:h, :w]
-            self.field = [yy + dy, xx + dx]
+            # the reference seeds RandomState(None) per clip; here the seed comes from the slot's own generator so that the
+            # stream stays deterministic per (seed, rank, slot)
+            state = np.random.RandomState(int(rng.integers(0, 2 ** 31 - 1)))
+            self.matrix = affine_from_points(*elastic_affine_points((h, w), w * 0.08, state))
+            self.field = elastic_indices((h, w), w * 2, w * 0.15, state)
 
     def _geom(self, a, label):
         if self.matrix is not None:
-            if label:
-                a = warp_affine(a, self.matrix, 0, 'constant', -1.0)
-                a = ndimage.map_coordinates(a, self.field, order=0, mode='constant', cval=-1.0)
-            else:
-                a = warp_affine(a, self.matrix, 1, 'mirror')
-                a = ndimage.map_coordinates(a, self.field, order=1, mode='reflect')
+            a = transformed_image(a, self.matrix, self.field, seg=label)
         return a
 
     def _orient(self, a):
@@ -166,10 +201,9 @@ class ClipAugmenter(object):
         h, w = self.crop
         img = img[self.y0:self.y0 + h, self.x0:self.x0 + w].astype(np.float64)
         seg = seg[self.y0:self.y0 + h, self.x0:self.x0 + w].astype(np.float32).copy()
-        if self.randomize:      # contrast factor in [0.5, 1.5], brightness +-10 % of the sequence maximum
+        if self.randomize:      # contrast factor in [0.5, 1.5], brightness +-10 % of the sequence maximum (:342-348)
             factor, delta = self.rng.random() + 0.5, (self.rng.random() - 0.5) * 0.2 * img_max
-            m = img.mean()
-            img = (img - m) * factor + m + delta
+            img = adjust_brightness(adjust_contrast(img, factor), delta)
         img = self._geom(img, False)
         if self.matrix is not None:
             if not np.all(seg == -1):
@@ -219,6 +253,8 @@ class CTCRAMReaderSequence2D(object):
         self._queues = None
         self._threads = []
         self._stop = False
+        self._error = None
+        self._wake = None
         self.q_stat_list = []
 
     # ---- loading -------------------------------------------------------------------------------------------
@@ -295,30 +331,27 @@ class CTCRAMReaderSequence2D(object):
         self._slots = [self._clip_stream(b) for b in range(self.batch_size)]
         if self.num_threads > 1 and not debug:
             self._queues = [queue.Queue(maxsize=self.queue_capacity) for _ in range(self.batch_size)]
+            self._wake = threading.Event()      # set by stop(): idle workers wake up at once
 
             def work(slots):
                 # An exception in a producer (non-finite frame, unreadable file ...) must reach the training loop: the
-                # reference stops its coordinator (DataHandeling.py:425-428).  It travels through the queue as the item.
+                # reference stops its coordinator for ALL threads (DataHandeling.py:425-428).  The error is kept on the
+                # reader, `_stop` ends every worker, and get_batch -- which never blocks without a timeout -- re-raises it
+                # whichever slot queue it happens to be waiting on.
                 try:
                     while not self._stop:
+                        busy = False
                         for b in slots:
                             if self._queues[b].full():
                                 continue
                             self._queues[b].put(next(self._slots[b]))
-                        if all(self._queues[b].full() for b in slots):
-                            threading.Event().wait(0.005)
+                            busy = True
+                        if not busy:
+                            self._wake.wait(0.005)
                 except BaseException as exc:      # noqa: B902 -- re-raised by get_batch in the consumer thread
+                    if self._error is None:
+                        self._error = exc
                     self._stop = True
-                    for b in slots:
-                        while True:
-                            try:
-                                self._queues[b].put_nowait(exc)
-                                break
-                            except queue.Full:
-                                try:
-                                    self._queues[b].get_nowait()
-                                except queue.Empty:
-                                    pass
 
             n = min(self.num_threads, self.batch_size)
             for i in range(n):
@@ -330,6 +363,23 @@ class CTCRAMReaderSequence2D(object):
 
     def stop(self):
         self._stop = True
+        if self._wake is not None:
+            self._wake.set()
+
+    def _next_item(self, b):
+        """Next frame of slot b.  With worker threads: wait on the slot queue in short timeouts, surfacing a producer's
+        exception (from ANY worker) and a stopped / dead owner instead of blocking forever."""
+        if self._queues is None:
+            return next(self._slots[b])
+        import queue
+        while True:
+            try:
+                return self._queues[b].get(timeout=0.05)
+            except queue.Empty:
+                if self._error is not None:
+                    raise self._error
+                if self._stop or not any(th.is_alive() for th in self._threads):
+                    raise RuntimeError('the clip reader was stopped while a batch was being assembled')
 
     def get_batch(self):
         if self._slots is None:
@@ -342,10 +392,9 @@ class CTCRAMReaderSequence2D(object):
         keep = np.ones(B, np.float32)
         for b in range(B):
             for t in range(T):
-                item = self._queues[b].get() if self._queues is not None else next(self._slots[b])
-                if isinstance(item, BaseException):      # a producer thread died: surface its error here
-                    raise item
-                image[b, t], seg[b, t], full[b, t], keep[b] = item      # keep: the flag of the window's last frame
+                if self._error is not None:              # a producer thread died: surface its error here
+                    raise self._error
+                image[b, t], seg[b, t], full[b, t], keep[b] = self._next_item(b)   # keep: the flag of the window's last frame
         axis = 2 if self.data_format[1] == 'C' else 4
         return np.expand_dims(image, axis), np.expand_dims(seg, axis), full, keep
 

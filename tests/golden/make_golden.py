@@ -11,6 +11,11 @@ Outputs (all in tests/golden/):
   edge_rule.npz          DataHandeling.CTCRAMReaderSequence2D._fix_transformed_segmentation cases
   bbox.npz               utils.bbox_crop / bbox_fill cases
   default_params.json    Networks.DEFAULT_NET_DOWN_PARAMS and Params.CTCParams defaults
+  elastic.npz            the importable augmentation helpers of DataHandeling.py:152-197,239-260 with a seeded RandomState:
+                         control points of the random affine (as handed to cv2.getAffineTransform), elastic sampling
+                         coordinates, brightness / contrast, and the resampling half of _get_transformed_image_ (the
+                         cv2.warpAffine call is recorded -- dsize, border mode / value, interpolation flag -- and passed
+                         through as the identity warp, OpenCV being absent)
 """
 import json
 import os
@@ -166,6 +171,50 @@ def main():
     crop, loc = ref_utils.bbox_crop(img, margin=3)
     filled = ref_utils.bbox_fill(img.astype(np.float32), np.ones_like(crop, np.float32), loc)
     np.savez_compressed(os.path.join(OUT, 'bbox.npz'), img=img, crop=crop, loc=np.array(loc), filled=filled)
+
+    # ---- augmentation helpers: seeded RandomState in place of RandomState(None) ----
+    cv2 = sys.modules['cv2']
+    cv2.BORDER_CONSTANT, cv2.BORDER_REFLECT_101, cv2.INTER_NEAREST, cv2.INTER_LINEAR = 0, 4, 0, 1      # OpenCV's enum values
+    R = ref_data.CTCRAMReaderSequence2D
+    real_state = np.random.RandomState
+    el = {}
+    for ci, (shape, seed) in enumerate([((32, 32), 11), ((24, 40), 12), ((40, 24), 13)]):
+        seen = {}
+
+        def get_affine(p1, p2):
+            seen['pts1'], seen['pts2'] = np.array(p1), np.array(p2)
+            return np.float64([[1, 0, 0], [0, 1, 0]])
+
+        cv2.getAffineTransform = get_affine
+        np.random.RandomState = lambda s_=None: real_state(seed)
+        try:
+            _, state = R._get_elastic_affine_matrix_(shape, shape[1] * 0.08)
+        finally:
+            np.random.RandomState = real_state
+        idx = R._get_indices4elastic_transform(shape, shape[1] * 2, shape[1] * 0.15, state)
+        calls = []
+
+        def warp(image, m, dsize, **kw):
+            calls.append((tuple(dsize), kw.get('borderMode'), kw.get('borderValue', 0), kw.get('flags', cv2.INTER_LINEAR)))
+            return image
+
+        cv2.warpAffine = warp
+        img = rng.standard_normal(shape)
+        lab = np.zeros(shape, np.float32)
+        lab[shape[0] // 4: shape[0] // 2, shape[1] // 4: 3 * shape[1] // 4] = 1
+        lab[shape[0] // 2 + 2: shape[0] - 3, 3: shape[1] // 2] = 2
+        out_img = R._get_transformed_image_(img, None, idx, seg=False)
+        out_lab = R._get_transformed_image_(lab, None, idx, seg=True)
+        el.update({'shape%d' % ci: np.array(shape), 'seed%d' % ci: seed, 'pts1_%d' % ci: seen['pts1'], 'pts2_%d' % ci: seen['pts2'],
+                   'rows%d' % ci: idx[0], 'cols%d' % ci: idx[1], 'img%d' % ci: img, 'lab%d' % ci: lab,
+                   'out_img%d' % ci: out_img, 'out_lab%d' % ci: out_lab,
+                   'warp_calls%d' % ci: np.array([[c[0][0], c[0][1], c[1], c[2], c[3]] for c in calls], np.float64)})
+    frame = rng.standard_normal((20, 28)).astype(np.float64) * 3 + 1
+    el['pc_in'] = frame
+    el['pc_factor'], el['pc_delta'] = 1.37, -0.42
+    el['pc_contrast'] = R._adjust_contrast_(frame, 1.37)
+    el['pc_both'] = R._adjust_brightness_(R._adjust_contrast_(frame, 1.37), -0.42)
+    np.savez_compressed(os.path.join(OUT, 'elastic.npz'), **el)
 
     # ---- parameter dicts ----
     P = ref_params.CTCParams

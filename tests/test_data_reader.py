@@ -139,3 +139,51 @@ def test_short_clips_and_producer_errors_surface(tmp_path):
         for _ in range(200):
             r2.get_batch()
     r2.stop()
+
+
+def test_producer_error_never_hangs_get_batch(tmp_path):
+    """The consumer may be parked on the queue of a HEALTHY worker when another worker dies: the error must still surface
+    (shared reader error + timed waits).  Repeated, because the failure used to depend on thread timing."""
+    root = str(tmp_path)
+    _make_ctc(root, n_frames=4)
+    for rep in range(25):
+        r = _reader(root, unroll_len=2, num_threads=2, batch_size=3, queue_capacity=4, seed=rep)
+        r._read_sequence_to_ram_()
+        key = next(iter(r.sequence_data))
+        r.sequence_data[key]['images'][rep % 4][:] = np.nan
+        r._read_sequence_to_ram_ = lambda: None
+        with pytest.raises(ValueError, match='non-finite'):
+            for _ in range(200):
+                r.get_batch()
+        assert r._stop and all(not th.is_alive() or th.join(1.0) is None for th in r._threads)
+    # stop() while a consumer waits: a clean error, not a hang
+    r = _reader(root, unroll_len=2, num_threads=2, deal_with_end=2)
+    r.get_batch()
+    r.stop()
+    with pytest.raises(RuntimeError, match='stopped'):
+        for _ in range(200):
+            r.get_batch()
+
+
+def test_augmentation_helpers_match_the_reference_goldens():
+    """tests/golden/elastic.npz was produced by the reference's own static helpers (DataHandeling.py:152-197,239-260) with a
+    seeded RandomState; the build's helpers must reproduce them draw for draw."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'elastic.npz'))
+    for ci in range(3):
+        shape = tuple(int(v) for v in g['shape%d' % ci])
+        state = np.random.RandomState(int(g['seed%d' % ci]))
+        p1, p2 = D.elastic_affine_points(shape, shape[1] * 0.08, state)
+        assert p1.dtype == np.float32 and np.array_equal(p1, g['pts1_%d' % ci]) and np.array_equal(p2, g['pts2_%d' % ci])
+        rows, cols = D.elastic_indices(shape, shape[1] * 2, shape[1] * 0.15, state)         # same state: draws continue
+        assert rows.shape == (shape[0] * shape[1], 1)
+        assert np.array_equal(rows, g['rows%d' % ci]) and np.array_equal(cols, g['cols%d' % ci])
+        ident = np.float64([[1, 0, 0], [0, 1, 0]])
+        out_img = D.transformed_image(g['img%d' % ci], ident, (rows, cols), seg=False)
+        out_lab = D.transformed_image(g['lab%d' % ci], ident, (rows, cols), seg=True)
+        assert np.allclose(out_img, g['out_img%d' % ci], atol=1e-12) and np.array_equal(out_lab, g['out_lab%d' % ci])
+        # what the reference asks of cv2.warpAffine: dsize = (w, h); image: BORDER_REFLECT_101 (4), bilinear; labels:
+        # BORDER_CONSTANT (0) with -1, INTER_NEAREST (0) -- the modes warp_affine() is called with in transformed_image()
+        calls = g['warp_calls%d' % ci]
+        assert calls[0].tolist() == [shape[1], shape[0], 4, 0, 1] and calls[1].tolist() == [shape[1], shape[0], 0, -1, 0]
+    assert np.array_equal(D.adjust_contrast(g['pc_in'], float(g['pc_factor'])), g['pc_contrast'])
+    assert np.array_equal(D.adjust_brightness(D.adjust_contrast(g['pc_in'], float(g['pc_factor'])), float(g['pc_delta'])), g['pc_both'])
