@@ -3,8 +3,13 @@
 synthetic 256x256 clips, BASELINE.json config-2 per GPU (T=8, B=4 slots/GPU, Params.py widths:
 5x5 ConvLSTM @128/256/256/512, 3x3 encoder/decoder, fp32), weak-scaled data-parallel over N GPUs.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                          torch.distributed.run, one rank per GPU, backend nccl = RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The line carries `dp` = what the collective layer actually saw (backend, dist.get_world_size(), the device of every rank,
+gradient all-reduce launches per step and their stand-alone duration).  A mismatch between --gpus, WORLD_SIZE, the process
+group and the visible devices is an ERROR (exit code 2), never a one-GPU number under an N-GPU label.
 
 A step = forward(training) + weighted CE + backward (BPTT inside the window) + Adam + recurrent
 state mask [+ bucketed RCCL gradient all-reduce].  Inputs are resident in HBM before the timed
@@ -148,6 +153,77 @@ def cpu_baseline(net, budget_s=60.0):
                                   '%d training steps after warm-up, %d threads' % (n1, threads)}}
 
 
+def _die(msg):
+    print('bench.py: ' + msg, file=sys.stderr, flush=True)
+    sys.exit(2)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks, one per GPU, under
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port) and hand back its exit code.  LU_DP_BACKEND=gloo lets the
+    ranks share devices (control-flow checks on a 1-GPU box); the default backend nccl (= RCCL) needs a device per rank."""
+    import socket
+    import subprocess
+    backend = os.environ.get('LU_DP_BACKEND') or 'nccl'
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (backend == 'nccl' and n_dev < n):
+        _die('--gpus %d needs %d visible GPUs for the %s backend, this node shows %d' % (n, n, backend, n_dev))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: launching %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
+
+
+def dp_report(dp, dev_index, engine, steps, launched, sync_bn):
+    """What the collective layer saw, measured on the live process group (every rank calls this): backend, group size, the
+    device of each rank, gradient all-reduce launches per step, and -- timed stand-alone after the timed region with HIP
+    events, on scratch buffers of the real bucket sizes -- how long the gradient buckets and one SyncBN-sized all-reduce
+    take when nothing overlaps them."""
+    import torch.distributed as dist
+    if dp.world_size == 1:
+        return {'backend': None, 'world_size': 1, 'devices': [{'rank': 0, 'device': dev_index,
+                                                               'name': torch.cuda.get_device_name(dev_index)}]}
+    mine = {'rank': dp.rank, 'local_rank': dp.local_rank, 'device': dev_index, 'name': torch.cuda.get_device_name(dev_index),
+            'pid': os.getpid()}
+    everyone = [None] * dp.world_size
+    dist.all_gather_object(everyone, mine)
+    dev = torch.device('cuda', dev_index)
+    sizes = [e - s_ for (s_, e) in dp.last_ranges] or [engine.n_flat]
+    scratch = torch.zeros(max(sizes), device=dev, dtype=torch.float32)
+    small = torch.zeros(1024, device=dev, dtype=torch.float32)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    grad_ms = timed(lambda: [dist.all_reduce(scratch[:n_]) for n_ in sizes], 3)
+    small_ms = timed(lambda: dist.all_reduce(small), 20)
+    n_bn = sum(1 for name in engine.P if name.endswith('.gamma'))
+    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'devices': everyone,
+            'distinct_devices': len({d['device'] for d in everyone}),
+            'allreduce_launches_per_step': round(launched / max(steps, 1), 2),
+            'gradient_bucket_bytes': [4 * n_ for n_ in sizes],
+            'allreduce_ms_per_step': round(grad_ms, 3),
+            'allreduce_what': 'the gradient buckets of one step all-reduced back to back on scratch buffers, nothing else '
+                              'running (max over ranks); inside the step they overlap the encoder backward',
+            'small_allreduce_ms': round(small_ms, 4),
+            'syncbn_allreduces_per_step': 2 * n_bn if sync_bn else 0,
+            'syncbn_ms_per_step_est': round(2 * n_bn * small_ms, 3) if sync_bn else 0.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,6 +241,17 @@ def main():
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        _die('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)               # does not return
+    if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        _die('--gpus %d but the launcher started WORLD_SIZE=%s ranks' % (args.gpus, os.environ.get('WORLD_SIZE')))
+    if not torch.cuda.is_available():
+        _die('no GPU visible: the training path has no CPU fallback')
+    backend_wanted = os.environ.get('LU_DP_BACKEND') or 'nccl'
+    if args.gpus > 1 and backend_wanted == 'nccl' and torch.cuda.device_count() < args.gpus:
+        _die('--gpus %d on RCCL needs one device per rank, %d visible' % (args.gpus, torch.cuda.device_count()))
 
     import Params
     from lu_native import ops
@@ -172,8 +259,8 @@ def main():
     import train2D
 
     dp = DataParallel()
-    if dp.world_size != args.gpus:
-        print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size), file=sys.stderr)
+    if dp.world_size > 1 and torch.distributed.get_world_size() != args.gpus:
+        _die('process group has %d ranks, --gpus %d' % (torch.distributed.get_world_size(), args.gpus))
     dev_index = dp.local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -198,6 +285,7 @@ def main():
         one_step(i)
     torch.cuda.synchronize()
     dp.barrier()
+    launched0 = dp.launched
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
@@ -207,6 +295,7 @@ def main():
     if dp.world_size > 1:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    dp_info = dp_report(dp, dev_index, trainer.engine, args.steps, dp.launched - launched0, args.sync_bn)
     ms_per_step = 1e3 * elapsed / args.steps
     frames_per_s = dp.world_size * B * T * args.steps / elapsed
 
@@ -340,7 +429,7 @@ def main():
             cpu = {'value': None, 'unit': 'frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
     if dp.rank == 0:
         line = {
-            'metric': 'training frames/sec (seq_len*batch) at 256x256',
+            'metric': 'training frames/sec (seq_len*batch) at %dx%d' % (H, W),
             'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
@@ -352,6 +441,7 @@ def main():
                                     'bf16 MFMA operands on the wide stride-1 convs (fp32 master weights / accumulate / wgrad)'),
                        'global_batch': B * dp.world_size, 'seq_len': T,
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
+            'dp': dp_info,
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

@@ -238,6 +238,7 @@ class DownBlock2D(object):
         if e.states is None:
             return
         keep = torch.as_tensor(np.asarray(is_last_batch), dtype=torch.float32).reshape(-1).to(e.device)
+        e.invalidate_state_copies(self._bi)
         for st in e.states[self._bi]:
             if st is not None:
                 ops.scale_frames(st[0], keep)

@@ -21,6 +21,8 @@ class DataParallel(object):
         self._pending = []
         self.launched = 0    # collectives issued so far (tests / logs)
         self._carry = None   # (start, end) range waiting to reach bucket size
+        self.last_ranges = []  # bucket ranges of the most recent step (bench.py times all-reduces of these sizes)
+        self._ranges = []
         self.flat = None
         if self.world_size > 1 and not dist.is_initialized():
             if backend is None:
@@ -70,6 +72,7 @@ class DataParallel(object):
 
     def _launch(self, start, end):
         self.launched += 1
+        self._ranges.append((start, end))
         self._pending.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
@@ -80,6 +83,8 @@ class DataParallel(object):
         for w in self._pending:
             w.wait()
         self._pending = []
+        if self._ranges:
+            self.last_ranges, self._ranges = self._ranges, []
 
     def shard_slots(self, n_slots):
         """Batch slots owned by this rank: [rank*n/W, (rank+1)*n/W)."""

@@ -99,8 +99,26 @@ class Engine:
         self.overlap_wgrad = precision == 'bf16'
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
-        self.persistent_states = False   # True (lu_native.graph): inference copies the new state INTO the existing state
+        self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
                                          # tensors instead of adopting the step's output tensors as the state
+
+    @property
+    def persistent_states(self):
+        return self._persistent_states
+
+    @persistent_states.setter
+    def persistent_states(self, on):
+        self._persistent_states = bool(on)
+        self._state16.clear()            # cached bf16 copies are keyed by tensor identity: in-place state updates defeat that
+
+    def invalidate_state_copies(self, bi=None):
+        """Every in-place writer of the recurrent state (block-level resets, graph resets) calls this: the bf16 copy of h
+        that inference keeps beside the state is keyed by tensor identity and would otherwise outlive the edit."""
+        if bi is None:
+            self._state16.clear()
+        else:
+            for key in [k for k in self._state16 if k[0] == bi]:
+                del self._state16[key]
 
     # ------------------------------------------------------------------ build
     def build(self, in_channels, device):
@@ -338,8 +356,10 @@ class Engine:
             if self.persistent_states and st is not None:      # hipGraph replay: the state buffers keep their addresses
                 st[0].copy_(h_prev)
                 st[1].copy_(c_prev)
+                self._state16.pop((bi, li), None)              # (a bf16 copy left by an earlier eager frame is stale now)
             elif self.persistent_states:
                 self.states[bi][li] = [h_prev.clone(), c_prev.clone()]
+                self._state16.pop((bi, li), None)
             else:
                 self.states[bi][li] = [h_prev, c_prev]
                 self._state16[(bi, li)] = (h_prev, h16_prev)

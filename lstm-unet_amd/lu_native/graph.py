@@ -33,6 +33,7 @@ class GraphedFrame(object):
 
     def reset_states(self, states=None):
         """Zero the recurrent state (or restore `states` from a snapshot) -- in place, the graph owns the buffers."""
+        self.model.engine.invalidate_state_copies()
         for bi, blk in enumerate(self.model.engine.states):
             for li, st in enumerate(blk):
                 for j, t in enumerate(st):

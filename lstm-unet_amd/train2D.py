@@ -97,8 +97,12 @@ class Trainer(object):
                 'adam_m': None if self.optimizer.m is None else self.optimizer.m.cpu(),
                 'adam_v': None if self.optimizer.v is None else self.optimizer.v.cpu(),
                 'adam_iterations': self.optimizer.iterations,
-                'states': [[[None, None] if st[0] is None else [torch.from_numpy(st[0]), torch.from_numpy(st[1])]
-                            for st in blk] for blk in self.model.get_states()]}
+                'states': self.states_for_checkpoint()}
+
+    def states_for_checkpoint(self):
+        """The recurrent (h, c) of every ConvLSTM as host tensors -- all a non-zero rank writes under data parallelism."""
+        return [[[None, None] if st[0] is None else [torch.from_numpy(st[0]), torch.from_numpy(st[1])]
+                 for st in blk] for blk in self.model.get_states()]
 
     def load_state_dict(self, sd, in_channels=1):
         e = self.engine
@@ -140,6 +144,10 @@ def train(params):
                       params.learning_rate, dp=dp, sync_bn=getattr(params, 'sync_bn', False),
                       precision=getattr(params, 'precision', 'fp32'))
     model = trainer.model
+    if dp.world_size > 1:                    # one run directory for the job: rank 0's (the time stamp is per process)
+        dirs = [params.experiment_log_dir, params.experiment_save_dir]
+        torch.distributed.broadcast_object_list(dirs, src=0)
+        params.experiment_log_dir, params.experiment_save_dir = dirs
     train_data_provider, val_data_provider = params.train_data_provider, params.val_data_provider
     train_data_provider.start_queues(None)
     val_data_provider.start_queues(None)
@@ -157,19 +165,34 @@ def train(params):
                 dp.all_reduce_(t)
                 t.mul_(1.0 / dp.world_size)
 
-    def save_ckpt():
+    saved_states = []
+
+    def save_ckpt(collective=True):
+        """collective=True: a regular save point that EVERY rank reaches at the same step (BN statistics are averaged over
+        the ranks first -- an all-reduce).  collective=False: the error path, which may run on ONE rank only (SIGINT to one
+        pid, a spot-instance notice on one node ...): no collective may be issued there -- the peers sit in other
+        all-reduces -- so the rank writes what it has, rank-local."""
         if params.dry_run:
             return None
-        sync_bn_stats()                      # (collective: every rank takes part)
+        if collective:
+            sync_bn_stats()
         if dp.world_size > 1:                # recurrent states are rank-local clip streams: one small file per rank
             os.makedirs(ckpt_dir, exist_ok=True)
-            torch.save(trainer.state_dict()['states'], os.path.join(ckpt_dir, 'states-%d.rank%d.pt' % (trainer.step, dp.rank)))
+            own = os.path.join(ckpt_dir, 'states-%d.rank%d.pt' % (trainer.step, dp.rank))
+            torch.save(trainer.states_for_checkpoint(), own)
+            if own not in saved_states:
+                saved_states.append(own)
+            while len(saved_states) > params.save_checkpoint_max_to_keep:      # same rotation as ckpt-*.pt
+                old = saved_states.pop(0)
+                if os.path.exists(old):
+                    os.remove(old)
         if not is_main:
             return None
         os.makedirs(ckpt_dir, exist_ok=True)
         path = os.path.join(ckpt_dir, 'ckpt-%d.pt' % trainer.step)
         torch.save(trainer.state_dict(), path)
-        saved.append(path)
+        if path not in saved:                # (the error path may re-write the checkpoint of the step just saved)
+            saved.append(path)
         while len(saved) > params.save_checkpoint_max_to_keep:
             old = saved.pop(0)
             if os.path.exists(old):
@@ -187,7 +210,12 @@ def train(params):
                 sd = torch.load(path, map_location='cpu')
                 if dp.world_size > 1:            # this rank's own clip-stream states, or none (zeros) if it has no file
                     own = os.path.join(os.path.dirname(path), 'states-%d.rank%d.pt' % (sd['step'], dp.rank))
-                    sd['states'] = torch.load(own, map_location='cpu') if os.path.exists(own) else None
+                    if os.path.exists(own):
+                        sd['states'] = torch.load(own, map_location='cpu')
+                    else:
+                        log_print('rank {}: no recurrent-state file {} -- its clip streams restart from zero state'.format(
+                            dp.rank, own))
+                        sd['states'] = None
                 trainer.load_state_dict(sd)
                 log_print('Restored from {}'.format(path))
             except FileNotFoundError:
@@ -228,25 +256,36 @@ def train(params):
 
     template = '{}: Step {}, Loss: {}, Accuracy: {}'
     val_states = model.get_states()
+    # True while every rank is known to be at the same point of the loop: normal completion, or a failure that the per-step
+    # flag all-reduce has spread to all ranks.  Only then may the shutdown path issue collectives.
+    in_step_with_peers = False
+
+    def agree_on_failure(local_err):
+        """One scalar all-reduce: a rank that fails (data error, spot-instance notice) takes the others with it at the same
+        loop position instead of leaving them in a gradient all-reduce."""
+        if dp.world_size > 1:
+            flag = torch.tensor([1.0 if local_err is not None else 0.0], device=Nets._device())
+            dp.all_reduce_(flag)
+            if float(flag.item()) > 0 and local_err is None:
+                local_err = ValueError('another data-parallel rank reported an error')
+        if local_err is not None:
+            local_err._lu_agreed = True      # every rank raises here, at the same loop position
+            raise local_err
+
     try:
         for _ in range(trainer.step, params.num_iterations + 1):
+            local_err = None
             if params.aws:
                 import requests
                 r = requests.get('http://169.254.169.254/latest/meta-data/spot/instance-action')
                 if not r.status_code == 404:
-                    raise AWSError('Quitting Spot Instance Gracefully')
-            batch_err = None
-            try:
-                image_sequence, seg_sequence, _, is_last_batch = train_data_provider.get_batch()
-            except ValueError as exc:
-                batch_err = exc
-            if dp.world_size > 1:                # a rank that fails must take the others with it, not leave them in an all-reduce
-                flag = torch.tensor([1.0 if batch_err is not None else 0.0], device=Nets._device())
-                dp.all_reduce_(flag)
-                if float(flag.item()) > 0 and batch_err is None:
-                    batch_err = ValueError('another data-parallel rank reported a data error')
-            if batch_err is not None:
-                raise batch_err
+                    local_err = AWSError('Quitting Spot Instance Gracefully')
+            if local_err is None:
+                try:
+                    image_sequence, seg_sequence, _, is_last_batch = train_data_provider.get_batch()
+                except ValueError as exc:
+                    local_err = exc
+            agree_on_failure(local_err)
             profiling = bool(params.profile) and is_main and not params.dry_run and \
                 (trainer.step + 1) % params.write_to_tb_interval == 0
             if profiling:                        # --profile (train2D.py:152-160): this step under per-kernel HIP events
@@ -285,7 +324,12 @@ def train(params):
             if not step % params.validation_interval:
                 train_states = model.get_states()
                 model.set_states(val_states)
-                v_img, v_seg, _, v_last = val_data_provider.get_batch()
+                local_err = None
+                try:
+                    v_img, v_seg, _, v_last = val_data_provider.get_batch()
+                except ValueError as exc:
+                    local_err = exc
+                agree_on_failure(local_err)
                 v_sm, v_pred, v_loss = trainer.val_step(v_img, v_seg)
                 model.reset_states_per_batch(v_last)
                 val_loss(v_loss)
@@ -298,16 +342,18 @@ def train(params):
                     tboard('val', step, val_loss, val_seg, v_img, v_seg, v_sm)
                 val_states = model.get_states()
                 model.set_states(train_states)
+        in_step_with_peers = True                # the loop ran to its end on every rank
     except (KeyboardInterrupt, ValueError, AWSError) as err:
+        # agree_on_failure raised on every rank at once; anything else (SIGINT to one pid, an error inside a step) may be
+        # this rank's alone -- no collectives from here on in that case
+        in_step_with_peers = dp.world_size == 1 or (isinstance(err, (ValueError, AWSError)) and
+                                                    getattr(err, '_lu_agreed', False))
         if not params.dry_run:
             log_print('Saving Model Before closing due to error: {}'.format(str(err)))
-            save_ckpt()
+            save_ckpt(collective=False)
     finally:
-        if not params.dry_run and trainer.engine.plan is not None:
-            try:
-                sync_bn_stats()
-            except Exception:      # noqa: BLE001 -- a dead peer must not keep rank 0 from writing its model
-                pass
+        if not params.dry_run and trainer.engine.plan is not None and in_step_with_peers:
+            sync_bn_stats()
         if not params.dry_run and is_main and trainer.engine.plan is not None:
             model_fname = os.path.join(params.experiment_save_dir, 'model.ckpt')
             model.save_weights(model_fname, save_format=getattr(params, 'save_format', None))

@@ -2,6 +2,8 @@
 import importlib.util
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -25,3 +27,53 @@ def test_algorithmic_flops_match_survey():
     per_launch = b.lstm_step_flops(net, 256, 256, 4)
     assert [round(x / 1e9) for x in per_launch] == [866, 1288, 429, 322]
     assert b.PEAK_FP32_MFMA_TFLOPS == 157.3
+
+
+def _run_bench(extra, env_extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()[-3000:]
+
+
+def test_bench_refuses_mismatched_launches():
+    """`--gpus N` must never print a one-GPU number under an N-GPU label: mismatches are exit code 2 (runs without a GPU)."""
+    rc, line, err = _run_bench(['--gpus', '2'], {'WORLD_SIZE': '4', 'RANK': '0'})
+    assert rc == 2 and line is None and 'WORLD_SIZE=4' in err
+    rc, line, err = _run_bench(['--gpus', '0'], {})
+    assert rc == 2 and line is None
+
+
+SMALL = ['--steps', '2', '--warmup', '1', '--size', '64', '--batch', '1', '--unroll', '2', '--no-cpu-baseline', '--no-infer',
+         '--no-bf16']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_bench_self_launches_n_ranks(backend):
+    """`python bench.py --gpus 2` (no launcher) must start two ranks by itself and say what the collective layer saw.
+    gloo: both ranks share the one GPU of the test box (control flow of the whole DP bench path on the HIP kernels);
+    nccl (= RCCL): one device per rank, skipped on a box with fewer than two."""
+    import torch
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        rc, line, err = _run_bench(['--gpus', '2'] + SMALL, {'LU_DP_BACKEND': 'nccl'})
+        assert rc == 2 and line is None and 'needs 2 visible GPUs' in err      # refuses instead of measuring one GPU
+        pytest.skip('RCCL needs one device per rank: %d visible' % torch.cuda.device_count())
+    rc, line, err = _run_bench(['--gpus', '2', '--sync-bn'] + SMALL, {'LU_DP_BACKEND': backend})
+    assert rc == 0 and line is not None, err
+    assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['config']['global_batch'] == 2
+    dp = line['dp']
+    assert dp['world_size'] == 2 and dp['backend'] == backend and [d['rank'] for d in dp['devices']] == [0, 1]
+    assert dp['distinct_devices'] == (1 if backend == 'gloo' else 2)
+    assert dp['allreduce_launches_per_step'] >= 1 and dp['allreduce_ms_per_step'] > 0 and dp['syncbn_allreduces_per_step'] == 32
+    assert line['metric'].endswith('at 64x64')
+    # whole-job rate = all ranks' frames over the max-over-ranks time
+    assert abs(line['value'] - 2 * 1 * 2 / (line['ms_per_step'] * 1e-3)) <= 0.01 * line['value']
+    print('bench --gpus 2 over %s: %s' % (backend, {k: dp[k] for k in dp if k != 'devices'}))

@@ -80,3 +80,71 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     assert masks == ['mask000.tif', 'mask001.tif', 'mask002.tif']
     m = np.asarray(Image.open(out_dir / masks[0]))
     assert m.shape == (size + 3, size + 5) and m.dtype == np.uint16
+
+
+DP_LOOP_WORKER = r'''
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from engine_backend import engine_backend
+from conftest import tiny_net
+import Params, train2D
+from lu_native.dp import DataParallel
+rank = int(os.environ['RANK'])
+with engine_backend('emu'):
+    Params.CTCParams.net_kernel_params = tiny_net(3)
+    params = Params.CTCParams(dict(experiment_name='t', crop_size=(16, 16), batch_size=1, unroll_len=2, num_iterations=8,
+                                   validation_interval=100, print_to_console_interval=1, save_checkpoint_iteration=1,
+                                   save_checkpoint_max_to_keep=2, save_checkpoint_dir=%(tmp)r, save_log_dir=%(tmp)r,
+                                   data_format='NCHW', learning_rate=1e-3, write_to_tb_interval=100))
+    prov = params.train_data_provider
+    real, calls = prov.get_batch, [0]
+    def flaky():
+        calls[0] += 1
+        if rank == 1 and calls[0] == 5:
+            raise ValueError('non-finite values in frame 3 after augmentation')
+        return real()
+    prov.get_batch = flaky
+    collectives = []
+    orig = DataParallel.all_reduce_
+    DataParallel.all_reduce_ = lambda self, t: (collectives.append(tuple(t.shape)), orig(self, t))[1]
+    trainer = train2D.train(params)
+    n_bn = len(trainer.engine.S)
+    # after the agreed failure: exactly one more round of BN-statistics averaging (the `finally` of a loop that every rank
+    # left together) and NONE from the error-path checkpoint
+    tail = collectives[-n_bn:]
+    print('RANK', rank, 'steps', trainer.step, 'tail', len(tail), flush=True)
+    np.save(os.path.join(%(tmp)r, 'done_%%d.npy' %% rank), np.array([trainer.step, len(collectives)]))
+'''
+
+
+def test_dp_loop_failure_on_one_rank_stops_all_ranks_without_hanging(tmp_path):
+    """A data error on ONE rank (reader ValueError) must end the loop on every rank at the same step, the error-path
+    checkpoint must not issue collectives (it may run on one rank only), and per-rank state files rotate with
+    save_checkpoint_max_to_keep (train2D.py:145-246 is single-device; SURVEY §8e)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text(DP_LOOP_WORKER % {'root': root, 'tmp': str(tmp_path)})
+    port = 29700 + os.getpid() % 1200
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), LU_DP_BACKEND='gloo',
+                                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    a, b = np.load(tmp_path / 'done_0.npy'), np.load(tmp_path / 'done_1.npy')
+    assert a[0] == b[0] == 4 and a[1] == b[1]              # four completed steps on both ranks, same number of collectives
+    assert 'another data-parallel rank reported an error' in outs[0] and 'non-finite' in outs[1]
+    ck = os.listdir(os.path.join(str(tmp_path), 'LSTMUNet', 't'))
+    assert len(ck) == 1                                     # one run directory for the job (rank 0's time stamp)
+    run_dir = os.path.join(str(tmp_path), 'LSTMUNet', 't', ck[0])
+    files = sorted(os.listdir(os.path.join(run_dir, 'tf_ckpts')))
+    for r in range(2):
+        mine = [f for f in files if f.endswith('.rank%d.pt' % r)]
+        assert len(mine) == 2, files                        # rotated like ckpt-*.pt (max_to_keep = 2)
+    assert os.path.exists(os.path.join(run_dir, 'model.ckpt'))

@@ -358,3 +358,37 @@ def test_hipgraph_replay_of_streaming_forward_is_bit_identical():
     g.reset_states()
     for f, w in zip(frames, want):
         assert torch.equal(g(f)[1], w)
+
+
+@pytest.mark.gpu
+def test_bf16_inference_state_copy_survives_no_in_place_state_edit():
+    """bf16 inference keeps a bf16 copy of the carried h beside the state (keyed by tensor identity).  Every in-place
+    state writer must drop it: (1) a block-level reset_states_per_batch (Networks.py:77-84) must act like the model-level one,
+    (2) a hipGraph captured AFTER eager frames must not bake the stale copy in.  Wide net so that the bf16 kernels run."""
+    import Networks
+    from conftest import tiny_net
+    from lu_native.graph import GraphedFrame
+    net = tiny_net(3, (64, 32, 32, 32), (16, 16, 16, 8))
+    torch.manual_seed(5)
+    frames = [torch.randn(2, 1, 1, 40, 48) for _ in range(4)]
+    keep = np.array([0.0, 1.0], np.float32)
+    a = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1, precision='bf16')
+    b = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1, precision='bf16')
+    for f in frames[:2]:
+        a(f, training=False)
+        b(f, training=False)
+    a.reset_states_per_batch(keep)                       # model-level: the engine's own route
+    for blk in b.DownLayers:                             # block-level, as the reference's model does it (Networks.py:279-281)
+        blk.reset_states_per_batch(keep)
+    for f in frames[2:]:
+        assert torch.equal(a(f, training=False)[1], b(f, training=False)[1])
+    # graph capture after eager frames
+    one = [f[:1].contiguous() for f in frames]
+    eager = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1, precision='bf16')
+    want = [eager(f, training=False)[1].clone() for f in one]
+    g_model = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1, precision='bf16')
+    g_model(one[3], training=False)                      # an eager frame first: leaves a bf16 state copy behind
+    g = GraphedFrame(g_model, one[0])
+    g.reset_states()
+    for f, w in zip(one, want):
+        assert torch.equal(g(f)[1], w)
