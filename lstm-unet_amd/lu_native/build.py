@@ -10,43 +10,83 @@ SOURCES = ['lu_conv.hip', 'lu_wgrad.hip', 'lu_pointwise.hip', 'lu_postprocess.hi
 LIB = os.path.join(CSRC, 'liblstmunet_hip.so')
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+STAMP = LIB + '.srchash'      # sha256 of (flags + every source byte) the library was built from; ships beside the .so
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'lu_device.h'),
             os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'lstm_unet_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        with open(d, 'rb') as fh:
+            h.update(b'\0' + os.path.basename(d).encode() + b'\0' + fh.read())
+    return h.hexdigest()
+
+
+def build_id():
+    """sha256 of the library file itself (first 16 hex digits): stamped on bench lines and on every counter table under
+    profiles/ so that a table collected from another binary is recognisable as stale."""
+    import hashlib
+    with open(LIB, 'rb') as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
+def needs_build():
+    """Content-addressed, not mtime-based: the library is reused only if it was built from exactly these source bytes and
+    flags (a checkout, a copy to the GPU box or a touched file do not matter; an edited kernel always does)."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return True
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-x', 'hip'] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    digest = source_hash()
+    with tempfile.TemporaryDirectory(prefix='lu_build_') as tmp:      # objects never land in the tree (nothing extra ships)
+        def compile_one(src):
+            obj = os.path.join(tmp, src.replace('.hip', '.o'))
+            cmd = [hipcc] + FLAGS + ['-c', '-x', 'hip', os.path.join(CSRC, src), '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(len(SOURCES)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB + '.tmp']
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    os.replace(LIB + '.tmp', LIB)
+    with open(STAMP, 'w') as fh:
+        fh.write(digest + '\n')
     return LIB
 
 
 def build_ablation(bits, verbose=True):
     """TOOLS ONLY (tools/kbench.py): lu_conv.hip with -DLU_ABLATION=<bits>, which compiles parts of the fragment kernel's loop
     out (1 weight loads, 2 LDS fragment reads, 4 halo prefetch, 8 epilogue, 16 chunk barrier) to see what bounds it.
-    Separate files (liblstmunet_abl<bits>.so): the product library never contains these switches."""
+    Built under gpurun_out/abl/ (scratch, never shipped with a snapshot): the product library never contains these switches."""
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'gpurun_out', 'abl')
+    os.makedirs(out_dir, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, ('abl%d_' % bits if src == 'lu_conv.hip' else 'abl_') + src.replace('.hip', '.o'))
+        obj = os.path.join(out_dir, ('abl%d_' % bits if src == 'lu_conv.hip' else 'abl_') + src.replace('.hip', '.o'))
         if src == 'lu_conv.hip' or not os.path.exists(obj) or os.path.getmtime(obj) < os.path.getmtime(os.path.join(CSRC, src)):
-            cmd = base + (['-DLU_ABLATION=%d' % bits] if src == 'lu_conv.hip' else []) + ['-c', '-x', 'hip', os.path.join(CSRC, src), '-o', obj]
+            cmd = [hipcc] + FLAGS + (['-DLU_ABLATION=%d' % bits] if src == 'lu_conv.hip' else []) + \
+                  ['-c', '-x', 'hip', os.path.join(CSRC, src), '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(obj)
-    out = os.path.join(CSRC, 'liblstmunet_abl%d.so' % bits)
+    out = os.path.join(out_dir, 'liblstmunet_abl%d.so' % bits)
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
     return out
 

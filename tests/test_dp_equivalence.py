@@ -32,11 +32,12 @@ with engine_backend('emu'):
     tr = train2D.Trainer(Networks.ULSTMnet2D, tiny_net(3), 'NHWC', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=sync_bn, seed=3)
     sl = slice(dp.rank, dp.rank + 1)
     _, _, loss = tr.train_step(d['x'][sl], d['gt'][sl])
+    grads1 = tr.engine.flat_grads.numpy().copy()          # all-reduced, before Adam touches anything
     tr.model.reset_states_per_batch(np.ones(1, np.float32))
     _, _, loss2 = tr.train_step(d['x'][sl, ::-1].copy(), d['gt'][sl, ::-1].copy())
     if dp.rank == 0:
         np.savez(os.path.join(%(tmp)r, 'dp_out_%%d.npz' %% int(sync_bn)), params=tr.engine.flat_params.numpy(),
-                 loss=np.array([float(loss), float(loss2)]))
+                 loss=np.array([float(loss), float(loss2)]), grads1=grads1)
     dp.barrier()
 '''
 
@@ -62,6 +63,7 @@ def test_dp2_equals_single_process(tmp_path):
     with engine_backend('emu'):
         tr = train2D.Trainer(Networks.ULSTMnet2D, tiny_net(3), 'NHWC', [0.15, 0.25, 0.6], 1e-3, seed=3)
         _, _, l1 = tr.train_step(x, gt)
+        ref_grads1 = tr.engine.flat_grads.numpy().copy()
         tr.model.reset_states_per_batch(np.ones(2, np.float32))
         _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
         ref = tr.engine.flat_params.numpy().copy()
@@ -69,6 +71,13 @@ def test_dp2_equals_single_process(tmp_path):
     sync = np.load(tmp_path / 'dp_out_1.npz')
     local = np.load(tmp_path / 'dp_out_0.npz')
     assert np.abs(sync['loss'] - ref_loss).max() <= 1e-5, (sync['loss'], ref_loss)
+    # the all-reduced GRADIENTS of step 1 (pre-Adam: a wrong scale on any bucket shows here, Adam would normalise it away)
+    g_err = np.abs(sync['grads1'] - ref_grads1).max() / np.abs(ref_grads1).max()
+    print('dp2 vs single, step-1 gradients: max err / max|g| = %.3e' % g_err)
+    assert g_err <= 1e-6, g_err
+    for name, s_, e_ in tr.engine.segments:               # ... and per bucket, relative to the bucket's own scale
+        ref_b, got_b = ref_grads1[s_:e_], sync['grads1'][s_:e_]
+        assert np.abs(got_b - ref_b).max() <= 1e-5 * max(np.abs(ref_b).max(), 1e-30), name
     # Adam normalises the step size, so compare weights loosely in count and tightly in the bulk
     diff = np.abs(sync['params'] - ref)
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= 2e-3, (diff.max(), (diff > 1e-4).mean())
@@ -95,12 +104,13 @@ if os.environ.get('LU_TEST_NO_OVERLAP'):
     tr.engine.overlap_wgrad = False
 sl = slice(dp.rank, dp.rank + 1)
 _, _, loss = tr.train_step(d['x'][sl], d['gt'][sl])
+grads1 = tr.engine.flat_grads.cpu().numpy()
 tr.model.reset_states_per_batch(np.ones(1, np.float32))
 _, _, loss2 = tr.train_step(d['x'][sl, ::-1].copy(), d['gt'][sl, ::-1].copy())
 torch.cuda.synchronize()
 if dp.rank == 0:
     np.savez(os.path.join(%(tmp)r, 'dp_gpu_out.npz'), params=tr.engine.flat_params.cpu().numpy(),
-             loss=np.array([float(loss), float(loss2)]))
+             loss=np.array([float(loss), float(loss2)]), grads1=grads1)
 dp.barrier()
 '''
 
@@ -134,11 +144,17 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     if os.environ.get('LU_TEST_NO_OVERLAP'):
         tr.engine.overlap_wgrad = False
     _, _, l1 = tr.train_step(x, gt)
+    ref_grads1 = tr.engine.flat_grads.cpu().numpy()
     tr.model.reset_states_per_batch(np.ones(2, np.float32))
     _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
     ref = tr.engine.flat_params.cpu().numpy()
     got = np.load(tmp_path / 'dp_gpu_out.npz')
     assert np.abs(got['loss'] - np.array([float(l1), float(l2)])).max() <= 1e-5
+    # pre-Adam all-reduced gradients of step 1: fp32 to summation-order noise; bf16 mode re-rounds a few activations
+    # (pooled-vs-whole-batch statistics differ in the last bits), stated 2e-3 of the largest gradient
+    g_err = np.abs(got['grads1'] - ref_grads1).max() / np.abs(ref_grads1).max()
+    print('dp2 vs single (%s), step-1 gradients: max err / max|g| = %.3e' % (precision, g_err))
+    assert g_err <= (2e-6 if precision == 'fp32' else 2e-3), g_err
     diff = np.abs(got['params'] - ref)
     print('dp2 vs single (%s): max %.3e, fraction > 1e-4: %.3e' % (precision, diff.max(), (diff > 1e-4).mean()))
     # bf16: the two wide ConvLSTM layers of this net (4F = 128 columns) do run on the bf16 MFMA kernels; pooled-vs-whole-batch
