@@ -354,6 +354,9 @@ int lu_add_inplace(float* y, const float* x, int64_t n, lu_stream_t stream);
  *   lu_post_label_stats          per-label bounding box, 4 x Euler number (8-conn) and component count: an object has
  *                                holes iff components - Euler > 0
  *   lu_post_fill_object  :80-91  per-object binary_fill_holes with the reference's additive label quirk
+ *   lu_post_fill_all     :80-91  the same for ALL objects in one launch, driven by the device-side statistics (no host
+ *                                read in between); reports when the reference's label order matters (nested objects)
+ *   lu_post_newid        :93-123 size / FOV filter and consecutive numbering from the device-side count and areas
  *   lu_post_bbox_of_label        bounding box of one label value in the current map
  *   lu_post_present      :93-103 labels present inside the field of view
  *   lu_post_relabel      :113-123 consecutive uint16 ids of the kept labels
@@ -366,6 +369,10 @@ int lu_post_label_stats(const int32_t* labels, int32_t H, int32_t W, int32_t num
                         int32_t* e4, int32_t* ncomp, lu_stream_t stream);
 int lu_post_fill_object(int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t x0, int32_t y0, int32_t w, int32_t h,
                         void* workspace, int32_t* dirty, lu_stream_t stream);
+int lu_post_fill_all(int32_t* labels, int32_t H, int32_t W, const int32_t* num_labels, const int32_t* bbox, const int32_t* e4,
+                     const int32_t* ncomp, int32_t* flags, lu_stream_t stream);
+int lu_post_newid(const int32_t* num_labels, const int32_t* area, const int32_t* present, int32_t min_size, int32_t max_size,
+                  int32_t table_size, int32_t* newid, const int32_t* flags, int32_t* tail, lu_stream_t stream);
 int lu_post_bbox_of_label(const int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t* box, lu_stream_t stream);
 int lu_post_present(const int32_t* labels, int32_t H, int32_t W, int32_t fov, int32_t single_column, int32_t num_labels,
                     int32_t* present, lu_stream_t stream);

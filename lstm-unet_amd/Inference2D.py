@@ -40,24 +40,26 @@ def postprocess(softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, f
 
 
 class PostPipeline(object):
-    """Software pipeline of the per-frame path: the post-processing of frame t (a chain of small kernels with two or three
-    device -> host reads, lu_native/post.py) runs on its OWN HIP stream while the forward of frame t + 1 -- already enqueued
-    on the main stream when push() is called -- keeps the chip busy.  push(t, softmax) returns the frames finished by then
-    as [(t, labels, softmax)] (one frame late), flush() the last one.  Results are those of postprocess(): same kernels,
-    same order per frame."""
+    """Software pipeline of the per-frame path: the post-processing of frame t (lu_native/post.py: a device-driven chain of
+    small kernels ending in ONE device -> host copy, no host decision in between) is enqueued on its OWN HIP stream right
+    after the forward that produced its softmax, and runs there while the forward of frame t + 1 keeps the chip busy.
+    push(t, softmax) enqueues frame t and returns the frames finished by then as [(t, labels, softmax)] (one frame late),
+    flush() the last one.  Two processors alternate, so frame t - 1's buffers (and its exact fallback for nested objects)
+    are untouched by frame t's launches.  Results are those of postprocess(): same kernels, same order per frame."""
 
     def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False):
         self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
         self.stream = None
         self.pending = None
+        self._procs = None
+        self._n = 0
 
     def _finish(self):
         import torch
-        t, sm, ready = self.pending
+        t, sm, proc, job = self.pending
         self.pending = None
         with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ready)
-            labels = postprocess(sm, *self.args)      # host-blocking reads synchronise this stream only
+            labels = proc.collect(job)                # waits for frame t's copy; replays nested-object frames exactly
         return [(t, labels, sm)]
 
     def push(self, t, softmax_chw):
@@ -65,12 +67,19 @@ class PostPipeline(object):
         if softmax_chw.device.type != 'cuda':        # the host emulator of the test-suite: nothing to overlap
             return [(t, postprocess(softmax_chw, *self.args), softmax_chw)]
         if self.stream is None:
+            from lu_native.post import PostProcessor
             self.stream = torch.cuda.Stream()
-        done = self._finish() if self.pending is not None else []
+            self._procs = [PostProcessor(), PostProcessor()]
         ready = torch.cuda.Event()
         ready.record()                                # after the forward that produced softmax_chw (current stream)
         softmax_chw.record_stream(self.stream)
-        self.pending = (t, softmax_chw, ready)
+        proc = self._procs[self._n & 1]
+        self._n += 1
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            job = proc.enqueue(softmax_chw, *self.args)
+        done = self._finish() if self.pending is not None else []
+        self.pending = (t, softmax_chw, proc, job)
         return done
 
     def flush(self):

@@ -23,6 +23,9 @@
 //                       border are the holes; L += n there -- the reference's additive quirk included; a `dirty` flag
 //                       reports a hole that contained another label (the host then falls back to the strictly sequential
 //                       order of the reference for the remaining labels)                                          (:80-91)
+//   device-driven tail  fill_all_kernel fills the holes of ALL objects in one launch (one workgroup per object, crop flooded
+//                       in LDS) and newid_kernel numbers the kept labels, so that a frame needs no host decision and ONE
+//                       device -> host copy; the per-object path above remains the exact fallback for nested objects
 //   FOV presence / relabel   which labels survive the field-of-view mask (single-column quirk of :97 selectable), final
 //                       consecutive ids as uint16                                                              (:93-123)
 #include <stdint.h>
@@ -369,6 +372,134 @@ __global__ void relabel_kernel(const int32_t* __restrict__ lab, const int32_t* _
     }
 }
 
+// ---- device-driven tail of the frame (no host decision between label statistics and the final map) --------------------
+// Hole filling of ALL objects in one launch: a workgroup takes the labels v with holes (components - Euler number > 0, read
+// from the device arrays) one at a time, stages the object's crop (bounding box + 1 pixel, clipped) in LDS as one byte per
+// pixel -- 0 wall (== v), 1 open, 2 open and connected (4-conn) to the crop border -- and floods from the border with row /
+// column sweeps until nothing changes; open pixels the flood never reached are the holes: L += v.
+// Objects are processed concurrently although the reference walks them in label order: when no hole holds a non-zero label
+// all holes are disjoint regions of zeros, so the order cannot matter.  When one does (nested objects: the additive quirk,
+// flags[0]), or a crop does not fit (flags[1]), the host discards this result and replays the reference's strict order from
+// its snapshot of the map.  A pixel another workgroup fills concurrently is read as 0 or as that label -- "not v" either way.
+constexpr int FILL_MAX_PIX = 48 * 1024;
+
+__global__ __launch_bounds__(PT) void fill_all_kernel(int32_t* lab, int H, int W, const int32_t* __restrict__ num_ptr,
+                                                     const int32_t* __restrict__ bbox, const int32_t* __restrict__ e4,
+                                                     const int32_t* __restrict__ ncomp, int32_t* flags) {
+    __shared__ unsigned char st[FILL_MAX_PIX];
+    __shared__ int changed;
+    const int num = *num_ptr;
+    const int tid = threadIdx.x;
+    for (int v = 1 + (int)blockIdx.x; v < num; v += (int)gridDim.x) {
+        const int q = e4[v] >= 0 ? e4[v] / 4 : -((-e4[v] + 3) / 4);      // floor division, as the host's e4 // 4
+        if (ncomp[v] - q <= 0) continue;
+        const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
+        if (bx1 < bx0 || by1 < by0) continue;
+        const int x0 = bx0 > 0 ? bx0 - 1 : 0, y0 = by0 > 0 ? by0 - 1 : 0;
+        const int x1 = bx1 < W - 1 ? bx1 + 1 : W - 1, y1 = by1 < H - 1 ? by1 + 1 : H - 1;
+        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+        if ((int64_t)w * h > FILL_MAX_PIX) {
+            if (tid == 0) flags[1] = 1;
+            continue;
+        }
+        for (int i = tid; i < w * h; i += PT) {
+            const int y = i / w, x = i - y * w;
+            const int val = lab[(int64_t)(y0 + y) * W + x0 + x];
+            st[i] = val == v ? 0 : ((x == 0 || y == 0 || x == w - 1 || y == h - 1) ? 2 : 1);
+        }
+        __syncthreads();
+        for (;;) {
+            if (tid == 0) changed = 0;
+            __syncthreads();
+            bool mine = false;
+            for (int y = tid; y < h; y += PT) {          // row sweeps, both directions
+                unsigned char* r = st + y * w;
+                bool carry = false;
+                for (int x = 0; x < w; ++x) {
+                    const int s_ = r[x];
+                    if (s_ == 0) carry = false;
+                    else if (s_ == 2) carry = true;
+                    else if (carry) { r[x] = 2; mine = true; }
+                }
+                carry = false;
+                for (int x = w - 1; x >= 0; --x) {
+                    const int s_ = r[x];
+                    if (s_ == 0) carry = false;
+                    else if (s_ == 2) carry = true;
+                    else if (carry) { r[x] = 2; mine = true; }
+                }
+            }
+            __syncthreads();
+            for (int x = tid; x < w; x += PT) {          // column sweeps
+                bool carry = false;
+                for (int y = 0; y < h; ++y) {
+                    const int s_ = st[y * w + x];
+                    if (s_ == 0) carry = false;
+                    else if (s_ == 2) carry = true;
+                    else if (carry) { st[y * w + x] = 2; mine = true; }
+                }
+                carry = false;
+                for (int y = h - 1; y >= 0; --y) {
+                    const int s_ = st[y * w + x];
+                    if (s_ == 0) carry = false;
+                    else if (s_ == 2) carry = true;
+                    else if (carry) { st[y * w + x] = 2; mine = true; }
+                }
+            }
+            if (mine) changed = 1;
+            __syncthreads();
+            const int again = changed;
+            __syncthreads();
+            if (!again) break;
+        }
+        for (int i = tid; i < w * h; i += PT) {
+            if (st[i] != 1) continue;
+            const int y = i / w, x = i - y * w;
+            const int64_t p = (int64_t)(y0 + y) * W + x0 + x;
+            const int old = lab[p];
+            if (old != 0) flags[0] = 1;      // the hole held another label: the reference's order matters from here on
+            lab[p] = old + v;
+        }
+        __syncthreads();
+    }
+}
+
+// newid[v] = 1, 2, ... over the kept labels in label order (area inside [min_size, max_size], present in the field of view
+// when a presence table is given), 0 for every other entry of the table; tail[0..2] = label count, dirty flag, oversize flag
+// behind the uint16 map so that ONE device -> host copy carries the frame's result and its validity.
+__global__ __launch_bounds__(1024) void newid_kernel(const int32_t* __restrict__ num_ptr, const int32_t* __restrict__ area,
+                                                    const int32_t* __restrict__ present, int min_size, int max_size, int nmax,
+                                                    int32_t* __restrict__ newid, const int32_t* __restrict__ flags,
+                                                    int32_t* __restrict__ tail) {
+    __shared__ int part[1024];
+    __shared__ int base;
+    const int num = *num_ptr < nmax ? *num_ptr : nmax;
+    const int tid = threadIdx.x;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < nmax; start += 1024) {
+        const int v = start + tid;
+        const int keep = (v >= 1 && v < num && area[v] >= min_size && area[v] <= max_size && (!present || present[v])) ? 1 : 0;
+        part[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan (Hillis-Steele)
+            const int add = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        if (v < nmax) newid[v] = keep ? base + part[tid] : 0;
+        __syncthreads();
+        if (tid == 1023) base += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0 && tail) {
+        tail[0] = *num_ptr;
+        tail[1] = flags[0];
+        tail[2] = flags[1];
+    }
+}
+
 int run_ccl(const int32_t* val, int32_t* parent, int W, Rect r, int mode, int n, int nl, lu_stream_t stream) {
     const int64_t total = (int64_t)r.w * r.h;
     LU_LAUNCH(ccl_init_kernel, dim3(pgrid(total)), dim3(PT), stream, val, parent, W, r, mode, n, nl);
@@ -456,6 +587,33 @@ extern "C" int lu_post_fill_object(int32_t* labels, int32_t H, int32_t W, int32_
     LU_LAUNCH(clear_flag_kernel, g, b, stream, (const int32_t*)parent, flag, W, r);
     LU_LAUNCH(border_flag_kernel, dim3(pgrid(2 * (int64_t)(w + h))), b, stream, (const int32_t*)parent, flag, W, r);
     LU_LAUNCH(object_fill_kernel, g, b, stream, labels, (const int32_t*)parent, (const int32_t*)flag, W, r, n, dirty);
+    return LU_CHECK_LAUNCH();
+}
+
+/* Device-driven hole filling of every object at once (no host read between lu_post_label_stats and the final map):
+ * num_labels / bbox / e4 / ncomp are the DEVICE arrays the two calls above filled.  flags[0] is set when a hole held a
+ * non-zero label (nested objects: the reference's additive quirk makes its label order matter), flags[1] when an object's
+ * crop exceeds the kernel's LDS staging -- in both cases the host restores its snapshot of `labels` and replays
+ * Inference2D.py:80-91 object by object with lu_post_fill_object.  flags is never cleared here. */
+extern "C" int lu_post_fill_all(int32_t* labels, int32_t H, int32_t W, const int32_t* num_labels, const int32_t* bbox,
+                                const int32_t* e4, const int32_t* ncomp, int32_t* flags, lu_stream_t stream) {
+    LU_REQUIRE(labels && num_labels && bbox && e4 && ncomp && flags && H > 0 && W > 0, "lu_post_fill_all: bad arguments");
+    int blocks = lu_post_max_labels(H, W);
+    if (blocks > 2048) blocks = 2048;
+    LU_LAUNCH(fill_all_kernel, dim3(blocks), dim3(PT), stream, labels, H, W, num_labels, bbox, e4, ncomp, flags);
+    return LU_CHECK_LAUNCH();
+}
+
+/* Size / field-of-view filter and consecutive numbering on the device (Inference2D.py:93-123): newid[v] for all
+ * table_size entries (0 = dropped), from the DEVICE label count and areas; present may be NULL (no FOV mask).
+ * tail (may be NULL) receives {label count, flags[0], flags[1]} -- placed behind the uint16 map by the caller so that one
+ * copy brings back the frame. */
+extern "C" int lu_post_newid(const int32_t* num_labels, const int32_t* area, const int32_t* present, int32_t min_size,
+                             int32_t max_size, int32_t table_size, int32_t* newid, const int32_t* flags, int32_t* tail,
+                             lu_stream_t stream) {
+    LU_REQUIRE(num_labels && area && newid && flags && table_size >= 1, "lu_post_newid: bad arguments");
+    LU_LAUNCH(newid_kernel, dim3(1), dim3(1024), stream, num_labels, area, present, min_size, max_size, table_size, newid,
+              flags, tail);
     return LU_CHECK_LAUNCH();
 }
 

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 5          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 6          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -93,6 +93,8 @@ PROTOTYPES = {
     'lu_post_label': (C.c_int, [P, i32, i32, f32, f64, P, P, P, P, S]),
     'lu_post_label_stats': (C.c_int, [P, i32, i32, i32, P, P, P, P, S]),
     'lu_post_fill_object': (C.c_int, [P, i32, i32, i32, i32, i32, i32, i32, P, P, S]),
+    'lu_post_fill_all': (C.c_int, [P, i32, i32, P, P, P, P, P, S]),
+    'lu_post_newid': (C.c_int, [P, P, P, i32, i32, i32, P, P, P, S]),
     'lu_post_bbox_of_label': (C.c_int, [P, i32, i32, i32, P, S]),
     'lu_post_present': (C.c_int, [P, i32, i32, i32, i32, i32, P, S]),
     'lu_post_relabel': (C.c_int, [P, i32, i32, P, i32, P, S]),

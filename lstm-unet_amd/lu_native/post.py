@@ -1,21 +1,31 @@
 """Host sequencing of the device post-processing (include/lstm_unet_hip.h `lu_post_*`, csrc/lu_postprocess.hip):
 softmax [3,H,W] on the device -> uint16 instance labels, reference Inference2D.py:66-123.
 
-Two small device -> host reads per frame (label count + per-label statistics in one, and the FOV presence flags; the label
-map itself has to come back for the TIFF anyway).  Objects with holes are found for ALL labels at once from the bit-quad Euler numbers
-(holes = components - Euler number); the reference's per-object loop (`for n in range(1, num_cells)`, :80-91) is then run
-only over those, in label order.  Its additive quirk (a hole pixel that already carries label m becomes m + n) can change
-which pixels later labels own; the fill kernel reports that (`dirty`) and the remaining labels are then processed strictly
-one by one from the current map, exactly like the reference.  No CPU arithmetic path: device tensors in, device kernels."""
+The frame is DEVICE-DRIVEN: labelling, per-label statistics, the hole filling of every object (`lu_post_fill_all`: one
+workgroup per object with holes, found from the bit-quad Euler numbers, holes = components - Euler number), the field-of-view
+presence table, the size filter + consecutive numbering (`lu_post_newid`) and the relabelling are enqueued back to back with
+no host decision in between, and ONE device -> host copy brings back the uint16 map together with three words {label count,
+dirty, oversize}.  `enqueue()` returns at once (the copy lands in pinned memory behind an event); `collect()` waits for it.
+
+The reference's per-object loop (`for n in range(1, num_cells)`, :80-91) has an additive quirk -- a hole pixel that already
+carries label m becomes m + n -- which makes its label ORDER matter when objects are nested.  The fill kernel reports that
+(`dirty`; also a crop too large for its LDS staging): collect() then restores the snapshot of the map taken before the fill
+and replays the reference's strict order object by object (`lu_post_fill_object`, host-sequenced: the rare path).
+No CPU arithmetic path: device tensors in, device kernels."""
 import numpy as np
 import torch
 
 from . import calls, ops
 
 
+class _Job(object):
+    __slots__ = ('args', 'event', 'stages', 'H', 'W')
+
+
 class PostProcessor(object):
     def __init__(self):
         self._shape = None
+        self.fallbacks = 0       # frames that needed the strictly sequential replay (nested objects)
 
     def _alloc(self, H, W, dev):
         if self._shape == (H, W, dev):
@@ -25,19 +35,26 @@ class PostProcessor(object):
         self.nmax = int(lib.lu_post_max_labels(H, W))
         self.ws = torch.empty(int(lib.lu_post_workspace_bytes(H, W)) // 4 + 4, dtype=torch.int32, device=dev)
         self.labels = torch.empty((H, W), dtype=torch.int32, device=dev)
-        # one buffer for everything the host reads: num_labels | dirty | area | bbox | e4 | ncomp | present
+        self.snapshot = torch.empty((H, W), dtype=torch.int32, device=dev)
+        # per-label tables: num_labels | dirty | oversize | pad | area | bbox | e4 | ncomp | present
         n = self.nmax
-        self.small = torch.zeros(2 + 8 * n, dtype=torch.int32, device=dev)
-        self.off = {'num': 0, 'dirty': 1, 'area': 2, 'bbox': 2 + n, 'e4': 2 + 5 * n, 'ncomp': 2 + 6 * n, 'present': 2 + 7 * n}
+        self.small = torch.zeros(4 + 8 * n, dtype=torch.int32, device=dev)
+        self.off = {'num': 0, 'dirty': 1, 'area': 4, 'bbox': 4 + n, 'e4': 4 + 5 * n, 'ncomp': 4 + 6 * n, 'present': 4 + 7 * n}
         self.newid = torch.zeros(n, dtype=torch.int32, device=dev)
         self.box = torch.zeros(4, dtype=torch.int32, device=dev)
-        self.out = torch.empty((H, W), dtype=torch.int16, device=dev)
+        # the frame's result: uint16 map, then (4-byte aligned) {label count, dirty, oversize, 0}
+        self.map_words = (H * W + 1) // 2
+        self.out = torch.zeros(self.map_words + 4, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(self.map_words + 4, dtype=torch.int32)
+        if dev.type == 'cuda':
+            self.host = self.host.pin_memory()
 
     def _p(self, name):
         return self.small.data_ptr() + 4 * self.off[name]
 
-    def __call__(self, softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, stages=None):
-        """softmax_chw: [3,H,W] float32 device tensor -> numpy uint16 [H,W].  stages (dict): receives intermediate label maps."""
+    # ------------------------------------------------------------------------------------------------------------------
+    def enqueue(self, softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, stages=None):
+        """Launch the whole frame on the current stream; no host synchronisation (unless `stages` asks for intermediate maps)."""
         sm = softmax_chw
         if sm.dim() != 3 or sm.shape[0] != 3:
             raise ValueError('expected a [3, H, W] softmax, got %s' % (tuple(sm.shape),))
@@ -47,61 +64,101 @@ class PostProcessor(object):
         self._alloc(H, W, sm.device)
         lib, st, ck = ops.lib(), ops._stream(), calls.check
         ws, L = self.ws.data_ptr(), self.labels.data_ptr()
-        self.small[:2].zero_()
+        self.small[:4].zero_()
         ck(lib, lib.lu_post_label(sm.data_ptr(), H, W, 0.2, float(edge_dist), ws, L, self._p('num'), self._p('area'), st),
            'lu_post_label')
-        # the statistics pass is sized by the BOUND on the label count (a few thousand idle table entries), so that the
-        # count itself and the statistics come back in ONE device -> host read
+        # sized by the BOUND on the label count: the count itself stays on the device
         ck(lib, lib.lu_post_label_stats(L, H, W, self.nmax, ws, self._p('bbox'), self._p('e4'), self._p('ncomp'), st),
            'lu_post_label_stats')
-        host = self.small.cpu().numpy()                     # sync 1
-        num = int(host[0])
-        if num > self.nmax:
-            raise calls.NativeError('label count %d exceeds the bound %d' % (num, self.nmax))
+        self.snapshot.copy_(self.labels)
         if stages is not None:
             stages['absorbed'] = self.labels.cpu().numpy().copy()
-        areas = None
-        if num > 1:
-            o, n = self.off, self.nmax
-            areas = host[o['area']:o['area'] + num].astype(np.int64)
-            bbox = host[o['bbox']:o['bbox'] + 4 * num].reshape(num, 4)
-            e4, ncomp = host[o['e4']:o['e4'] + num], host[o['ncomp']:o['ncomp'] + num]
-            holes = ncomp - e4 // 4
-            assert not np.any(e4[1:] % 4), 'bit-quad Euler count not a multiple of 4'
-            todo = [v for v in range(1, num) if holes[v] > 0]
-            sequential_from = None
-            for v in todo:
-                x0, y0, x1, y1 = [int(t) for t in bbox[v]]
+        ck(lib, lib.lu_post_fill_all(L, H, W, self._p('num'), self._p('bbox'), self._p('e4'), self._p('ncomp'),
+                                     self._p('dirty'), st), 'lu_post_fill_all')
+        job = _Job()
+        job.args = (min_cell_size, max_cell_size, fov, fov_fix)
+        job.stages, job.H, job.W = stages, H, W
+        self._tail(job)
+        return job
+
+    def _tail(self, job):
+        """FOV presence, numbering, relabel, and the one copy to the host."""
+        lib, st, ck = ops.lib(), ops._stream(), calls.check
+        H, W, L = job.H, job.W, self.labels.data_ptr()
+        min_cell_size, max_cell_size, fov, fov_fix = job.args
+        present = 0
+        if fov:
+            ck(lib, lib.lu_post_present(L, H, W, int(fov), 0 if fov_fix else 1, self.nmax, self._p('present'), st),
+               'lu_post_present')
+            present = self._p('present')
+        big = 2 ** 31 - 1
+        ck(lib, lib.lu_post_newid(self._p('num'), self._p('area'), present, int(min(max(min_cell_size, -big), big)),
+                                  int(min(max_cell_size, big)), self.nmax, self.newid.data_ptr(), self._p('dirty'),
+                                  self.out.data_ptr() + 4 * self.map_words, st), 'lu_post_newid')
+        ck(lib, lib.lu_post_relabel(L, H, W, self.newid.data_ptr(), self.nmax, self.out.data_ptr(), st), 'lu_post_relabel')
+        self.host.copy_(self.out, non_blocking=True)
+        if self.out.device.type == 'cuda':
+            job.event = torch.cuda.Event()
+            job.event.record()
+        else:
+            job.event = None
+
+    def collect(self, job):
+        """Wait for the frame enqueued as `job` (the most recent enqueue of THIS processor) -> numpy uint16 [H,W]."""
+        if job.event is not None:
+            job.event.synchronize()
+        H, W = job.H, job.W
+        tail = self.host[self.map_words:].numpy()
+        num, dirty, oversize = int(tail[0]), int(tail[1]), int(tail[2])
+        if num > self.nmax:
+            raise calls.NativeError('label count %d exceeds the bound %d' % (num, self.nmax))
+        if dirty or oversize:
+            self.fallbacks += 1
+            self._replay_in_reference_order(job, num)
+            if job.event is not None:
+                job.event.synchronize()
+        if job.stages is not None:
+            job.stages['filled'] = self.labels.cpu().numpy().copy()
+            o = self.off['area']
+            job.stages['areas'] = None if num <= 1 else self.small[o:o + num].cpu().numpy().astype(np.int64)
+        flat = self.host[:self.map_words].numpy().view(np.uint16)[:H * W]
+        return flat.reshape(H, W).copy()
+
+    def __call__(self, softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, stages=None):
+        """softmax_chw: [3,H,W] float32 device tensor -> numpy uint16 [H,W].  stages (dict): receives intermediate label maps."""
+        return self.collect(self.enqueue(softmax_chw, edge_dist, min_cell_size, max_cell_size, fov, fov_fix, stages))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _replay_in_reference_order(self, job, num):
+        """Nested objects: start again from the map before any fill and walk the labels as Inference2D.py:80-91 does.  Labels
+        with holes (from the statistics) are filled in order until one reports the additive quirk; from there on every label
+        is processed one by one from the CURRENT map (its pixel set may have changed)."""
+        lib, st, ck = ops.lib(), ops._stream(), calls.check
+        H, W = job.H, job.W
+        ws, L = self.ws.data_ptr(), self.labels.data_ptr()
+        self.labels.copy_(self.snapshot)
+        self.small[1:3].zero_()
+        o, n = self.off, self.nmax
+        host = self.small.cpu().numpy()
+        bbox = host[o['bbox']:o['bbox'] + 4 * num].reshape(num, 4)
+        e4, ncomp = host[o['e4']:o['e4'] + num], host[o['ncomp']:o['ncomp'] + num]
+        holes = ncomp - e4 // 4
+        assert not np.any(e4[1:] % 4), 'bit-quad Euler count not a multiple of 4'
+        sequential_from = None
+        for v in [v for v in range(1, num) if holes[v] > 0]:
+            x0, y0, x1, y1 = [int(t) for t in bbox[v]]
+            self._fill(lib, st, ws, L, H, W, v, x0, y0, x1, y1)
+            if int(self.small[1].item()):               # a hole held another label: strict reference order from here on
+                sequential_from = v + 1
+                break
+        if sequential_from is not None:
+            for v in range(sequential_from, num):
+                ck(lib, lib.lu_post_bbox_of_label(L, H, W, v, self.box.data_ptr(), st), 'lu_post_bbox_of_label')
+                x0, y0, x1, y1 = [int(t) for t in self.box.cpu().numpy()]
+                if x1 < 0:
+                    continue                            # `if not np.any(bw): continue`
                 self._fill(lib, st, ws, L, H, W, v, x0, y0, x1, y1)
-                if int(self.small[1].item()):               # a hole held another label: strict reference order from here on
-                    sequential_from = v + 1
-                    break
-            if sequential_from is not None:
-                for v in range(sequential_from, num):
-                    ck(lib, lib.lu_post_bbox_of_label(L, H, W, v, self.box.data_ptr(), st), 'lu_post_bbox_of_label')
-                    x0, y0, x1, y1 = [int(t) for t in self.box.cpu().numpy()]
-                    if x1 < 0:
-                        continue                            # `if not np.any(bw): continue`
-                    self._fill(lib, st, ws, L, H, W, v, x0, y0, x1, y1)
-        if stages is not None:
-            stages['filled'] = self.labels.cpu().numpy().copy()
-            stages['areas'] = None if areas is None else areas.copy()
-        newid = np.zeros(self.nmax, np.int32)
-        if num > 1:
-            present = None
-            if fov:
-                ck(lib, lib.lu_post_present(L, H, W, int(fov), 0 if fov_fix else 1, num, self._p('present'), st),
-                   'lu_post_present')
-                o = self.off['present']
-                present = self.small[o:o + num].cpu().numpy()       # sync 2
-            p = 0
-            for v in range(1, num):
-                if min_cell_size <= areas[v] <= max_cell_size and (present is None or present[v]):
-                    p += 1
-                    newid[v] = p
-        self.newid.copy_(torch.from_numpy(newid))
-        ck(lib, lib.lu_post_relabel(L, H, W, self.newid.data_ptr(), max(num, 1), self.out.data_ptr(), st), 'lu_post_relabel')
-        return self.out.cpu().numpy().view(np.uint16).copy()
+        self._tail(job)
 
     def _fill(self, lib, st, ws, L, H, W, v, x0, y0, x1, y1):
         cx0, cy0, cx1, cy1 = max(0, x0 - 1), max(0, y0 - 1), min(W - 1, x1 + 1), min(H - 1, y1 + 1)

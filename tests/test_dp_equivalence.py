@@ -162,3 +162,71 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     # that into 1e-4-sized steps on ~0.5 % of the weights (measured 1.06e-3 / 5.2e-3, identical with the side stream off)
     frac = 2e-3 if precision == 'fp32' else 1e-2
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= frac, (diff.max(), (diff > 1e-4).mean())
+
+
+RCCL_WORKER = r'''
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from conftest import tiny_net
+import train2D, Networks
+from lu_native.dp import DataParallel
+dp = DataParallel(backend='nccl')       # RCCL: one device per rank (LOCAL_RANK)
+assert torch.distributed.get_backend() == 'nccl' and torch.cuda.current_device() == dp.local_rank
+d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
+net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3,
+                     precision=sys.argv[1])
+per = d['x'].shape[0] // dp.world_size
+sl = slice(dp.rank * per, (dp.rank + 1) * per)
+_, _, loss = tr.train_step(d['x'][sl], d['gt'][sl])
+grads1 = tr.engine.flat_grads.cpu().numpy()
+tr.model.reset_states_per_batch(np.ones(per, np.float32))
+_, _, loss2 = tr.train_step(d['x'][sl, ::-1].copy(), d['gt'][sl, ::-1].copy())
+torch.cuda.synchronize()
+if dp.rank == 0:
+    np.savez(os.path.join(%(tmp)r, 'dp_rccl_out.npz'), params=tr.engine.flat_params.cpu().numpy(),
+             loss=np.array([float(loss), float(loss2)]), grads1=grads1, launched=np.array([dp.launched]))
+dp.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_ranks', [2, 4, 8])
+def test_dpN_syncbn_over_rccl_equals_single_process(tmp_path, n_ranks):
+    """The self-check for the first multi-GPU box: N ranks, one device each, backend nccl (= RCCL over xGMI), SyncBN:
+    loss and pre-Adam gradients must equal the single-process step on the N-slot batch (fp32: summation-order noise).
+    Skipped when the box has fewer than N devices (the one-GPU test box runs the gloo variant above instead)."""
+    if torch.cuda.device_count() < n_ranks:
+        pytest.skip('needs %d GPUs, %d visible' % (n_ranks, torch.cuda.device_count()))
+    import train2D
+    import Networks
+    rng = np.random.default_rng(n_ranks)
+    x = rng.standard_normal((n_ranks, 3, 1, 24, 32)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(n_ranks, 3, 1, 24, 32)).astype(np.float32)
+    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
+    script = tmp_path / 'worker_rccl.py'
+    script.write_text(RCCL_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    port = 29600 + (os.getpid() + 7 * n_ranks) % 1500
+    env = {k: v for k, v in os.environ.items() if k != 'LU_DP_BACKEND'}
+    procs = [subprocess.Popen([sys.executable, str(script), 'fp32'],
+                              env=dict(env, RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(n_ranks)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+    tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, seed=3)
+    _, _, l1 = tr.train_step(x, gt)
+    ref_grads1 = tr.engine.flat_grads.cpu().numpy()
+    tr.model.reset_states_per_batch(np.ones(n_ranks, np.float32))
+    _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
+    got = np.load(tmp_path / 'dp_rccl_out.npz')
+    g_err = np.abs(got['grads1'] - ref_grads1).max() / np.abs(ref_grads1).max()
+    print('dp%d over RCCL vs single: loss err %.3e, step-1 gradient err / max|g| %.3e, all-reduce launches %d' %
+          (n_ranks, np.abs(got['loss'] - np.array([float(l1), float(l2)])).max(), g_err, int(got['launched'][0])))
+    assert np.abs(got['loss'] - np.array([float(l1), float(l2)])).max() <= 1e-5 and g_err <= 2e-6

@@ -196,3 +196,48 @@ def test_post_pipeline_returns_the_same_label_maps(dev):
     assert [t for t, _, _ in got] == list(range(len(sms)))
     for (t, labels, _), ref in zip(got, want):
         assert np.array_equal(labels, ref), t
+
+
+def test_device_driven_fill_and_its_exact_fallback(dev):
+    """The frame is device-driven (lu_post_fill_all + lu_post_newid, one device -> host copy); nested objects -- where the
+    reference's additive quirk makes the label order matter -- and crops beyond the kernel's LDS staging fall back to the
+    strictly sequential replay.  Both routes must give the oracle's map, and each must actually be taken where expected."""
+    import Inference2D
+    import torch
+    from lu_native.post import PostProcessor
+    proc = PostProcessor()
+    kw = dict(edge_dist=2, min_cell_size=1, max_cell_size=10 ** 6)
+    sm = _scenario('holes_after_absorption')                     # holes, nothing nested: device route
+    st = {}
+    got = proc(torch.from_numpy(sm).to(dev), stages=st, **kw)
+    assert proc.fallbacks == 0 and (st['filled'] != st['absorbed']).sum() >= 2
+    assert np.array_equal(got, po.postprocess(sm, **kw))
+    sm = _scenario('c_ring_closed_by_edge')                      # a cell inside a closed ring: the quirk -> replay
+    got = proc(torch.from_numpy(sm).to(dev), **kw)
+    assert proc.fallbacks == 1 and np.array_equal(got, po.postprocess(sm, **kw))
+    # several rings with holes and no nesting, processed concurrently by different workgroups
+    H, W = 60, 90
+    cell = np.zeros((H, W), np.float32)
+    for k, (cy, cx) in enumerate([(12, 12), (12, 40), (14, 70), (42, 20), (40, 55)]):
+        yy, xx = np.mgrid[:H, :W]
+        r2 = (yy - cy) ** 2 + (xx - cx) ** 2
+        cell[(r2 <= (9 + k % 2) ** 2) & (r2 >= (4 + k % 3) ** 2)] = 1
+    logits = np.stack([np.ones((H, W), np.float32), 3 * cell, np.zeros((H, W), np.float32)])
+    e = np.exp(logits - logits.max(0))
+    sm = (e / e.sum(0)).astype(np.float32)
+    before = proc.fallbacks
+    got = proc(torch.from_numpy(sm).to(dev), **kw)
+    ref = po.postprocess(sm, **kw)
+    assert proc.fallbacks == before and np.array_equal(got, ref) and ref.max() == 5
+    assert all(ref[cy, cx] == ref[cy, cx + 7] != 0 for cy, cx in [(12, 12), (12, 40), (42, 20)])      # holes took the ring label
+    if dev.type == 'cuda':                                       # a ring whose crop exceeds the LDS staging (48 K pixels)
+        H, W = 300, 320
+        yy, xx = np.mgrid[:H, :W]
+        r2 = (yy - 150) ** 2 + (xx - 160) ** 2
+        cell = ((r2 <= 140 ** 2) & (r2 >= 120 ** 2)).astype(np.float32)
+        logits = np.stack([np.ones((H, W), np.float32), 3 * cell, np.zeros((H, W), np.float32)])
+        e = np.exp(logits - logits.max(0))
+        sm = (e / e.sum(0)).astype(np.float32)
+        before = proc.fallbacks
+        got = proc(torch.from_numpy(sm).to(dev), **kw)
+        assert proc.fallbacks == before + 1 and np.array_equal(got, po.postprocess(sm, **kw))
