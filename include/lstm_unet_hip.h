@@ -74,8 +74,10 @@ enum {
                                   * packed as ONE tap by lu_pack_weights_taps_bf16 */
     LU_CONV_F_NO_BALANCE = 1024, /* few-tile launches (<= 2048 tile x split work items): keep the m-tile-per-XCD block
                                   * numbering instead of the balanced one (equal runs of work items per XCD) -- A/B */
-    LU_CONV_F_SLABS_ONLY = 2048  /* LU_EPI_BIAS, splits > 1: stop after the partial slabs -- workspace[s][frames*Hout*Wout][N],
+    LU_CONV_F_SLABS_ONLY = 2048, /* LU_EPI_BIAS, splits > 1: stop after the partial slabs -- workspace[s][frames*Hout*Wout][N],
                                   * bias NOT added, `out` unused; the consumer sums them (lu_lstm_gates_fwd_slabs) */
+    LU_CONV_F_NO_NARROW = 4096   /* precision 1, stride-1 3x3 / 5x5 with N = 32 / 64: take the gather kernel instead of the narrow
+                                  * blocks of the halo kernel (A/B runs and tests: the two must agree) */
 };
 
 typedef struct lu_conv_desc {

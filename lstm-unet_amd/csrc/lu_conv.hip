@@ -871,12 +871,12 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap
 // 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
 // Epilogue of the fragment kernels (both loop generations): bias / K-split stores, or the fused ConvLSTM gate block with
 // its exchange of the four gate fragments through the (dead) halo LDS.
-template <int EPI, int RW>
+template <int EPI, int RW, int NFR = 4>
 __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[RW], unsigned char* Ah, int f, int y0, int x0,
                                               int nt, int n0, int ks) {
-    constexpr int BN = 128, TW = 32, EX_LD = BN + 4;
+    constexpr int BN = 32 * NFR, TW = 32, EX_LD = BN + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / NFR, wn = wave % NFR;
     if (LU_DBG(a, 8)) {      // ablation: no epilogue (one store keeps the accumulators alive)
         float t = 0.f;
 #pragma unroll
@@ -978,10 +978,14 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 // block input; the im2col image of the thin first input) -- a piece is then 8 channels = 16 raw bytes, half as many
 // loads, no conversion.  The element type is a compile-time property of the launch: a run-time (even uniform) branch
 // around the loads makes the compiler's vmcnt accounting conservative (measured: 5-28 % slower).
-template <int K, int EPI, int RW, bool F32, bool B16>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
+// NFR = column fragments (of 32) per block: 4 (128 columns, 2 row groups of waves) for the wide layers; 2 / 1 for the narrow
+// decoder tail (N = 64 / 32: 4 / 8 row groups of RW = 2 / 1 rows, i.e. the same 8 x 32 patch) -- those layers are bound by
+// HBM, not by the matrix pipe, and all they need is the halo staged once and every wave busy on its own rows.
+template <int K, int EPI, int RW, bool F32, bool B16, int NFR = 4>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
 __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_frag_kernel(ConvArgs a) {
     static_assert(!(F32 && B16), "bf16 tensors feed the bf16 MFMA only");
-    constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32;
+    static_assert(NFR == 4 || (EPI == LU_EPI_BIAS && (NFR == 1 || NFR == 2)), "narrow blocks: bias epilogue only");
+    constexpr int BN = 32 * NFR, NT = 512, TH = (8 / NFR) * RW, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
     constexpr int CKS = F32 ? CK : CKB;                // channels per stage
     constexpr int PC = B16 ? 8 : 4;                    // channels per 16-byte piece
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     LU_DYN_LDS(unsigned char, Ah);                     // [2][AH_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / NFR, wn = wave % NFR;
     int tile, nt, ks;
     if (!lu_block_tile(a, tile, nt, ks)) return;
     const int f = tile / a.tiles_pf;
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     const int q = tid % G;                 // channel group inside the chunk
     // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
     const int nfr = (a.N + 31) >> 5;
-    const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
+    const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * NFR + wn;
     const bool frag_ok = frag < nfr;
     // Per-source fields live in registers and are picked with selects: indexing a.src[st.s] inside the tap loop costs a
     // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         if (D == 4 && it + 2 < it1) step(it + 2, S2());
     }
 
-    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+    frag_epilogue<EPI, RW, NFR>(a, acc, Ah, f, y0, x0, nt, n0, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1724,6 +1728,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // dynamic LDS of conv_halo_frag_kernel<K, *, RW, *>: two halo images of 80 bytes per pixel
 size_t halo_bf16_lds(int K, int RW) { return (size_t)2 * (2 * RW + K - 1) * (32 + K - 1) * LDB * sizeof(unsigned short); }
+// (narrow blocks, NFR = 1 / 2: 8 / NFR row groups of RW = NFR rows -- the 8-row patch, same bytes as RW = 4)
 
 }  // namespace
 
@@ -1816,7 +1821,10 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     // halo-reuse kernel: stride-1 SAME 3x3 / 5x5, wide 16-byte-aligned outputs, <= 25 % of the 8x32 patches wasted
     const int64_t tiles_x = (d->Wout + 31) / 32;
     int th = 8;      // patch height; the bf16 kernel takes 16-row patches when that still leaves >= 1 block per CU
-    if (d->precision != 0 && d->k == 5) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
+    // bf16, N = 32 / 64 (the decoder tail): narrow blocks of the fragment kernel, always 8-row patches
+    const bool narrow_n = d->precision == 1 && d->epilogue == LU_EPI_BIAS && (d->N == 32 || d->N == 64) &&
+                          !(d->flags & LU_CONV_F_NO_NARROW);
+    if (d->precision != 0 && d->k == 5 && !narrow_n) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
         const int64_t nt_est = d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128;
         const int force = (d->flags & LU_CONV_F_PATCH16) ? 16 : (d->flags & LU_CONV_F_PATCH8) ? 8 : 0;      // tests and A/B runs
         const int64_t sp = d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits;
@@ -1826,7 +1834,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     }
     const int64_t tiles_y = (d->Hout + th - 1) / th;
     const bool halo = d->stride == 1 && d->dil == 1 && k_h == d->k && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
-                      d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec && d->N > 64 &&
+                      d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec &&
+                      (d->N > 64 || narrow_n) &&
                       a.n_src > 0 && d->out_row_stride == 0 &&
                       (d->precision != 0 || (tiles_y * tiles_x * 256 * 4 <= (int64_t)d->Hout * d->Wout * 5 &&
                                              !(d->flags & LU_CONV_F_NO_HALO)));
@@ -1840,7 +1849,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     bool src16 = false;      // all sources bf16 tensors (a property of the launch: mixed element types are rejected)
     for (int s2 = 0; s2 < a.n_src; ++s2) {
         LU_REQUIRE(!a.src[s2].bf16 || (halo && d->precision == 1),
-                   "lu_conv2d_fwd: bf16 activations are read by the bf16 halo kernel only (stride-1 3x3 / 5x5, N > 64)");
+                   "lu_conv2d_fwd: bf16 activations are read by the bf16 halo kernel only (stride-1 3x3 / 5x5, N > 64 or N = 32 / 64)");
         LU_REQUIRE(a.src[s2].bf16 == a.src[0].bf16, "lu_conv2d_fwd: the sources of one launch must share an element type");
         LU_REQUIRE(!a.src[s2].bf16 || (a.src[s2].C % 8 == 0 && a.src[s2].pix_stride % 8 == 0 && a.src[s2].frame_stride % 8 == 0),
                    "lu_conv2d_fwd: a bf16 source needs C, pixel and frame strides that are multiples of 8 (source %d)", s2);
@@ -1953,8 +1962,25 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     }
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
         a.n_tiles = (d->N + 127) / 128;
+        const bool narrow = halo && d->N <= 64;      // N = 32 / 64: one block covers every column (NFR = 1 / 2)
         const dim3 gridb = tile_grid();
-        if (halo && !gen1 && src16 && d->k == 5 && th == 16)
+        if (narrow && d->N == 32 && d->k == 5 && src16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 1, false, true, 1>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (narrow && d->N == 32 && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 1, false, false, 1>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (narrow && d->N == 32 && src16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 1, false, true, 1>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (narrow && d->N == 32)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 1, false, false, 1>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (narrow && d->k == 5 && src16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 2, false, true, 2>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (narrow && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 2, false, false, 2>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (narrow && src16)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, true, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (narrow)
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, false, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (halo && !gen1 && src16 && d->k == 5 && th == 16)
             LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && !gen1 && src16 && d->k == 5)
             LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);

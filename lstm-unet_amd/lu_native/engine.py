@@ -191,6 +191,12 @@ class Engine:
     def _bf16_conv(self, k, stride, n_out):
         return self.precision == 'bf16' and stride == 1 and k in (3, 5) and n_out > 64 and n_out % 4 == 0
 
+    def _bf16_unit(self, k, stride, n_out):
+        """Conv2D layers (and their input gradients, n_out = the gradient's columns) that run on bf16 MFMA operands: every
+        layer with >= 64 output columns, and the 32-column stride-1 3x3 / 5x5 layers of the decoder tail (narrow blocks of
+        the halo kernel; oracle/torch_oracle.py restates the same rule)."""
+        return self.precision == 'bf16' and (n_out >= 64 or (n_out == 32 and stride == 1 and k in (3, 5)))
+
     def _pack(self, name, role, make, co=0, cs=None, packer=None):
         ver = self.flat_params._version       # in-place torch updates (copy_, torch optimisers) bump it; the raw-pointer
         if ver != self._packed_version:       # Adam kernel does not, hence Adam.apply_gradients -> weights_changed()
@@ -236,12 +242,31 @@ class Engine:
         layer's weight gradient in bf16 mode."""
         wname = f'{prefix}.conv.{ci}.kernel'
         w = self.P[wname]
-        vec = all(x.shape[3] % 4 == 0 and x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-                  for (x, _, _) in srcs)      # the bf16 kernel reads 16-byte channel groups
-        # bf16: halo kernel where it applies, the gather kernel otherwise -- except narrow outputs (N < 64: 128-column
-        # blocks would idle 3 of 4 column fragments; measured slower than the fp32 32/64-column tiles)
-        if vec and self.precision == 'bf16' and w.shape[3] >= 64:
-            pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs: w[:, :, co:co + cs, :], co, cs)) for (x, co, cs) in srcs]
+        bf = self._bf16_unit(w.shape[0], spec['stride'], w.shape[3])
+        fsrcs = srcs      # what the forward launch reads (the tape keeps `srcs`: the weight gradients see the real tensors)
+        if bf and any(x.shape[3] % 4 for (x, _, _) in srcs):
+            # thin sources (the 1-channel image skip of the last up block): the bf16 kernel reads 16-byte channel groups, so
+            # they get zero pad channels (and zero weight rows) for this launch -- 33 MB at config-2, once per step
+            fsrcs = []
+            for (x, co, cs) in srcs:
+                if x.shape[3] % 4:
+                    xp = torch.zeros(x.shape[:3] + (-(-x.shape[3] // 4) * 4,), device=x.device, dtype=torch.float32)
+                    xp[..., :x.shape[3]] = x
+                    x = xp
+                fsrcs.append((x, co, cs))
+        vec = all(x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[3] % 4 == 0
+                  for (x, _, _) in fsrcs)      # the bf16 kernel reads 16-byte channel groups
+        # bf16: halo kernel where it applies (N = 32 / 64: its narrow blocks), the gather kernel otherwise; N < 32 stays on the
+        # fp32 tiles (128-column blocks would idle 3 of 4 column fragments; measured slower)
+        if vec and bf:
+            def padded(co, cs, cp):
+                if cp == cs:
+                    return w[:, :, co:co + cs, :]
+                wp = torch.zeros((w.shape[0], w.shape[1], cp, w.shape[3]), device=w.device, dtype=torch.float32)
+                wp[:, :, :cs] = w[:, :, co:co + cs, :]
+                return wp
+            pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs, cp=x.shape[3]: padded(co, cs, cp), co, cs))
+                     for (x, co, cs) in fsrcs]
         else:
             pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
         if with_bn and tape is None and not training:
@@ -292,7 +317,7 @@ class Engine:
                 ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
                                  dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
-                                        bf16=self.precision == 'bf16' and cs >= 64) if need else None)
+                                        bf16=self._bf16_unit(gw.shape[0], spec['stride'], cs)) if need else None)
         rec['srcs'] = rec['alt16'] = None
         return dxs
 

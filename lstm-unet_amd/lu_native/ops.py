@@ -143,8 +143,9 @@ def conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, 
     post = (scale, shift, alpha): inference BatchNorm affine + LeakyReLU folded into the store / the slab reduce.
     slabs_only: return (workspace, splits) with the partial slabs instead of reducing them (None when no split applies)."""
     channels = sum(x.shape[3] for x, _ in pairs)
-    halo = stride == 1 and dil == 1 and k in (3, 5) and N > 64 and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     prec = max([w.precision for _, w in pairs if isinstance(w, PackedW)] + [0])
+    narrow = prec == 1 and N in (32, 64) and not (CONV_FLAGS & cabi.LU_CONV_F_NO_NARROW)      # narrow blocks of the bf16 halo kernel
+    halo = stride == 1 and dil == 1 and k in (3, 5) and (N > 64 or narrow) and N % 4 == 0     # mirrors lu_conv2d_fwd's kernel choice
     extra_flags = 0
     if k_h:
         splits = 1

@@ -114,8 +114,8 @@ class TorchULSTM:
     def __init__(self, net_params, in_channels, params, dtype=torch.float64, pad_image=False,
                  bn_eps=1e-3, bn_momentum=0.99, bf16_operands=False, resize='tf2.0'):
         """bf16_operands: restate Engine(precision='bf16') -- the convolutions that mode runs on the bf16 MFMA
-        (ConvLSTM gate convolutions with 3x3 / 5x5 kernels and 4F > 64 columns; Conv2D layers with >= 64 output
-        channels whose sources all have C % 4 == 0) see bf16-rounded operands, everything else stays in `dtype`."""
+        (ConvLSTM gate convolutions with 3x3 / 5x5 kernels and 4F > 64 columns; Conv2D layers with >= 64 output channels, or
+        exactly 32 for stride-1 3x3 / 5x5 layers) see bf16-rounded operands, everything else stays in `dtype`."""
         self.bf16_operands = bool(bf16_operands)
         self.resize = resize
         self.net_params = net_params
@@ -151,7 +151,9 @@ class TorchULSTM:
 
         def cbl(prefix, ci, l, act, with_bn=True, cins=None):
             w_ = P[f'{prefix}.conv.{ci}.kernel']
-            rnd = self.bf16_operands and w_.shape[3] >= 64 and all(c % 4 == 0 for c in (cins or (w_.shape[2],)))
+            n_out, ksz = w_.shape[3], w_.shape[0]
+            wide = n_out >= 64 or (n_out == 32 and ksz in (3, 5) and l['stride'] == 1)      # (narrow blocks of the halo kernel)
+            rnd = self.bf16_operands and wide      # (thin sources are zero-padded to 4 channels by the engine, not excluded)
             y = conv2d_same(act, w_, P[f'{prefix}.conv.{ci}.bias'], l['stride'], rounded=rnd)
             if not with_bn:
                 return y

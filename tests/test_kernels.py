@@ -257,6 +257,26 @@ def test_conv_f32_fragment_weights_variant(be, patch):
         KH.conv2d(be, [rnd(1, 8, 8, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=2, flags=flags)
 
 
+def test_conv_bf16_narrow_blocks(be):
+    """N = 32 / 64 stride-1 3x3 / 5x5 layers in bf16 mode (the decoder tail): narrow blocks of the halo fragment
+    kernel -- 8 / 4 row groups of waves over 1 / 2 column fragments of the same 8 x 32 patch.  Against the oracle on
+    bf16-rounded operands, and against the gather kernel (LU_CONV_F_NO_NARROW), which walks another (chunk, tap) order:
+    summation-order noise only.  Ragged frames, several chunks, two sources, K split, bf16 tensors as sources."""
+    R = KH.bf16_round
+    for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 32, 32, 3, 1), (2, 9, 37, 64, 32, 3, 1), (1, 17, 40, 100, 64, 3, 1),
+                                     (1, 8, 33, 36, 64, 5, 1), (1, 11, 30, 20, 32, 5, 1), (1, 16, 32, 256, 64, 3, 2)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1)
+        close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
+        close(got, KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=cabi.LU_CONV_F_NO_NARROW), 5e-5)
+        if Cc % 8 == 0:
+            assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, bf16_src=(0,)))
+    xa, xb = rnd(2, 12, 34, 40), rnd(2, 12, 34, 24)                # two sources (UpBlock concat), N = 64
+    wa, wb = rnd(3, 3, 40, 64, scale=0.1), rnd(3, 3, 24, 64, scale=0.1)
+    ref = npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb))
+    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1), ref, 5e-5)
+
+
 def test_conv_bf16_gather_variant(be):
     """General bf16 kernel (precision = 1 outside the halo kernel's domain): stride 2 (TF-SAME asymmetric pads), 1x1 and
     7x7 kernels, narrow / ragged outputs, two sources, K split, strided output rows."""

@@ -215,29 +215,31 @@ def test_device_driven_fill_and_its_exact_fallback(dev):
     sm = _scenario('c_ring_closed_by_edge')                      # a cell inside a closed ring: the quirk -> replay
     got = proc(torch.from_numpy(sm).to(dev), **kw)
     assert proc.fallbacks == 1 and np.array_equal(got, po.postprocess(sm, **kw))
-    # several rings with holes and no nesting, processed concurrently by different workgroups
-    H, W = 60, 90
-    cell = np.zeros((H, W), np.float32)
-    for k, (cy, cx) in enumerate([(12, 12), (12, 40), (14, 70), (42, 20), (40, 55)]):
-        yy, xx = np.mgrid[:H, :W]
-        r2 = (yy - cy) ** 2 + (xx - cx) ** 2
-        cell[(r2 <= (9 + k % 2) ** 2) & (r2 >= (4 + k % 3) ** 2)] = 1
-    logits = np.stack([np.ones((H, W), np.float32), 3 * cell, np.zeros((H, W), np.float32)])
-    e = np.exp(logits - logits.max(0))
-    sm = (e / e.sum(0)).astype(np.float32)
+    # several open rings closed by absorbed edge pixels (holes that exist only AFTER absorption), nothing nested: processed
+    # concurrently by different workgroups of ONE launch
+    def rings(H, W, boxes, gap=2):
+        cell, edge = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+        for (y0, x0, h, w, t) in boxes:                           # a t-thick rectangular ring with a gap on its left side
+            cell[y0:y0 + h, x0:x0 + w] = 1
+            cell[y0 + t:y0 + h - t, x0 + t:x0 + w - t] = 0
+            gy = y0 + h // 2
+            cell[gy:gy + gap, x0:x0 + t] = 0
+            edge[gy:gy + gap, x0:x0 + t] = 1
+        logits = np.stack([np.ones((H, W), np.float32), 3 * cell, 3 * edge])
+        e = np.exp(logits - logits.max(0))
+        return (e / e.sum(0)).astype(np.float32)
+
+    boxes = [(3, 3, 16, 18, 3), (4, 30, 20, 14, 4), (5, 52, 14, 30, 3), (30, 6, 24, 22, 4), (32, 40, 20, 40, 5)]
+    sm = rings(60, 90, boxes)
     before = proc.fallbacks
-    got = proc(torch.from_numpy(sm).to(dev), **kw)
+    st = {}
+    got = proc(torch.from_numpy(sm).to(dev), stages=st, **kw)
     ref = po.postprocess(sm, **kw)
     assert proc.fallbacks == before and np.array_equal(got, ref) and ref.max() == 5
-    assert all(ref[cy, cx] == ref[cy, cx + 7] != 0 for cy, cx in [(12, 12), (12, 40), (42, 20)])      # holes took the ring label
+    for (y0, x0, h, w, t) in boxes:                               # every ring's interior took the ring's label in the per-object fill
+        assert st['absorbed'][y0 + h // 2 - 1, x0 + w // 2] == 0 and ref[y0 + h // 2 - 1, x0 + w // 2] == ref[y0 + 1, x0 + 1] != 0
     if dev.type == 'cuda':                                       # a ring whose crop exceeds the LDS staging (48 K pixels)
-        H, W = 300, 320
-        yy, xx = np.mgrid[:H, :W]
-        r2 = (yy - 150) ** 2 + (xx - 160) ** 2
-        cell = ((r2 <= 140 ** 2) & (r2 >= 120 ** 2)).astype(np.float32)
-        logits = np.stack([np.ones((H, W), np.float32), 3 * cell, np.zeros((H, W), np.float32)])
-        e = np.exp(logits - logits.max(0))
-        sm = (e / e.sum(0)).astype(np.float32)
+        sm = rings(300, 320, [(10, 12, 270, 290, 12), (100, 100, 40, 40, 5)])
         before = proc.fallbacks
         got = proc(torch.from_numpy(sm).to(dev), **kw)
         assert proc.fallbacks == before + 1 and np.array_equal(got, po.postprocess(sm, **kw))

@@ -1,7 +1,7 @@
 # quick regression + speed check (usage: bash tools/gpu/r03_check.sh <tag> [all])
 tag=${1:-chk}
 if [ "$2" = "all" ]; then
-  python -m pytest tests -q -m gpu -x -s > gpurun_out/${tag}_tests.log 2>&1
+  python -m pytest tests -q -m gpu -s > gpurun_out/${tag}_tests.log 2>&1
 else
   python -m pytest tests/test_kernels.py tests/test_engine.py tests/test_fullsize_gpu.py tests/test_drivers.py -q -m gpu -x > gpurun_out/${tag}_tests.log 2>&1
 fi
