@@ -963,10 +963,15 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     // (ragged: W % 16 != 0 -- fp32 kernel only, rows walked in ceil(W / 16) runs with a masked tail; from 40 pixels on, where the
     // masked share is <= 17 %: config-4's 248- and 124-pixel levels ran the one-tap-per-block kernel at 113 TFLOP/s without it)
     const bool ragged_w = d->Wout % 16 != 0 && d->Wout >= 40 && !xb && !yb && !(d->flags & LU_WGRAD_F_NO_RAGGED);
+    // bf16 mode: the narrow decoder layers (C >= 32) take the bf16 kernel-row variant too (masked channel / column tiles: the
+    // layers are HBM-bound, what counts is that x / dy are read once per slab and the MFMA is 16x the fp32 one)
+    const bool narrow_bf16 = d->precision == 1 && d->Wout % PRB == 0 && !(d->flags & LU_WGRAD_F_NO_NARROW_BF16);
     const bool row_variant = xvec && yvec && d->stride == 1 && (d->k == 3 || d->k == 5) && (d->Wout % 16 == 0 || ragged_w) &&
-                             d->C >= 64 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_ROW);
+                             d->C >= (narrow_bf16 ? 32 : 64) && d->Wout == d->Win && d->Hout == d->Hin &&
+                             !(d->flags & LU_WGRAD_F_NO_ROW);
     const bool small3 = !xb && !yb && xvec && yvec && d->stride == 1 && d->k == 3 && d->C <= 64 && d->N <= 64 &&
-                        d->Wout % 16 == 0 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_SMALL3);
+                        d->Wout % 16 == 0 && d->Wout == d->Win && d->Hout == d->Hin && !(d->flags & LU_WGRAD_F_NO_SMALL3) &&
+                        !(narrow_bf16 && row_variant);
     // (a 1x1 layer with >= 32 channels also fits the bf16 kernel-row scheme: one tap, no halo -- the im2col chunk of a thin input)
     const bool row_k1 = xvec && yvec && d->stride == 1 && d->k == 1 && d->precision == 1 && d->C >= 32 && d->Wout == d->Win &&
                         d->Hout == d->Hin && !d->dbias && !(d->flags & LU_WGRAD_F_NO_ROW);

@@ -281,8 +281,9 @@ def bf16_row_wgrad_ok(x, dy, k, stride):
         q = 8 if t.dtype == torch.bfloat16 else 4
         return ch % q == 0 and t.stride(2) % q == 0 and t.stride(0) % q == 0 and t.data_ptr() % 16 == 0
 
-    small3 = k == 3 and Cin <= 64 and N <= 64 and x.dtype == torch.float32 and dy.dtype == torch.float32
-    shape_ok = (k in (3, 5) and Cin >= 64 and not small3) or (k == 1 and Cin >= 32)
+    narrow = not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_NARROW_BF16)      # C >= 32: masked tiles of the same kernel (decoder tail)
+    small3 = k == 3 and Cin <= 64 and N <= 64 and x.dtype == torch.float32 and dy.dtype == torch.float32 and not narrow
+    shape_ok = (k in (3, 5) and Cin >= (32 if narrow else 64) and not small3) or (k == 1 and Cin >= 32)
     if stride == 2:      # the stride-2 3x3 layers (first convolution of a down block)
         return (k == 3 and Cin >= 64 and Wout % 32 == 0 and vec(x, Cin) and vec(dy, N) and Hout == (Hin + 1) // 2 and
                 Wout == (Win + 1) // 2 and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
@@ -310,9 +311,11 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     small3 = (aligned and not xb and not yb and stride == 1 and k == 3 and Cin <= 64 and N <= 64 and Wout % 16 == 0 and
               Hout == Hin and Wout == Win and
               not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_SMALL3))      # all-taps kernel of the narrow decoder layers (takes precedence)
+    bf16_row = bf16 and bf16_row_wgrad_ok(x, dy, k, stride)
+    if bf16_row and stride == 1 and k in (3, 5):
+        small3, row_variant = False, True      # (bf16 mode: the narrow layers ride the bf16 kernel-row variant as well)
     if small3:
         row_variant = False
-    bf16_row = bf16 and bf16_row_wgrad_ok(x, dy, k, stride)
     assert bf16_row or not (xb or yb), 'bf16 operands need the bf16 kernel-row weight gradient'
     if bf16_row and stride == 2:
         row_variant = True           # (the bias gradient rides on this launch as well)

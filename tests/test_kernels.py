@@ -502,6 +502,18 @@ def _wgrad_bf16_cases(be, flags=0):
     x, dy = rnd(2, 4, 32, 32), rnd(2, 4, 32, 72)              # 1x1 problem over 32 rows: the im2col chunk of a thin input
     _, gw = _torch_conv_grads(R(x), rnd(1, 1, 32, 72), R(dy), 1)
     close(KH.conv2d_wgrad(be, x, dy, 1, 1, splits=2, precision=1, x_bf16=True, dy_bf16=True), gw, 2e-4)
+    # the narrow decoder layers (C = 32 / 64 / 36, N = 32 / 64): masked channel / column tiles of the same kernel; with
+    # LU_WGRAD_F_NO_NARROW_BF16 they stay on the fp32 all-taps kernel (full precision) -- the two differ by the operand rounding
+    for (fr, H, W, Cc, N, k, sp) in [(2, 6, 32, 32, 32, 3, 2), (1, 5, 64, 64, 32, 3, 1), (1, 4, 32, 64, 64, 3, 3),
+                                     (1, 6, 32, 36, 64, 5, 2)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        _, gw = _torch_conv_grads(R(x), rnd(k, k, Cc, N), R(dy), 1)
+        got, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags, dbias0=np.zeros(N, np.float32))
+        close(got, gw, 2e-4)
+        close(db, dy.reshape(-1, N).sum(0), 2e-4)
+        _, gfull = _torch_conv_grads(x, rnd(k, k, Cc, N), dy, 1)
+        if k == 3:
+            close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_WGRAD_F_NO_NARROW_BF16), gfull, 2e-4)
     with pytest.raises(RuntimeError):                         # bf16 operands need the bf16 kernel-row variant
         KH.conv2d_wgrad(be, rnd(1, 4, 16, 64), rnd(1, 4, 16, 128), 3, 1, precision=1, dy_bf16=True)
 
