@@ -97,6 +97,7 @@ class Engine:
         # GPU, bf16 mode: weight gradients go to a side HIP stream (see _wgrad_side: +0.6 % measured; neutral in fp32, where
         # the HBM-bound share of backward is 8x smaller); bench.py's per-kernel timing pass and the host emulator run in line
         self.overlap_wgrad = precision == 'bf16'
+        self.narrow_bf16 = True      # A/B (bench.py --ab-old-tail): False keeps the N = 32 decoder layers on the fp32 kernels
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
@@ -195,7 +196,7 @@ class Engine:
         """Conv2D layers (and their input gradients, n_out = the gradient's columns) that run on bf16 MFMA operands: every
         layer with >= 64 output columns, and the 32-column stride-1 3x3 / 5x5 layers of the decoder tail (narrow blocks of
         the halo kernel; oracle/torch_oracle.py restates the same rule)."""
-        return self.precision == 'bf16' and (n_out >= 64 or (n_out == 32 and stride == 1 and k in (3, 5)))
+        return self.precision == 'bf16' and (n_out >= 64 or (self.narrow_bf16 and n_out == 32 and stride == 1 and k in (3, 5)))
 
     def _pack(self, name, role, make, co=0, cs=None, packer=None):
         ver = self.flat_params._version       # in-place torch updates (copy_, torch optimisers) bump it; the raw-pointer
