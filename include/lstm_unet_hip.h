@@ -165,6 +165,13 @@ int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N,
 int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int ks, int C, int N, int pad_t, int pad_l,
                              int pady0, int pady1, int padx0, int padx1, lu_stream_t stream);
 
+/* bf16 mode, stride-2 3x3 layers on even input extents: the whole input gradient (all four parity classes) in ONE launch
+ * on bf16 MFMA operands.  packed = lu_pack_weights_taps_bf16(sub viewed as [9][1][Nf][C]) of the nine tap matrices
+ * lu_stride2_dgrad_weights(w, sub, 3, 2, C, Nf, 0, 0, 1, 0, 1, 0) wrote; dy [frames, Hd, Wd, Nf] fp32, dx dense
+ * [frames, 2 Hd, 2 Wd, C] fp32. */
+int lu_conv2d_s2_dgrad_bf16(const float* dy, int64_t dy_frame_stride, int32_t dy_pix_stride, const void* packed, int32_t frames,
+                            int32_t Hd, int32_t Wd, int32_t Nf, int32_t C, float* dx, lu_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient:  dw[kh,kw,c,n] (+)= sum_{f,oy,ox} x[f, oy*stride+kh-pad_t, ox*stride+kw-pad_l, c] * dy[f,oy,ox,n]
  * (tape.gradient w.r.t. every conv kernel, train2D.py:92).  Split over pixels into `splits` slabs

@@ -1451,6 +1451,151 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Input gradient of a stride-2 3x3 convolution (first layer of a down block; TF-SAME on even extents: pad 0 before, 1
+// after), bf16 MFMA operands, ALL FOUR output parity classes in one pass over dy.
+//   dx[2a+py, 2b+px, c] = sum over the taps (kh, kw) with kh = py (mod 2), kw = px (mod 2) of dy[a - (kh - py)/2, b - (kw - px)/2, n] w[kh, kw, c, n]
+// i.e. 4 + 2 + 2 + 1 = 9 (tap, class) products over a 2 x 2 window of dy -- the same dy tile feeds all of them.  Round 2
+// launched four gather convolutions (one per class): blocks of 4-16 k-steps, bound by their prologue / epilogue at
+// ~100 TFLOP/s.  Here a block of 4 waves owns a 2 x 32-pixel tile of dy-space x 128 input channels and keeps the four
+// classes' accumulators (4 x 2 rows x one 32-column fragment per wave = 128 VGPRs); per 32-channel chunk of dy the 3 x 33
+// pixel halo is staged once in LDS (bf16, 80-byte pitch as in the halo kernels) and the nine products read shifted rows of
+// it; weights come from L2 in MFMA-fragment order (lu_stride2_dgrad_weights -> lu_pack_weights_taps_bf16: the nine tap
+// matrices in class order).  The next chunk's halo is fetched while the current one is multiplied.
+// ---------------------------------------------------------------------------------------------------------
+struct S2DgradArgs {
+    const float* dy;
+    const unsigned char* w;      // packed taps: [9][Nf / 32 chunks][ceil(C / 32) fragments][2 KB]
+    float* dx;
+    int64_t dy_fs;
+    int32_t dy_ps, Hd, Wd, Nf, C;
+    int32_t tiles_x, tiles_pf, m_tiles, n_tiles;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_s2_dgrad_bf16_kernel(S2DgradArgs a) {
+    constexpr int NT = 256, RW = 2, TW = 32, HWD = TW + 1, HHT = RW + 1, HP = HHT * HWD, PITCH = 80;
+    constexpr int G = 8;                                    // 16-byte pieces (4 fp32 channels) per pixel and chunk
+    constexpr int HPASS = (HP * G + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][HP * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    // block -> (dy tile, column tile): the column tiles of one dy tile are neighbours on one XCD (block b runs on XCD b % 8)
+    const int slot = blockIdx.x >> 3;
+    const int nt = slot % a.n_tiles;
+    const int tile = (slot / a.n_tiles) * 8 + (blockIdx.x & 7);
+    if (tile >= a.m_tiles) return;
+    const int f = tile / a.tiles_pf;
+    const int t2 = tile - f * a.tiles_pf;
+    const int y0 = (t2 / a.tiles_x) * RW, x0 = (t2 % a.tiles_x) * TW;
+    const int nfr = (a.C + 31) >> 5, nch = a.Nf >> 5;
+    const int frag = nt * 4 + wn;
+    const bool frag_ok = frag < nfr;
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const float* const dyf = a.dy + (int64_t)f * a.dy_fs;
+    const unsigned char* const wl = a.w + (int64_t)frag * 2048 + lane * 16;
+    const int q = tid % G;
+
+    auto piece_load = [&](int p, int chunk, lu_u4& r) {
+        const int hp = (tid + NT * p) / G;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool ok = hp < HP && iy >= 0 && iy < a.Hd && ix >= 0 && ix < a.Wd;
+        const int64_t off = (int64_t)(iy * a.Wd + ix) * a.dy_ps + chunk * 32 + 4 * q;
+        r = *(ok ? reinterpret_cast<const lu_u4*>(dyf + off) : zp);
+    };
+    auto piece_store = [&](int p, int hb, const lu_u4& r) {
+        const int hp = (tid + NT * p) / G;
+        if (hp < HP) {
+            lu_u2 v;
+            v.x = lu_pack2bf(lu_bits2f(r.x), lu_bits2f(r.y));
+            v.y = lu_pack2bf(lu_bits2f(r.z), lu_bits2f(r.w));
+            *reinterpret_cast<lu_u2*>(&Ah[hb][hp * PITCH + 8 * q]) = v;
+        }
+    };
+    auto load_b = [&](int tap, int chunk, float4& b0, float4& b1) {
+        const unsigned char* wp = wl + ((int64_t)tap * nch + chunk) * nfr * 2048;
+        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : lu_zero16);
+        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_zero16);
+    };
+
+    f32x16 acc[4][RW];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+
+    {
+        lu_u4 rh[HPASS];
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) piece_load(p, 0, rh[p]);
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) piece_store(p, 0, rh[p]);
+    }
+    __syncthreads();
+    const int khalf16 = 16 * (lane >> 5);
+    int hb = 0;
+    float4 b0, b1;
+    load_b(0, 0, b0, b1);
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool more = chunk + 1 < nch;
+        lu_u4 rn[HPASS];
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) piece_load(p, more ? chunk + 1 : chunk, rn[p]);      // (last chunk: re-read, unused)
+        // tap t: class, dy offset (row, column) -- the class order of lu_stride2_dgrad_weights for k = 3, pads 0
+        constexpr int T_CLS[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+        constexpr int T_DY[9] = {-1, -1, 0, 0, -1, 0, 0, 0, 0};
+        constexpr int T_DX[9] = {-1, 0, -1, 0, 0, 0, -1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float4 n0v, n1v;
+            if (t + 1 < 9) load_b(t + 1, chunk, n0v, n1v);
+            else load_b(0, more ? chunk + 1 : chunk, n0v, n1v);
+            const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
+            // halo row hy = (output row i) + 1 + dy, halo column = pixel + 1 + dx
+            const unsigned char* ab = &Ah[hb][((1 + T_DY[t]) * HWD + (lane & 31) + 1 + T_DX[t]) * PITCH + khalf16];
+            lu_bf16x8 a0[RW], a1[RW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
+                a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH + 32);
+            }
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[T_CLS[t]][i] = lu_mfma_bf16(a0[i], bv0, acc[T_CLS[t]][i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[T_CLS[t]][i] = lu_mfma_bf16(a1[i], bv1, acc[T_CLS[t]][i]);
+            b0 = n0v;
+            b1 = n1v;
+        }
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_store(p, hb ^ 1, rn[p]);
+        }
+        __syncthreads();
+        hb ^= 1;
+    }
+    // epilogue: class (py, px) of dy-space pixel (a, b) is dx[2a + py, 2b + px]
+    const int Hin = 2 * a.Hd, Win = 2 * a.Wd;
+    const int col = frag * 32 + (lane & 31);
+    if (!frag_ok || col >= a.C) return;
+    float* const dxf = a.dx + (int64_t)f * Hin * Win * a.C + col;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int ay = y0 + i;
+            if (ay >= a.Hd) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bx = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (bx >= a.Wd) continue;
+                dxf[((int64_t)(2 * ay + py) * Win + 2 * bx + px) * a.C] = acc[c][i][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // General bf16-MFMA convolution (precision = 1 where the halo kernel does not apply): stride 1 / 2, any k <= 7, any
 // pads, narrow outputs, strided output rows (parity planes of a stride-2 input gradient).  Implicit GEMM over
 // 256 linear pixels x 128 columns per block; a stage is one (tap, 32-channel chunk): the [256][32] activation slab is
@@ -2057,6 +2202,38 @@ extern "C" int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int k
     const unsigned g = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     LU_LAUNCH(s2_dgrad_weights_kernel, dim3(g), dim3(256), stream, w, sub, k, C, N, pt, pl, pady0, pady1, padx0, padx1, ny0,
               ny1, nx0, nx1);
+    return LU_CHECK_LAUNCH();
+}
+
+/* Input gradient of a stride-2 3x3 convolution on even input extents (TF-SAME pads 0 / 1), all four parity classes in ONE
+ * launch on bf16 MFMA operands (reference layers: Networks.py:52-56, the first Conv2D of a down block).
+ *   dy [frames, Hd, Wd, Nf] fp32 (frame / pixel strides given), packed = lu_pack_weights_taps_bf16 of the nine tap matrices
+ *   [Nf][C] that lu_stride2_dgrad_weights(w, ..., k = 3, pad_t = pad_l = 0) writes (class order), dx dense [frames, 2 Hd, 2 Wd, C]. */
+extern "C" int lu_conv2d_s2_dgrad_bf16(const float* dy, int64_t dy_frame_stride, int32_t dy_pix_stride, const void* packed,
+                                       int32_t frames, int32_t Hd, int32_t Wd, int32_t Nf, int32_t C, float* dx,
+                                       lu_stream_t stream) {
+    LU_REQUIRE(dy && packed && dx && frames > 0 && Hd > 0 && Wd > 0 && Nf > 0 && C > 0, "lu_conv2d_s2_dgrad_bf16: bad arguments");
+    LU_REQUIRE(Nf % 32 == 0 && dy_pix_stride % 4 == 0 && dy_frame_stride % 4 == 0 && aligned16(dy),
+               "lu_conv2d_s2_dgrad_bf16: dy needs Nf %% 32 == 0 and 16-byte aligned pixels");
+    S2DgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy;
+    a.w = (const unsigned char*)packed;
+    a.dx = dx;
+    a.dy_fs = dy_frame_stride;
+    a.dy_ps = dy_pix_stride;
+    a.Hd = Hd;
+    a.Wd = Wd;
+    a.Nf = Nf;
+    a.C = C;
+    a.tiles_x = (Wd + 31) / 32;
+    a.tiles_pf = ((Hd + 1) / 2) * a.tiles_x;
+    const int64_t m_tiles = (int64_t)frames * a.tiles_pf;
+    LU_REQUIRE(m_tiles < ((int64_t)1 << 27), "lu_conv2d_s2_dgrad_bf16: too many tiles");
+    a.m_tiles = (int32_t)m_tiles;
+    a.n_tiles = (C + 127) / 128;
+    const int64_t m8 = (m_tiles + 7) / 8 * 8;
+    LU_LAUNCH(conv_s2_dgrad_bf16_kernel, dim3((unsigned)(m8 * a.n_tiles)), dim3(256), stream, a);
     return LU_CHECK_LAUNCH();
 }
 

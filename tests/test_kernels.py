@@ -277,6 +277,22 @@ def test_conv_bf16_narrow_blocks(be):
     close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1), ref, 5e-5)
 
 
+def test_conv_s2_dgrad_fused_bf16(be):
+    """bf16 mode: input gradient of the stride-2 3x3 layers (Networks.py:52-56) with all four output parity classes in one
+    launch.  Against torch's gradient on bf16-rounded operands (summation order only), and against the four parity-plane
+    launches it replaces.  Ragged tiles (Wd not a multiple of 32, odd Hd), several chunks, C beyond one 128-column tile."""
+    R = KH.bf16_round
+    for (fr, Hd, Wd, Cc, N) in [(1, 4, 32, 32, 32), (2, 5, 37, 64, 96), (1, 3, 16, 160, 64), (1, 8, 64, 128, 128)]:
+        H, W = 2 * Hd, 2 * Wd
+        w, dy = rnd(3, 3, Cc, N, scale=0.2), rnd(fr, Hd, Wd, N)
+        gx, _ = _torch_conv_grads(rnd(fr, H, W, Cc), R(w), R(dy), 2)
+        got = KH.conv2d_dgrad_s2_fused_bf16(be, dy, w)
+        close(got, gx, 5e-5)
+        full, _ = _torch_conv_grads(rnd(fr, H, W, Cc), w, dy, 2)
+        close(KH.conv2d_dgrad_s2_parity(be, dy, w, (H, W)), full, 5e-5)      # (the fp32 four-plane form, for reference)
+        assert np.abs(got - full).max() <= 2.0 ** -6 * np.abs(full).max()
+
+
 def test_conv_bf16_gather_variant(be):
     """General bf16 kernel (precision = 1 outside the halo kernel's domain): stride 2 (TF-SAME asymmetric pads), 1x1 and
     7x7 kernels, narrow / ragged outputs, two sources, K split, strided output rows."""
