@@ -256,6 +256,7 @@ def main():
         _die('--gpus %d on RCCL needs one device per rank, %d visible' % (args.gpus, torch.cuda.device_count()))
 
     import Params
+    from lu_native import build as lu_build
     from lu_native import ops
     from lu_native.dp import DataParallel
     import train2D
@@ -315,18 +316,20 @@ def main():
     torch.cuda.synchronize()
     if dp.rank == 0:
         ev, ops.EVENT_LOG = ops.EVENT_LOG, None
-        traffic_db, traffic_src = {}, None
+        traffic_db, traffic_src, traffic_build = {}, None, None
+        build_id = lu_build.build_id()
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only): a STATIC table
             if (H, W, T, B) == (256, 256, 8, 4):      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
-                name = 'r02_pmc_traffic.json' if args.precision == 'fp32' else 'r02_pmc_traffic_bf16.json'
-                if not os.path.exists(os.path.join(ROOT, 'profiles', name)):
-                    name = name.replace('r02_', 'r01_')
+                sfx = '' if args.precision == 'fp32' else '_bf16'
+                name = next(n for n in ('r03_pmc_traffic%s.json' % sfx, 'r02_pmc_traffic%s.json' % sfx, 'r01_pmc_traffic%s.json' % sfx)
+                            if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     blob = json.load(fh)
                 traffic_db = blob['kernels']
+                traffic_build = blob.get('build_id')
                 traffic_src = 'profiles/%s (static table from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s)' % (
-                    name, blob.get('collected', 'round 1 binary'))
-        except (OSError, KeyError, ValueError):
+                    name, blob.get('collected', 'an earlier binary'))
+        except (OSError, KeyError, ValueError, StopIteration):
             traffic_db = {}
 
         def traffic_of(kind):
@@ -355,8 +358,11 @@ def main():
             r_['traffic'] = traffic_of(r_['kernel'])
         if rows:
             roofline = dict(rows[0])            # the dominant kernel class = largest share of the step
-            roofline['traffic_unit'] = 'bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE'
+            roofline['traffic_unit'] = ('L2-fabric bytes per launch INCLUDING Infinity-Cache hits (an upper bound on HBM bytes): '
+                                        'rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes')
             roofline['traffic_source'] = traffic_src
+            roofline['traffic_build_id'] = traffic_build
+            roofline['traffic_stale'] = bool(traffic_db) and traffic_build != build_id      # table from another binary
             roofline['all_mfma_kernels'] = rows
             roofline['hbm_kernels'] = hbm_rows
     # ---- secondary metric: streaming inference (Inference2D.py:45-62: B=1, T=1, pad_image=True, stateful) ----
@@ -448,6 +454,7 @@ def main():
                                     'bf16 MFMA operands on the wide stride-1 convs (fp32 master weights / accumulate / wgrad)'),
                        'global_batch': B * dp.world_size, 'seq_len': T,
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
+            'build_id': lu_build.build_id(),      # sha256[:16] of liblstmunet_hip.so
             'dp': dp_info,
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),

@@ -47,12 +47,13 @@ class PostPipeline(object):
     flush() the last one.  Two processors alternate, so frame t - 1's buffers (and its exact fallback for nested objects)
     are untouched by frame t's launches.  Results are those of postprocess(): same kernels, same order per frame."""
 
-    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False):
+    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=True):
         self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
         self.stream = None
         self.pending = None
         self._procs = None
         self._n = 0
+        self.graph = graph       # replay the frame's post-processing launches from a hipGraph (lu_native.post)
 
     def _finish(self):
         import torch
@@ -69,7 +70,7 @@ class PostPipeline(object):
         if self.stream is None:
             from lu_native.post import PostProcessor
             self.stream = torch.cuda.Stream()
-            self._procs = [PostProcessor(), PostProcessor()]
+            self._procs = [PostProcessor(graph=self.graph), PostProcessor(graph=self.graph)]
         ready = torch.cuda.Event()
         ready.record()                                # after the forward that produced softmax_chw (current stream)
         softmax_chw.record_stream(self.stream)

@@ -196,6 +196,16 @@ def test_post_pipeline_returns_the_same_label_maps(dev):
     assert [t for t, _, _ in got] == list(range(len(sms)))
     for (t, labels, _), ref in zip(got, want):
         assert np.array_equal(labels, ref), t
+    if dev.type == 'cuda':
+        # the pipeline replays each processor's launch sequence from a hipGraph (one host call per frame); nested-object frames
+        # (even seeds) still take the exact sequential fallback behind it -- and the eager pipeline gives the same maps
+        assert sum(p.replays for p in pipe._procs) == len(sms) and sum(p.fallbacks for p in pipe._procs) >= 1
+        eager = Inference2D.PostPipeline(kw['edge_dist'], kw['min_cell_size'], kw['max_cell_size'], kw['fov'], graph=False)
+        got2 = []
+        for t, sm in enumerate(sms):
+            got2 += eager.push(t, torch.from_numpy(sm).to(dev))
+        got2 += eager.flush()
+        assert all(np.array_equal(a[1], b[1]) for a, b in zip(got, got2)) and sum(p.replays for p in eager._procs) == 0
 
 
 def test_device_driven_fill_and_its_exact_fallback(dev):

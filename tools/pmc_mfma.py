@@ -4,8 +4,16 @@ GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is 
 usage: python tools/pmc_mfma.py gpurun_out/pmc_mfma_fp32 gpurun_out/pmc_mfma_bf16 profiles/r01_pmc_mfma_util.json"""
 import glob
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lstm-unet_amd'))
+
+
+def _build_id():
+    from lu_native import build
+    return build.build_id()
 
 
 def summarize(path):
@@ -27,7 +35,7 @@ def summarize(path):
 
 
 if __name__ == '__main__':
-    res = {'note': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of bench.py --steps 1 --warmup 1 '
+    res = {'build_id': _build_id(), 'note': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of bench.py --steps 1 --warmup 1 '
                    '(config-2); utilisation = MFMA-busy cycles / SIMD cycles available at the measured clock',
            'fp32': summarize(sys.argv[1]), 'bf16': summarize(sys.argv[2])}
     with open(sys.argv[3], 'w') as fh:

@@ -4,8 +4,16 @@ wide coalesced read (MI355X_MICROARCH.md §HBM), so reads are doubled; WRITE_SIZ
 usage: python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01_pmc_traffic.json"""
 import glob
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lstm-unet_amd'))
+
+
+def _build_id():
+    from lu_native import build
+    return build.build_id()
 
 
 def per_kernel(path, counter):
@@ -27,7 +35,7 @@ def main(fetch_dir, write_dir, dst):
                   'fetch_size_raw_kib': fk[1], 'write_bytes_per_launch': wk[1] * 1024.0,
                   'traffic_bytes_per_launch': 2.0 * fk[1] * 1024.0 + wk[1] * 1024.0}
     with open(dst, 'w') as fh:
-        json.dump({'note': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of '
+        json.dump({'build_id': _build_id(), 'note': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of '
                            'bench.py --steps 1 --warmup 1; FETCH_SIZE doubled per the gfx950 correction; L2 fabric-side '
                            'bytes (Infinity-Cache hits included)', 'kernels': res}, fh, indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]['traffic_bytes_per_launch'] * kv[1]['launches'])[:6]:
