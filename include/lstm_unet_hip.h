@@ -383,6 +383,15 @@ int lu_post_fill_all(int32_t* labels, int32_t H, int32_t W, const int32_t* num_l
                      const int32_t* ncomp, int32_t* flags, lu_stream_t stream);
 int lu_post_newid(const int32_t* num_labels, const int32_t* area, const int32_t* present, int32_t min_size, int32_t max_size,
                   int32_t table_size, int32_t* newid, const int32_t* flags, int32_t* tail, lu_stream_t stream);
+/* One frame in ONE call (label + statistics + snapshot + device-driven hole fill + presence + numbering + relabel + the
+ * copy to pinned host memory), and its tail alone (after the host's exact replay of a nested-object frame).  tables: int32
+ * [4 + 8 * lu_post_max_labels] = num | dirty | oversize | pad | area | bbox | e4 | ncomp | present; out / host_out: the uint16 map
+ * padded to whole int32 words, then {num, dirty, oversize, 0}. */
+int lu_post_frame(const float* softmax_chw, int32_t H, int32_t W, float edge_thresh, double edge_dist, int32_t min_size,
+                  int32_t max_size, int32_t fov, int32_t single_column, void* workspace, int32_t* labels, int32_t* snapshot,
+                  int32_t* tables, int32_t* newid, void* out, void* host_out, lu_stream_t stream);
+int lu_post_frame_tail(int32_t H, int32_t W, int32_t min_size, int32_t max_size, int32_t fov, int32_t single_column,
+                       const int32_t* labels, int32_t* tables, int32_t* newid, void* out, void* host_out, lu_stream_t stream);
 int lu_post_bbox_of_label(const int32_t* labels, int32_t H, int32_t W, int32_t n, int32_t* box, lu_stream_t stream);
 int lu_post_present(const int32_t* labels, int32_t H, int32_t W, int32_t fov, int32_t single_column, int32_t num_labels,
                     int32_t* present, lu_stream_t stream);

@@ -47,13 +47,13 @@ class PostPipeline(object):
     flush() the last one.  Two processors alternate, so frame t - 1's buffers (and its exact fallback for nested objects)
     are untouched by frame t's launches.  Results are those of postprocess(): same kernels, same order per frame."""
 
-    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=True):
+    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=False):
         self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
         self.stream = None
         self.pending = None
         self._procs = None
         self._n = 0
-        self.graph = graph       # replay the frame's post-processing launches from a hipGraph (lu_native.post)
+        self.graph = graph       # replay the frame's launches from a hipGraph (lu_native.post: measured slower, off by default)
 
     def _finish(self):
         import torch

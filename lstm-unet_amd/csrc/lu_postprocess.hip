@@ -166,6 +166,10 @@ __global__ void fill32_kernel(int32_t* __restrict__ a, int32_t v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT) a[i] = v;
 }
 
+__global__ void copy32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (int64_t)gridDim.x * PT) dst[i] = src[i];
+}
+
 __global__ void fg_key_kernel(const int32_t* __restrict__ parent, int32_t* __restrict__ key, int H, int W) {
     const int64_t hw = (int64_t)H * W;
     const int bw = (W + 1) / 2;
@@ -614,6 +618,59 @@ extern "C" int lu_post_newid(const int32_t* num_labels, const int32_t* area, con
     LU_REQUIRE(num_labels && area && newid && flags && table_size >= 1, "lu_post_newid: bad arguments");
     LU_LAUNCH(newid_kernel, dim3(1), dim3(1024), stream, num_labels, area, present, min_size, max_size, table_size, newid,
               flags, tail);
+    return LU_CHECK_LAUNCH();
+}
+
+/* One frame, one call: everything Inference2D.py:66-123 needs from the device, enqueued back to back on `stream` with no
+ * host decision in between (the host thread pays ONE foreign call instead of ~12 calls and as many tensor-library copies;
+ * at bf16 streaming rates -- 1.7 ms of forward per frame -- that host time is what bounds the frame rate).
+ *   tables    : int32 [4 + 8 * lu_post_max_labels]: num | dirty | oversize | pad | area | bbox (4 per label) | e4 | ncomp | present
+ *   snapshot  : int32 [H * W] copy of the label map taken before the hole filling (the exact fallback starts from it)
+ *   out       : device, 4-byte aligned: uint16 map [H * W] padded to a multiple of 4 bytes, then int32 {num, dirty, oversize, 0}
+ *   host_out  : the same bytes in PINNED host memory (asynchronous device -> host copy behind the kernels), or NULL
+ * fov = 0: no field-of-view mask. */
+extern "C" int lu_post_frame(const float* softmax_chw, int32_t H, int32_t W, float edge_thresh, double edge_dist,
+                             int32_t min_size, int32_t max_size, int32_t fov, int32_t single_column, void* workspace,
+                             int32_t* labels, int32_t* snapshot, int32_t* tables, int32_t* newid, void* out, void* host_out,
+                             lu_stream_t stream) {
+    LU_REQUIRE(softmax_chw && workspace && labels && snapshot && tables && newid && out && H > 0 && W > 0,
+               "lu_post_frame: bad arguments");
+    const int n = lu_post_max_labels(H, W);
+    const int64_t hw = (int64_t)H * W;
+    int32_t *num = tables, *flags = tables + 1, *area = tables + 4, *bbox = tables + 4 + n, *e4 = tables + 4 + 5 * n,
+            *ncomp = tables + 4 + 6 * n, *present = tables + 4 + 7 * n;
+    LU_LAUNCH(fill32_kernel, dim3(1), dim3(PT), stream, tables, 0, (int64_t)4);
+    if (lu_post_label(softmax_chw, H, W, edge_thresh, edge_dist, workspace, labels, num, area, stream)) return 1;
+    if (lu_post_label_stats(labels, H, W, n, workspace, bbox, e4, ncomp, stream)) return 1;
+    LU_LAUNCH(copy32_kernel, dim3(pgrid(hw)), dim3(PT), stream, (const int32_t*)labels, snapshot, hw);
+    if (lu_post_fill_all(labels, H, W, num, bbox, e4, ncomp, flags, stream)) return 1;
+    return lu_post_frame_tail(H, W, min_size, max_size, fov, single_column, labels, tables, newid, out, host_out, stream);
+}
+
+/* The part of lu_post_frame behind the hole filling (presence table, numbering, relabel, copy to the host) -- also what the
+ * host runs after its exact sequential replay of a nested-object frame. */
+extern "C" int lu_post_frame_tail(int32_t H, int32_t W, int32_t min_size, int32_t max_size, int32_t fov, int32_t single_column,
+                                  const int32_t* labels, int32_t* tables, int32_t* newid, void* out, void* host_out,
+                                  lu_stream_t stream) {
+    LU_REQUIRE(labels && tables && newid && out && H > 0 && W > 0, "lu_post_frame_tail: bad arguments");
+    const int n = lu_post_max_labels(H, W);
+    const int64_t hw = (int64_t)H * W;
+    const int64_t map_words = (hw + 1) / 2;
+    int32_t *num = tables, *flags = tables + 1, *area = tables + 4, *present = tables + 4 + 7 * n;
+    if (fov && lu_post_present(labels, H, W, fov, single_column, n, present, stream)) return 1;
+    if (lu_post_newid(num, area, fov ? present : nullptr, min_size, max_size, n, newid, flags, (int32_t*)out + map_words, stream))
+        return 1;
+    if (lu_post_relabel(labels, H, W, newid, n, (uint16_t*)out, stream)) return 1;
+    if (host_out) {
+#ifdef LU_EMU
+        memcpy(host_out, out, (size_t)(map_words + 4) * 4);
+#else
+        if (hipMemcpyAsync(host_out, out, (size_t)(map_words + 4) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) {
+            lu_set_error("lu_post_frame_tail: device -> host copy failed");
+            return 1;
+        }
+#endif
+    }
     return LU_CHECK_LAUNCH();
 }
 

@@ -98,6 +98,8 @@ PROTOTYPES = {
     'lu_post_fill_object': (C.c_int, [P, i32, i32, i32, i32, i32, i32, i32, P, P, S]),
     'lu_post_fill_all': (C.c_int, [P, i32, i32, P, P, P, P, P, S]),
     'lu_post_newid': (C.c_int, [P, P, P, i32, i32, i32, P, P, P, S]),
+    'lu_post_frame': (C.c_int, [P, i32, i32, f32, f64, i32, i32, i32, i32, P, P, P, P, P, P, P, S]),
+    'lu_post_frame_tail': (C.c_int, [i32, i32, i32, i32, i32, i32, P, P, P, P, P, S]),
     'lu_post_bbox_of_label': (C.c_int, [P, i32, i32, i32, P, S]),
     'lu_post_present': (C.c_int, [P, i32, i32, i32, i32, i32, P, S]),
     'lu_post_relabel': (C.c_int, [P, i32, i32, P, i32, P, S]),

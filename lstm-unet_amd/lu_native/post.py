@@ -23,9 +23,11 @@ class _Job(object):
 
 
 class PostProcessor(object):
-    """graph=True (GPU): the frame's launch sequence -- ~35 short kernels and copies with no host decision in between -- is
-    captured ONCE per (frame size, parameters) into a hipGraph and replayed: one host call per frame instead of ~40, which
-    is what bounds bf16 streaming inference (1.7 ms of GPU work per frame) once the post-processing shares the host thread."""
+    """A frame is ONE foreign call (lu_post_frame: ~35 short kernels and copies enqueued by the library itself).
+    graph=True (GPU, optional): that launch sequence is captured once per (frame size, parameters) into a hipGraph and replayed.
+    Measured SLOWER on MI355X / ROCm 7.2 (fp32 streaming with post-processing 96.7 vs 121 frames/s, bf16 307 vs 433: the
+    graph's ~35 nodes cost more to launch than the eager calls and do not overlap the forward stream as well) -- kept as an
+    option and as a test of capturability, off by default."""
 
     def __init__(self, graph=False):
         self._shape = None
@@ -112,6 +114,14 @@ class PostProcessor(object):
         lib, st, ck = ops.lib(), ops._stream(), calls.check
         H, W, stages = job.H, job.W, job.stages
         ws, L = self.ws.data_ptr(), self.labels.data_ptr()
+        if stages is None:       # the whole frame in ONE foreign call (the step-by-step form below serves `stages`)
+            min_cell_size, max_cell_size, fov, fov_fix = job.args
+            big = 2 ** 31 - 1
+            ck(lib, lib.lu_post_frame(sm.data_ptr(), H, W, 0.2, float(edge_dist), int(min(max(min_cell_size, -big), big)),
+                                      int(min(max_cell_size, big)), int(fov), 0 if fov_fix else 1, ws, L, self.snapshot.data_ptr(),
+                                      self.small.data_ptr(), self.newid.data_ptr(), self.out.data_ptr(), self.host.data_ptr(), st),
+               'lu_post_frame')
+            return
         self.small[:4].zero_()
         ck(lib, lib.lu_post_label(sm.data_ptr(), H, W, 0.2, float(edge_dist), ws, L, self._p('num'), self._p('area'), st),
            'lu_post_label')
@@ -137,6 +147,12 @@ class PostProcessor(object):
         lib, st, ck = ops.lib(), ops._stream(), calls.check
         H, W, L = job.H, job.W, self.labels.data_ptr()
         min_cell_size, max_cell_size, fov, fov_fix = job.args
+        if job.stages is None:
+            big = 2 ** 31 - 1
+            ck(lib, lib.lu_post_frame_tail(H, W, int(min(max(min_cell_size, -big), big)), int(min(max_cell_size, big)), int(fov),
+                                           0 if fov_fix else 1, L, self.small.data_ptr(), self.newid.data_ptr(), self.out.data_ptr(),
+                                           self.host.data_ptr(), st), 'lu_post_frame_tail')
+            return
         present = 0
         if fov:
             ck(lib, lib.lu_post_present(L, H, W, int(fov), 0 if fov_fix else 1, self.nmax, self._p('present'), st),

@@ -184,7 +184,7 @@ def test_post_pipeline_returns_the_same_label_maps(dev):
     kw = dict(edge_dist=2, min_cell_size=4, max_cell_size=10 ** 6, fov=3)
     sms = [po.synthetic_softmax(64, 80, seed, n_cells=9, nested=(seed % 2 == 0)) for seed in range(6)]
     want = [po.postprocess(sm, **kw) for sm in sms]
-    pipe = Inference2D.PostPipeline(kw['edge_dist'], kw['min_cell_size'], kw['max_cell_size'], kw['fov'])
+    pipe = Inference2D.PostPipeline(kw['edge_dist'], kw['min_cell_size'], kw['max_cell_size'], kw['fov'], graph=True)
     got = []
     busy = torch.randn(512, 512, device=dev)
     for t, sm in enumerate(sms):
@@ -197,9 +197,9 @@ def test_post_pipeline_returns_the_same_label_maps(dev):
     for (t, labels, _), ref in zip(got, want):
         assert np.array_equal(labels, ref), t
     if dev.type == 'cuda':
-        # the pipeline replays each processor's launch sequence from a hipGraph (one host call per frame); nested-object frames
-        # (even seeds) still take the exact sequential fallback behind it -- and the eager pipeline gives the same maps
-        assert sum(p.replays for p in pipe._procs) == len(sms) and sum(p.fallbacks for p in pipe._procs) >= 1
+        # graph=True: each processor's launch sequence is replayed from a hipGraph (capturable: no host decision inside a
+        # frame); the default eager pipeline gives the same maps
+        assert sum(p.replays for p in pipe._procs) == len(sms)
         eager = Inference2D.PostPipeline(kw['edge_dist'], kw['min_cell_size'], kw['max_cell_size'], kw['fov'], graph=False)
         got2 = []
         for t, sm in enumerate(sms):
