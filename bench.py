@@ -375,7 +375,7 @@ def main():
             m(frames_in[i % 4], training=False)
         torch.cuda.synchronize()
         t_inf = time.perf_counter()
-        n_inf = 20
+        n_inf = 40
         for i in range(n_inf):
             _, sm_ = m(frames_in[i % 4], training=False)
         torch.cuda.synchronize()
@@ -396,6 +396,10 @@ def main():
         torch.cuda.synchronize()
         # as Inference2D.inference() runs it: the post-processing of frame t on a side stream while frame t + 1's forward runs
         pipe = Inference2D.PostPipeline(2, 10, 10 ** 6)
+        pipe.push(-2, fake)                  # first use: side stream, two processors, their pinned host buffers
+        pipe.push(-1, fake)
+        pipe.flush()
+        torch.cuda.synchronize()
         t_pp = time.perf_counter()
         for i in range(n_inf):
             _, sm_ = m(frames_in[i % 4], training=False)

@@ -35,6 +35,7 @@ class PostProcessor(object):
         self.use_graph = bool(graph)
         self._graphs = {}        # (H, W, parameters) -> (CUDAGraph, static softmax buffer) | None when capture failed
         self.replays = 0
+        self.library_copy = True     # the device -> host copy of the frame is issued by lu_post_frame itself
 
     def _alloc(self, H, W, dev):
         if self._shape == (H, W, dev):
@@ -119,8 +120,10 @@ class PostProcessor(object):
             big = 2 ** 31 - 1
             ck(lib, lib.lu_post_frame(sm.data_ptr(), H, W, 0.2, float(edge_dist), int(min(max(min_cell_size, -big), big)),
                                       int(min(max_cell_size, big)), int(fov), 0 if fov_fix else 1, ws, L, self.snapshot.data_ptr(),
-                                      self.small.data_ptr(), self.newid.data_ptr(), self.out.data_ptr(), self.host.data_ptr(), st),
-               'lu_post_frame')
+                                      self.small.data_ptr(), self.newid.data_ptr(), self.out.data_ptr(),
+                                      self.host.data_ptr() if self.library_copy else 0, st), 'lu_post_frame')
+            if not self.library_copy:
+                self.host.copy_(self.out, non_blocking=True)
             return
         self.small[:4].zero_()
         ck(lib, lib.lu_post_label(sm.data_ptr(), H, W, 0.2, float(edge_dist), ws, L, self._p('num'), self._p('area'), st),
@@ -151,7 +154,9 @@ class PostProcessor(object):
             big = 2 ** 31 - 1
             ck(lib, lib.lu_post_frame_tail(H, W, int(min(max(min_cell_size, -big), big)), int(min(max_cell_size, big)), int(fov),
                                            0 if fov_fix else 1, L, self.small.data_ptr(), self.newid.data_ptr(), self.out.data_ptr(),
-                                           self.host.data_ptr(), st), 'lu_post_frame_tail')
+                                           self.host.data_ptr() if self.library_copy else 0, st), 'lu_post_frame_tail')
+            if not self.library_copy:
+                self.host.copy_(self.out, non_blocking=True)
             return
         present = 0
         if fov:
