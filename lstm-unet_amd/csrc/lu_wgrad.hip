@@ -249,12 +249,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // same run widened by K-1 pixels ([16+K-1][64]); tap kw simply reads it shifted by kw rows.  Load bytes per FLOP
 // drop 2.3x versus one-tap-per-block; 8 waves (2 x 4), K accumulators each -> 4 waves/SIMD.
 // ---------------------------------------------------------------------------------------------------------
-template <int K, bool RG>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
+// KPT = pixels per stage: 16, or 32 where W % 32 == 0 (half as many block-wide barriers per MFMA; LDS 59 KB, still two
+// blocks per CU) -- the loaders then make two passes per stage.
+template <int K, bool RG, int KPT = 16>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
 __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
+    constexpr int KP = KPT;      // (shadows the file-level stage length inside this kernel)
+    static_assert(KPT == 16 || (KPT == 32 && !RG), "32-pixel stages: aligned widths only");
     constexpr int BMw = 64, BNw = 128, XP = KP + K - 1, NT = 512;
+    constexpr int XPASS = (XP * 16 + NT - 1) / NT, YPASS = KP * 32 / NT;      // float4 items per thread and stage
     __shared__ __attribute__((aligned(16))) float Xs[2][XP * BMw];
     __shared__ __attribute__((aligned(16))) float Ys[2][KP * BNw];
-    __shared__ __attribute__((aligned(16))) float Bsum[KP * BNw];     // bias-gradient partial sums (kernel row 0 blocks only)
+    __shared__ __attribute__((aligned(16))) float Bsum[16 * BNw];     // bias-gradient partial sums: one float4 slot per loader thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     // Workgroup id % 8 picks the XCD and x is the fastest grid index: with 8 (16, ...) column tiles the K * c_tiles blocks
@@ -294,7 +299,11 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     }
     const int xrow = tid >> 4, xq = tid & 15;      // x tile: XP rows x 16 float4 (threads < XP*16)
     const int yrow = tid >> 5, yq = tid & 31;      // dy tile: 16 rows x 32 float4
-    float4 rx = make_float4(0.f, 0.f, 0.f, 0.f), ry = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rx[XPASS], ry[YPASS];
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < YPASS; ++i) ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     // bias gradient = column sums of dy: the blocks of kernel row 0 / channel tile 0 see every dy element of their
     // (column tile, pixel slab) exactly once in `ry`, so they add it up on the side (exact fp32, no extra HBM pass).
     // The running sums live in LDS, one float4 slot per loader thread: nothing is held in registers across the MFMAs.
@@ -307,27 +316,41 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     if (want_bias) *bslot = make_float4(0.f, 0.f, 0.f, 0.f);
     auto bias_acc = [&]() {
         float4 t = *bslot;
-        t.x += ry.x;
-        t.y += ry.y;
-        t.z += ry.z;
-        t.w += ry.w;
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) {      // (rows yrow, yrow + 16: same column group, same slot)
+            t.x += ry[i].x;
+            t.y += ry[i].y;
+            t.z += ry[i].z;
+            t.w += ry[i].w;
+        }
         *bslot = t;
     };
     auto load_stage = [&](int it) {
         const int iy = oy + kh - a.pad_t;
-        const int ix = ox0 - a.pad_l + xrow;
         const int c = c0 + 4 * xq;
-        const bool okx = xrow < XP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.C;
-        const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
-        rx = *reinterpret_cast<const float4*>(okx ? px : zp);
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int xr = xrow + 32 * i;
+            const int ix = ox0 - a.pad_l + xr;
+            const bool okx = xr < XP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.C;
+            const float* px = a.x + pf * a.x_fs + ((int64_t)iy * a.Win + ix) * a.x_ps + c;
+            rx[i] = *reinterpret_cast<const float4*>(okx ? px : zp);
+        }
         const int n = n0 + 4 * yq;
-        const bool oky = (RG ? ox0 + yrow < a.Wout : p_begin + (int64_t)it * KP + yrow < p_end) && n < a.N;
-        const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0 + yrow) * a.dy_ps + n;
-        ry = *reinterpret_cast<const float4*>(oky ? py : zp);
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) {
+            const int yr = yrow + 16 * i;
+            const bool oky = (RG ? ox0 + yr < a.Wout : p_begin + (int64_t)it * KP + yr < p_end) && n < a.N;
+            const float* py = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0 + yr) * a.dy_ps + n;
+            ry[i] = *reinterpret_cast<const float4*>(oky ? py : zp);
+        }
     };
     auto store_stage = [&](int buf) {
-        if (xrow < XP) *reinterpret_cast<float4*>(&Xs[buf][xrow * BMw + 4 * xq]) = rx;
-        *reinterpret_cast<float4*>(&Ys[buf][yrow * BNw + 4 * yq]) = ry;
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i)
+            if (xrow + 32 * i < XP) *reinterpret_cast<float4*>(&Xs[buf][(xrow + 32 * i) * BMw + 4 * xq]) = rx[i];
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) *reinterpret_cast<float4*>(&Ys[buf][(yrow + 16 * i) * BNw + 4 * yq]) = ry[i];
     };
     auto advance = [&]() {
         ox0 += KP;
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         if (tid < BNw) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < KP; ++r) s += red[r * BNw + tid];
+            for (int r = 0; r < 16; ++r) s += red[r * BNw + tid];
             if (n0 + tid < a.N) a.bias_ws[((int64_t)bz * brc + bme) * a.N + n0 + tid] = s;
         }
     }
@@ -1049,7 +1072,9 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         }
         a.xfold = (nxt == 1 || nxt == 2 || nxt == 4) ? 8 / nxt : 1;
         dim3 grid((unsigned)(nxt * a.xfold), (unsigned)(d->k * a.c_tiles), (unsigned)((splits + a.xfold - 1) / a.xfold));
+        const bool kp32 = !a.ragged && d->Wout % 32 == 0 && !(d->flags & LU_WGRAD_F_KP16);      // 32-pixel stages
         if (d->k == 5 && a.ragged) LU_LAUNCH((wgrad_row_kernel<5, true>), grid, dim3(512), stream, a);
+        else if (d->k == 5 && kp32) LU_LAUNCH((wgrad_row_kernel<5, false, 32>), grid, dim3(512), stream, a);
         else if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5, false>), grid, dim3(512), stream, a);
         else if (a.ragged) LU_LAUNCH((wgrad_row_kernel<3, true>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_row_kernel<3, false>), grid, dim3(512), stream, a);

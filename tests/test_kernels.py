@@ -444,6 +444,22 @@ def test_wgrad_kernel_row_ragged_widths(be):
         KH.conv2d_wgrad(be, rnd(1, 4, 40, 64), rnd(1, 4, 40, 64), 3, 1, dbias0=rnd(64), flags=nr)
 
 
+def test_wgrad_kernel_row_32_pixel_stages(be):
+    """fp32 kernel-row weight gradient of the 5x5 layers with 32-pixel stages (W % 32 == 0: two loader passes per stage, half
+    the block-wide barriers per MFMA).  The MFMA k order over the pixels is unchanged, so dw is bit-identical to the 16-pixel
+    instance (LU_WGRAD_F_KP16); the bias sums fold two rows into one slot (summation order only)."""
+    for (fr, H, W, Cc, N, sp) in [(2, 5, 32, 72, 136, 3), (1, 4, 64, 64, 128, 2), (1, 3, 96, 132, 72, 1), (3, 2, 32, 64, 520, 4)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        _, ref = _torch_conv_grads(x, rnd(5, 5, Cc, N), dy, 1)
+        db0 = rnd(N)
+        dw, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
+        close(dw, ref, 2e-4)
+        close(db, dy.reshape(-1, N).astype(np.float64).sum(0) + db0, 2e-4)
+        dw16, db16 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0, flags=cabi.LU_WGRAD_F_KP16)
+        assert np.array_equal(dw, dw16)
+        close(db, db16, 1e-5)
+
+
 def test_wgrad_all_taps_narrow_layers(be):
     """wgrad_small3_kernel: stride-1 3x3 layers with C <= 64 and N <= 64 (W % 16 == 0) -- all nine taps per block, ragged
     channel counts, pixel splits, fused bias gradient."""

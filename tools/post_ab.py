@@ -46,3 +46,22 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(40):
     pp(fake, 2, 10, 10 ** 6)
 print('post alone, synchronous: %.3f ms/frame' % ((time.perf_counter() - t0) / 40 * 1e3))
+# a full Fluo-C2DL-MSC-size frame with hundreds of objects (BASELINE config-4 frame size): device-driven route and, for a map
+# with nested objects, the exact sequential replay
+from oracle import postprocess_oracle as po      # (tool: the synthetic softmax generator lives beside the oracle)
+import json
+big = {}
+for nested in (False, True):
+    sm = torch.from_numpy(po.synthetic_softmax(832, 992, seed=1 + nested, n_cells=400, nested=nested, noise=0.25, rmax=16)).to(dev)
+    pp = post.PostProcessor()
+    lab = pp(sm, 2, 10, 5000)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(10):
+        lab = pp(sm, 2, 10, 5000)
+    dt = (time.perf_counter() - t0) / 10 * 1e3
+    big['nested' if nested else 'plain'] = {'ms_per_frame': round(dt, 3), 'objects': int(lab.max()), 'sequential_replays': pp.fallbacks,
+                                            'frames': 11}
+    print('832x992, %d objects, nested=%s: %.3f ms/frame synchronous, sequential replays %d of 11' % (lab.max(), nested, dt, pp.fallbacks))
+if len(sys.argv) > 2:
+    json.dump({'what': 'GPU post-processing of one 832x992 frame (softmax on the device -> uint16 label map on the host), synchronous',
+               'cases': big}, open(sys.argv[2], 'w'), indent=1)
