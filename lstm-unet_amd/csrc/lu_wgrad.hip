@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // same run widened by K-1 pixels ([16+K-1][64]); tap kw simply reads it shifted by kw rows.  Load bytes per FLOP
 // drop 2.3x versus one-tap-per-block; 8 waves (2 x 4), K accumulators each -> 4 waves/SIMD.
 // ---------------------------------------------------------------------------------------------------------
-// KPT = pixels per stage: 16, or 32 where W % 32 == 0 (half as many block-wide barriers per MFMA; LDS 59 KB, still two
-// blocks per CU) -- the loaders then make two passes per stage.
+// KPT = pixels per stage: 16, or -- LU_WGRAD_F_KP32, W % 32 == 0 -- 32 (half as many block-wide barriers per MFMA, two loader
+// passes per stage, LDS 59 KB).  Measured SLOWER on MI355X (config-2: 0.800 vs 0.834 of the fp32 MFMA peak on this kernel,
+// 574.4 vs 567.3 ms per step, same box, alternating runs): kept as an opt-in instance and a recorded negative result.
 template <int K, bool RG, int KPT = 16>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
 __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     constexpr int KP = KPT;      // (shadows the file-level stage length inside this kernel)
@@ -1072,7 +1073,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         }
         a.xfold = (nxt == 1 || nxt == 2 || nxt == 4) ? 8 / nxt : 1;
         dim3 grid((unsigned)(nxt * a.xfold), (unsigned)(d->k * a.c_tiles), (unsigned)((splits + a.xfold - 1) / a.xfold));
-        const bool kp32 = !a.ragged && d->Wout % 32 == 0 && !(d->flags & LU_WGRAD_F_KP16);      // 32-pixel stages
+        const bool kp32 = !a.ragged && d->Wout % 32 == 0 && (d->flags & LU_WGRAD_F_KP32);      // 32-pixel stages: opt-in (measured slower)
         if (d->k == 5 && a.ragged) LU_LAUNCH((wgrad_row_kernel<5, true>), grid, dim3(512), stream, a);
         else if (d->k == 5 && kp32) LU_LAUNCH((wgrad_row_kernel<5, false, 32>), grid, dim3(512), stream, a);
         else if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5, false>), grid, dim3(512), stream, a);

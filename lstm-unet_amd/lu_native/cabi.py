@@ -17,7 +17,7 @@ LU_CONV_F_NO_NARROW = 4096
 LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE, LU_WGRAD_F_PRB32 = 1, 2, 4, 8, 16, 32
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128
-LU_WGRAD_F_KP16 = 256
+LU_WGRAD_F_KP32 = 256
 
 
 class ConvSrc(C.Structure):

@@ -445,17 +445,18 @@ def test_wgrad_kernel_row_ragged_widths(be):
 
 
 def test_wgrad_kernel_row_32_pixel_stages(be):
-    """fp32 kernel-row weight gradient of the 5x5 layers with 32-pixel stages (W % 32 == 0: two loader passes per stage, half
-    the block-wide barriers per MFMA).  The MFMA k order over the pixels is unchanged, so dw is bit-identical to the 16-pixel
-    instance (LU_WGRAD_F_KP16); the bias sums fold two rows into one slot (summation order only)."""
+    """fp32 kernel-row weight gradient of the 5x5 layers with 32-pixel stages (LU_WGRAD_F_KP32, W % 32 == 0: two loader passes
+    per stage, half the block-wide barriers per MFMA -- an opt-in instance: measured slower).  The MFMA k order over
+    the pixels is unchanged, so dw is bit-identical to the default 16-pixel instance; the bias sums fold two rows into one
+    slot (summation order only)."""
     for (fr, H, W, Cc, N, sp) in [(2, 5, 32, 72, 136, 3), (1, 4, 64, 64, 128, 2), (1, 3, 96, 132, 72, 1), (3, 2, 32, 64, 520, 4)]:
         x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
         _, ref = _torch_conv_grads(x, rnd(5, 5, Cc, N), dy, 1)
         db0 = rnd(N)
-        dw, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
+        dw, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0, flags=cabi.LU_WGRAD_F_KP32)
         close(dw, ref, 2e-4)
         close(db, dy.reshape(-1, N).astype(np.float64).sum(0) + db0, 2e-4)
-        dw16, db16 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0, flags=cabi.LU_WGRAD_F_KP16)
+        dw16, db16 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
         assert np.array_equal(dw, dw16)
         close(db, db16, 1e-5)
 
