@@ -210,6 +210,7 @@ enum {
     LU_WGRAD_F_SMALL_TILE = 16,  /* general kernel: 128 x 128 instead of 128 x 256 tiles */
     LU_WGRAD_F_PRB32 = 32,       /* bf16 kernel-row variant: 32-pixel stages where 64-pixel ones would be taken (A/B, tests) */
     LU_WGRAD_F_NO_RAGGED = 64,   /* fp32 kernel-row variant: only for W % 16 == 0 (other widths: the one-tap-per-block kernel) -- A/B */
+    LU_WGRAD_F_NO_SLIDE = 512,   /* fp32 kernel-row variant: every k-pair re-reads its K x rows from LDS (the instance of rounds 1-2; A/B) */
     LU_WGRAD_F_KP32 = 256,       /* fp32 kernel-row variant, 5x5, W % 32 == 0: 32-pixel stages (A/B: measured slower than 16) */
     LU_WGRAD_F_NO_NARROW_BF16 = 128  /* precision 1: keep the narrow layers (C < 64) on the fp32 all-taps / general kernels -- A/B */
 };

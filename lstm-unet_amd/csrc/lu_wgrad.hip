@@ -252,7 +252,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // KPT = pixels per stage: 16, or -- LU_WGRAD_F_KP32, W % 32 == 0 -- 32 (half as many block-wide barriers per MFMA, two loader
 // passes per stage, LDS 59 KB).  Measured SLOWER on MI355X (config-2: 0.800 vs 0.834 of the fp32 MFMA peak on this kernel,
 // 574.4 vs 567.3 ms per step, same box, alternating runs): kept as an opt-in instance and a recorded negative result.
-template <int K, bool RG, int KPT = 16>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
+// SLIDE: the K x-rows a k-pair reads (rows kk2 + khalf + t) overlap the next pair's (kk2 + 2 + ...) in K - 2 rows: keep them
+// in registers and fetch only two new values per pair -- 3 instead of 6 LDS reads per 5 MFMAs (the LDS pipe of a CU with 16
+// resident waves was ~60 % busy on those reads).  Same values, same MFMA order: bit-identical results.
+template <int K, bool RG, int KPT = 16, bool SLIDE = true>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
 __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     constexpr int KP = KPT;      // (shadows the file-level stage length inside this kernel)
     static_assert(KPT == 16 || (KPT == 32 && !RG), "32-pixel stages: aligned widths only");
@@ -377,11 +380,18 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
+    float av[K];      // (SLIDE: carried from one k-pair of a stage to the next)
     auto mma_pair = [&](int buf, int kk2) {
         const float bv = Ys[buf][(kk2 + khalf) * BNw + wn * 32 + l31];
-        float av[K];
+        if (!SLIDE || kk2 == 0) {
 #pragma unroll
-        for (int t = 0; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
+            for (int t = 0; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
+        } else {
+#pragma unroll
+            for (int t = 0; t + 2 < K; ++t) av[t] = av[t + 2];
+#pragma unroll
+            for (int t = K - 2; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
+        }
 #pragma unroll
         for (int t = 0; t < K; ++t) acc[t] = lu_mfma(av[t], bv, acc[t]);
     };
@@ -1076,8 +1086,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         const bool kp32 = !a.ragged && d->Wout % 32 == 0 && (d->flags & LU_WGRAD_F_KP32);      // 32-pixel stages: opt-in (measured slower)
         if (d->k == 5 && a.ragged) LU_LAUNCH((wgrad_row_kernel<5, true>), grid, dim3(512), stream, a);
         else if (d->k == 5 && kp32) LU_LAUNCH((wgrad_row_kernel<5, false, 32>), grid, dim3(512), stream, a);
+        else if (d->k == 5 && (d->flags & LU_WGRAD_F_NO_SLIDE)) LU_LAUNCH((wgrad_row_kernel<5, false, 16, false>), grid, dim3(512), stream, a);
         else if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5, false>), grid, dim3(512), stream, a);
         else if (a.ragged) LU_LAUNCH((wgrad_row_kernel<3, true>), grid, dim3(512), stream, a);
+        else if (d->flags & LU_WGRAD_F_NO_SLIDE) LU_LAUNCH((wgrad_row_kernel<3, false, 16, false>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_row_kernel<3, false>), grid, dim3(512), stream, a);
     } else if (!xvec) {
         const int gy = (a.kk * d->C + 31) / 32;

@@ -18,6 +18,7 @@ LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_W
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128
 LU_WGRAD_F_KP32 = 256
+LU_WGRAD_F_NO_SLIDE = 512
 
 
 class ConvSrc(C.Structure):

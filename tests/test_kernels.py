@@ -459,6 +459,11 @@ def test_wgrad_kernel_row_32_pixel_stages(be):
         dw16, db16 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
         assert np.array_equal(dw, dw16)
         close(db, db16, 1e-5)
+        # ... and to the instance that re-reads all K x rows per k-pair instead of sliding them through registers
+        assert np.array_equal(dw16, KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, flags=cabi.LU_WGRAD_F_NO_SLIDE))
+        x3, dy3 = x[..., :64], dy[..., :128]
+        assert np.array_equal(KH.conv2d_wgrad(be, x3, dy3, 3, 1, splits=sp),
+                              KH.conv2d_wgrad(be, x3, dy3, 3, 1, splits=sp, flags=cabi.LU_WGRAD_F_NO_SLIDE))
 
 
 def test_wgrad_all_taps_narrow_layers(be):
