@@ -37,3 +37,4 @@ for mode in fp32 bf16; do
   (cd $R && python tools/prof_summary.py gpurun_out/${tag}_prof_$mode gpurun_out/${tag}_${short}_kernel_stats | head -2; rm -rf gpurun_out/${tag}_prof_$mode)
 done
 cd $R && bash tools/gpu/r02_inf_prof.sh ${tag}_inf 2>&1 | grep "launches/frame"
+python tools/post_ab.py bf16 gpurun_out/${tag}_post_832x992.json 2>&1 | grep -v amdgpu | tail -9
