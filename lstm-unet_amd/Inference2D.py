@@ -40,27 +40,29 @@ def postprocess(softmax_chw, edge_dist=2, min_cell_size=10, max_cell_size=100, f
 
 
 class PostPipeline(object):
-    """Software pipeline of the per-frame path: the post-processing of frame t (lu_native/post.py: a device-driven chain of
-    small kernels ending in ONE device -> host copy, no host decision in between) is enqueued on its OWN HIP stream right
-    after the forward that produced its softmax, and runs there while the forward of frame t + 1 keeps the chip busy.
-    push(t, softmax) enqueues frame t and returns the frames finished by then as [(t, labels, softmax)] (one frame late),
-    flush() the last one.  Two processors alternate, so frame t - 1's buffers (and its exact fallback for nested objects)
-    are untouched by frame t's launches.  Results are those of postprocess(): same kernels, same order per frame."""
+    """Software pipeline of the per-frame path: the post-processing of frame t (lu_native/post.py: ONE foreign call that
+    enqueues a device-driven chain of small kernels ending in one device -> host copy) goes to its OWN HIP stream right after
+    the forward that produced its softmax, and runs there while the forwards of the next frames keep the chip busy.
+    push(t, softmax) enqueues frame t and returns the frames that are certainly finished by then as [(t, labels, softmax)]
+    -- TWO frames late -- and flush() the rest.  Two frames, because the host must never wait for a frame whose kernels still
+    share the GPU with the current forward: at bf16 rates (1.7 ms per frame, host and GPU neck and neck) collecting frame
+    t - 1 stalled the launch thread until the forward of frame t had drained, and the frame rate halved at random (290 vs 580
+    frames/s measured).  Two processors alternate; frame t - 2's buffers are collected before frame t re-uses them.
+    Results are those of postprocess(): same kernels, same order per frame."""
 
     def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=False):
         self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
         self.stream = None
-        self.pending = None
+        self.pending = []
         self._procs = None
         self._n = 0
         self.graph = graph       # replay the frame's launches from a hipGraph (lu_native.post: measured slower, off by default)
 
     def _finish(self):
         import torch
-        t, sm, proc, job = self.pending
-        self.pending = None
+        t, sm, proc, job = self.pending.pop(0)
         with torch.cuda.stream(self.stream):
-            labels = proc.collect(job)                # waits for frame t's copy; replays nested-object frames exactly
+            labels = proc.collect(job)                # waits for that frame's copy (oversize crops: replays it from the host)
         return [(t, labels, sm)]
 
     def push(self, t, softmax_chw):
@@ -71,6 +73,7 @@ class PostPipeline(object):
             from lu_native.post import PostProcessor
             self.stream = torch.cuda.Stream()
             self._procs = [PostProcessor(graph=self.graph), PostProcessor(graph=self.graph)]
+        done = self._finish() if len(self.pending) == 2 else []      # frame t - 2 (its processor is the one re-used now)
         ready = torch.cuda.Event()
         ready.record()                                # after the forward that produced softmax_chw (current stream)
         softmax_chw.record_stream(self.stream)
@@ -79,12 +82,14 @@ class PostPipeline(object):
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
             job = proc.enqueue(softmax_chw, *self.args)
-        done = self._finish() if self.pending is not None else []
-        self.pending = (t, softmax_chw, proc, job)
+        self.pending.append((t, softmax_chw, proc, job))
         return done
 
     def flush(self):
-        return self._finish() if self.pending is not None else []
+        out = []
+        while self.pending:
+            out += self._finish()
+        return out
 
 
 def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0, on_device=False, graph=False):
@@ -162,7 +167,7 @@ def inference(params):
                                     graph=use_graph):
             if params.dry_run:
                 continue
-            emit(pipe.push(t, sm))            # labels of frame t - 1, computed while frame t's forward runs
+            emit(pipe.push(t, sm))            # labels of frame t - 2, computed while the next forwards run
         emit(pipe.flush())
         for job in pending:
             job.result()

@@ -387,89 +387,144 @@ __global__ void relabel_kernel(const int32_t* __restrict__ lab, const int32_t* _
 // its snapshot of the map.  A pixel another workgroup fills concurrently is read as 0 or as that label -- "not v" either way.
 constexpr int FILL_MAX_PIX = 48 * 1024;
 
+// One object: stage the crop of label v (bbox + 1 pixel, clipped) in LDS, flood the "not v" pixels from the crop border, add v
+// to what the flood never reached.  -> 0 ok, 1 crop too large (nothing done).  *hit is set when a hole held a non-zero label.
+// GROW (the sequential replay): a pixel that changes from m to m + v extends label (m + v)'s bounding box in the table, so that
+// later labels are cropped from boxes that CONTAIN their current pixel set (a box that is too large is harmless: everything
+// outside an object's true box is "not v" and connected to the crop border, so the same components are holes).
+template <bool GROW>
+__device__ __forceinline__ int fill_one_object(int32_t* lab, int H, int W, int v, int32_t* bbox, int nmax, unsigned char* st,
+                                               int* changed, int* hit) {
+    const int tid = threadIdx.x;
+    const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
+    if (bx1 < bx0 || by1 < by0) return 0;      // the label does not occur (`if not np.any(bw): continue`)
+    const int x0 = bx0 > 0 ? bx0 - 1 : 0, y0 = by0 > 0 ? by0 - 1 : 0;
+    const int x1 = bx1 < W - 1 ? bx1 + 1 : W - 1, y1 = by1 < H - 1 ? by1 + 1 : H - 1;
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    if ((int64_t)w * h > FILL_MAX_PIX) return 1;
+    for (int i = tid; i < w * h; i += PT) {
+        const int y = i / w, x = i - y * w;
+        const int val = lab[(int64_t)(y0 + y) * W + x0 + x];
+        st[i] = val == v ? 0 : ((x == 0 || y == 0 || x == w - 1 || y == h - 1) ? 2 : 1);
+    }
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) *changed = 0;
+        __syncthreads();
+        bool mine = false;
+        for (int y = tid; y < h; y += PT) {          // row sweeps, both directions
+            unsigned char* r = st + y * w;
+            bool carry = false;
+            for (int x = 0; x < w; ++x) {
+                const int s_ = r[x];
+                if (s_ == 0) carry = false;
+                else if (s_ == 2) carry = true;
+                else if (carry) { r[x] = 2; mine = true; }
+            }
+            carry = false;
+            for (int x = w - 1; x >= 0; --x) {
+                const int s_ = r[x];
+                if (s_ == 0) carry = false;
+                else if (s_ == 2) carry = true;
+                else if (carry) { r[x] = 2; mine = true; }
+            }
+        }
+        __syncthreads();
+        for (int x = tid; x < w; x += PT) {          // column sweeps
+            bool carry = false;
+            for (int y = 0; y < h; ++y) {
+                const int s_ = st[y * w + x];
+                if (s_ == 0) carry = false;
+                else if (s_ == 2) carry = true;
+                else if (carry) { st[y * w + x] = 2; mine = true; }
+            }
+            carry = false;
+            for (int y = h - 1; y >= 0; --y) {
+                const int s_ = st[y * w + x];
+                if (s_ == 0) carry = false;
+                else if (s_ == 2) carry = true;
+                else if (carry) { st[y * w + x] = 2; mine = true; }
+            }
+        }
+        if (mine) *changed = 1;
+        __syncthreads();
+        const int again = *changed;
+        __syncthreads();
+        if (!again) break;
+    }
+    for (int i = tid; i < w * h; i += PT) {
+        if (st[i] != 1) continue;
+        const int y = i / w, x = i - y * w;
+        const int64_t p = (int64_t)(y0 + y) * W + x0 + x;
+        const int old = lab[p];
+        if (old != 0) *hit = 1;      // the hole held another label: the reference's order matters from here on
+        const int nv = old + v;
+        lab[p] = nv;
+        if (GROW && old != 0 && nv < nmax) {
+            atomicMin(&bbox[4 * nv], x0 + x);
+            atomicMin(&bbox[4 * nv + 1], y0 + y);
+            atomicMax(&bbox[4 * nv + 2], x0 + x);
+            atomicMax(&bbox[4 * nv + 3], y0 + y);
+        }
+    }
+    __syncthreads();
+    return 0;
+}
+
+__device__ __forceinline__ bool label_has_holes(const int32_t* e4, const int32_t* ncomp, int v) {
+    const int q = e4[v] >= 0 ? e4[v] / 4 : -((-e4[v] + 3) / 4);      // floor division, as the host's e4 // 4
+    return ncomp[v] - q > 0;
+}
+
 __global__ __launch_bounds__(PT) void fill_all_kernel(int32_t* lab, int H, int W, const int32_t* __restrict__ num_ptr,
-                                                     const int32_t* __restrict__ bbox, const int32_t* __restrict__ e4,
+                                                     int32_t* bbox, const int32_t* __restrict__ e4,
                                                      const int32_t* __restrict__ ncomp, int32_t* flags) {
     __shared__ unsigned char st[FILL_MAX_PIX];
-    __shared__ int changed;
+    __shared__ int changed, hit;
     const int num = *num_ptr;
-    const int tid = threadIdx.x;
+    if (threadIdx.x == 0) hit = 0;
+    __syncthreads();
     for (int v = 1 + (int)blockIdx.x; v < num; v += (int)gridDim.x) {
-        const int q = e4[v] >= 0 ? e4[v] / 4 : -((-e4[v] + 3) / 4);      // floor division, as the host's e4 // 4
-        if (ncomp[v] - q <= 0) continue;
-        const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
-        if (bx1 < bx0 || by1 < by0) continue;
-        const int x0 = bx0 > 0 ? bx0 - 1 : 0, y0 = by0 > 0 ? by0 - 1 : 0;
-        const int x1 = bx1 < W - 1 ? bx1 + 1 : W - 1, y1 = by1 < H - 1 ? by1 + 1 : H - 1;
-        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-        if ((int64_t)w * h > FILL_MAX_PIX) {
-            if (tid == 0) flags[1] = 1;
-            continue;
-        }
-        for (int i = tid; i < w * h; i += PT) {
-            const int y = i / w, x = i - y * w;
-            const int val = lab[(int64_t)(y0 + y) * W + x0 + x];
-            st[i] = val == v ? 0 : ((x == 0 || y == 0 || x == w - 1 || y == h - 1) ? 2 : 1);
-        }
-        __syncthreads();
-        for (;;) {
-            if (tid == 0) changed = 0;
-            __syncthreads();
-            bool mine = false;
-            for (int y = tid; y < h; y += PT) {          // row sweeps, both directions
-                unsigned char* r = st + y * w;
-                bool carry = false;
-                for (int x = 0; x < w; ++x) {
-                    const int s_ = r[x];
-                    if (s_ == 0) carry = false;
-                    else if (s_ == 2) carry = true;
-                    else if (carry) { r[x] = 2; mine = true; }
-                }
-                carry = false;
-                for (int x = w - 1; x >= 0; --x) {
-                    const int s_ = r[x];
-                    if (s_ == 0) carry = false;
-                    else if (s_ == 2) carry = true;
-                    else if (carry) { r[x] = 2; mine = true; }
-                }
-            }
-            __syncthreads();
-            for (int x = tid; x < w; x += PT) {          // column sweeps
-                bool carry = false;
-                for (int y = 0; y < h; ++y) {
-                    const int s_ = st[y * w + x];
-                    if (s_ == 0) carry = false;
-                    else if (s_ == 2) carry = true;
-                    else if (carry) { st[y * w + x] = 2; mine = true; }
-                }
-                carry = false;
-                for (int y = h - 1; y >= 0; --y) {
-                    const int s_ = st[y * w + x];
-                    if (s_ == 0) carry = false;
-                    else if (s_ == 2) carry = true;
-                    else if (carry) { st[y * w + x] = 2; mine = true; }
-                }
-            }
-            if (mine) changed = 1;
-            __syncthreads();
-            const int again = changed;
-            __syncthreads();
-            if (!again) break;
-        }
-        for (int i = tid; i < w * h; i += PT) {
-            if (st[i] != 1) continue;
-            const int y = i / w, x = i - y * w;
-            const int64_t p = (int64_t)(y0 + y) * W + x0 + x;
-            const int old = lab[p];
-            if (old != 0) flags[0] = 1;      // the hole held another label: the reference's order matters from here on
-            lab[p] = old + v;
-        }
-        __syncthreads();
+        if (!label_has_holes(e4, ncomp, v)) continue;
+        if (fill_one_object<false>(lab, H, W, v, bbox, 0, st, &changed, &hit) && threadIdx.x == 0) flags[1] = 1;
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && hit) flags[0] = 1;
+}
+
+// Nested objects (flags[0] set by the concurrent pass above): the reference's order matters.  Restore the map from its
+// snapshot (grid-wide) ...
+__global__ void restore_if_dirty_kernel(int32_t* __restrict__ lab, const int32_t* __restrict__ snapshot, int64_t hw,
+                                        const int32_t* __restrict__ flags) {
+    if (flags[0] == 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * PT + threadIdx.x; i < hw; i += (int64_t)gridDim.x * PT) lab[i] = snapshot[i];
+}
+
+// ... and replay Inference2D.py:80-91 in label order with ONE workgroup, still on the device: labels with holes (from the
+// statistics) until a hole holds another label, from there on EVERY label, each from the current map (bounding boxes grown as
+// labels gain pixels).  flags[2] = 1: the frame was replayed here; flags[1] = 1: a crop did not fit -- the host replays it.
+__global__ __launch_bounds__(PT) void fill_sequential_kernel(int32_t* lab, int H, int W, const int32_t* __restrict__ num_ptr,
+                                                            int32_t* bbox, const int32_t* __restrict__ e4,
+                                                            const int32_t* __restrict__ ncomp, int nmax, int32_t* flags) {
+    __shared__ unsigned char st[FILL_MAX_PIX];
+    __shared__ int changed, strict;
+    if (flags[0] == 0 || flags[1] != 0) return;      // nothing nested -- or an oversize crop: left to the host
+    const int num = *num_ptr < nmax ? *num_ptr : nmax;
+    if (threadIdx.x == 0) strict = 0;
+    __syncthreads();
+    for (int v = 1; v < num; ++v) {
+        const bool all = strict != 0;                // (uniform: written before the barrier that ends fill_one_object)
+        if (!all && !label_has_holes(e4, ncomp, v)) continue;
+        if (fill_one_object<true>(lab, H, W, v, bbox, nmax, st, &changed, &strict)) {
+            if (threadIdx.x == 0) flags[1] = 1;
+            return;
+        }
+    }
+    if (threadIdx.x == 0) flags[2] = 1;
 }
 
 // newid[v] = 1, 2, ... over the kept labels in label order (area inside [min_size, max_size], present in the field of view
-// when a presence table is given), 0 for every other entry of the table; tail[0..2] = label count, dirty flag, oversize flag
+// when a presence table is given), 0 for every other entry of the table; tail[0..3] = label count, dirty, oversize, replayed flags
 // behind the uint16 map so that ONE device -> host copy carries the frame's result and its validity.
 __global__ __launch_bounds__(1024) void newid_kernel(const int32_t* __restrict__ num_ptr, const int32_t* __restrict__ area,
                                                     const int32_t* __restrict__ present, int min_size, int max_size, int nmax,
@@ -501,6 +556,7 @@ __global__ __launch_bounds__(1024) void newid_kernel(const int32_t* __restrict__
         tail[0] = *num_ptr;
         tail[1] = flags[0];
         tail[2] = flags[1];
+        tail[3] = flags[2];      // the nested-object replay ran on the device
     }
 }
 
@@ -604,7 +660,7 @@ extern "C" int lu_post_fill_all(int32_t* labels, int32_t H, int32_t W, const int
     LU_REQUIRE(labels && num_labels && bbox && e4 && ncomp && flags && H > 0 && W > 0, "lu_post_fill_all: bad arguments");
     int blocks = lu_post_max_labels(H, W);
     if (blocks > 2048) blocks = 2048;
-    LU_LAUNCH(fill_all_kernel, dim3(blocks), dim3(PT), stream, labels, H, W, num_labels, bbox, e4, ncomp, flags);
+    LU_LAUNCH(fill_all_kernel, dim3(blocks), dim3(PT), stream, labels, H, W, num_labels, (int32_t*)bbox, e4, ncomp, flags);
     return LU_CHECK_LAUNCH();
 }
 
@@ -644,6 +700,10 @@ extern "C" int lu_post_frame(const float* softmax_chw, int32_t H, int32_t W, flo
     if (lu_post_label_stats(labels, H, W, n, workspace, bbox, e4, ncomp, stream)) return 1;
     LU_LAUNCH(copy32_kernel, dim3(pgrid(hw)), dim3(PT), stream, (const int32_t*)labels, snapshot, hw);
     if (lu_post_fill_all(labels, H, W, num, bbox, e4, ncomp, flags, stream)) return 1;
+    // nested objects: exact replay in label order, still on the device (both launches return at once when nothing is nested)
+    LU_LAUNCH(restore_if_dirty_kernel, dim3(pgrid(hw)), dim3(PT), stream, labels, (const int32_t*)snapshot, hw, (const int32_t*)flags);
+    LU_LAUNCH(fill_sequential_kernel, dim3(1), dim3(PT), stream, labels, H, W, (const int32_t*)num, bbox, (const int32_t*)e4,
+              (const int32_t*)ncomp, n, flags);
     return lu_post_frame_tail(H, W, min_size, max_size, fov, single_column, labels, tables, newid, out, host_out, stream);
 }
 

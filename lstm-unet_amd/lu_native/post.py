@@ -8,9 +8,11 @@ no host decision in between, and ONE device -> host copy brings back the uint16 
 dirty, oversize}.  `enqueue()` returns at once (the copy lands in pinned memory behind an event); `collect()` waits for it.
 
 The reference's per-object loop (`for n in range(1, num_cells)`, :80-91) has an additive quirk -- a hole pixel that already
-carries label m becomes m + n -- which makes its label ORDER matter when objects are nested.  The fill kernel reports that
-(`dirty`; also a crop too large for its LDS staging): collect() then restores the snapshot of the map taken before the fill
-and replays the reference's strict order object by object (`lu_post_fill_object`, host-sequenced: the rare path).
+carries label m becomes m + n -- which makes its label ORDER matter when objects are nested.  The concurrent fill reports that
+(`dirty`); the library then restores the snapshot of the map and replays the reference's strict order with ONE workgroup, still
+on the device and inside the same call (`replayed`).  Only a crop too large for the kernels' LDS staging (`oversize`) -- or a
+`stages` run, which keeps the step-by-step form -- makes collect() replay the frame object by object from the host
+(`lu_post_fill_object`).
 No CPU arithmetic path: device tensors in, device kernels."""
 import numpy as np
 import torch
@@ -31,7 +33,8 @@ class PostProcessor(object):
 
     def __init__(self, graph=False):
         self._shape = None
-        self.fallbacks = 0       # frames that needed the strictly sequential replay (nested objects)
+        self.fallbacks = 0       # frames replayed object by object from the HOST (oversize crops; `stages` runs)
+        self.device_replays = 0  # frames with nested objects, replayed in label order by ONE workgroup on the device
         self.use_graph = bool(graph)
         self._graphs = {}        # (H, W, parameters) -> (CUDAGraph, static softmax buffer) | None when capture failed
         self.replays = 0
@@ -176,10 +179,11 @@ class PostProcessor(object):
             job.event.synchronize()
         H, W = job.H, job.W
         tail = self.host[self.map_words:].numpy()
-        num, dirty, oversize = int(tail[0]), int(tail[1]), int(tail[2])
+        num, dirty, oversize, replayed = int(tail[0]), int(tail[1]), int(tail[2]), int(tail[3])
         if num > self.nmax:
             raise calls.NativeError('label count %d exceeds the bound %d' % (num, self.nmax))
-        if dirty or oversize:
+        self.device_replays += 1 if (replayed and not oversize) else 0
+        if oversize or (dirty and not replayed):
             self.fallbacks += 1
             self._replay_in_reference_order(job, num)
             self._record(job)

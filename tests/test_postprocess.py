@@ -124,6 +124,8 @@ def _check(dev, sm, **kw):
     if st_got['areas'] is not None:
         assert np.array_equal(st_got['areas'], st_ref['areas'])
     assert np.array_equal(got, ref)
+    # the same frame without `stages`: one lu_post_frame call, nested objects replayed in label order on the device
+    assert np.array_equal(Inference2D.postprocess(torch.from_numpy(sm).to(dev), **kw), ref), 'device-driven frame'
     return ref, st_ref
 
 
@@ -222,8 +224,11 @@ def test_device_driven_fill_and_its_exact_fallback(dev):
     got = proc(torch.from_numpy(sm).to(dev), stages=st, **kw)
     assert proc.fallbacks == 0 and (st['filled'] != st['absorbed']).sum() >= 2
     assert np.array_equal(got, po.postprocess(sm, **kw))
-    sm = _scenario('c_ring_closed_by_edge')                      # a cell inside a closed ring: the quirk -> replay
-    got = proc(torch.from_numpy(sm).to(dev), **kw)
+    sm = _scenario('c_ring_closed_by_edge')                      # a cell inside a closed ring: the quirk -> replay in label order
+    got = proc(torch.from_numpy(sm).to(dev), **kw)               # ... by one workgroup on the device
+    assert proc.device_replays == 1 and proc.fallbacks == 0 and np.array_equal(got, po.postprocess(sm, **kw))
+    st = {}
+    got = proc(torch.from_numpy(sm).to(dev), stages=st, **kw)    # ... and object by object from the host (the `stages` form)
     assert proc.fallbacks == 1 and np.array_equal(got, po.postprocess(sm, **kw))
     # several open rings closed by absorbed edge pixels (holes that exist only AFTER absorption), nothing nested: processed
     # concurrently by different workgroups of ONE launch
