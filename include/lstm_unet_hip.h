@@ -367,7 +367,9 @@ int lu_add_inplace(float* y, const float* x, int64_t n, lu_stream_t stream);
  *                                holes iff components - Euler > 0
  *   lu_post_fill_object  :80-91  per-object binary_fill_holes with the reference's additive label quirk
  *   lu_post_fill_all     :80-91  the same for ALL objects in one launch, driven by the device-side statistics (no host
- *                                read in between); reports when the reference's label order matters (nested objects)
+ *                                read in between); reports when the reference's label order matters (nested objects) or a crop
+ *                                exceeds its LDS staging -- lu_post_frame then replays the frame in label order with one
+ *                                workgroup on the device
  *   lu_post_newid        :93-123 size / FOV filter and consecutive numbering from the device-side count and areas
  *   lu_post_bbox_of_label        bounding box of one label value in the current map
  *   lu_post_present      :93-103 labels present inside the field of view

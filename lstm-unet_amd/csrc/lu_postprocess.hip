@@ -382,9 +382,9 @@ __global__ void relabel_kernel(const int32_t* __restrict__ lab, const int32_t* _
 // pixel -- 0 wall (== v), 1 open, 2 open and connected (4-conn) to the crop border -- and floods from the border with row /
 // column sweeps until nothing changes; open pixels the flood never reached are the holes: L += v.
 // Objects are processed concurrently although the reference walks them in label order: when no hole holds a non-zero label
-// all holes are disjoint regions of zeros, so the order cannot matter.  When one does (nested objects: the additive quirk,
-// flags[0]), or a crop does not fit (flags[1]), the host discards this result and replays the reference's strict order from
-// its snapshot of the map.  A pixel another workgroup fills concurrently is read as 0 or as that label -- "not v" either way.
+// all holes are disjoint regions of zeros, so the order cannot matter.  When one does (nested objects: the additive quirk), or a
+// crop does not fit the LDS staging, flags[0] is set: this result is discarded and the reference's strict order replayed from
+// the snapshot of the map by fill_sequential_kernel (one workgroup, still on the device).  A pixel another workgroup fills concurrently is read as 0 or as that label -- "not v" either way.
 constexpr int FILL_MAX_PIX = 48 * 1024;
 
 // One object: stage the crop of label v (bbox + 1 pixel, clipped) in LDS, flood the "not v" pixels from the crop border, add v
@@ -392,16 +392,20 @@ constexpr int FILL_MAX_PIX = 48 * 1024;
 // GROW (the sequential replay): a pixel that changes from m to m + v extends label (m + v)'s bounding box in the table, so that
 // later labels are cropped from boxes that CONTAIN their current pixel set (a box that is too large is harmless: everything
 // outside an object's true box is "not v" and connected to the crop border, so the same components are holes).
+// A crop beyond the LDS staging (FILL_MAX_PIX) is flooded in `big` (global scratch of `big_cap` bytes, sequential replay only).
 template <bool GROW>
 __device__ __forceinline__ int fill_one_object(int32_t* lab, int H, int W, int v, int32_t* bbox, int nmax, unsigned char* st,
-                                               int* changed, int* hit) {
+                                               int* changed, int* hit, unsigned char* big = nullptr, int64_t big_cap = 0) {
     const int tid = threadIdx.x;
     const int bx0 = bbox[4 * v], by0 = bbox[4 * v + 1], bx1 = bbox[4 * v + 2], by1 = bbox[4 * v + 3];
     if (bx1 < bx0 || by1 < by0) return 0;      // the label does not occur (`if not np.any(bw): continue`)
     const int x0 = bx0 > 0 ? bx0 - 1 : 0, y0 = by0 > 0 ? by0 - 1 : 0;
     const int x1 = bx1 < W - 1 ? bx1 + 1 : W - 1, y1 = by1 < H - 1 ? by1 + 1 : H - 1;
     const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-    if ((int64_t)w * h > FILL_MAX_PIX) return 1;
+    if ((int64_t)w * h > FILL_MAX_PIX) {
+        if (!big || (int64_t)w * h > big_cap) return 1;
+        st = big;
+    }
     for (int i = tid; i < w * h; i += PT) {
         const int y = i / w, x = i - y * w;
         const int val = lab[(int64_t)(y0 + y) * W + x0 + x];
@@ -486,7 +490,8 @@ __global__ __launch_bounds__(PT) void fill_all_kernel(int32_t* lab, int H, int W
     __syncthreads();
     for (int v = 1 + (int)blockIdx.x; v < num; v += (int)gridDim.x) {
         if (!label_has_holes(e4, ncomp, v)) continue;
-        if (fill_one_object<false>(lab, H, W, v, bbox, 0, st, &changed, &hit) && threadIdx.x == 0) flags[1] = 1;
+        // (a crop beyond the LDS staging: left to the sequential replay, which floods it in global scratch)
+        if (fill_one_object<false>(lab, H, W, v, bbox, 0, st, &changed, &hit) && threadIdx.x == 0) hit = 1;
     }
     __syncthreads();
     if (threadIdx.x == 0 && hit) flags[0] = 1;
@@ -505,7 +510,8 @@ __global__ void restore_if_dirty_kernel(int32_t* __restrict__ lab, const int32_t
 // labels gain pixels).  flags[2] = 1: the frame was replayed here; flags[1] = 1: a crop did not fit -- the host replays it.
 __global__ __launch_bounds__(PT) void fill_sequential_kernel(int32_t* lab, int H, int W, const int32_t* __restrict__ num_ptr,
                                                             int32_t* bbox, const int32_t* __restrict__ e4,
-                                                            const int32_t* __restrict__ ncomp, int nmax, int32_t* flags) {
+                                                            const int32_t* __restrict__ ncomp, int nmax, int32_t* flags,
+                                                            unsigned char* big, int64_t big_cap) {
     __shared__ unsigned char st[FILL_MAX_PIX];
     __shared__ int changed, strict;
     if (flags[0] == 0 || flags[1] != 0) return;      // nothing nested -- or an oversize crop: left to the host
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(PT) void fill_sequential_kernel(int32_t* lab, int H
     for (int v = 1; v < num; ++v) {
         const bool all = strict != 0;                // (uniform: written before the barrier that ends fill_one_object)
         if (!all && !label_has_holes(e4, ncomp, v)) continue;
-        if (fill_one_object<true>(lab, H, W, v, bbox, nmax, st, &changed, &strict)) {
+        if (fill_one_object<true>(lab, H, W, v, bbox, nmax, st, &changed, &strict, big, big_cap)) {
             if (threadIdx.x == 0) flags[1] = 1;
             return;
         }
@@ -652,9 +658,10 @@ extern "C" int lu_post_fill_object(int32_t* labels, int32_t H, int32_t W, int32_
 
 /* Device-driven hole filling of every object at once (no host read between lu_post_label_stats and the final map):
  * num_labels / bbox / e4 / ncomp are the DEVICE arrays the two calls above filled.  flags[0] is set when a hole held a
- * non-zero label (nested objects: the reference's additive quirk makes its label order matter), flags[1] when an object's
- * crop exceeds the kernel's LDS staging -- in both cases the host restores its snapshot of `labels` and replays
- * Inference2D.py:80-91 object by object with lu_post_fill_object.  flags is never cleared here. */
+ * non-zero label (nested objects: the reference's additive quirk makes its label order matter) or an object's crop exceeds
+ * the kernel's LDS staging -- the result is then to be discarded: lu_post_frame restores the snapshot and replays
+ * Inference2D.py:80-91 in label order on the device; a host that sequences the calls itself replays it object by object with
+ * lu_post_fill_object.  flags is never cleared here. */
 extern "C" int lu_post_fill_all(int32_t* labels, int32_t H, int32_t W, const int32_t* num_labels, const int32_t* bbox,
                                 const int32_t* e4, const int32_t* ncomp, int32_t* flags, lu_stream_t stream) {
     LU_REQUIRE(labels && num_labels && bbox && e4 && ncomp && flags && H > 0 && W > 0, "lu_post_fill_all: bad arguments");
@@ -702,8 +709,9 @@ extern "C" int lu_post_frame(const float* softmax_chw, int32_t H, int32_t W, flo
     if (lu_post_fill_all(labels, H, W, num, bbox, e4, ncomp, flags, stream)) return 1;
     // nested objects: exact replay in label order, still on the device (both launches return at once when nothing is nested)
     LU_LAUNCH(restore_if_dirty_kernel, dim3(pgrid(hw)), dim3(PT), stream, labels, (const int32_t*)snapshot, hw, (const int32_t*)flags);
+    // (global scratch for crops beyond the LDS staging: the `flag` plane of the workspace, 4 H W bytes, idle at this point)
     LU_LAUNCH(fill_sequential_kernel, dim3(1), dim3(PT), stream, labels, H, W, (const int32_t*)num, bbox, (const int32_t*)e4,
-              (const int32_t*)ncomp, n, flags);
+              (const int32_t*)ncomp, n, flags, (unsigned char*)((int32_t*)workspace + 3 * hw), (int64_t)4 * hw);
     return lu_post_frame_tail(H, W, min_size, max_size, fov, single_column, labels, tables, newid, out, host_out, stream);
 }
 

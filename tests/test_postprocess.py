@@ -255,6 +255,7 @@ def test_device_driven_fill_and_its_exact_fallback(dev):
         assert st['absorbed'][y0 + h // 2 - 1, x0 + w // 2] == 0 and ref[y0 + h // 2 - 1, x0 + w // 2] == ref[y0 + 1, x0 + 1] != 0
     if dev.type == 'cuda':                                       # a ring whose crop exceeds the LDS staging (48 K pixels)
         sm = rings(300, 320, [(10, 12, 270, 290, 12), (100, 100, 40, 40, 5)])
-        before = proc.fallbacks
+        before, before_host = proc.device_replays, proc.fallbacks      # ... goes to the one-workgroup replay (global scratch)
         got = proc(torch.from_numpy(sm).to(dev), **kw)
-        assert proc.fallbacks == before + 1 and np.array_equal(got, po.postprocess(sm, **kw))
+        assert proc.device_replays == before + 1 and proc.fallbacks == before_host
+        assert np.array_equal(got, po.postprocess(sm, **kw))
