@@ -327,6 +327,69 @@ def read_bundle(prefix, names=None, verify=True):
     return out
 
 
+def read_scalar_string(prefix, name, verify=True):
+    """The bytes of a scalar DT_STRING tensor (e.g. the object graph), or None when the bundle has no such entry."""
+    entries = list_bundle(prefix)
+    e = entries.get(name.decode() if isinstance(name, bytes) else name)
+    if e is None or e['dtype'] != DT_STRING:
+        return None
+    n_sh = 1 + max(x['shard'] for x in entries.values())
+    with open('%s.data-%05d-of-%05d' % (prefix, e['shard'], n_sh), 'rb') as fh:
+        fh.seek(e['offset'])
+        raw = fh.read(e['size'])
+    if verify and e['crc'] is not None and unmask_crc(e['crc']) != _string_tensor_crc(raw):
+        raise ValueError('%s: string tensor checksum mismatch' % name)
+    length, pos = get_varint(raw, 0)
+    return raw[pos + 4:pos + 4 + length]             # varint length | uint32 checksum of the lengths | bytes
+
+
+def _string_tensor_crc(raw):
+    """Running checksum of a scalar string tensor as TensorFlow computes it (see _string_tensor_bytes)."""
+    length, pos = get_varint(raw, 0)
+    crc = crc32c(struct.pack('<Q', length))
+    crc = crc32c(raw[pos:pos + 4], crc)
+    return crc32c(raw[pos + 4:pos + 4 + length], crc)
+
+
+def parse_object_graph(blob):
+    """TrackableObjectGraph bytes -> [{'children': {local_name: node_id}, 'key': checkpoint_key or None}], node 0 = root."""
+    nodes = []
+    for num, _, body in pb_fields(blob):
+        if num != 1:
+            continue
+        node = {'children': {}, 'key': None}
+        for n2, _, v in pb_fields(body):
+            if n2 == 1:                                # ObjectReference {1: node_id, 2: local_name}
+                ref = dict((a, b) for a, _, b in pb_fields(v))
+                node['children'][bytes(ref.get(2, b'')).decode()] = int(ref.get(1, 0))
+            elif n2 == 2:                              # SerializedTensor {1: name, 2: full_name, 3: checkpoint_key}
+                att = dict((a, b) for a, _, b in pb_fields(v))
+                if bytes(att.get(1, b'')) == b'VARIABLE_VALUE':
+                    node['key'] = bytes(att.get(3, b'')).decode()
+        nodes.append(node)
+    return nodes
+
+
+def resolve_through_object_graph(prefix, paths):
+    """{attribute path: checkpoint key} for the variables reachable by walking the checkpoint's OWN object graph from the root
+    along the attribute names (`DownLayers/0/ConvLSTM/0/cell/kernel`): whatever keys the writing TensorFlow chose -- attribute
+    paths, `layer_with_weights-N/...` aliases at any depth -- the graph names them.  Paths it cannot reach are left out."""
+    blob = read_scalar_string(prefix, OBJECT_GRAPH_KEY)
+    if not blob:
+        return {}
+    nodes = parse_object_graph(blob)
+    out = {}
+    for path in paths:
+        nid = 0
+        for part in path.split('/'):
+            nid = nodes[nid]['children'].get(part) if nid is not None and nid < len(nodes) else None
+            if nid is None:
+                break
+        if nid is not None and nid < len(nodes) and nodes[nid]['key']:
+            out[path] = nodes[nid]['key']
+    return out
+
+
 def _string_tensor_bytes(items):
     """On-disk form of a DT_STRING tensor: varint64 lengths | uint32 masked crc of the lengths (as uint64) | bytes; returns
     (data, unmasked running crc over lengths-as-uint64, the length checksum, the string bytes)."""
@@ -441,7 +504,13 @@ def load_model_weights(model, prefix):
     want = checkpoint_names(e)
     n_down = len(e.plan['down'])
     have = {}
-    for key in list_bundle(prefix):
+    listed = list_bundle(prefix)
+    # first choice: the checkpoint's own object graph (handles key aliasing at any depth: the reference's blocks are k.Model
+    # subclasses too, so a TensorFlow that writes `layer_with_weights-N` names does so inside the blocks as well)
+    for path, key in resolve_through_object_graph(prefix, want.values()).items():
+        if key in listed:
+            have[path] = key
+    for key in listed:
         if not key.endswith(SUFFIX):
             continue
         path = key[:-len(SUFFIX)]
@@ -449,7 +518,7 @@ def load_model_weights(model, prefix):
         if m:       # blocks enumerated in construction order: down blocks first, then up blocks (Networks.py:195-205)
             j = int(m.group(1))
             path = ('DownLayers/%d/' % j if j < n_down else 'UpLayers/%d/' % (j - n_down)) + path[m.end():]
-        have[path] = key
+        have.setdefault(path, key)
     missing = [p for p in want.values() if p not in have]
     if missing:
         raise KeyError('checkpoint %s lacks %d model variables, e.g. %s; it holds e.g. %s' %

@@ -356,7 +356,9 @@ def train(params):
             sync_bn_stats()
         if not params.dry_run and is_main and trainer.engine.plan is not None:
             model_fname = os.path.join(params.experiment_save_dir, 'model.ckpt')
-            model.save_weights(model_fname, save_format=getattr(params, 'save_format', None))
+            # as the reference does (train2D.py:235): a TensorFlow tensor bundle model.ckpt.index + .data-00000-of-00001, which
+            # the reference's own Inference2D.py (and ours) loads; params.save_format = 'pt' writes a torch blob instead
+            model.save_weights(model_fname, save_format=getattr(params, 'save_format', 'tf'))
             with open(os.path.join(params.experiment_save_dir, 'model_params.pickle'), 'wb') as fobj:
                 pickle.dump({'name': model.__class__.__name__, 'params': (params.net_kernel_params,)}, fobj,
                             protocol=pickle.HIGHEST_PROTOCOL)

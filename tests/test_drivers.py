@@ -39,7 +39,7 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     trainer = train2D.train(params)
     assert trainer.step == 4          # range(step, num_iterations + 1), as the reference loop (train2D.py:145)
     save_dir = params.experiment_save_dir
-    assert os.path.exists(os.path.join(save_dir, 'model.ckpt'))
+    assert os.path.exists(os.path.join(save_dir, 'model.ckpt.index'))      # a TensorFlow tensor bundle, like the reference's
     with open(os.path.join(save_dir, 'model_params.pickle'), 'rb') as f:
         meta = pickle.load(f)
     assert meta['name'] == 'ULSTMnet2D' and meta['params'][0] == net
@@ -147,4 +147,4 @@ def test_dp_loop_failure_on_one_rank_stops_all_ranks_without_hanging(tmp_path):
     for r in range(2):
         mine = [f for f in files if f.endswith('.rank%d.pt' % r)]
         assert len(mine) == 2, files                        # rotated like ckpt-*.pt (max_to_keep = 2)
-    assert os.path.exists(os.path.join(run_dir, 'model.ckpt'))
+    assert os.path.exists(os.path.join(run_dir, 'model.ckpt.index'))

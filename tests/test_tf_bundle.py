@@ -165,9 +165,49 @@ def test_model_checkpoint_names_and_round_trip(tmp_path):
         tb.write_bundle(prefix + '.missing', alias)
         with pytest.raises(KeyError):
             Networks.ULSTMnet2D(net, 'NHWC', True).load_weights(prefix + '.missing')
+        # NESTED aliasing (the reference's blocks are k.Model subclasses too): keys like
+        # layer_with_weights-0/layer_with_weights-1/kernel resolve through the checkpoint's own object graph, at any depth
+        nested, graph_paths = {}, {}
+        for k, v in blob.items():
+            path = k[:-len(tb.SUFFIX)]
+            side, bi, kind, idx, rest = path.split('/', 4)
+            j = int(bi) + (0 if side == 'DownLayers' else 4)
+            inner = {'ConvLSTM': 0, 'Conv': 1, 'BN': 2}[kind] * 10 + int(idx)
+            key = 'layer_with_weights-%d/layer_with_weights-%d/%s' % (j, inner, rest) + tb.SUFFIX
+            nested[key] = v
+            graph_paths[path] = key
+        # the graph has the attribute paths, its leaves name the aliased keys
+        tb.write_bundle(prefix + '.nested', nested, strings={tb.OBJECT_GRAPH_KEY: _regraph(tb, graph_paths)})
+        res = tb.resolve_through_object_graph(prefix + '.nested', list(graph_paths))
+        assert res == graph_paths
+        m4 = Networks.ULSTMnet2D(net, 'NHWC', True, seed=6)
+        m4.load_weights(prefix + '.nested')
+        d4 = m4.engine.export_params()
+        assert all(np.array_equal(a[k], d4[k]) for k in a)
         # and the ADVICE item: weights can be reloaded after the public autograd path has been used
         m.parameters()
         m.load_weights(prefix)
+
+
+def _regraph(tb, path_to_key):
+    """TrackableObjectGraph whose variable leaves sit at the attribute paths but carry arbitrary checkpoint keys."""
+    nodes = [{'children': [], 'key': None}]
+    index = {(): 0}
+    for path in sorted(path_to_key):
+        parts = tuple(path.split('/'))
+        for d in range(1, len(parts) + 1):
+            if parts[:d] not in index:
+                index[parts[:d]] = len(nodes)
+                nodes.append({'children': [], 'key': None})
+                nodes[index[parts[:d - 1]]]['children'].append((index[parts[:d]], parts[d - 1]))
+        nodes[index[parts]]['key'] = path_to_key[path]
+    out = b''
+    for n in nodes:
+        body = b''.join(tb.pb_bytes(1, tb.pb_varint(1, cid) + tb.pb_bytes(2, nm.encode())) for cid, nm in n['children'])
+        if n['key'] is not None:
+            body += tb.pb_bytes(2, tb.pb_bytes(1, b'VARIABLE_VALUE') + tb.pb_bytes(2, b'v') + tb.pb_bytes(3, n['key'].encode()))
+        out += tb.pb_bytes(1, body)
+    return out
 
 
 def test_object_graph_proto():
