@@ -831,18 +831,30 @@ constexpr int LDB = CKB + 8; // bf16 elements per halo pixel in LDS (80 B: confl
 // packed index of (tap, chunk, column n, channel c):  fragment-major, then k-step, lane, element
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C,
                                          int N, unsigned short* __restrict__ out) {
+    // one thread = one lane's fragment (8 consecutive channels of one column): eight reads that are coalesced ACROSS the lanes
+    // (consecutive columns), one 16-byte store (75 M weights are re-packed after every optimiser step)
     const int nchunk = (C + CKB - 1) / CKB, nfr = (N + 31) / 32;
-    const int64_t total = (int64_t)kk * nchunk * nfr * 1024;
+    const int64_t total = (int64_t)kk * nchunk * nfr * 128;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), ln = (int)((i >> 3) & 63), j = (int)((i >> 9) & 1);
-        int64_t t = i >> 10;
+        const int ln = (int)(i & 63), j = (int)((i >> 6) & 1);
+        int64_t t = i >> 7;
         const int fr = (int)(t % nfr);
         t /= nfr;
         const int chunk = (int)(t % nchunk);
         const int tap = (int)(t / nchunk);
         const int n = fr * 32 + (ln & 31);
-        const int c = chunk * CKB + 16 * j + 8 * (ln >> 5) + e;
-        out[i] = (c < C && n < N) ? lu_f2bf(w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n]) : (unsigned short)0;
+        const int c0 = chunk * CKB + 16 * j + 8 * (ln >> 5);
+        const float* src = w + (int64_t)tap * tap_stride + (int64_t)c0 * row_stride + n;
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (c0 + e < C && n < N) ? lu_f2bf(src[(int64_t)e * row_stride]) : (unsigned short)0;
+        lu_u4 pk;
+        pk.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+        pk.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+        pk.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+        pk.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+        *reinterpret_cast<lu_u4*>(out + (i << 3)) = pk;
     }
 }
 
@@ -2244,7 +2256,7 @@ extern "C" size_t lu_pack_weights_bf16_bytes(int k, int C, int N) {
 extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N,
                                     void* out, lu_stream_t stream) {
     LU_REQUIRE(w && out && k > 0 && C > 0 && N > 0, "lu_pack_weights_bf16: bad arguments");
-    const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 1024;
+    const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 128;      // one thread per 8 elements
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N,
               (unsigned short*)out);
@@ -2254,7 +2266,7 @@ extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_
 extern "C" int lu_pack_weights_taps_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int taps, int C, int N,
                                          void* out, lu_stream_t stream) {
     LU_REQUIRE(w && out && taps > 0 && C > 0 && N > 0, "lu_pack_weights_taps_bf16: bad arguments");
-    const int64_t total = (int64_t)taps * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 1024;
+    const int64_t total = (int64_t)taps * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 128;      // one thread per 8 elements
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, taps, C, N,
               (unsigned short*)out);

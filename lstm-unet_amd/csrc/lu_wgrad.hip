@@ -899,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_small3_kernel(WgradArgs a) {
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ dw,
                                     int C, int N, int64_t tap_stride, int row_stride, float beta,
                                     const float* __restrict__ bias_ws, float* __restrict__ dbias, float dbias_beta,
-                                    int bias_rows, int dw_blocks) {
+                                    int bias_rows, int dw_blocks, int vec4) {
     // blocks [0, dw_blocks): the weight gradient.  Blocks beyond: the bias gradient riding on the same launch (its own
     // 40-microsecond launch per layer added up to 0.7 ms per step) -- 16 columns x 16 row lanes per block over the
     // [bias_rows][N] partial column sums (a few hundred rows: one thread per column would be one long dependent chain).
@@ -917,6 +917,45 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
 #pragma unroll
             for (int j = 0; j < 16; j += 4) t += (red[j][cl] + red[j + 1][cl]) + (red[j + 2][cl] + red[j + 3][cl]);
             dbias[n] = (dbias_beta != 0.f ? dbias_beta * dbias[n] : 0.f) + t;
+        }
+        return;
+    }
+    if (vec4) {      // four consecutive columns per thread (N % 4 == 0: same (tap, c) row), 16-byte loads, four slabs in flight;
+                     // every element is still summed over the slabs in order 0, 1, 2, ...: bit-identical to the scalar form
+        const int64_t slab4 = slab >> 2;
+        for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < slab4; i4 += (int64_t)dw_blocks * blockDim.x) {
+            const int64_t i = i4 << 2;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 4 <= splits; z += 4) {
+                const float4 a0 = *reinterpret_cast<const float4*>(ws + (int64_t)z * slab + i);
+                const float4 a1 = *reinterpret_cast<const float4*>(ws + (int64_t)(z + 1) * slab + i);
+                const float4 a2 = *reinterpret_cast<const float4*>(ws + (int64_t)(z + 2) * slab + i);
+                const float4 a3 = *reinterpret_cast<const float4*>(ws + (int64_t)(z + 3) * slab + i);
+                s.x = (((s.x + a0.x) + a1.x) + a2.x) + a3.x;
+                s.y = (((s.y + a0.y) + a1.y) + a2.y) + a3.y;
+                s.z = (((s.z + a0.z) + a1.z) + a2.z) + a3.z;
+                s.w = (((s.w + a0.w) + a1.w) + a2.w) + a3.w;
+            }
+            for (; z < splits; ++z) {
+                const float4 a0 = *reinterpret_cast<const float4*>(ws + (int64_t)z * slab + i);
+                s.x += a0.x;
+                s.y += a0.y;
+                s.z += a0.z;
+                s.w += a0.w;
+            }
+            const int64_t row = i / N;
+            const int n = (int)(i - row * N);
+            const int64_t tap = row / C;
+            const int c = (int)(row - tap * C);
+            float4* o = reinterpret_cast<float4*>(dw + tap * tap_stride + (int64_t)c * row_stride + n);
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (beta != 0.f) t = *o;
+            s.x = (beta != 0.f ? beta * t.x : 0.f) + s.x;      // (the scalar form's expression, element by element)
+            s.y = (beta != 0.f ? beta * t.y : 0.f) + s.y;
+            s.z = (beta != 0.f ? beta * t.z : 0.f) + s.z;
+            s.w = (beta != 0.f ? beta * t.w : 0.f) + s.w;
+            *o = s;
         }
         return;
     }
@@ -1115,10 +1154,13 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
 #undef LU_WG
     int rc = LU_CHECK_LAUNCH();
     if (rc || d->phase == 1) return rc;
-    const unsigned rgrid = (unsigned)((a.slab + 255) / 256 < 4096 ? (a.slab + 255) / 256 : 4096);
+    const int vec4 = (d->N % 4 == 0 && d->dw_tap_stride % 4 == 0 && d->dw_row_stride % 4 == 0 && aligned16(d->dw) &&
+                      aligned16(a.ws)) ? 1 : 0;      // (slab = k*k*C*N is then a multiple of 4 as well)
+    const int64_t items = vec4 ? a.slab / 4 : a.slab;
+    const unsigned rgrid = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     const unsigned bgrid = d->dbias ? (unsigned)((d->N + 15) / 16) : 0;
     LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid + bgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,
               d->N, d->dw_tap_stride, d->dw_row_stride, d->beta, (const float*)(d->dbias ? a.bias_ws : nullptr), d->dbias,
-              d->dbias_beta, splits * bias_rows_per_split, (int)rgrid);
+              d->dbias_beta, splits * bias_rows_per_split, (int)rgrid, vec4);
     return LU_CHECK_LAUNCH();
 }
