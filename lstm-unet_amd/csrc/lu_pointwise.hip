@@ -343,21 +343,23 @@ __global__ void colreduce_kernel(Fn fn, int64_t rows, int C, int64_t rows_per_bl
 // dependent chains instead of 4 long ones -- the kernel is pure latency (26 us -> ~8 us per BatchNorm pass).
 __global__ void colreduce_final_kernel(const double* __restrict__ partial, int nblk, int C, double* out_d, float* out_f,
                                        float beta, int mode) {
-    __shared__ double red[16][17];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    // block = 8 flattened (q, c) entries x 32 partial-block lanes, fixed summation order: a column's up to ~1000 partials are
+    // 32 short dependent chains (16 lanes x 16 columns took 41 us per call at 2048 partial blocks)
+    __shared__ double red[32][9];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int nq = mode == 0 ? 2 : 1;
-    const int i = blockIdx.x * 16 + cl;          // flattened (q, c)
+    const int i = blockIdx.x * 8 + cl;          // flattened (q, c)
     const bool ok = i < nq * C;
     const int q = ok ? i / C : 0, c = ok ? i - q * C : 0;
     double s = 0.0;
     if (ok)
-        for (int b = rl; b < nblk; b += 16) s += partial[((int64_t)b * 2 + q) * C + c];
+        for (int b = rl; b < nblk; b += 32) s += partial[((int64_t)b * 2 + q) * C + c];
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && ok) {
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; j += 4) t += (red[j][cl] + red[j + 1][cl]) + (red[j + 2][cl] + red[j + 3][cl]);
+        for (int j = 0; j < 32; j += 4) t += (red[j][cl] + red[j + 1][cl]) + (red[j + 2][cl] + red[j + 3][cl]);
         if (mode == 0) out_d[i] = t;
         else out_f[c] = (beta != 0.f ? beta * out_f[c] : 0.f) + (float)t;
     }
@@ -379,7 +381,7 @@ inline ColPlan4 col_plan4(int64_t rows, int C) {
     while (p.lpr < g && p.lpr < 64) p.lpr *= 2;
     p.ctiles = (g + 63) / 64;
     const int rl = NT / p.lpr;
-    int64_t target = 2048 / p.ctiles;
+    int64_t target = 1024 / p.ctiles;      // (the final pass walks the partial blocks: 2048 of them cost it 41 us per call)
     if (target < 1) target = 1;
     p.rows_per_blk = (rows + target - 1) / target;
     if (p.rows_per_blk < 4 * rl) p.rows_per_blk = 4 * rl;
@@ -427,7 +429,7 @@ struct FnBnBwd4 {
 
 template <class Fn4>
 __global__ void colreduce4_kernel(Fn4 fn, int64_t rows, int C, int64_t rows_per_blk, int lpr, double* __restrict__ partial) {
-    __shared__ float red[2][NT * 4];
+    __shared__ __attribute__((aligned(16))) float red[2][NT * 4];
     const int cl = threadIdx.x % lpr, rl = threadIdx.x / lpr, nrl = NT / lpr;
     const int c = (blockIdx.y * 64 + cl) * 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
@@ -464,7 +466,7 @@ int run_colreduce4(Fn4 fn, int64_t rows, int C, void* ws, double* out_d, lu_stre
               (double*)ws);
     int rc = LU_CHECK_LAUNCH();
     if (rc) return rc;
-    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + 15) / 16), dim3(NT), stream, (const double*)ws, p.nblk, C, out_d,
+    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + 7) / 8), dim3(NT), stream, (const double*)ws, p.nblk, C, out_d,
               (float*)nullptr, 0.f, 0);
     return LU_CHECK_LAUNCH();
 }
@@ -481,7 +483,7 @@ int run_colreduce(Fn fn, int64_t rows, int C, void* ws, double* out_d, float* ou
               (double*)ws);
     int rc = LU_CHECK_LAUNCH();
     if (rc) return rc;
-    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + 15) / 16), dim3(NT), stream, (const double*)ws, p.nblk, C,
+    LU_LAUNCH(colreduce_final_kernel, dim3((2 * C + 7) / 8), dim3(NT), stream, (const double*)ws, p.nblk, C,
               out_d, out_f, beta, mode);
     return LU_CHECK_LAUNCH();
 }
@@ -564,19 +566,24 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const flo
     const float inv_n = (float)(1.0 / count);
     if (vec4) {      // 16-byte loads / stores; C % 4 == 0: the four elements are four consecutive channels
         const int64_t n4 = total >> 2;
+        const int c4n = C >> 2;
         for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-            const int c = (int)((i * 4) % C);
+            const int c = (int)(i % c4n) * 4;
             const float4 xv = reinterpret_cast<const float4*>(x)[i];
             const float4 dv = reinterpret_cast<const float4*>(dy)[i];
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+            const double2 a01 = *reinterpret_cast<const double2*>(sums + c), a23 = *reinterpret_cast<const double2*>(sums + c + 2);
+            const double2 b01 = *reinterpret_cast<const double2*>(sums + C + c), b23 = *reinterpret_cast<const double2*>(sums + C + c + 2);
             float4 o;
-#define LU_BWD(m, k)                                                                                            \
-    {                                                                                                           \
-        const float zz = xv.m * scale[c + k] + shift[c + k];                                                    \
-        const float dz = dv.m * (zz > 0.f ? 1.f : alpha);                                                       \
-        const float xhat = (xv.m - mean[c + k]) * invstd[c + k];                                                \
-        o.m = scale[c + k] * (dz - (float)sums[c + k] * inv_n - xhat * (float)sums[C + c + k] * inv_n);         \
+#define LU_BWD(m, s0_, s1_)                                                                  \
+    {                                                                                        \
+        const float zz = xv.m * sc.m + sh.m;                                                 \
+        const float dz = dv.m * (zz > 0.f ? 1.f : alpha);                                    \
+        const float xhat = (xv.m - mu.m) * is.m;                                             \
+        o.m = sc.m * (dz - (float)(s0_) * inv_n - xhat * (float)(s1_) * inv_n);              \
     }
-            LU_BWD(x, 0) LU_BWD(y, 1) LU_BWD(z, 2) LU_BWD(w, 3)
+            LU_BWD(x, a01.x, b01.x) LU_BWD(y, a01.y, b01.y) LU_BWD(z, a23.x, b23.x) LU_BWD(w, a23.y, b23.y)
 #undef LU_BWD
             reinterpret_cast<float4*>(dx)[i] = o;
         }
@@ -1019,7 +1026,7 @@ extern "C" int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const floa
     LU_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums && dx && rows > 0 && C > 0 && count > 0,
                "lu_bn_lrelu_bwd_apply: bad arguments");
     const int64_t total = rows * C;
-    const int vec4 = (vec4_ok(x, dy, C) && vec4_ok(dx, dx, C)) ? 1 : 0;
+    const int vec4 = (vec4_ok(x, dy, C) && vec4_ok(dx, scale, C) && vec4_ok(shift, save_mean, C) && vec4_ok(save_invstd, sums, C)) ? 1 : 0;
     LU_LAUNCH(bn_lrelu_bwd_apply_kernel, dim3(grid_for(vec4 ? total / 4 : total)), dim3(NT), stream, x, dy, scale, shift,
               save_mean, save_invstd, alpha, sums, count, dx, dgamma, dbeta, total, (int)C, vec4);
     return LU_CHECK_LAUNCH();

@@ -920,6 +920,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
         }
         return;
     }
+    if (vec4 == 2) {      // tiny slab, many slabs (thin / 1x1 layers: a few hundred elements x 1024 slabs): 16 elements x 16 slab
+                          // lanes per block, fixed order -- one thread per element would walk all the slabs alone (155 us measured)
+        __shared__ float red[16][17];
+        const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const int64_t i = (int64_t)blockIdx.x * 16 + cl;
+        float s = 0.f;
+        if (i < slab)
+            for (int z = rl; z < splits; z += 16) s += ws[(int64_t)z * slab + i];
+        red[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0 && i < slab) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) t += (red[j][cl] + red[j + 1][cl]) + (red[j + 2][cl] + red[j + 3][cl]);
+            const int64_t row = i / N;
+            const int n = (int)(i - row * N);
+            const int64_t tap = row / C;
+            const int c = (int)(row - tap * C);
+            float* o = dw + tap * tap_stride + (int64_t)c * row_stride + n;
+            *o = (beta != 0.f ? beta * *o : 0.f) + t;
+        }
+        return;
+    }
     if (vec4) {      // four consecutive columns per thread (N % 4 == 0: same (tap, c) row), 16-byte loads, four slabs in flight;
                      // every element is still summed over the slabs in order 0, 1, 2, ...: bit-identical to the scalar form
         const int64_t slab4 = slab >> 2;
@@ -1156,11 +1179,12 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     if (rc || d->phase == 1) return rc;
     const int vec4 = (d->N % 4 == 0 && d->dw_tap_stride % 4 == 0 && d->dw_row_stride % 4 == 0 && aligned16(d->dw) &&
                       aligned16(a.ws)) ? 1 : 0;      // (slab = k*k*C*N is then a multiple of 4 as well)
-    const int64_t items = vec4 ? a.slab / 4 : a.slab;
+    const bool tiny = a.slab <= 16384 && splits >= 64;      // thin / 1x1 layers: parallel over the slabs as well
+    const int64_t items = tiny ? a.slab * 16 : vec4 ? a.slab / 4 : a.slab;
     const unsigned rgrid = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     const unsigned bgrid = d->dbias ? (unsigned)((d->N + 15) / 16) : 0;
     LU_LAUNCH(wgrad_reduce_kernel, dim3(rgrid + bgrid), dim3(256), stream, (const float*)a.ws, a.slab, splits, d->dw, d->C,
               d->N, d->dw_tap_stride, d->dw_row_stride, d->beta, (const float*)(d->dbias ? a.bias_ws : nullptr), d->dbias,
-              d->dbias_beta, splits * bias_rows_per_split, (int)rgrid, vec4);
+              d->dbias_beta, splits * bias_rows_per_split, (int)rgrid, tiny ? 2 : vec4);
     return LU_CHECK_LAUNCH();
 }

@@ -147,7 +147,7 @@ def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=5, cus=256):
     (round 1: ~3000 blocks = 38 slabs of 26 MB at level 1 = 1 GB per launch; now 16 slabs)."""
     inner = k * -(-Cin // ct) * -(-N // 128)
     per_round = cus * (1 if ct == 128 else 2)
-    if inner <= 4:       # narrow layers (one channel tile, one column tile): 856 slabs of a 74 KB gradient made the slab REDUCE the
+    if inner <= 4 and Cin <= 64 and ct == 64:      # narrow layers (one channel tile, one column tile): 856 slabs of a 74 KB gradient made the slab REDUCE the
         rounds = 1       # long pole (74 blocks streaming 63 MB: 0.29 ms); one round of blocks = 170 slabs
     s = max(8, int(round(rounds * per_round / float(inner) / 8.0)) * 8)
     while s > 8 and pixels // s < 2048:
