@@ -527,18 +527,21 @@ __global__ void bn_lrelu_apply_kernel(const float* __restrict__ x, float* __rest
                                       const float* __restrict__ shift, float alpha, int64_t total, int C) {
     if (VEC) {
         const int64_t n4 = total >> 2;
+        const int c4n = C >> 2;
+        const bool pow2 = (c4n & (c4n - 1)) == 0;      // channel quad of element i without a 64-bit division
         for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-            const int c = (int)((i * 4) % C);
-            float4 v = reinterpret_cast<const float4*>(x)[i];
+            const int c = (pow2 ? (int)(i & (c4n - 1)) : (int)(i % c4n)) * 4;
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
             float4 o;
             float t;
-            t = fmaf(v.x, scale[c], shift[c]);
+            t = fmaf(v.x, sc.x, sh.x);
             o.x = t > 0.f ? t : alpha * t;
-            t = fmaf(v.y, scale[c + 1], shift[c + 1]);
+            t = fmaf(v.y, sc.y, sh.y);
             o.y = t > 0.f ? t : alpha * t;
-            t = fmaf(v.z, scale[c + 2], shift[c + 2]);
+            t = fmaf(v.z, sc.z, sh.z);
             o.z = t > 0.f ? t : alpha * t;
-            t = fmaf(v.w, scale[c + 3], shift[c + 3]);
+            t = fmaf(v.w, sc.w, sh.w);
             o.w = t > 0.f ? t : alpha * t;
             reinterpret_cast<float4*>(y)[i] = o;
         }
@@ -567,8 +570,9 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const flo
     if (vec4) {      // 16-byte loads / stores; C % 4 == 0: the four elements are four consecutive channels
         const int64_t n4 = total >> 2;
         const int c4n = C >> 2;
+        const bool pow2 = (c4n & (c4n - 1)) == 0;
         for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-            const int c = (int)(i % c4n) * 4;
+            const int c = (pow2 ? (int)(i & (c4n - 1)) : (int)(i % c4n)) * 4;
             const float4 xv = reinterpret_cast<const float4*>(x)[i];
             const float4 dv = reinterpret_cast<const float4*>(dy)[i];
             const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
@@ -996,7 +1000,8 @@ extern "C" int lu_bn_lrelu_apply(const float* x, float* y, const float* scale, c
                                  int64_t rows, int32_t C, lu_stream_t stream) {
     LU_REQUIRE(x && y && scale && shift && rows > 0 && C > 0, "lu_bn_lrelu_apply: bad arguments");
     const int64_t total = rows * C;
-    const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) |
+                                       reinterpret_cast<uintptr_t>(shift)) & 15) == 0;
     if (vec)
         LU_LAUNCH((bn_lrelu_apply_kernel<true>), dim3(grid_for(total / 4)), dim3(NT), stream, x, y, scale, shift,
                   alpha, total, (int)C);
