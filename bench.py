@@ -240,6 +240,7 @@ def main():
     ap.add_argument('--no-wgrad-overlap', action='store_true', help='A/B: weight gradients in line instead of on the side stream')
     ap.add_argument('--wgrad-flags', type=int, default=0, help='A/B: LU_WGRAD_F_* bits OR-ed into every weight-gradient descriptor')
     ap.add_argument('--conv-flags', type=int, default=0, help='A/B: LU_CONV_F_* bits OR-ed into every convolution descriptor')
+    ap.add_argument('--ab-f32-act', action='store_true', help='A/B: bf16 mode with every activation stored as fp32 (round 2 / early round 3)')
     ap.add_argument('--ab-old-tail', action='store_true',
                     help='A/B: bf16 mode with the decoder tail on the kernels of round 2 (gather / fp32 tiles, fp32 all-taps weight gradients)')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
@@ -280,6 +281,8 @@ def main():
     batches = synthetic_batches(4, B, T, H, W, dp.rank, dev)
     if args.no_wgrad_overlap:
         trainer.engine.overlap_wgrad = False
+    if args.ab_f32_act:
+        trainer.engine.act_bf16 = False
     ops.WGRAD_FLAGS |= args.wgrad_flags
     ops.CONV_FLAGS |= args.conv_flags
     if args.ab_old_tail:

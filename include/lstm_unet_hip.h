@@ -303,6 +303,12 @@ int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const float* scale, c
  * ------------------------------------------------------------------------------------------- */
 int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t legacy,
                       lu_stream_t stream);
+/* bf16-mode variants with a bf16 RESULT (round to nearest even after the fp32 arithmetic): for activations whose every consumer
+ * rounds them to bf16 MFMA operands anyway -- the values the convolutions see are unchanged, the bytes halve.  C % 4 == 0. */
+int lu_upsample2x_fwd_bf16(const float* x, void* y_bf16, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t legacy,
+                           lu_stream_t stream);
+int lu_bn_lrelu_apply_bf16(const float* x, void* y_bf16, const float* scale, const float* shift, float alpha, int64_t rows,
+                           int32_t C, lu_stream_t stream);
 /* dx[frames,H,W,C] = transpose of the above applied to dy (pixel stride dy_pix_stride, first C channels) */
 int lu_upsample2x_bwd(const float* dy, int32_t dy_pix_stride, float* dx, int32_t frames, int32_t H, int32_t W,
                       int32_t C, int32_t legacy, lu_stream_t stream);

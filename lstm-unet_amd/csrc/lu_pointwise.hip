@@ -554,6 +554,34 @@ __global__ void bn_lrelu_apply_kernel(const float* __restrict__ x, float* __rest
     }
 }
 
+// bf16 result (bf16 mode, training: an activation whose every consumer rounds it to a bf16 MFMA operand): C % 4 == 0
+__global__ void bn_lrelu_apply_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                           const float* __restrict__ scale, const float* __restrict__ shift, float alpha,
+                                           int64_t total, int C) {
+    const int64_t n4 = total >> 2;
+    const int c4n = C >> 2;
+    const bool pow2 = (c4n & (c4n - 1)) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const int c = (pow2 ? (int)(i & (c4n - 1)) : (int)(i % c4n)) * 4;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 o;
+        float t;
+        t = fmaf(v.x, sc.x, sh.x);
+        o.x = t > 0.f ? t : alpha * t;
+        t = fmaf(v.y, sc.y, sh.y);
+        o.y = t > 0.f ? t : alpha * t;
+        t = fmaf(v.z, sc.z, sh.z);
+        o.z = t > 0.f ? t : alpha * t;
+        t = fmaf(v.w, sc.w, sh.w);
+        o.w = t > 0.f ? t : alpha * t;
+        lu_u2 pk;
+        pk.x = lu_pack2bf(o.x, o.y);
+        pk.y = lu_pack2bf(o.z, o.w);
+        *reinterpret_cast<lu_u2*>(y + i * 4) = pk;
+    }
+}
+
 __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -622,7 +650,9 @@ __device__ __forceinline__ void up2_taps(int o, int n_in, int legacy, int& lo, i
 
 // VW = 4: four channels per thread (C % 4 == 0, 16-byte aligned): 16-byte loads / stores and a quarter of the index
 // arithmetic -- the same per-element expressions as VW = 1, so both produce the same bits.
-template <int VW>
+// OB16: the result is stored as bf16 (round to nearest even after the fp32 interpolation) -- bf16 mode, where the only consumer is
+// a convolution that rounds its operands to bf16 anyway: same values, half the bytes written and read.
+template <int VW, bool OB16 = false>
 __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int frames, int H, int W,
                                       int C, int legacy) {
     const int CV = C / VW;
@@ -660,7 +690,12 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
             const float top = v00[e] * (1.f - fx) + v01[e] * fx, bot = v10[e] * (1.f - fx) + v11[e] * fx;
             o[e] = top * (1.f - fy) + bot * fy;
         }
-        if (VW == 4)
+        if (OB16) {
+            lu_u2 v;
+            v.x = lu_pack2bf(o[0], o[VW > 1 ? 1 : 0]);
+            v.y = lu_pack2bf(o[VW > 2 ? 2 : 0], o[VW > 3 ? 3 : 0]);
+            *reinterpret_cast<lu_u2*>(reinterpret_cast<unsigned short*>(y) + i * 4) = v;      // (VW = 4 only)
+        } else if (VW == 4)
             *reinterpret_cast<float4*>(y + i * 4) = *reinterpret_cast<const float4*>(o);
         else
             y[i] = o[0];
@@ -1047,6 +1082,31 @@ extern "C" int lu_upsample2x_fwd(const float* x, float* y, int32_t frames, int32
     else
         LU_LAUNCH((upsample2x_fwd_kernel<1>), dim3(grid_for(total)), dim3(NT), stream, x, y, (int)frames, (int)H, (int)W,
                   (int)C, (int)legacy);
+    return LU_CHECK_LAUNCH();
+}
+
+/* lu_upsample2x_fwd with a bf16 result (C % 4 == 0, 16-byte aligned x, 8-byte aligned y) */
+extern "C" int lu_upsample2x_fwd_bf16(const float* x, void* y_bf16, int32_t frames, int32_t H, int32_t W, int32_t C,
+                                      int32_t legacy, lu_stream_t stream) {
+    LU_REQUIRE(x && y_bf16 && frames > 0 && H > 0 && W > 0 && C > 0 && (legacy == 0 || legacy == 1), "lu_upsample2x_fwd_bf16: bad arguments");
+    LU_REQUIRE(C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y_bf16) & 7) == 0,
+               "lu_upsample2x_fwd_bf16: needs C %% 4 == 0 and aligned tensors");
+    const int64_t total = (int64_t)frames * 4 * H * W * C;
+    LU_LAUNCH((upsample2x_fwd_kernel<4, true>), dim3(grid_for(total / 4)), dim3(NT), stream, x, (float*)y_bf16, (int)frames, (int)H,
+              (int)W, (int)C, (int)legacy);
+    return LU_CHECK_LAUNCH();
+}
+
+/* lu_bn_lrelu_apply with a bf16 result (C % 4 == 0, 16-byte aligned x / scale / shift, 8-byte aligned y) */
+extern "C" int lu_bn_lrelu_apply_bf16(const float* x, void* y_bf16, const float* scale, const float* shift, float alpha,
+                                      int64_t rows, int32_t C, lu_stream_t stream) {
+    LU_REQUIRE(x && y_bf16 && scale && shift && rows > 0 && C > 0, "lu_bn_lrelu_apply_bf16: bad arguments");
+    LU_REQUIRE(C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y_bf16) & 7) == 0,
+               "lu_bn_lrelu_apply_bf16: needs C %% 4 == 0 and aligned tensors");
+    const int64_t total = rows * C;
+    LU_LAUNCH(bn_lrelu_apply_bf16_kernel, dim3(grid_for(total / 4)), dim3(NT), stream, x, (unsigned short*)y_bf16, scale, shift,
+              alpha, total, (int)C);
     return LU_CHECK_LAUNCH();
 }
 

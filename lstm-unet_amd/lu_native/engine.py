@@ -98,6 +98,10 @@ class Engine:
         # the HBM-bound share of backward is 8x smaller); bench.py's per-kernel timing pass and the host emulator run in line
         self.overlap_wgrad = precision == 'bf16'
         self.narrow_bf16 = True      # A/B (bench.py --ab-old-tail): False keeps the N = 32 decoder layers on the fp32 kernels
+        # bf16 mode, training: activations whose every consumer rounds them to bf16 MFMA operands (the next convolution, a
+        # ConvLSTM input, the weight gradients) are STORED as bf16 -- BatchNorm'd outputs inside / between blocks, the up-sampled
+        # decoder inputs.  No value a kernel computes with changes; the bytes written and re-read halve.  (A/B: bench.py --ab-f32-act)
+        self.act_bf16 = True
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
@@ -209,7 +213,7 @@ class Engine:
             pw = self._packed[key] = (packer or ops.pack_bf16)(make())
         return pw
 
-    def _bn_forward(self, prefix, y, training, rec):
+    def _bn_forward(self, prefix, y, training, rec, z16=False):
         gamma, beta = self.P[prefix + '.gamma'], self.P[prefix + '.beta']
         mm, mv = self.S[prefix + '.moving_mean'], self.S[prefix + '.moving_var']
         if training:
@@ -224,7 +228,9 @@ class Engine:
             self._bn_epoch += 1      # the raw-pointer kernel moved mm / mv without bumping their torch versions
         else:
             scale, shift = self._bn_affine_infer(prefix)
-        return ops.bn_lrelu_apply(y, scale, shift, LRELU_ALPHA)
+        # (W % 32 == 0: the domain of the bf16 kernel-row weight gradient -- on other widths a weight gradient reads this
+        # tensor in fp32, unrounded, and storing it as bf16 WOULD change a value)
+        return ops.bn_lrelu_apply(y, scale, shift, LRELU_ALPHA, out_bf16=z16 and y.shape[-1] % 8 == 0 and y.shape[2] % 32 == 0)
 
     def _bn_affine_infer(self, prefix):
         """Inference-mode scale / shift of one BatchNorm: functions of the weights and moving statistics only, computed once
@@ -237,25 +243,41 @@ class Engine:
                                                                          mm, mv, BN_EPS))
         return hit[1]
 
-    def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape, alt16=None):
+    def _conv_unit(self, prefix, ci, spec, srcs, with_bn, training, tape, alt16=None, z16=False):
         """srcs: [(x, c_off, c_sub)]; Conv2D -> [BN -> LeakyReLU]  (Networks.py:69-72,146-151).
         alt16: a bf16 copy of the (single) source, if one exists (the ConvLSTM output of a down block): the x operand of the
-        layer's weight gradient in bf16 mode."""
+        layer's weight gradient in bf16 mode.
+        z16: the caller knows that every consumer of this unit's activation rounds it to bf16 -- store it as bf16 (training,
+        bf16 mode; sources may themselves arrive as bf16 tensors for the same reason)."""
         wname = f'{prefix}.conv.{ci}.kernel'
         w = self.P[wname]
         bf = self._bf16_unit(w.shape[0], spec['stride'], w.shape[3])
+        any16 = any(x.dtype == torch.bfloat16 for (x, _, _) in srcs)
+        if any16 and not (bf and all(x.dtype == torch.bfloat16 or x.shape[3] % 4 or x.shape[3] % 8 == 0 for (x, _, _) in srcs)):
+            # a consumer outside the bf16 kernels' domain (fp32 unit, odd channel counts): give it fp32 tensors
+            srcs = [(ops.to_f32(x) if x.dtype == torch.bfloat16 else x, co, cs) for (x, co, cs) in srcs]
+            any16 = False
         fsrcs = srcs      # what the forward launch reads (the tape keeps `srcs`: the weight gradients see the real tensors)
-        if bf and any(x.shape[3] % 4 for (x, _, _) in srcs):
+        if bf and (any16 or any(x.shape[3] % 4 for (x, _, _) in srcs)):
             # thin sources (the 1-channel image skip of the last up block): the bf16 kernel reads 16-byte channel groups, so
-            # they get zero pad channels (and zero weight rows) for this launch -- 33 MB at config-2, once per step
+            # they get zero pad channels (and zero weight rows) for this launch -- 33 MB at config-2, once per step; all sources
+            # of a launch share one element type, so next to a bf16 tensor the others become bf16 as well
             fsrcs = []
             for (x, co, cs) in srcs:
-                if x.shape[3] % 4:
+                if any16 and x.dtype != torch.bfloat16:
+                    if x.shape[3] % 8:
+                        xp = torch.zeros(x.shape[:3] + (-(-x.shape[3] // 8) * 8,), device=x.device, dtype=torch.bfloat16)
+                        xp[..., :x.shape[3]] = x      # (round to nearest even, like the kernels' own conversion)
+                        x = xp
+                    else:
+                        x = ops.to_bf16(x)
+                elif x.shape[3] % 4:
                     xp = torch.zeros(x.shape[:3] + (-(-x.shape[3] // 4) * 4,), device=x.device, dtype=torch.float32)
                     xp[..., :x.shape[3]] = x
                     x = xp
                 fsrcs.append((x, co, cs))
-        vec = all(x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[3] % 4 == 0
+        q = 8 if any16 else 4
+        vec = all(x.stride(2) % q == 0 and x.stride(0) % q == 0 and x.data_ptr() % 16 == 0 and x.shape[3] % q == 0
                   for (x, _, _) in fsrcs)      # the bf16 kernel reads 16-byte channel groups
         # bf16: halo kernel where it applies (N = 32 / 64: its narrow blocks), the gather kernel otherwise; N < 32 stays on the
         # fp32 tiles (128-column blocks would idle 3 of 4 column fragments; measured slower)
@@ -269,6 +291,8 @@ class Engine:
             pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs, cp=x.shape[3]: padded(co, cs, cp), co, cs))
                      for (x, co, cs) in fsrcs]
         else:
+            if any16:
+                srcs = [(ops.to_f32(x) if x.dtype == torch.bfloat16 else x, co, cs) for (x, co, cs) in srcs]
             pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
         if with_bn and tape is None and not training:
             # inference: BatchNorm is a per-channel affine -- it and the LeakyReLU ride on the conv's store / slab reduce
@@ -283,7 +307,8 @@ class Engine:
             return y
         if rec is not None:
             rec['y'] = y
-        return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec)
+        return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec,
+                                z16=z16 and tape is not None and self.precision == 'bf16' and self.act_bf16)
 
     def _conv_unit_backward(self, rec, dz, need_dx):
         """-> list of input gradients (one per source, None where not needed)."""
@@ -314,6 +339,8 @@ class Engine:
             a16 = rec.get('alt16')
             if a16 is not None and self.precision == 'bf16' and ops.bf16_row_wgrad_ok(a16, dy, gw.shape[0], spec['stride']):
                 x = a16
+            if x.dtype == torch.bfloat16 and not ops.bf16_row_wgrad_ok(x, dy, gw.shape[0], spec['stride']):
+                x = ops.to_f32(x)      # (a layer shape outside the bf16 kernel-row weight gradient: it reads fp32)
             with self._wgrad_side(x, dy):
                 ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
                                  dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
@@ -339,6 +366,8 @@ class Engine:
         tape16 = bf and ops.fused_step_applies(B, H, W, F, True)
         x_center = tape16 and Cin % 4 != 0 and k * k * Cin <= 32      # thin image: im2col chunk, one tap
         src16 = tape16 and (x_center or Cin % 8 == 0)                 # both operands of the step as bf16 tensors
+        if x_seq.dtype == torch.bfloat16 and not (src16 and not x_center):
+            x_seq = ops.to_f32(x_seq)      # (this layer's step reads fp32: the producer stored bf16 for its other consumers)
         x5 = x_seq.view(T, B, H, W, -1)
         x16 = None
         if bf:
@@ -348,7 +377,8 @@ class Engine:
                 x5 = ops.im2col_bf16(x_seq, k).view(T, B, H, W, 32)
             elif src16:
                 kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w)
-                x16 = ops.to_bf16(x_seq)      # one pass per window; also the x operand of the hoisted weight gradient
+                # one pass per window; also the x operand of the hoisted weight gradient (or the producer stored it as bf16)
+                x16 = x_seq if x_seq.dtype == torch.bfloat16 else ops.to_bf16(x_seq)
                 x5 = x16.view(T, B, H, W, -1)
             else:
                 kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w)
@@ -487,7 +517,7 @@ class Engine:
             elif ker_16:
                 ops.conv2d_wgrad(x16 if x16 is not None else x_seq, dz_seq, gk, 1, bf16=True)
             else:
-                ops.conv2d_wgrad(x_seq, dz_f32(), gk, 1, bf16=bf)
+                ops.conv2d_wgrad(ops.to_f32(x_seq) if x_seq.dtype == torch.bfloat16 else x_seq, dz_f32(), gk, 1, bf16=bf)
         dx = None
         if need_dx:
             dx = ops.conv2d_dgrad(dz_seq if (dx_bf or not tape16) else dz_f32(), kernel, (H, W), 1, bf16=dx_bf)
@@ -518,15 +548,24 @@ class Engine:
             self._h16_seq = None
             for li, l in enumerate(blk['lstm']):
                 seq = self._lstm_forward(bi, li, l, seq, T, B, tape)
+            n_dc = len(blk['conv'])
             for ci, l in enumerate(blk['conv']):
+                # consumers of this activation: the block's next convolution; after the last one the next block's ConvLSTM, the
+                # decoder's skip convolution and -- last block -- the first up block (a bilinear resize needs the fp32 tensor)
+                z16 = not (bi == len(plan['down']) - 1 and ci == n_dc - 1 and plan['up'][0]['up_factor'] == 2)
                 seq = self._conv_unit(f'down.{bi}', ci, l, [(seq, 0, l['cin'])], True, training, tape,
-                                      alt16=self._h16_seq if ci == 0 else None)
+                                      alt16=self._h16_seq if ci == 0 else None, z16=z16)
             self._h16_seq = None
             act = seq
         up_in = act
         for bi, (blk, skip) in enumerate(zip(plan['up'], skips[::-1])):
             if blk['up_factor'] == 2:
-                u = ops.upsample2x(up_in, self.resize)
+                c0 = blk['conv'][0]
+                u16 = (tape is not None and self.precision == 'bf16' and self.act_bf16 and blk['c_up'] % 8 == 0 and
+                       (2 * up_in.shape[2]) % 32 == 0 and self._bf16_unit(c0['k'], c0['stride'], c0['cout']))      # its consumer rounds it to bf16 anyway
+                if up_in.dtype == torch.bfloat16:
+                    up_in = ops.to_f32(up_in)
+                u = ops.upsample2x(up_in, self.resize, out_bf16=u16)
                 if tape is not None:
                     tape.append({'kind': 'up', 'in_hw': (up_in.shape[1], up_in.shape[2])})
             else:
@@ -536,7 +575,9 @@ class Engine:
             for ci, l in enumerate(blk['conv']):
                 last = blk['return_logits'] and ci == n - 1
                 srcs = [(u, 0, blk['c_up']), (skip, blk['c_up'], blk['c_skip'])] if ci == 0 else [(a, 0, l['cin'])]
-                a = self._conv_unit(f'up.{bi}', ci, l, srcs, not last, training, tape)
+                nxt = blk['conv'][ci + 1] if ci + 1 < n else None      # the consumer inside the block (the block's output is resized)
+                a = self._conv_unit(f'up.{bi}', ci, l, srcs, not last, training, tape,
+                                    z16=nxt is not None and self._bf16_unit(nxt['k'], nxt['stride'], nxt['cout']))
             up_in = a
         logits = up_in
         if any(py) or any(px):

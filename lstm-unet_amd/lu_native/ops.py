@@ -554,9 +554,16 @@ def bn_finalize_infer(gamma, beta, mm, mv, eps):
     return scale, shift
 
 
-def bn_lrelu_apply(y, scale, shift, alpha, out=None):
+def bn_lrelu_apply(y, scale, shift, alpha, out=None, out_bf16=False):
+    """out_bf16: the activation is stored rounded to bf16 (every consumer is a bf16-operand convolution / weight gradient)."""
     _chk(y, scale, shift)
     Cc = y.shape[-1]
+    if out_bf16:
+        out = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16)
+        with _timed('hbm:bn_lrelu_apply_kernel (normalise + LeakyReLU: 1 read + 1 write)', 6.0 * y.numel()):
+            calls.check(lib(), lib().lu_bn_lrelu_apply_bf16(y.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), alpha,
+                                                            y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_apply_bf16')
+        return out
     if out is None:
         out = torch.empty_like(y)
     with _timed('hbm:bn_lrelu_apply_kernel (normalise + LeakyReLU: 1 read + 1 write)', 8.0 * y.numel()):
@@ -598,9 +605,15 @@ def _legacy(resize):
     return 1 if resize == 'tf2.0' else 0
 
 
-def upsample2x(x, resize='tf2.0'):
+def upsample2x(x, resize='tf2.0', out_bf16=False):
+    """out_bf16: store the result rounded to bf16 (its only consumer is a bf16-operand convolution: same values, half the bytes)."""
     _chk(x)
     frames, H, W, Cc = x.shape
+    if out_bf16:
+        y = torch.empty((frames, 2 * H, 2 * W, Cc), device=x.device, dtype=torch.bfloat16)
+        calls.check(lib(), lib().lu_upsample2x_fwd_bf16(x.data_ptr(), y.data_ptr(), frames, H, W, Cc, _legacy(resize), _stream()),
+                    'lu_upsample2x_fwd_bf16')
+        return y
     y = torch.empty((frames, 2 * H, 2 * W, Cc), device=x.device, dtype=torch.float32)
     calls.check(lib(), lib().lu_upsample2x_fwd(x.data_ptr(), y.data_ptr(), frames, H, W, Cc, _legacy(resize), _stream()),
                 'lu_upsample2x_fwd')

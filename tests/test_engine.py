@@ -295,6 +295,56 @@ def test_bf16_precision_mode(dev, monkeypatch, which):
     assert np.abs(from_tb(l16, B, T) - ref['logits']).max() <= 3e-2 * np.abs(ref['logits']).max()
 
 
+ACT16_NET = {'down_conv_kernels': [[(3, 64), (3, 64)], [(3, 72), (3, 72)], [(3, 40)]],
+             'lstm_kernels': [[(5, 32)], [(3, 32)], [(3, 24)]],
+             'up_conv_kernels': [[(3, 64), (3, 64)], [(3, 64), (3, 40)], [(3, 32), (3, 32), (1, 3)]]}
+
+
+def test_bf16_activations_stored_as_bf16_change_no_value(dev):
+    """bf16 mode stores the activations whose every consumer rounds them to bf16 MFMA operands AS bf16 (BatchNorm'd outputs
+    inside / between blocks, the up-sampled decoder inputs; Engine.act_bf16).  The claim is that no kernel then computes with a
+    different value: logits, loss and EVERY gradient tensor of a training step must be bit-identical to the same step with fp32
+    storage.  The net covers: bf16 block outputs feeding a ConvLSTM, a skip convolution and (last block) the first up block;
+    up-sampled bf16 tensors next to a bf16 skip and next to the 1-channel image (padded to 8 bf16 channels); N = 32 / 40 / 64 / 72
+    units, a 40-channel tensor (C % 8 == 0) and the 1x1 logits convolution, whose input stays fp32."""
+    from lu_native import ops
+    from lu_native.engine import Engine
+    net, cin, B, T, H, W = ACT16_NET, 1, 2, 2, 16, 128      # (widths 128 / 64 / 32: every level inside the bf16 weight gradient's domain)
+    rng = np.random.default_rng(33)
+    p = perturbed_params(net, cin, 5)
+    x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+    cwt = torch.tensor([0.15, 0.25, 0.6], dtype=torch.float32, device=dev)
+    res, n16 = {}, {}
+    real = ops.bn_lrelu_apply
+    for act16 in (True, False):
+        count = [0]
+
+        def spy(*a, **k):
+            count[0] += int(bool(k.get('out_bf16')))
+            return real(*a, **k)
+        ops.bn_lrelu_apply = spy
+        try:
+            e = Engine(net, pad_image=False, precision='bf16')
+            e.act_bf16 = act16
+            e.overlap_wgrad = False
+            e.build(cin, dev)
+            e.load_params(p)
+            lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+            g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+            sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+            e.backward(ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0).view(lg.shape))
+        finally:
+            ops.bn_lrelu_apply = real
+        n16[act16] = count[0]
+        res[act16] = (lg.cpu().numpy(), float(ops.wce_loss(sums).cpu()[0]), {k: v.cpu().numpy() for k, v in e.G.items()})
+    assert n16[True] >= 6 and n16[False] == 0, n16          # the switch does something: bf16 activations are produced
+    (la, lossa, ga), (lb, lossb, gb) = res[True], res[False]
+    assert np.array_equal(la, lb) and lossa == lossb
+    bad = [k for k in ga if not np.array_equal(ga[k], gb[k])]
+    assert not bad, bad
+
+
 @pytest.mark.gpu
 def test_bf16_mode_ragged_inference_shapes():
     """bf16 mode on frame sizes that are not multiples of anything (35 x 37, reflect-padded to 48 x 48 inside): streaming
