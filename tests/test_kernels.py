@@ -681,6 +681,28 @@ def test_upsample_fwd_bwd(be, resize):
     close(be.host(dx), gx.numpy(), 1e-5)
 
 
+def test_bf16_result_variants_of_apply_and_resize(be):
+    """lu_bn_lrelu_apply_bf16 / lu_upsample2x_fwd_bf16 (bf16 mode: activations whose every consumer rounds them to bf16): the
+    fp32 result of the plain entry point, rounded to nearest even at the store -- bit for bit."""
+    rows, Cc = 200, 24
+    x, scale, shift = rnd(rows, Cc, scale=2.0), f32(0.5 + RNG.random(Cc)), rnd(Cc, scale=0.3)
+    xd, sd, hd = be.dev(x), be.dev(scale), be.dev(shift)
+    y32, y16 = be.empty(x.shape), be.empty(x.shape, np.int16)
+    ck(be, be.lib.lu_bn_lrelu_apply(be.ptr(xd), be.ptr(y32), be.ptr(sd), be.ptr(hd), 0.3, rows, Cc, be.stream), 'apply')
+    ck(be, be.lib.lu_bn_lrelu_apply_bf16(be.ptr(xd), be.ptr(y16), be.ptr(sd), be.ptr(hd), 0.3, rows, Cc, be.stream), 'apply16')
+    assert np.array_equal(be.host(y16), KH.bf16_bits(be.host(y32)))
+    for legacy in (1, 0):
+        fr, H, W, Cc = 2, 5, 6, 8
+        x = rnd(fr, H, W, Cc)
+        xd = be.dev(x)
+        u32, u16 = be.empty((fr, 2 * H, 2 * W, Cc)), be.empty((fr, 2 * H, 2 * W, Cc), np.int16)
+        ck(be, be.lib.lu_upsample2x_fwd(be.ptr(xd), be.ptr(u32), fr, H, W, Cc, legacy, be.stream), 'up')
+        ck(be, be.lib.lu_upsample2x_fwd_bf16(be.ptr(xd), be.ptr(u16), fr, H, W, Cc, legacy, be.stream), 'up16')
+        assert np.array_equal(be.host(u16), KH.bf16_bits(be.host(u32)))
+    with pytest.raises(RuntimeError):      # C % 4 != 0: the caller keeps such tensors in fp32
+        ck(be, be.lib.lu_bn_lrelu_apply_bf16(be.ptr(xd), be.ptr(y16), be.ptr(sd), be.ptr(hd), 0.3, 10, 6, be.stream), 'apply16')
+
+
 def test_window_copy_reflect_crop_embed(be):
     x = rnd(2, 5, 6, 2)
     xd = be.dev(x)
