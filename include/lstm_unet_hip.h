@@ -172,6 +172,11 @@ int lu_stride2_dgrad_weights(const float* w, float* sub, int k, int ks, int C, i
 int lu_conv2d_s2_dgrad_bf16(const float* dy, int64_t dy_frame_stride, int32_t dy_pix_stride, const void* packed, int32_t frames,
                             int32_t Hd, int32_t Wd, int32_t Nf, int32_t C, float* dx, lu_stream_t stream);
 
+/* bf16 mode, the same stride-2 3x3 layers FORWARD: reads a bf16 tensor (the bf16 copy of the ConvLSTM output the tape keeps),
+ * weights packed by lu_pack_weights_bf16; out = conv + bias, fp32 dense [frames, Hin / 2, Win / 2, N].  Even extents. */
+int lu_conv2d_s2_fwd_bf16(const void* x_bf16, int64_t x_frame_stride, int32_t x_pix_stride, const void* packed, const float* bias,
+                          int32_t frames, int32_t Hin, int32_t Win, int32_t C, int32_t N, float* out, lu_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient:  dw[kh,kw,c,n] (+)= sum_{f,oy,ox} x[f, oy*stride+kh-pad_t, ox*stride+kw-pad_l, c] * dy[f,oy,ox,n]
  * (tape.gradient w.r.t. every conv kernel, train2D.py:92).  Split over pixels into `splits` slabs

@@ -1608,6 +1608,140 @@ __global__ __launch_bounds__(256, 2) void conv_s2_dgrad_bf16_kernel(S2DgradArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Stride-2 3x3 FORWARD convolution (first layer of a down block, TF-SAME on even extents: pad 0 before, 1 after) on bf16 MFMA
+// operands, reading the bf16 copy of the ConvLSTM output that the bf16 tape keeps anyway.  The gather kernel ran these at
+// twice their HBM time on the fp32 tensor (0.57 ms for 0.8 GB at level 0).  Block = 4 output rows x 32 output pixels x 128
+// columns (8 waves: 2 row pairs x 4 column fragments); the 9 x 65 input pixels under the tile are staged once per 32-channel
+// chunk, SPLIT BY COLUMN PARITY ([row][33 even | 32 odd] pixels, 80-byte pitch): tap kw then reads 32 consecutive entries --
+// even[ox] / odd[ox] / even[ox + 1] -- i.e. the same conflict-free ds_read_b128 fragments as the stride-1 kernels.  Weights in
+// MFMA-fragment order from L2 (lu_pack_weights_bf16); the next chunk's pixels are in flight while the current one is multiplied.
+// ---------------------------------------------------------------------------------------------------------
+struct S2FwdArgs {
+    const unsigned short* x;      // bf16 [frames, Hin, Win, C]
+    const unsigned char* w;       // packed [9][ceil(C / 32)][ceil(N / 32)][2 KB]
+    const float* bias;
+    float* out;                   // fp32 dense [frames, Hin / 2, Win / 2, N]
+    int64_t x_fs;
+    int32_t x_ps, Hin, Win, C, N;
+    int32_t tiles_x, tiles_pf, m_tiles, n_tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_s2_fwd_bf16_kernel(S2FwdArgs a) {
+    constexpr int NT = 512, R = 4, RW = 2, TW = 32, HR = 2 * R + 1, HC = 2 * TW + 1, HP = HR * HC, PITCH = 80;
+    constexpr int G = 4;                                    // 16-byte pieces (8 bf16 channels) per pixel and chunk
+    constexpr int HPASS = (HP * G + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[HP * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int slot = blockIdx.x >> 3;
+    const int nt = slot % a.n_tiles;
+    const int tile = (slot / a.n_tiles) * 8 + (blockIdx.x & 7);
+    if (tile >= a.m_tiles) return;
+    const int Hout = a.Hin >> 1, Wout = a.Win >> 1;
+    const int f = tile / a.tiles_pf;
+    const int t2 = tile - f * a.tiles_pf;
+    const int y0 = (t2 / a.tiles_x) * R, x0 = (t2 % a.tiles_x) * TW;
+    const int nfr = (a.N + 31) >> 5, nch = (a.C + 31) >> 5;
+    const int frag = nt * 4 + wn;
+    const bool frag_ok = frag < nfr;
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const unsigned short* const xf = a.x + (int64_t)f * a.x_fs;
+    const unsigned char* const wl = a.w + (int64_t)frag * 2048 + lane * 16;
+    const int q = tid % G;
+
+    auto piece_load = [&](int p, int chunk, lu_u4& r) {
+        const int hp = (tid + NT * p) / G;
+        const int hr = hp / HC, hc = hp - hr * HC;
+        const int iy = 2 * y0 + hr, ix = 2 * x0 + hc;
+        const int c = chunk * 32 + 8 * q;
+        const bool ok = hp < HP && iy < a.Hin && ix < a.Win && c < a.C;
+        r = *(ok ? reinterpret_cast<const lu_u4*>(xf + (int64_t)(iy * a.Win + ix) * a.x_ps + c) : zp);
+    };
+    auto piece_store = [&](int p, const lu_u4& r) {
+        const int hp = (tid + NT * p) / G;
+        if (hp < HP) {
+            const int hr = hp / HC, hc = hp - hr * HC;
+            const int slot_ = hr * HC + ((hc & 1) ? 33 + (hc >> 1) : (hc >> 1));      // [33 even | 32 odd] columns
+            *reinterpret_cast<lu_u4*>(&Ah[slot_ * PITCH + 16 * q]) = r;
+        }
+    };
+    auto load_b = [&](int tap, int chunk, float4& b0, float4& b1) {
+        const unsigned char* wp = wl + ((int64_t)tap * nch + chunk) * nfr * 2048;
+        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : lu_zero16);
+        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_zero16);
+    };
+
+    f32x16 acc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    {
+        lu_u4 rh[HPASS];
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) piece_load(p, 0, rh[p]);
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) piece_store(p, rh[p]);
+    }
+    __syncthreads();
+    const int khalf16 = 16 * (lane >> 5);
+    float4 b0, b1, c0, c1;
+    load_b(0, 0, b0, b1);
+    load_b(1, 0, c0, c1);
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool more = chunk + 1 < nch;
+        lu_u4 rn[HPASS];
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) piece_load(p, more ? chunk + 1 : chunk, rn[p]);      // (last chunk: re-read, unused)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - 3 * kh;
+            float4 n0v, n1v;      // fragments of the tap after next (two taps of weights in flight)
+            if (t + 2 < 9) load_b(t + 2, chunk, n0v, n1v);
+            else load_b(t + 2 - 9, more ? chunk + 1 : chunk, n0v, n1v);
+            const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
+            const int col = (kw == 1 ? 33 : 0) + (kw == 2 ? 1 : 0) + (lane & 31);
+            const unsigned char* ab = &Ah[((2 * RW * wm + kh) * HC + col) * PITCH + khalf16];
+            lu_bf16x8 a0[RW], a1[RW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {      // output row RW wm + i reads input rows 2 (RW wm + i) + kh
+                a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + 2 * i * HC * PITCH);
+                a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + 2 * i * HC * PITCH + 32);
+            }
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(a0[i], bv0, acc[i]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
+            b0 = c0;
+            b1 = c1;
+            c0 = n0v;
+            c1 = n1v;
+        }
+        __syncthreads();                      // every wave is done with this chunk's pixels
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_store(p, rn[p]);
+        }
+        __syncthreads();
+    }
+    const int col = frag * 32 + (lane & 31);
+    if (!frag_ok || col >= a.N) return;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+    float* const of = a.out + (int64_t)f * Hout * Wout * a.N + col;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int oy = y0 + RW * wm + i;
+        if (oy >= Hout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (ox >= Wout) continue;
+            of[((int64_t)oy * Wout + ox) * a.N] = acc[i][r] + bv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // General bf16-MFMA convolution (precision = 1 where the halo kernel does not apply): stride 1 / 2, any k <= 7, any
 // pads, narrow outputs, strided output rows (parity planes of a stride-2 input gradient).  Implicit GEMM over
 // 256 linear pixels x 128 columns per block; a stage is one (tap, 32-channel chunk): the [256][32] activation slab is
@@ -2246,6 +2380,39 @@ extern "C" int lu_conv2d_s2_dgrad_bf16(const float* dy, int64_t dy_frame_stride,
     a.n_tiles = (C + 127) / 128;
     const int64_t m8 = (m_tiles + 7) / 8 * 8;
     LU_LAUNCH(conv_s2_dgrad_bf16_kernel, dim3((unsigned)(m8 * a.n_tiles)), dim3(256), stream, a);
+    return LU_CHECK_LAUNCH();
+}
+
+/* Stride-2 3x3 forward convolution on even input extents (TF-SAME pads 0 / 1; Networks.py:52-56: the first Conv2D of a down
+ * block) reading a BF16 tensor x [frames, Hin, Win, C] (C % 8 == 0; the bf16 copy of the ConvLSTM output), weights packed by
+ * lu_pack_weights_bf16(w [3,3,C,N]), out fp32 dense [frames, Hin / 2, Win / 2, N] = conv + bias. */
+extern "C" int lu_conv2d_s2_fwd_bf16(const void* x_bf16, int64_t x_frame_stride, int32_t x_pix_stride, const void* packed,
+                                     const float* bias, int32_t frames, int32_t Hin, int32_t Win, int32_t C, int32_t N,
+                                     float* out, lu_stream_t stream) {
+    LU_REQUIRE(x_bf16 && packed && out && frames > 0 && Hin > 0 && Win > 0 && C > 0 && N > 0, "lu_conv2d_s2_fwd_bf16: bad arguments");
+    LU_REQUIRE(Hin % 2 == 0 && Win % 2 == 0 && C % 8 == 0 && x_pix_stride % 8 == 0 && x_frame_stride % 8 == 0 && aligned16(x_bf16),
+               "lu_conv2d_s2_fwd_bf16: needs even extents, C %% 8 == 0 and 16-byte aligned pixels");
+    S2FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const unsigned short*)x_bf16;
+    a.w = (const unsigned char*)packed;
+    a.bias = bias;
+    a.out = out;
+    a.x_fs = x_frame_stride;
+    a.x_ps = x_pix_stride;
+    a.Hin = Hin;
+    a.Win = Win;
+    a.C = C;
+    a.N = N;
+    const int Hout = Hin / 2, Wout = Win / 2;
+    a.tiles_x = (Wout + 31) / 32;
+    a.tiles_pf = ((Hout + 3) / 4) * a.tiles_x;
+    const int64_t m_tiles = (int64_t)frames * a.tiles_pf;
+    LU_REQUIRE(m_tiles < ((int64_t)1 << 27), "lu_conv2d_s2_fwd_bf16: too many tiles");
+    a.m_tiles = (int32_t)m_tiles;
+    a.n_tiles = (N + 127) / 128;
+    const int64_t m8 = (m_tiles + 7) / 8 * 8;
+    LU_LAUNCH(conv_s2_fwd_bf16_kernel, dim3((unsigned)(m8 * a.n_tiles)), dim3(512), stream, a);
     return LU_CHECK_LAUNCH();
 }
 

@@ -92,6 +92,7 @@ PROTOTYPES = {
     'lu_transpose_inner': (C.c_int, [P, P, i64, i32, i32, S]),
     'lu_add_inplace': (C.c_int, [P, P, i64, S]),
     'lu_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),
+    'lu_conv2d_s2_fwd_bf16': (C.c_int, [P, i64, i32, P, P, i32, i32, i32, i32, i32, P, S]),
     'lu_conv2d_s2_dgrad_bf16': (C.c_int, [P, i64, i32, P, i32, i32, i32, i32, i32, P, S]),
     'lu_upsample2x_fwd_bf16': (C.c_int, [P, P, i32, i32, i32, i32, i32, S]),
     'lu_bn_lrelu_apply_bf16': (C.c_int, [P, P, P, P, f32, i64, i32, S]),

@@ -102,6 +102,7 @@ class Engine:
         # ConvLSTM input, the weight gradients) are STORED as bf16 -- BatchNorm'd outputs inside / between blocks, the up-sampled
         # decoder inputs.  No value a kernel computes with changes; the bytes written and re-read halve.  (A/B: bench.py --ab-f32-act)
         self.act_bf16 = True
+        self.s2_fwd_bf16 = True      # stride-2 forward convs behind a ConvLSTM read its bf16 copy (A/B: bench.py --conv-flags 4096 turns it off)
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
@@ -294,6 +295,18 @@ class Engine:
             if any16:
                 srcs = [(ops.to_f32(x) if x.dtype == torch.bfloat16 else x, co, cs) for (x, co, cs) in srcs]
             pairs = [(x, w[:, :, co:co + cs, :]) for (x, co, cs) in srcs]
+        if (bf and spec['stride'] == 2 and w.shape[0] == 3 and alt16 is not None and len(srcs) == 1 and self.s2_fwd_bf16 and
+                alt16.shape[1] % 2 == 0 and alt16.shape[2] % 2 == 0 and alt16.shape[3] % 8 == 0 and tape is not None):
+            # the stride-2 layer behind a ConvLSTM, training: read the bf16 copy of its output (same rounded operands as the
+            # gather kernel forms from the fp32 tensor, half the bytes, input pixels staged by column parity)
+            y = ops.conv2d_s2_fwd_bf16(alt16, self._pack(wname, 'fwd', lambda: w), self.P[f'{prefix}.conv.{ci}.bias'])
+            rec = {'kind': 'conv', 'prefix': prefix, 'ci': ci, 'spec': spec, 'srcs': srcs, 'bn': with_bn, 'alt16': alt16}
+            tape.append(rec)
+            if not with_bn:
+                return y
+            rec['y'] = y
+            return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec,
+                                    z16=z16 and self.precision == 'bf16' and self.act_bf16)
         if with_bn and tape is None and not training:
             # inference: BatchNorm is a per-channel affine -- it and the LeakyReLU ride on the conv's store / slab reduce
             scale, shift = self._bn_affine_infer(f'{prefix}.bn.{ci}')

@@ -199,6 +199,21 @@ def conv2d(pairs, bias, stride=1, out=None, post=None):
     return conv_raw(pairs, frames, Hin, Win, Hout, Wout, k, stride, 1, pt, pl, N, bias, out, post=post)
 
 
+def conv2d_s2_fwd_bf16(x16, pw, bias):
+    """Stride-2 3x3 SAME convolution of a bf16 tensor (even extents) with bf16-packed weights -> fp32 [frames, H/2, W/2, N]."""
+    _chk(x16, pw.data, bias)
+    assert x16.dtype == torch.bfloat16 and x16.dim() == 4 and x16.stride(3) == 1 and x16.stride(1) == x16.shape[2] * x16.stride(2)
+    frames, H, W, Cc = x16.shape
+    k, _, _, N = pw.shape
+    assert k == 3 and H % 2 == 0 and W % 2 == 0 and pw.shape[2] == Cc
+    out = torch.empty((frames, H // 2, W // 2, N), device=x16.device, dtype=torch.float32)
+    with _timed('conv_s2_fwd_bf16_kernel (bf16-MFMA stride-2 forward convolution on the bf16 ConvLSTM output)',
+                2.0 * 9 * Cc * N * frames * (H // 2) * (W // 2)):
+        calls.check(lib(), lib().lu_conv2d_s2_fwd_bf16(x16.data_ptr(), x16.stride(0), x16.stride(2), pw.data.data_ptr(), _p(bias),
+                                                       frames, H, W, Cc, N, out.data_ptr(), _stream()), 'lu_conv2d_s2_fwd_bf16')
+    return out
+
+
 def flip_transpose(w, c_off=0, c_sub=None):
     """dense [k,k,C,N] kernel, channels [c_off, c_off+c_sub) -> dense [k,k,N,c_sub] kernel of the
     input-gradient convolution (spatially flipped, channel-transposed)."""

@@ -195,6 +195,20 @@ def conv2d_dgrad_s2_parity(be, dy, w, in_hw):
     return be.host(out)
 
 
+def conv2d_s2_fwd_bf16(be, x, w, b):
+    """Stride-2 3x3 forward convolution on even extents from a bf16 tensor (lu_conv2d_s2_fwd_bf16)."""
+    k, _, Cc, N = w.shape
+    frames, H, W, _ = x.shape
+    assert k == 3
+    xd, wd = be.dev(bf16_bits(x), np.int16), be.dev(w)
+    packed = pack_bf16(be, wd, 3, Cc, N)
+    bd = be.dev(b) if b is not None else None
+    out = be.empty((frames, H // 2, W // 2, N))
+    calls.check(be.lib, be.lib.lu_conv2d_s2_fwd_bf16(be.ptr(xd), H * W * Cc, Cc, be.ptr(packed), be.ptr(bd) if bd is not None else None,
+                                                     frames, H, W, Cc, N, be.ptr(out), be.stream), 's2 fwd')
+    return be.host(out)
+
+
 def conv2d_dgrad_s2_fused_bf16(be, dy, w):
     """Stride-2 3x3 input gradient on even extents, all four parity classes in one launch (lu_conv2d_s2_dgrad_bf16)."""
     k, _, Cc, N = w.shape

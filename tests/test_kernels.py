@@ -277,6 +277,18 @@ def test_conv_bf16_narrow_blocks(be):
     close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1), ref, 5e-5)
 
 
+def test_conv_s2_fwd_bf16(be):
+    """bf16 mode: the stride-2 3x3 forward convolution (Networks.py:52-56) reading the bf16 copy of the ConvLSTM output, input
+    pixels staged by column parity.  Against the oracle on bf16-rounded operands and against the gather kernel it replaces;
+    ragged tiles, several chunks, N beyond one 128-column tile, channel counts that are not multiples of 32."""
+    R = KH.bf16_round
+    for (fr, H, W, Cc, N) in [(1, 8, 64, 32, 32), (2, 10, 74, 64, 96), (1, 6, 32, 40, 160), (1, 16, 128, 128, 128)]:
+        x, w, b = rnd(fr, H, W, Cc), rnd(3, 3, Cc, N, scale=0.2), rnd(N)
+        got = KH.conv2d_s2_fwd_bf16(be, x, w, b)
+        close(got, npo.conv2d_same(R(x), R(w), b, 2), 5e-5)
+        close(got, KH.conv2d(be, [x], [w], b, 3, 2, precision=1), 5e-5)
+
+
 def test_conv_s2_dgrad_fused_bf16(be):
     """bf16 mode: input gradient of the stride-2 3x3 layers (Networks.py:52-56) with all four output parity classes in one
     launch.  Against torch's gradient on bf16-rounded operands (summation order only), and against the four parity-plane
