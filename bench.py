@@ -285,12 +285,15 @@ def main():
         trainer.engine.act_bf16 = False
     ops.WGRAD_FLAGS |= args.wgrad_flags
     ops.CONV_FLAGS |= args.conv_flags
-    if args.conv_flags & 4096:      # (LU_CONV_F_NO_NARROW doubles as the A/B switch of the round-3 stride-2 kernels)
-        trainer.engine.s2_fwd_bf16 = False
+    if args.conv_flags & 4096:      # (LU_CONV_F_NO_NARROW doubles as the A/B switch of the round-3 stride-2 kernels; the gather kernel
+        trainer.engine.s2_fwd_bf16 = False      # it sends the N = 32 / 64 layers to reads fp32 tensors only)
+        trainer.engine.narrow_bf16 = False
+        trainer.engine.act_bf16 = False
     if args.ab_old_tail:
         from lu_native import cabi
         trainer.engine.narrow_bf16 = False
         trainer.engine.s2_fwd_bf16 = False
+        trainer.engine.act_bf16 = False
         ops.CONV_FLAGS |= cabi.LU_CONV_F_NO_NARROW
         ops.WGRAD_FLAGS |= cabi.LU_WGRAD_F_NO_NARROW_BF16
 

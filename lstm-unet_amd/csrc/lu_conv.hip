@@ -1546,8 +1546,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_dgrad_bf16_kernel(S2DgradArgs 
     __syncthreads();
     const int khalf16 = 16 * (lane >> 5);
     int hb = 0;
-    float4 b0, b1;
+    float4 b0, b1, c0, c1;      // the weight fragments of the current tap and of the next one (two taps in flight)
     load_b(0, 0, b0, b1);
+    load_b(1, 0, c0, c1);
     for (int chunk = 0; chunk < nch; ++chunk) {
         const bool more = chunk + 1 < nch;
         lu_u4 rn[HPASS];
@@ -1560,8 +1561,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2_dgrad_bf16_kernel(S2DgradArgs 
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             float4 n0v, n1v;
-            if (t + 1 < 9) load_b(t + 1, chunk, n0v, n1v);
-            else load_b(0, more ? chunk + 1 : chunk, n0v, n1v);
+            if (t + 2 < 9) load_b(t + 2, chunk, n0v, n1v);
+            else load_b(t + 2 - 9, more ? chunk + 1 : chunk, n0v, n1v);
             const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
             // halo row hy = (output row i) + 1 + dy, halo column = pixel + 1 + dx
             const unsigned char* ab = &Ah[hb][((1 + T_DY[t]) * HWD + (lane & 31) + 1 + T_DX[t]) * PITCH + khalf16];
@@ -1575,8 +1576,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2_dgrad_bf16_kernel(S2DgradArgs 
             for (int i = 0; i < RW; ++i) acc[T_CLS[t]][i] = lu_mfma_bf16(a0[i], bv0, acc[T_CLS[t]][i]);
 #pragma unroll
             for (int i = 0; i < RW; ++i) acc[T_CLS[t]][i] = lu_mfma_bf16(a1[i], bv1, acc[T_CLS[t]][i]);
-            b0 = n0v;
-            b1 = n1v;
+            b0 = c0;
+            b1 = c1;
+            c0 = n0v;
+            c1 = n1v;
         }
         if (more) {
 #pragma unroll
