@@ -624,23 +624,17 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         }
     };
 
-    // ---- halo gather bookkeeping (independent of source / chunk) ----
-    int hoff[HPASS];
-    bool hok[HPASS];
-#pragma unroll
-    for (int i = 0; i < HPASS; ++i) {
-        const int hp = (tid + NT * i) >> 2;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        hok[i] = hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        hoff[i] = iy * a.Win + ix;
-    }
+    // ---- halo gather: piece i of a thread is 4 channels of halo pixel (tid + 512 i) / 4.  The staging registers are a NATIVE
+    // vector type and the pixel offsets are recomputed per chunk (a handful of integer ops every K*K stages): as `float4 rh[]` +
+    // `int hoff[]` captured by the lambdas the arrays lived in SCRATCH memory (80 bytes per thread, rounds 1-2) -- every chunk the
+    // kernel waited for its halo loads right where it issued them (s_waitcnt vmcnt + scratch_store) instead of under the MFMAs
+    // of the stage, and the scratch lines showed up as 3-6x the algorithmic bytes in WRITE_SIZE / FETCH_SIZE.
     const int q = tid & 3;
     // ---- B bookkeeping: 16 rows x 32 float4, one per thread ----
     const int bq = tid & 31, brow = tid >> 5;
     const int bcol = (EPI == LU_EPI_LSTM) ? (bq >> 3) * a.F + nt * 32 + 4 * (bq & 7) : n0 + 4 * bq;
 
-    float4 rh[HPASS];
+    lu_u4 rh[HPASS];
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_halo = [&](const IterState& st) {
         const int c = st.chunk * CK + 4 * q;
@@ -649,15 +643,19 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         const bool cok = c < (st.s ? C_s1 : C_s0);
 #pragma unroll
         for (int i = 0; i < HPASS; ++i) {
-            const float* p = base + (int64_t)hoff[i] * ps;
-            rh[i] = *reinterpret_cast<const float4*>((hok[i] && cok) ? p : zp);
+            const int hp = (tid + NT * i) >> 2;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+            const bool ok = cok && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const float* p = base + (int64_t)(iy * a.Win + ix) * ps;
+            rh[i] = *reinterpret_cast<const lu_u4*>(ok ? p : zp);
         }
     };
     auto store_halo = [&]() {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i) {
             const int hp = (tid + NT * i) >> 2;
-            if (hp < HP) *reinterpret_cast<float4*>(&Ah[hp * A_LD + 4 * q]) = rh[i];
+            if (hp < HP) *reinterpret_cast<lu_u4*>(&Ah[hp * A_LD + 4 * q]) = rh[i];
         }
     };
     auto load_b = [&](const SrcInfo& si, bool thin, int tap_v, int chunk) {
