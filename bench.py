@@ -234,6 +234,8 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='clip slots per GPU')
     ap.add_argument('--unroll', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--by-shape', default=None, metavar='FILE',
+                    help='also write the HIP-event timings grouped by (kernel class, work per launch) -- one row per layer shape')
     ap.add_argument('--no-infer', action='store_true', help='skip the secondary streaming-inference measurement')
     ap.add_argument('--no-bf16', action='store_true', help='skip the secondary bf16-mode measurement of the same step')
     ap.add_argument('--sync-bn', action='store_true')
@@ -241,6 +243,8 @@ def main():
     ap.add_argument('--wgrad-flags', type=int, default=0, help='A/B: LU_WGRAD_F_* bits OR-ed into every weight-gradient descriptor')
     ap.add_argument('--conv-flags', type=int, default=0, help='A/B: LU_CONV_F_* bits OR-ed into every convolution descriptor')
     ap.add_argument('--ab-f32-act', action='store_true', help='A/B: bf16 mode with every activation stored as fp32 (round 2 / early round 3)')
+    ap.add_argument('--ab-no-prep', action='store_true',
+                    help='A/B: derived weight images one launch at a time per step, recurrent state copied / masked eagerly (before round 3)')
     ap.add_argument('--ab-old-tail', action='store_true',
                     help='A/B: bf16 mode with the decoder tail on the kernels of round 2 (gather / fp32 tiles, fp32 all-taps weight gradients)')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
@@ -283,6 +287,8 @@ def main():
         trainer.engine.overlap_wgrad = False
     if args.ab_f32_act:
         trainer.engine.act_bf16 = False
+    if args.ab_no_prep:
+        trainer.engine.prep_batch = False
     ops.WGRAD_FLAGS |= args.wgrad_flags
     ops.CONV_FLAGS |= args.conv_flags
     if args.conv_flags & 4096:      # (LU_CONV_F_NO_NARROW doubles as the A/B switch of the round-3 stride-2 kernels; the gather kernel
@@ -367,6 +373,10 @@ def main():
 
         from lu_native.profile import summarize_events
         rows, hbm_rows = summarize_events(ev)
+        if args.by_shape:
+            from lu_native.profile import by_shape
+            with open(args.by_shape, 'w') as fh:
+                json.dump({'build_id': build_id, 'precision': args.precision, 'rows': by_shape(ev)}, fh, indent=1)
         for r_ in rows:
             r_['traffic'] = traffic_of(r_['kernel'])
         if rows:

@@ -155,6 +155,25 @@ int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream);
 int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_tot, int N, int c_off, int C_sub,
                              lu_stream_t stream);
 
+/* All derived weight images of a step in one launch per dependency level (the optimiser changes every parameter at once; the
+ * reference has no counterpart: Keras layers read their variables directly, Networks.py:48-58).  One record per
+ * lu_weight_flip_transpose (kind 0: src = w, dst = wt, k, C_tot, N, c_off, C = C_sub; 256-thread blocks, one per (tap, 32 x 32
+ * tile): nblk = k*k * ceil(C_sub/32) * ceil(N/32)) or lu_pack_weights_bf16 (kind 1: src, tap_stride, row_stride, kk = k*k, C, N,
+ * dst; any nblk >= 1, the blocks stride over one thread per 8 packed elements).  The table lives in DEVICE memory, sorted by
+ * blk0, blk0 = running sum of nblk; results are those of the single calls, bit for bit. */
+typedef struct lu_prep_op {
+    int32_t kind;
+    int32_t blk0, nblk;
+    int32_t k;
+    const float* src;
+    void* dst;
+    int64_t tap_stride;
+    int32_t row_stride, kk;
+    int32_t C, N;
+    int32_t C_tot, c_off;
+} lu_prep_op;
+int lu_weight_prep_batch(const void* dev_ops, int n_ops, int total_blocks, lu_stream_t stream);
+
 /* Input gradient of a STRIDE-2 convolution without multiplying zeros: the four output parity classes
  * (py, px) are four small stride-1 convolutions of dy.  This packs their kernels:
  *   plane cls = 2*py+px:  sub_cls[ty][tx][n][c] = w[kh][kw][c][n],  kh = py + pad_t - 2*(ty - pady[py]), kw likewise,
@@ -353,6 +372,12 @@ int lu_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 
 /* state mask (Networks.py:77-84): x[f, :] *= keep[f] */
 int lu_scale_frames(float* x, const float* keep, int32_t frames, int64_t per_frame, lu_stream_t stream);
+
+/* the same mask applied while a training window STARTS (one pass instead of mask + copy + bf16 copy): dst[f, :] = src[f, :] *
+ * keep[f] (src NULL: zeros -- reset_states(None); keep NULL: plain copy), dst_bf16 (optional) = the rounded copy of dst the
+ * bf16 kernels read.  dst is slot 0 of the h / c tape of a ConvLSTM layer, src the state carried from the previous window. */
+int lu_state_begin(float* dst, void* dst_bf16, const float* src, const float* keep, int32_t frames, int64_t per_frame,
+                   lu_stream_t stream);
 
 /* [n, a, b] -> [n, b, a]  (NCHW <-> NHWC at the public boundary, losses.py:17-18, train2D.py:98-100) */
 int lu_transpose_inner(const float* x, float* y, int64_t n, int32_t a, int32_t b, lu_stream_t stream);

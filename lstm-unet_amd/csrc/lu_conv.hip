@@ -827,13 +827,13 @@ constexpr int CKB = 32;      // channels per stage (two k = 16 MFMA steps)
 constexpr int LDB = CKB + 8; // bf16 elements per halo pixel in LDS (80 B: conflict-free ds_read_b128, see A_LD)
 
 // packed index of (tap, chunk, column n, channel c):  fragment-major, then k-step, lane, element
-__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C,
-                                         int N, unsigned short* __restrict__ out) {
+__device__ __forceinline__ void pack_weights_bf16_body(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk,
+                                                       int C, int N, unsigned short* __restrict__ out, int64_t first, int64_t step) {
     // one thread = one lane's fragment (8 consecutive channels of one column): eight reads that are coalesced ACROSS the lanes
     // (consecutive columns), one 16-byte store (75 M weights are re-packed after every optimiser step)
     const int nchunk = (C + CKB - 1) / CKB, nfr = (N + 31) / 32;
     const int64_t total = (int64_t)kk * nchunk * nfr * 128;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = first; i < total; i += step) {
         const int ln = (int)(i & 63), j = (int)((i >> 6) & 1);
         int64_t t = i >> 7;
         const int fr = (int)(t % nfr);
@@ -854,6 +854,12 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t ta
         pk.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
         *reinterpret_cast<lu_u4*>(out + (i << 3)) = pk;
     }
+}
+
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C,
+                                         int N, unsigned short* __restrict__ out) {
+    pack_weights_bf16_body(w, tap_stride, row_stride, kk, C, N, out, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                           (int64_t)gridDim.x * blockDim.x);
 }
 
 // fp32 counterpart of pack_weights_bf16_kernel: [tap][16-channel chunk][column fragment][s][lane][4 floats] with
@@ -1969,12 +1975,9 @@ __global__ void post_affine_kernel(float* __restrict__ out, int64_t total, int N
 }
 
 // wt[kh'][kw'][co][ci] = w[k-1-kh'][k-1-kw'][c_off+ci][co]
-__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int C_tot, int N,
-                                      int c_off, int C_sub) {
-    // one block per (tap, 32x32 tile); LDS transpose for coalescing on both sides
-    __shared__ float tile[32][33];
-    const int tap = blockIdx.z;
-    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+// one block per (tap, 32x32 tile); LDS transpose for coalescing on both sides.  256 threads.
+__device__ __forceinline__ void flip_transpose_body(const float* __restrict__ w, float* __restrict__ wt, int k, int C_tot, int N,
+                                                    int c_off, int C_sub, int tap, int ci0, int co0, float (*tile)[33]) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
     const int src_tap = k * k - 1 - tap;
     for (int r = ty; r < 32; r += 8) {
@@ -1985,6 +1988,49 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
     for (int r = ty; r < 32; r += 8) {
         int co = co0 + r, ci = ci0 + tx;
         if (co < N && ci < C_sub) wt[((int64_t)tap * N + co) * C_sub + ci] = tile[tx][r];
+    }
+}
+
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int C_tot, int N,
+                                      int c_off, int C_sub) {
+    __shared__ float tile[32][33];
+    flip_transpose_body(w, wt, k, C_tot, N, c_off, C_sub, blockIdx.z, blockIdx.y * 32, blockIdx.x * 32, tile);
+}
+
+// Every derived weight image of a training step in TWO launches (lu_weight_prep_batch): the optimiser changes all
+// parameters at once, and ~80 separate 8-10 us flips / packs per step were 0.7 ms of a 75 ms bf16 step.  A block finds its
+// operation by bisection over the (block-offset sorted) table in device memory and runs the single-operation body on it.
+struct PrepOp {              // = lu_prep_op (include/lstm_unet_hip.h)
+    int32_t kind;            // 0: flip_transpose, 1: pack_weights_bf16
+    int32_t blk0, nblk;      // this operation's blocks: [blk0, blk0 + nblk)
+    int32_t k;               // flip: kernel size
+    const float* src;
+    void* dst;
+    int64_t tap_stride;      // pack: elements between taps / channel rows of src
+    int32_t row_stride, kk;  // pack: taps
+    int32_t C, N;            // pack: channels, columns.  flip: C_sub, N
+    int32_t C_tot, c_off;    // flip
+};
+
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const PrepOp* __restrict__ ops, int n_ops) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n_ops - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {        // last operation with blk0 <= b (uniform per block)
+        const int mid = (lo + hi + 1) >> 1;
+        if (ops[mid].blk0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PrepOp op = ops[lo];
+    const int lb = b - op.blk0;
+    if (lb >= op.nblk) return;
+    if (op.kind == 0) {
+        const int nx = (op.N + 31) / 32, ny = (op.C + 31) / 32;
+        const int tap = lb / (nx * ny), r = lb - tap * nx * ny;
+        flip_transpose_body(op.src, (float*)op.dst, op.k, op.C_tot, op.N, op.c_off, op.C, tap, (r / nx) * 32, (r % nx) * 32, tile);
+    } else {
+        pack_weights_bf16_body(op.src, op.tap_stride, op.row_stride, op.kk, op.C, op.N, (unsigned short*)op.dst,
+                               (int64_t)lb * 256 + threadIdx.x, (int64_t)op.nblk * 256);
     }
 }
 
@@ -2465,5 +2511,13 @@ extern "C" int lu_weight_flip_transpose(const float* w, float* wt, int k, int C_
                "lu_weight_flip_transpose: bad arguments");
     dim3 grid((N + 31) / 32, (C_sub + 31) / 32, k * k);
     LU_LAUNCH(flip_transpose_kernel, grid, dim3(256), stream, w, wt, k, C_tot, N, c_off, C_sub);
+    return LU_CHECK_LAUNCH();
+}
+
+/* dev_ops: n_ops lu_prep_op records in DEVICE memory, sorted by blk0, covering blocks [0, total_blocks). */
+extern "C" int lu_weight_prep_batch(const void* dev_ops, int n_ops, int total_blocks, lu_stream_t stream) {
+    static_assert(sizeof(PrepOp) == 64, "lu_prep_op layout");
+    LU_REQUIRE(dev_ops && n_ops > 0 && total_blocks > 0, "lu_weight_prep_batch: bad arguments");
+    LU_LAUNCH(weight_prep_batch_kernel, dim3((unsigned)total_blocks), dim3(256), stream, (const PrepOp*)dev_ops, n_ops);
     return LU_CHECK_LAUNCH();
 }

@@ -21,7 +21,7 @@ void lu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
-extern "C" int lu_abi_version(void) { return 6; }
+extern "C" int lu_abi_version(void) { return 7; }
 
 // ---------------------------------------------------------------------------------------------
 // CRC-32C (Castagnoli), slicing-by-8, HOST code: the checksum of TensorFlow tensor bundles (tf_bundle.py reads / writes
@@ -893,6 +893,40 @@ __global__ void scale_frames_kernel(float* __restrict__ x, const float* __restri
         x[i] *= keep[i / per_frame];
 }
 
+// Start of a training window for one ConvLSTM state tensor, one pass instead of three (keep mask in place, copy into slot 0 of
+// the tape, bf16 copy):  dst[f, :] = src ? src[f, :] * keep[f] : 0, dst16 = bf16(dst).  blockIdx.y = frame; VEC: float4 lanes.
+template <bool VEC>
+__global__ void state_begin_kernel(float* __restrict__ dst, unsigned short* __restrict__ dst16, const float* __restrict__ src,
+                                   const float* __restrict__ keep, int64_t per_frame) {
+    const int f = blockIdx.y;
+    const float kf = (src && keep) ? keep[f] : 1.f;
+    const int64_t base = (int64_t)f * per_frame;
+    if (VEC) {
+        const int64_t n4 = per_frame >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src) {
+                v = *reinterpret_cast<const float4*>(src + base + 4 * i);
+                if (keep) { v.x *= kf; v.y *= kf; v.z *= kf; v.w *= kf; }
+            }
+            *reinterpret_cast<float4*>(dst + base + 4 * i) = v;
+            if (dst16) {
+                lu_u2 b;
+                b.x = lu_pack2bf(v.x, v.y);
+                b.y = lu_pack2bf(v.z, v.w);
+                *reinterpret_cast<lu_u2*>(dst16 + base + 4 * i) = b;
+            }
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < per_frame; i += (int64_t)gridDim.x * NT) {
+            float v = 0.f;
+            if (src) v = keep ? src[base + i] * kf : src[base + i];
+            dst[base + i] = v;
+            if (dst16) dst16[base + i] = lu_f2bf(v);
+        }
+    }
+}
+
 __global__ void transpose_inner_kernel(const float* __restrict__ x, float* __restrict__ y, int a, int b) {
     __shared__ float tile[32][33];
     const int64_t n = blockIdx.z;
@@ -1187,6 +1221,22 @@ extern "C" int lu_scale_frames(float* x, const float* keep, int32_t frames, int6
     LU_REQUIRE(x && keep && frames > 0 && per_frame > 0, "lu_scale_frames: bad arguments");
     const int64_t total = (int64_t)frames * per_frame;
     LU_LAUNCH(scale_frames_kernel, dim3(grid_for(total)), dim3(NT), stream, x, keep, per_frame, total);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_state_begin(float* dst, void* dst_bf16, const float* src, const float* keep, int32_t frames, int64_t per_frame,
+                              lu_stream_t stream) {
+    LU_REQUIRE(dst && frames > 0 && frames < 65536 && per_frame > 0, "lu_state_begin: bad arguments");
+    const bool vec = per_frame % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dst_bf16) & 7) == 0;
+    unsigned gx = grid_for(vec ? per_frame / 4 : per_frame);
+    if (gx > 4096) gx = 4096;
+    if (vec)
+        LU_LAUNCH(state_begin_kernel<true>, dim3(gx, (unsigned)frames), dim3(NT), stream, dst, (unsigned short*)dst_bf16, src, keep,
+                  per_frame);
+    else
+        LU_LAUNCH(state_begin_kernel<false>, dim3(gx, (unsigned)frames), dim3(NT), stream, dst, (unsigned short*)dst_bf16, src, keep,
+                  per_frame);
     return LU_CHECK_LAUNCH();
 }
 

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 6          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 7          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -48,6 +48,11 @@ class WgradDesc(C.Structure):
                 ('dbias', c_f32p), ('dbias_beta', f32), ('phase', i32), ('x_dtype', i32), ('dy_dtype', i32), ('flags', i32)]
 
 
+class PrepOp(C.Structure):      # lu_prep_op: one flip (kind 0) / bf16 pack (kind 1) of lu_weight_prep_batch's device table
+    _fields_ = [('kind', i32), ('blk0', i32), ('nblk', i32), ('k', i32), ('src', c_f32p), ('dst', C.c_void_p),
+                ('tap_stride', i64), ('row_stride', i32), ('kk', i32), ('C', i32), ('N', i32), ('C_tot', i32), ('c_off', i32)]
+
+
 P = C.c_void_p
 S = C.c_void_p  # stream
 PROTOTYPES = {
@@ -62,6 +67,7 @@ PROTOTYPES = {
     'lu_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'lu_stride2_dgrad_weights': (C.c_int, [P, P] + [C.c_int] * 10 + [S]),
     'lu_weight_flip_transpose': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, S]),
+    'lu_weight_prep_batch': (C.c_int, [P, C.c_int, C.c_int, S]),
     'lu_conv2d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'lu_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), S]),
     'lu_lstm_gates_fwd': (C.c_int, [P, P, P, P, P, i32, i64, i32, i64, S]),
@@ -89,6 +95,7 @@ PROTOTYPES = {
     'lu_softmax3': (C.c_int, [P, P, i64, S]),
     'lu_adam_step': (C.c_int, [P, P, P, P, i64, f32, f32, f32, f32, f32, S]),
     'lu_scale_frames': (C.c_int, [P, P, i32, i64, S]),
+    'lu_state_begin': (C.c_int, [P, P, P, P, i32, i64, S]),
     'lu_transpose_inner': (C.c_int, [P, P, i64, i32, i32, S]),
     'lu_add_inplace': (C.c_int, [P, P, i64, S]),
     'lu_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import wbank
 from .plan import make_plan, param_specs, bn_stat_specs, init_tensor
 
 LRELU_ALPHA = 0.3   # k.layers.LeakyReLU() default
@@ -73,6 +74,10 @@ class Engine:
         self.resize = resize
         self._packed_version = -1
         self._packed = {}    # (param name, role, c_off, c_sub) -> ops.PackedW; dropped whenever the weights change
+        self.bank = wbank.WeightBank()      # flipped / packed images of parameter VIEWS: kept, refreshed by two launches per step
+        self._bank_stale = False
+        self.prep_batch = True       # A/B (bench.py --ab-no-prep): False = derived weight images rebuilt one launch at a time per step,
+                                     # state owned + masked eagerly (the round-2 behaviour)
         self.net_params = net_params
         self._plan_fn = plan_fn if plan_fn is not None else (lambda cin: make_plan(net_params, cin))
         self.pad_image = bool(pad_image)
@@ -84,7 +89,10 @@ class Engine:
         self.P = {}       # name -> view into flat_params
         self.G = {}       # name -> view into flat_grads
         self.S = {}       # BN moving statistics
-        self.states = None   # [block][layer] -> [h, c] device tensors or None
+        self._states = None  # [block][layer] -> [h, c] device tensors or None; read through `states` (see _own_states)
+        self._keep = None    # state mask of reset_states_per_batch not applied yet: the next training window applies it while
+                             # it copies the state into its tape (ops.state_begin), anything else through _own_states()
+        self._alias = set()  # (block, layer) whose state tensors are VIEWS of the last training tape (slot T of h_all / c_all)
         self.batch = None
         self.tape = None
         self.segments = []   # [(name, start, end)] gradient buckets in backward-completion order
@@ -107,6 +115,38 @@ class Engine:
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
                                          # tensors instead of adopting the step's output tensors as the state
+
+    @property
+    def states(self):
+        """[block][layer] -> [h, c] (or None = zeros), materialised: own tensors, pending mask applied."""
+        self._own_states()
+        return self._states
+
+    @states.setter
+    def states(self, value):
+        self._states = value
+        self._keep = None
+        self._alias = set()
+
+    def _own_states(self):
+        """A training window leaves the state as views of its tape and reset_states_per_batch only records its mask -- the
+        next training window consumes both in one pass per tensor.  Every other reader (inference, get / set_states, tests,
+        the hipGraph path) sees plain tensors: views are cloned (the tape may still be needed by backward, and must not stay
+        pinned), then the pending mask is applied in place."""
+        if self._states is None:
+            return
+        for (bi, li) in sorted(self._alias):
+            st = self._states[bi][li]
+            if st is not None:
+                self._states[bi][li] = [st[0].clone(), st[1].clone()]
+        self._alias = set()
+        if self._keep is not None:
+            keep, self._keep = self._keep, None
+            for blk in self._states:
+                for st in blk:
+                    if st is not None:
+                        ops.scale_frames(st[0], keep)
+                        ops.scale_frames(st[1], keep)
 
     @property
     def persistent_states(self):
@@ -192,6 +232,7 @@ class Engine:
     def weights_changed(self):
         """Optimiser step / checkpoint load: the cached bf16 weight images and inference BN affines are stale."""
         self._packed.clear()
+        self._bank_stale = True
         self._bn_epoch += 1
 
     def _bf16_conv(self, k, stride, n_out):
@@ -203,11 +244,23 @@ class Engine:
         the halo kernel; oracle/torch_oracle.py restates the same rule)."""
         return self.precision == 'bf16' and (n_out >= 64 or (self.narrow_bf16 and n_out == 32 and stride == 1 and k in (3, 5)))
 
-    def _pack(self, name, role, make, co=0, cs=None, packer=None):
+    def _sync_weight_images(self):
+        """Before any use of a derived weight image: drop the per-step cache and refresh the bank if the parameters changed."""
         ver = self.flat_params._version       # in-place torch updates (copy_, torch optimisers) bump it; the raw-pointer
         if ver != self._packed_version:       # Adam kernel does not, hence Adam.apply_gradients -> weights_changed()
             self._packed.clear()
             self._packed_version = ver
+            self._bank_stale = True
+        if self._bank_stale:
+            self._bank_stale = False
+            self.bank.refresh()
+
+    def _pack(self, name, role, make, co=0, cs=None, packer=None, view=None):
+        """bf16 fragment image of a kernel.  view: the parameter view it is packed from, when it is one (then the bank keeps
+        the image across steps); otherwise make() builds a temporary (zero-padded / rearranged) kernel once per step."""
+        self._sync_weight_images()
+        if view is not None and packer is None and self.prep_batch:
+            return self.bank.pack(view)
         key = (name, role, co, cs)
         pw = self._packed.get(key)
         if pw is None:
@@ -289,7 +342,8 @@ class Engine:
                 wp = torch.zeros((w.shape[0], w.shape[1], cp, w.shape[3]), device=w.device, dtype=torch.float32)
                 wp[:, :, :cs] = w[:, :, co:co + cs, :]
                 return wp
-            pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs, cp=x.shape[3]: padded(co, cs, cp), co, cs))
+            pairs = [(x, self._pack(wname, 'fwd', lambda co=co, cs=cs, cp=x.shape[3]: padded(co, cs, cp), co, cs,
+                                    view=w[:, :, co:co + cs, :] if x.shape[3] == cs else None))
                      for (x, co, cs) in fsrcs]
         else:
             if any16:
@@ -299,7 +353,7 @@ class Engine:
                 alt16.shape[1] % 2 == 0 and alt16.shape[2] % 2 == 0 and alt16.shape[3] % 8 == 0 and tape is not None):
             # the stride-2 layer behind a ConvLSTM, training: read the bf16 copy of its output (same rounded operands as the
             # gather kernel forms from the fp32 tensor, half the bytes, input pixels staged by column parity)
-            y = ops.conv2d_s2_fwd_bf16(alt16, self._pack(wname, 'fwd', lambda: w), self.P[f'{prefix}.conv.{ci}.bias'])
+            y = ops.conv2d_s2_fwd_bf16(alt16, self._pack(wname, 'fwd', lambda: w, view=w), self.P[f'{prefix}.conv.{ci}.bias'])
             rec = {'kind': 'conv', 'prefix': prefix, 'ci': ci, 'spec': spec, 'srcs': srcs, 'bn': with_bn, 'alt16': alt16}
             tape.append(rec)
             if not with_bn:
@@ -358,7 +412,8 @@ class Engine:
                 ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
                                  dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
-                                        bf16=self._bf16_unit(gw.shape[0], spec['stride'], cs)) if need else None)
+                                        bf16=self._bf16_unit(gw.shape[0], spec['stride'], cs),
+                                        bank=self.bank if self.prep_batch else None) if need else None)
         rec['srcs'] = rec['alt16'] = None
         return dxs
 
@@ -389,19 +444,19 @@ class Engine:
                 kernel = self._pack(pre + '.kernel', 'center', lambda w=w_in: w, packer=ops.pack_center_bf16)
                 x5 = ops.im2col_bf16(x_seq, k).view(T, B, H, W, 32)
             elif src16:
-                kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w)
+                kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w, view=w_in)
                 # one pass per window; also the x operand of the hoisted weight gradient (or the producer stored it as bf16)
                 x16 = x_seq if x_seq.dtype == torch.bfloat16 else ops.to_bf16(x_seq)
                 x5 = x16.view(T, B, H, W, -1)
             else:
-                kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w)
+                kernel = self._pack(pre + '.kernel', 'fwd', lambda w=w_in: w, view=w_in)
                 if Cin % 4 != 0:
                     # the bf16 kernel reads 16-byte channel groups: thin inputs get zero pad channels
                     cpad = -(-Cin // 4) * 4
                     x5 = torch.zeros((T, B, H, W, cpad), device=dev, dtype=torch.float32)
                     x5[..., :Cin] = x_seq.view(T, B, H, W, -1)
-            rec_k = self._pack(pre + '.recurrent_kernel', 'fwd', lambda w=rec_k: w)
-        st = self.states[bi][li]
+            rec_k = self._pack(pre + '.recurrent_kernel', 'fwd', lambda w=rec_k: w, view=rec_k)
+        st = self._states[bi][li]      # (forward() materialised it unless this is a training window)
         if st is not None and tuple(st[0].shape) != (B, H, W, F):
             raise ValueError('stateful ConvLSTM: batch/shape changed from %s to %s' % (tuple(st[0].shape), (B, H, W, F)))
         if tape is None:
@@ -427,34 +482,26 @@ class Engine:
                 st[1].copy_(c_prev)
                 self._state16.pop((bi, li), None)              # (a bf16 copy left by an earlier eager frame is stale now)
             elif self.persistent_states:
-                self.states[bi][li] = [h_prev.clone(), c_prev.clone()]
+                self._states[bi][li] = [h_prev.clone(), c_prev.clone()]
                 self._state16.pop((bi, li), None)
             else:
-                self.states[bi][li] = [h_prev, c_prev]
+                self._states[bi][li] = [h_prev, c_prev]
                 self._state16[(bi, li)] = (h_prev, h16_prev)
             self._h16_seq = None
             return h_seq.view(T * B, H, W, F)
         h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
-        if st is None:
-            h_all[0].zero_()
-            c_all[0].zero_()
-        else:
-            h_all[0].copy_(st[0])
-            c_all[0].copy_(st[1])
-        h16_all = None
-        if tape16:
-            h16_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.bfloat16)
-            ops.to_bf16(h_all[0], out=h16_all[0])
+        # slot 0 of the tape = the carried state times the pending mask of reset_states_per_batch (+ its bf16 copy): one pass
+        h16_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.bfloat16) if tape16 else None
+        ops.state_begin(h_all[0], None if st is None else st[0], self._keep, h16_all[0] if tape16 else None)
+        ops.state_begin(c_all[0], None if st is None else st[1], self._keep)
         gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.bfloat16 if tape16 else torch.float32)
         for t in range(T):
             ops.convlstm_step(x5[t], h16_all[t] if src16 else h_all[t], c_all[t], kernel, rec_k, bias, h_all[t + 1],
                               c_all[t + 1], gates[t], h16_out=h16_all[t + 1] if tape16 else None, x_center=x_center)
-        if st is None:
-            self.states[bi][li] = [h_all[T].clone(), c_all[T].clone()]
-        else:
-            st[0].copy_(h_all[T])
-            st[1].copy_(c_all[T])
+        # the new state IS slot T of this tape (no copy out); whoever needs it as a tensor of its own goes through `states`
+        self._states[bi][li] = [h_all[T], c_all[T]]
+        self._alias.add((bi, li))
         self._state16.pop((bi, li), None)
         if tape is not None:
             tape.append({'kind': 'lstm', 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'h_all': h_all, 'c_all': c_all,
@@ -477,10 +524,13 @@ class Engine:
         dh5 = dh_seq.view(T, B, H, W, F)
         dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
         dh_rec = None
-        rec_kt = ops.flip_transpose(rec_k) if T > 1 else None
-        rec_bf = rec_kt is not None and self._bf16_conv(k, 1, F)
-        if rec_bf:
-            rec_kt = ops.pack_bf16(rec_kt)
+        self._sync_weight_images()
+        rec_bf = T > 1 and self._bf16_conv(k, 1, F)
+        if not self.prep_batch:
+            rec_kt = ops.flip_transpose(rec_k) if T > 1 else None
+            rec_kt = ops.pack_bf16(rec_kt) if rec_bf else rec_kt
+        else:
+            rec_kt = (self.bank.flip_pack(rec_k) if rec_bf else self.bank.flip(rec_k)) if T > 1 else None
         p = (k - 1) // 2
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
@@ -533,7 +583,8 @@ class Engine:
                 ops.conv2d_wgrad(ops.to_f32(x_seq) if x_seq.dtype == torch.bfloat16 else x_seq, dz_f32(), gk, 1, bf16=bf)
         dx = None
         if need_dx:
-            dx = ops.conv2d_dgrad(dz_seq if (dx_bf or not tape16) else dz_f32(), kernel, (H, W), 1, bf16=dx_bf)
+            dx = ops.conv2d_dgrad(dz_seq if (dx_bf or not tape16) else dz_f32(), kernel, (H, W), 1, bf16=dx_bf,
+                                  bank=self.bank if self.prep_batch else None)
         rec['h_all'] = rec['c_all'] = rec['x'] = rec['h16_all'] = rec['x25'] = rec['x16'] = None
         return dx
 
@@ -547,6 +598,8 @@ class Engine:
             raise ValueError('stateful model: batch size is fixed at first call (%d), got %d' % (self.batch, B))
         plan = self.plan
         tape = [] if training else None
+        if not training:
+            self._own_states()      # inference reads the carried state in place
         _, H, W, _ = x_tb.shape
         py, px = model_pads(H, W, plan['total_stride'], self.pad_image)
         if any(py) or any(px):
@@ -597,6 +650,9 @@ class Engine:
             logits = ops.window_copy(logits, (H, W), (-py[0], -px[0]), 0)
         if training:
             self.tape = {'ops': tape, 'pads': (py, px), 'hw': (H, W), 'T': T, 'B': B}
+            self._keep = None       # every ConvLSTM layer applied the pending mask while it read its state
+            if not self.prep_batch:
+                self._own_states()
         return logits
 
     def _wgrad_side(self, *tensors):
@@ -629,6 +685,7 @@ class Engine:
         if self.tape is None:
             raise RuntimeError('backward() needs a training forward first')
         tp, self.tape = self.tape, None
+        self._sync_weight_images()
         tape = tp['ops']
         py, px = tp['pads']
         H, W = tp['hw']
@@ -696,15 +753,13 @@ class Engine:
     # ------------------------------------------------------------------ recurrent state API
     def reset_states_per_batch(self, keep):
         """h, c *= keep[b]  (1 = clip continues, 0 = clip ended; Networks.py:77-84)."""
-        if self.states is None:
+        if self._states is None:
             return
         keep = torch.as_tensor(keep, dtype=torch.float32).reshape(-1).to(self.device)
         self._state16.clear()
-        for blk in self.states:
-            for st in blk:
-                if st is not None:
-                    ops.scale_frames(st[0], keep)
-                    ops.scale_frames(st[1], keep)
+        self._keep = keep if self._keep is None else self._keep * keep      # applied by the next reader (see _own_states)
+        if not self.prep_batch:
+            self._own_states()
 
     def get_states(self):
         if self.states is None:

@@ -227,7 +227,7 @@ def flip_transpose(w, c_off=0, c_sub=None):
     return wt
 
 
-def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None, bf16=False):
+def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None, bf16=False, bank=None):
     """Gradient w.r.t. (channels [c_off, c_off+c_sub) of) the input of conv2d(x, w, stride): a
     convolution of the (zero-dilated when stride == 2) dy with the flipped / transposed kernel."""
     _chk(dy, w)
@@ -240,11 +240,12 @@ def conv2d_dgrad(dy, w, in_hw, stride, c_off=0, c_sub=None, out=None, bf16=False
     _chk(dy, w)
     if stride == 2 and c_off == 0 and (c_sub is None or c_sub == w.shape[2]) and out is None and k > 1:
         return _conv2d_dgrad_stride2(dy, w, Hin, Win, pt, pl, bf16)
-    wt = flip_transpose(w, c_off, c_sub)
+    # bank (lu_native/wbank.py): the flipped (+ packed) kernel is kept across steps and refreshed in a batch by its owner
+    wt = flip_transpose(w, c_off, c_sub) if bank is None else bank.flip(w, c_off, c_sub)
     frames, Hd, Wd, N = dy.shape
     Cs = wt.shape[3]
     if bf16 and stride == 1:      # (the zero-dilated form of a stride-2 layer's gradient has no bf16 kernel)
-        wt = pack_bf16(wt)
+        wt = pack_bf16(wt) if bank is None else bank.pack(wt)
     if out is None:
         out = torch.empty((frames, Hin, Win, Cs), device=dy.device, dtype=torch.float32)
     return conv_raw([(dy, wt)], frames, Hd, Wd, Hin, Win, k, 1, stride, k - 1 - pt, k - 1 - pl, Cs, None, out)
@@ -705,6 +706,16 @@ def scale_frames(x, keep):
     assert x.is_contiguous()
     calls.check(lib(), lib().lu_scale_frames(x.data_ptr(), keep.data_ptr(), x.shape[0], x.numel() // x.shape[0],
                                              _stream()), 'lu_scale_frames')
+
+
+def state_begin(dst, src, keep, dst16=None):
+    """dst [B,...] = src * keep[b] (src None: zeros; keep None: copy), dst16 = its bf16 copy -- lu_state_begin."""
+    _chk(dst, src, keep, dst16)
+    assert dst.is_contiguous() and (src is None or (src.is_contiguous() and src.shape == dst.shape))
+    assert dst16 is None or (dst16.is_contiguous() and dst16.shape == dst.shape and dst16.dtype == torch.bfloat16)
+    assert keep is None or keep.numel() == dst.shape[0]
+    calls.check(lib(), lib().lu_state_begin(dst.data_ptr(), _p(dst16), _p(src), _p(keep), dst.shape[0], dst.numel() // dst.shape[0],
+                                            _stream()), 'lu_state_begin')
 
 
 def transpose_inner(x, n, a, b):

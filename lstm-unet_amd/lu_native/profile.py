@@ -34,3 +34,24 @@ def summarize_events(events):
     rows.sort(key=lambda r_: -r_['ms_per_step'])
     hbm_rows.sort(key=lambda r_: -r_['ms_per_step'])
     return rows, hbm_rows
+
+
+def by_shape(events):
+    """The same events grouped by (kernel class, algorithmic work per launch) -- one row per layer shape, so that the levels of
+    the U-Net (and the tile-starved coarse ones among them) can be read apart inside a class: bench.py --by-shape."""
+    shapes = {}
+    for kind, work, e0, e1 in events:
+        c = shapes.setdefault((kind, float(work)), {'ms': 0.0, 'n': 0})
+        c['ms'] += e0.elapsed_time(e1)
+        c['n'] += 1
+    rows = []
+    for (kind, work), c in shapes.items():
+        if c['ms'] <= 0:
+            continue
+        hbm = kind.startswith('hbm:')
+        rate = work * c['n'] / (c['ms'] * 1e-3) / (1e9 if hbm else 1e12)
+        peak = PEAK_HBM_GBS if hbm else PEAK_BF16_MFMA_TFLOPS if 'bf16' in kind else PEAK_FP32_MFMA_TFLOPS
+        rows.append({'kernel': kind.split(' ')[0], 'work_per_launch': work, 'launches': c['n'], 'avg_launch_ms': round(c['ms'] / c['n'], 4),
+                     'ms_per_step': round(c['ms'], 3), 'achieved': round(rate, 1), 'frac': round(rate / peak, 4)})
+    rows.sort(key=lambda r_: -r_['ms_per_step'])
+    return rows

@@ -577,3 +577,50 @@ def test_block_and_layer_views_share_the_model_parameters(dev):
     ce = losses.WeightedCELoss(4, [0.15, 0.25, 0.6])
     host = logits.detach().cpu().numpy()
     assert abs(float(ce(gt, host)) - float(ce(gt, logits))) <= 1e-7
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precision):
+    """A training window leaves the state as views of its tape, reset_states_per_batch only records its mask, and the next
+    training window applies both in one pass (ops.state_begin); a reader in between (`states`, get_states, inference) makes
+    the state own its tensors and applies the mask in place.  Both routes must give the same bits, the derived weight images
+    refreshed in a batch (lu_native/wbank.py) the same bits as freshly built ones."""
+    from lu_native.engine import Adam, Engine
+    name, net, cin, B, T, H, W, pad = CASES[3]
+    if precision == 'bf16':      # wide enough for the bf16 kernels: packed forward kernels and packed flips in the bank
+        net, cin, B, T, H, W, pad = ACT16_NET, 1, 2, 2, 16, 32, False
+    rng = np.random.default_rng(5)
+    xs = [rng.standard_normal((B, T, H, W, cin)).astype(np.float32) for _ in range(3)]
+    keeps = [np.array([1.0, 0.0][:B], np.float32), np.array([0.0, 1.0][:B], np.float32)]
+    p = perturbed_params(net, cin, 4)
+    dl = rng.standard_normal((T * B, H, W, 3)).astype(np.float32) * 1e-2
+    outs = []
+    for lazy in (True, False):
+        e = Engine(net, pad_image=pad, precision=precision)
+        e.build(cin, dev)
+        e.load_params(p)
+        opt = Adam(e, lr=1e-3)
+        got = []
+        for w in range(3):
+            lg = e.forward(torch.from_numpy(to_tb(xs[w])).to(dev), T, B, True)
+            e.backward(torch.from_numpy(dl).to(dev))
+            opt.apply_gradients()
+            if not lazy:
+                e.bank = type(e.bank)()                        # fresh weight images every step instead of the batch refresh
+                assert len(e._alias) and e.states is not None and not e._alias      # reading `states` made them own tensors
+            if w < 2:
+                e.reset_states_per_batch(keeps[w])
+                if lazy:
+                    assert e._keep is not None and e._alias    # nothing applied yet
+                else:
+                    e.get_states()
+                    assert e._keep is None
+            got.append(lg.cpu().numpy())
+        if lazy:
+            assert e.bank.refreshes >= 2 and len(e.bank._flips) and (precision == 'fp32' or len(e.bank._packs))
+        got.append(e.flat_params.cpu().numpy())
+        st = e.get_states()
+        got += [t for blk in st for l in blk for t in l]
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

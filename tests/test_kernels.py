@@ -824,3 +824,51 @@ def test_bf16_tape_pointwise(be):
             for kw in range(k):
                 ref[..., (kh * k + kw) * cin:(kh * k + kw + 1) * cin] = xp[:, kh:kh + 6, kw:kw + 7, :]
         assert np.array_equal(KH.bf16_values(be.host(y)), R(ref))
+
+
+def test_weight_prep_batch_equals_the_single_calls(be):
+    """lu_weight_prep_batch: flips and bf16 packs of several kernels (ragged channel / column counts, a channel-slice flip, a
+    pack of a channel-slice VIEW, a pack of a flip's output in the second launch) from one device table each -- bit for bit the
+    images lu_weight_flip_transpose / lu_pack_weights_bf16 write."""
+    ws = [rnd(3, 3, 40, 70), rnd(5, 5, 33, 64), rnd(1, 1, 32, 3), rnd(3, 3, 65, 32)]
+    wd = [be.dev(w) for w in ws]
+    flips = [(0, 0, 40), (1, 0, 33), (3, 1, 64), (2, 0, 32)]            # (kernel, c_off, c_sub)
+    flip_ref = [KH.flip_transpose(be, ws[i], co, cs) for i, co, cs in flips]
+    flip_out = [be.empty(r.shape) for r in flip_ref]
+
+    def table(records):
+        arr = (cabi.PrepOp * len(records))()
+        blk = 0
+        for o, rec in zip(arr, records):
+            for name, val in rec.items():
+                setattr(o, name, val)
+            o.blk0 = blk
+            blk += rec['nblk']
+        return be.dev(np.frombuffer(bytes(arr), np.uint8), np.uint8), len(records), blk
+
+    recs = []
+    for (i, co, cs), out in zip(flips, flip_out):
+        k, _, Ct, N = ws[i].shape
+        recs.append(dict(kind=0, k=k, src=be.ptr(wd[i]), dst=be.ptr(out), C=cs, N=N, C_tot=Ct, c_off=co,
+                         nblk=k * k * -(-cs // 32) * -(-N // 32)))
+    t, n, blocks = table(recs)
+    calls.check(be.lib, be.lib.lu_weight_prep_batch(be.ptr(t), n, blocks, be.stream), 'prep flips')
+    for out, ref in zip(flip_out, flip_ref):
+        assert np.array_equal(be.host(out), ref)
+
+    # packs: whole kernels, a channel slice [8, 40) of kernel 0 (view strides), and the flip of kernel 1 (second level)
+    packs = [(wd[0], 0, 3, 40, 70, 40 * 70, 70), (wd[1], 0, 5, 33, 64, 33 * 64, 64), (wd[0], 8 * 70, 3, 32, 70, 40 * 70, 70),
+             (flip_out[1], 0, 5, 64, 33, 64 * 33, 33), (wd[2], 0, 1, 32, 3, 32 * 3, 3)]
+    refs, outs, recs = [], [], []
+    for nb, (src, off, k, Cc, N, ts, rs) in enumerate(packs):
+        nbytes = be.lib.lu_pack_weights_bf16_bytes(k, Cc, N)
+        ref, out = be.empty((nbytes // 4,)), be.empty((nbytes // 4,))
+        calls.check(be.lib, be.lib.lu_pack_weights_bf16(be.ptr(src, off), ts, rs, k, Cc, N, be.ptr(ref), be.stream), 'pack')
+        refs.append(ref)
+        outs.append(out)
+        recs.append(dict(kind=1, k=k, src=be.ptr(src, off), dst=be.ptr(out), tap_stride=ts, row_stride=rs, kk=k * k, C=Cc, N=N,
+                         nblk=1 + nb % 3))
+    t, n, blocks = table(recs)
+    calls.check(be.lib, be.lib.lu_weight_prep_batch(be.ptr(t), n, blocks, be.stream), 'prep packs')
+    for out, ref in zip(outs, refs):
+        assert np.array_equal(be.host(out).view(np.uint32), be.host(ref).view(np.uint32))
