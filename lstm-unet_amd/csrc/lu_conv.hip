@@ -887,7 +887,7 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap
 // 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
 // Epilogue of the fragment kernels (both loop generations): bias / K-split stores, or the fused ConvLSTM gate block with
 // its exchange of the four gate fragments through the (dead) halo LDS.
-template <int EPI, int RW, int NFR = 4>
+template <int EPI, int RW, int NFR = 4, bool FAST_TANH = false>      // FAST_TANH: lu_tanh_fast (the bf16-operand kernels)
 __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[RW], unsigned char* Ah, int f, int y0, int x0,
                                               int nt, int n0, int ks) {
     constexpr int BN = 32 * NFR, TW = 32, EX_LD = BN + 4;
@@ -919,6 +919,16 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
             bg = *reinterpret_cast<const float4*>(a.bias + 2 * F + ch);
             bo = *reinterpret_cast<const float4*>(a.bias + 3 * F + ch);
         }
+        // the previous cell state of all RW passes up front: inside the pass loop (two barriers per pass) every pass would wait
+        // for its own load -- RW global-memory latencies in a row, with one block per CU nothing else covers them
+        float4 cpv[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int oy = y0 + RW * g + i, ox = x0 + px;
+            const bool ok = oy < a.Hin && ox < a.Win;
+            cpv[i] = *reinterpret_cast<const float4*>(ok ? a.c_prev + (int64_t)f * a.c_prev_fs + ((int64_t)oy * a.Win + ox) * F + ch
+                                                         : lu_zero16);
+        }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             __syncthreads();                            // pass 0: all halo reads finished; later: previous pass consumed
@@ -934,15 +944,15 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
             const float* ex = &Ex[(g * TW + px) * EX_LD + 4 * cq];
             const float4 zi = *reinterpret_cast<const float4*>(ex), zf = *reinterpret_cast<const float4*>(ex + 32),
                          zg = *reinterpret_cast<const float4*>(ex + 64), zo = *reinterpret_cast<const float4*>(ex + 96);
-            const float4 cp = *reinterpret_cast<const float4*>(a.c_prev + (int64_t)f * a.c_prev_fs + pix * F + ch);
+            const float4 cp = cpv[i];
             float4 gi, gf, gg, go, cn, hn;
 #define LU_GATE(m)                                      \
     gi.m = hard_sigmoid(zi.m + bi.m);                   \
     gf.m = hard_sigmoid(zf.m + bf.m);                   \
-    gg.m = tanhf(zg.m + bg.m);                          \
+    gg.m = FAST_TANH ? lu_tanh_fast(zg.m + bg.m) : tanhf(zg.m + bg.m); \
     go.m = hard_sigmoid(zo.m + bo.m);                   \
     cn.m = fmaf(gf.m, cp.m, gi.m * gg.m);               \
-    hn.m = go.m * tanhf(cn.m);
+    hn.m = go.m * (FAST_TANH ? lu_tanh_fast(cn.m) : tanhf(cn.m));
             LU_GATE(x) LU_GATE(y) LU_GATE(z) LU_GATE(w)
 #undef LU_GATE
             *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
@@ -1273,7 +1283,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         if (D == 4 && it + 2 < it1) step(it + 2, S2());
     }
 
-    frag_epilogue<EPI, RW, NFR>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+    frag_epilogue<EPI, RW, NFR, !F32>(a, acc, Ah, f, y0, x0, nt, n0, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1463,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
             LU_SCHED_FENCE();
         }
     }
-    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+    frag_epilogue<EPI, RW, 4, true>(a, acc, Ah, f, y0, x0, nt, n0, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------

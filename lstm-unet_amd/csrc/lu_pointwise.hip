@@ -206,7 +206,7 @@ __global__ void lstm_gates_bwd_bf16_kernel(unsigned short* gates_dz, const float
                     dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float tc = tanhf(ccv[j]);
+            const float tc = lu_tanh_fast(ccv[j]);      // (bf16 mode: as in the fused step's gate block)
             const float dc = dhv[j] * go[j] * (1.f - tc * tc) + dci[j];
             zi[j] = dc * gg[j] * hsig_grad_from_out(gi[j]);
             zf[j] = dc * cpv[j] * hsig_grad_from_out(gf[j]);
