@@ -243,6 +243,7 @@ def main():
     ap.add_argument('--wgrad-flags', type=int, default=0, help='A/B: LU_WGRAD_F_* bits OR-ed into every weight-gradient descriptor')
     ap.add_argument('--conv-flags', type=int, default=0, help='A/B: LU_CONV_F_* bits OR-ed into every convolution descriptor')
     ap.add_argument('--ab-f32-act', action='store_true', help='A/B: bf16 mode with every activation stored as fp32 (round 2 / early round 3)')
+    ap.add_argument('--ab-f32-grad', action='store_true', help='A/B: bf16 mode with the BatchNorm-backward gradients stored as fp32')
     ap.add_argument('--ab-no-prep', action='store_true',
                     help='A/B: derived weight images one launch at a time per step, recurrent state copied / masked eagerly (before round 3)')
     ap.add_argument('--ab-old-tail', action='store_true',
@@ -287,19 +288,24 @@ def main():
         trainer.engine.overlap_wgrad = False
     if args.ab_f32_act:
         trainer.engine.act_bf16 = False
+        trainer.engine.grad_bf16 = False
     if args.ab_no_prep:
         trainer.engine.prep_batch = False
+    if args.ab_f32_grad:
+        trainer.engine.grad_bf16 = False
     ops.WGRAD_FLAGS |= args.wgrad_flags
     ops.CONV_FLAGS |= args.conv_flags
     if args.conv_flags & 4096:      # (LU_CONV_F_NO_NARROW doubles as the A/B switch of the round-3 stride-2 kernels; the gather kernel
         trainer.engine.s2_fwd_bf16 = False      # it sends the N = 32 / 64 layers to reads fp32 tensors only)
         trainer.engine.narrow_bf16 = False
         trainer.engine.act_bf16 = False
+        trainer.engine.grad_bf16 = False
     if args.ab_old_tail:
         from lu_native import cabi
         trainer.engine.narrow_bf16 = False
         trainer.engine.s2_fwd_bf16 = False
         trainer.engine.act_bf16 = False
+        trainer.engine.grad_bf16 = False
         ops.CONV_FLAGS |= cabi.LU_CONV_F_NO_NARROW
         ops.WGRAD_FLAGS |= cabi.LU_WGRAD_F_NO_NARROW_BF16
 

@@ -317,6 +317,12 @@ int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const float* scale, c
                           const float* save_mean, const float* save_invstd, float alpha, const double* sums,
                           double count, float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
                           lu_stream_t stream);
+/* bf16 mode: the same with dx stored as bf16 -- for layers whose input gradient and weight gradient both run on bf16 MFMA
+ * operands, i.e. whose every reader of dx rounds it to bf16 anyway (same values, half the bytes).  C % 4 == 0, aligned. */
+int lu_bn_lrelu_bwd_apply_bf16(const float* x, const float* dy, const float* scale, const float* shift,
+                               const float* save_mean, const float* save_invstd, float alpha, const double* sums,
+                               double count, void* dx_bf16, float* dgamma, float* dbeta, int64_t rows, int32_t C,
+                               lu_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bilinear x2 up-sampling, edge clamp (k.backend.resize_images(..., 'bilinear'), Networks.py:143).  The source coordinate

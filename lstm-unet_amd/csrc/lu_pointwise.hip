@@ -587,7 +587,7 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const flo
                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                           float alpha, const double* __restrict__ sums, double count,
                                           float* __restrict__ dx, float* dgamma, float* dbeta, int64_t total, int C,
-                                          int vec4) {
+                                          int vec4, unsigned short* __restrict__ dx16 = nullptr) {
     if (blockIdx.x == 0 && dgamma) {
         for (int c = threadIdx.x; c < C; c += NT) {
             dbeta[c] = (float)sums[c];
@@ -617,7 +617,14 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ x, const flo
     }
             LU_BWD(x, a01.x, b01.x) LU_BWD(y, a01.y, b01.y) LU_BWD(z, a23.x, b23.x) LU_BWD(w, a23.y, b23.y)
 #undef LU_BWD
-            reinterpret_cast<float4*>(dx)[i] = o;
+            if (dx16) {      // bf16 result (vec4 only): every consumer rounds dx to bf16 MFMA operands anyway
+                lu_u2 b;
+                b.x = lu_pack2bf(o.x, o.y);
+                b.y = lu_pack2bf(o.z, o.w);
+                reinterpret_cast<lu_u2*>(dx16)[i] = b;
+            } else {
+                reinterpret_cast<float4*>(dx)[i] = o;
+            }
         }
         return;
     }
@@ -1103,6 +1110,22 @@ extern "C" int lu_bn_lrelu_bwd_apply(const float* x, const float* dy, const floa
     const int vec4 = (vec4_ok(x, dy, C) && vec4_ok(dx, scale, C) && vec4_ok(shift, save_mean, C) && vec4_ok(save_invstd, sums, C)) ? 1 : 0;
     LU_LAUNCH(bn_lrelu_bwd_apply_kernel, dim3(grid_for(vec4 ? total / 4 : total)), dim3(NT), stream, x, dy, scale, shift,
               save_mean, save_invstd, alpha, sums, count, dx, dgamma, dbeta, total, (int)C, vec4);
+    return LU_CHECK_LAUNCH();
+}
+
+/* lu_bn_lrelu_bwd_apply with a bf16 result (C % 4 == 0, 16-byte aligned operands, 8-byte aligned dx) */
+extern "C" int lu_bn_lrelu_bwd_apply_bf16(const float* x, const float* dy, const float* scale, const float* shift,
+                                          const float* save_mean, const float* save_invstd, float alpha,
+                                          const double* sums, double count, void* dx_bf16, float* dgamma, float* dbeta,
+                                          int64_t rows, int32_t C, lu_stream_t stream) {
+    LU_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums && dx_bf16 && rows > 0 && C > 0 && count > 0,
+               "lu_bn_lrelu_bwd_apply_bf16: bad arguments");
+    LU_REQUIRE(vec4_ok(x, dy, C) && vec4_ok(scale, shift, C) && vec4_ok(save_mean, save_invstd, C) && vec4_ok(sums, sums, C) &&
+                   (reinterpret_cast<uintptr_t>(dx_bf16) & 7) == 0,
+               "lu_bn_lrelu_bwd_apply_bf16: needs C %% 4 == 0 and aligned tensors");
+    const int64_t total = rows * C;
+    LU_LAUNCH(bn_lrelu_bwd_apply_kernel, dim3(grid_for(total / 4)), dim3(NT), stream, x, dy, scale, shift, save_mean,
+              save_invstd, alpha, sums, count, (float*)nullptr, dgamma, dbeta, total, (int)C, 1, (unsigned short*)dx_bf16);
     return LU_CHECK_LAUNCH();
 }
 

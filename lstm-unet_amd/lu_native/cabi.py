@@ -85,6 +85,7 @@ PROTOTYPES = {
     'lu_bn_lrelu_apply': (C.c_int, [P, P, P, P, f32, i64, i32, S]),
     'lu_bn_lrelu_bwd_reduce': (C.c_int, [P, P, P, P, P, P, f32, i64, i32, P, P, S]),
     'lu_bn_lrelu_bwd_apply': (C.c_int, [P, P, P, P, P, P, f32, P, f64, P, P, P, i64, i32, S]),
+    'lu_bn_lrelu_bwd_apply_bf16': (C.c_int, [P, P, P, P, P, P, f32, P, f64, P, P, P, i64, i32, S]),
     'lu_upsample2x_fwd': (C.c_int, [P, P, i32, i32, i32, i32, i32, S]),
     'lu_upsample2x_bwd': (C.c_int, [P, i32, P, i32, i32, i32, i32, i32, S]),
     'lu_window_copy': (C.c_int, [P, i32, P, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, S]),

@@ -110,6 +110,8 @@ class Engine:
         # ConvLSTM input, the weight gradients) are STORED as bf16 -- BatchNorm'd outputs inside / between blocks, the up-sampled
         # decoder inputs.  No value a kernel computes with changes; the bytes written and re-read halve.  (A/B: bench.py --ab-f32-act)
         self.act_bf16 = True
+        self.grad_bf16 = True        # bf16 mode: the gradient a BatchNorm backward hands to its convolution is stored as bf16 when that
+                                     # layer's input gradient and weight gradient both round it to bf16 operands (A/B: --ab-f32-act)
         self.s2_fwd_bf16 = True      # stride-2 forward convs behind a ConvLSTM read its bf16 copy (A/B: bench.py --conv-flags 4096 turns it off)
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
@@ -377,6 +379,26 @@ class Engine:
         return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec,
                                 z16=z16 and tape is not None and self.precision == 'bf16' and self.act_bf16)
 
+    def _dy16_ok(self, rec, dz, need_dx):
+        """bf16 mode: may the gradient w.r.t. this unit's convolution output be STORED as bf16?  Yes when every reader rounds it
+        to bf16 MFMA operands anyway: the weight gradient of every source on the bf16 kernel-row variant, every input gradient
+        that is needed on the bf16 halo kernel.  (The conv bias in front of a BatchNorm then sums rounded values: its true
+        gradient is zero, what is computed is rounding noise either way.)"""
+        spec, k = rec['spec'], self.P[f"{rec['prefix']}.conv.{rec['ci']}.kernel"].shape[0]
+        N, W = dz.shape[3], dz.shape[2]
+        if not (self.precision == 'bf16' and self.grad_bf16 and spec['stride'] == 1 and k in (3, 5) and N % 8 == 0 and
+                W % 32 == 0 and dz.is_contiguous()):
+            return False
+        probe = torch.empty((1,) + tuple(dz.shape[1:]), device=dz.device, dtype=torch.bfloat16)
+        a16 = rec.get('alt16')
+        for (x, co, cs), need in zip(rec['srcs'], need_dx):
+            xc = a16 if (a16 is not None and ops.bf16_row_wgrad_ok(a16, probe, k, 1)) else x
+            if not ops.bf16_row_wgrad_ok(xc, probe, k, 1):
+                return False
+            if need and not (self._bf16_unit(k, 1, cs) and cs % 4 == 0):
+                return False
+        return True
+
     def _conv_unit_backward(self, rec, dz, need_dx):
         """-> list of input gradients (one per source, None where not needed)."""
         prefix, ci, spec = rec['prefix'], rec['ci'], rec['spec']
@@ -392,11 +414,12 @@ class Engine:
                 self.G[bn + '.gamma'].copy_(sums[Cc:])
                 self.dp.all_reduce_(sums)
                 dy = ops.bn_lrelu_bwd_apply(y, dz, rec['scale'], rec['shift'], rec['mean'], rec['invstd'],
-                                            LRELU_ALPHA, sums, rec['count'], None, None, out=dz)
+                                            LRELU_ALPHA, sums, rec['count'], None, None, out=dz,
+                                            out_bf16=self._dy16_ok(rec, dz, need_dx))
             else:
                 dy = ops.bn_lrelu_bwd_apply(y, dz, rec['scale'], rec['shift'], rec['mean'], rec['invstd'],
                                             LRELU_ALPHA, sums, rec['count'], self.G[bn + '.gamma'],
-                                            self.G[bn + '.beta'], out=dz)
+                                            self.G[bn + '.beta'], out=dz, out_bf16=self._dy16_ok(rec, dz, need_dx))
             rec['y'] = None
         else:
             dy = dz

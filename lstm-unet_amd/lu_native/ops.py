@@ -600,8 +600,17 @@ def bn_lrelu_bwd_reduce(y, dz, scale, shift, mean, invstd, alpha):
     return sums
 
 
-def bn_lrelu_bwd_apply(y, dz, scale, shift, mean, invstd, alpha, sums, count, dgamma, dbeta, out=None):
+def bn_lrelu_bwd_apply(y, dz, scale, shift, mean, invstd, alpha, sums, count, dgamma, dbeta, out=None, out_bf16=False):
+    """out_bf16: a NEW bf16 tensor holds the result (every reader rounds it to bf16 MFMA operands: same values, half the bytes)."""
     Cc = y.shape[-1]
+    if out_bf16:
+        out = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16)
+        with _timed('hbm:bn_lrelu_bwd_apply_kernel (BN + LeakyReLU backward: 2 reads + 1 write)', 10.0 * y.numel()):
+            calls.check(lib(), lib().lu_bn_lrelu_bwd_apply_bf16(y.data_ptr(), dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                                mean.data_ptr(), invstd.data_ptr(), alpha, sums.data_ptr(),
+                                                                float(count), out.data_ptr(), _p(dgamma), _p(dbeta),
+                                                                y.numel() // Cc, Cc, _stream()), 'lu_bn_lrelu_bwd_apply_bf16')
+        return out
     if out is None:
         out = torch.empty_like(y)
     with _timed('hbm:bn_lrelu_bwd_apply_kernel (BN + LeakyReLU backward: 2 reads + 1 write)', 12.0 * y.numel()):
