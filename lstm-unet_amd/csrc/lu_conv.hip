@@ -164,10 +164,10 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvArgs& a, const float
             zg += a.bias[2 * F + ch];
             zo += a.bias[3 * F + ch];
         }
-        const float gi = hard_sigmoid(zi), gf = hard_sigmoid(zf), gg = tanhf(zg), go = hard_sigmoid(zo);
+        const float gi = hard_sigmoid(zi), gf = hard_sigmoid(zf), gg = lu_tanh_fast(zg), go = hard_sigmoid(zo);
         const float cp = a.c_prev[(int64_t)f * a.c_prev_fs + pix * F + ch];
         const float cn = fmaf(gf, cp, gi * gg);      // explicit: every copy of the cell update must contract the same way
-        const float hn = go * tanhf(cn);
+        const float hn = go * lu_tanh_fast(cn);
         a.c_out[(int64_t)f * a.c_out_fs + pix * F + ch] = cn;
         a.h_out[(int64_t)f * a.h_fs + pix * F + ch] = hn;
         if (a.gates_out) {
@@ -887,7 +887,7 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap
 // 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
 // Epilogue of the fragment kernels (both loop generations): bias / K-split stores, or the fused ConvLSTM gate block with
 // its exchange of the four gate fragments through the (dead) halo LDS.
-template <int EPI, int RW, int NFR = 4, bool FAST_TANH = false>      // FAST_TANH: lu_tanh_fast (the bf16-operand kernels)
+template <int EPI, int RW, int NFR = 4>
 __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[RW], unsigned char* Ah, int f, int y0, int x0,
                                               int nt, int n0, int ks) {
     constexpr int BN = 32 * NFR, TW = 32, EX_LD = BN + 4;
@@ -949,10 +949,10 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 #define LU_GATE(m)                                      \
     gi.m = hard_sigmoid(zi.m + bi.m);                   \
     gf.m = hard_sigmoid(zf.m + bf.m);                   \
-    gg.m = FAST_TANH ? lu_tanh_fast(zg.m + bg.m) : tanhf(zg.m + bg.m); \
+    gg.m = lu_tanh_fast(zg.m + bg.m);                   \
     go.m = hard_sigmoid(zo.m + bo.m);                   \
     cn.m = fmaf(gf.m, cp.m, gi.m * gg.m);               \
-    hn.m = go.m * (FAST_TANH ? lu_tanh_fast(cn.m) : tanhf(cn.m));
+    hn.m = go.m * lu_tanh_fast(cn.m);
             LU_GATE(x) LU_GATE(y) LU_GATE(z) LU_GATE(w)
 #undef LU_GATE
             *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         if (D == 4 && it + 2 < it1) step(it + 2, S2());
     }
 
-    frag_epilogue<EPI, RW, NFR, !F32>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+    frag_epilogue<EPI, RW, NFR>(a, acc, Ah, f, y0, x0, nt, n0, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
             LU_SCHED_FENCE();
         }
     }
-    frag_epilogue<EPI, RW, 4, true>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------

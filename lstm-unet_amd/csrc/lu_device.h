@@ -130,10 +130,13 @@ __device__ __forceinline__ unsigned lu_pack2bf(float lo, float hi) {
 }
 #endif
 
-// tanh for the bf16-mode kernels, ~15 VALU instructions instead of the ~50 of ocml's tanhf: the gate block of the fused ConvLSTM
-// step evaluates 64 of them per thread and tile, and with one 16 x 32 tile per CU nothing covers that time (20 us of a 96 us
-// tile at the 256^2 level).  |x| >= 0.1: 1 - 2 / (exp(2|x|) + 1) on v_exp_f32 / v_rcp_f32 (absolute error ~1.5e-7; exp
-// overflow -> inf -> exactly 1); below: x - x^3/3 + 2x^5/15 (relative error < 6e-8).  The fp32 kernels keep tanhf.
+// tanh of every gate kernel (fused ConvLSTM epilogues, the pointwise gate forward / backward), ~15 VALU instructions instead of
+// the ~50 of ocml's tanhf: the gate block of the fused bf16 step evaluates 64 of them per thread and tile, and with one
+// 16 x 32 tile per CU nothing covers that time (20 us of a 96 us tile at the 256^2 level).  |x| >= 0.1: 1 - 2 / (exp(2|x|) + 1)
+// on v_exp_f32 / v_rcp_f32 (absolute error ~1.5e-7 = 1-2 ulp of the result's range; exp overflow -> inf -> exactly 1); below:
+// x - x^3/3 + 2x^5/15 (relative error < 6e-8).  ONE definition for all paths and both precisions: the fused and the unfused
+// (tile-starved / K-split) route of a layer must give the same bits, or the route choice -- which depends on the batch size --
+// shows up as bf16 re-rounding differences between a data-parallel run and the single-process run of the same batch.
 #ifdef LU_EMU
 static inline float lu_tanh_fast(float x) {
     const float ax = fabsf(x);

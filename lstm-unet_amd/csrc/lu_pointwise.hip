@@ -92,11 +92,11 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ z, const float* 
         const int64_t row = i / F;
         const int ch = (int)(i - row * F);
         const float* zp = z + row * 4 * F + ch;
-        const float gi = hsig(zp[0]), gf = hsig(zp[F]), gg = tanhf(zp[2 * F]), go = hsig(zp[3 * F]);
+        const float gi = hsig(zp[0]), gf = hsig(zp[F]), gg = lu_tanh_fast(zp[2 * F]), go = hsig(zp[3 * F]);
         const float cn = fmaf(gf, c_prev[i], gi * gg);      // (same contraction as the fused epilogues in lu_conv.hip)
         c_out[i] = cn;
         const int64_t f = row / ppf;
-        h_out[f * h_fs + (row - f * ppf) * F + ch] = go * tanhf(cn);
+        h_out[f * h_fs + (row - f * ppf) * F + ch] = go * lu_tanh_fast(cn);
         if (gates_out) {
             float* gp = gates_out + row * 4 * F + ch;
             gp[0] = gi;
@@ -130,11 +130,11 @@ __global__ void lstm_gates_fwd_slabs_kernel(const float* __restrict__ slabs, int
             zg += zp[2 * F];
             zo += zp[3 * F];
         }
-        const float gi = hsig(zi), gf = hsig(zf), gg = tanhf(zg), go = hsig(zo);
+        const float gi = hsig(zi), gf = hsig(zf), gg = lu_tanh_fast(zg), go = hsig(zo);
         const float cn = fmaf(gf, c_prev[i], gi * gg);
         c_out[i] = cn;
         const int64_t f = row / ppf;
-        h_out[f * h_fs + (row - f * ppf) * F + ch] = go * tanhf(cn);
+        h_out[f * h_fs + (row - f * ppf) * F + ch] = go * lu_tanh_fast(cn);
         if (gates_out) {
             float* gp = gates_out + row * 4 * F + ch;
             gp[0] = gi;
@@ -160,7 +160,7 @@ __global__ void lstm_gates_bwd_kernel(const float* gates, const float* __restric
         if (dh_b) dh += dh_b[i];
         const float* gp = gates + row * 4 * F + ch;
         const float gi = gp[0], gf = gp[F], gg = gp[2 * F], go = gp[3 * F];
-        const float tc = tanhf(c_cur[i]);
+        const float tc = lu_tanh_fast(c_cur[i]);
         float dc = dh * go * (1.f - tc * tc);
         if (dc_in) dc += dc_in[i];
         float* dp = dz + row * 4 * F + ch;
@@ -206,7 +206,7 @@ __global__ void lstm_gates_bwd_bf16_kernel(unsigned short* gates_dz, const float
                     dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float tc = lu_tanh_fast(ccv[j]);      // (bf16 mode: as in the fused step's gate block)
+            const float tc = lu_tanh_fast(ccv[j]);
             const float dc = dhv[j] * go[j] * (1.f - tc * tc) + dci[j];
             zi[j] = dc * gg[j] * hsig_grad_from_out(gi[j]);
             zf[j] = dc * cpv[j] * hsig_grad_from_out(gf[j]);

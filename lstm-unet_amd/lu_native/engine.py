@@ -382,8 +382,8 @@ class Engine:
     def _dy16_ok(self, rec, dz, need_dx):
         """bf16 mode: may the gradient w.r.t. this unit's convolution output be STORED as bf16?  Yes when every reader rounds it
         to bf16 MFMA operands anyway: the weight gradient of every source on the bf16 kernel-row variant, every input gradient
-        that is needed on the bf16 halo kernel.  (The conv bias in front of a BatchNorm then sums rounded values: its true
-        gradient is zero, what is computed is rounding noise either way.)"""
+        that is needed on the bf16 halo kernel.  (The conv bias in front of the BatchNorm then gets its exact gradient, zero,
+        instead of a column sum of rounded values: see _conv_unit_backward.)"""
         spec, k = rec['spec'], self.P[f"{rec['prefix']}.conv.{rec['ci']}.kernel"].shape[0]
         N, W = dz.shape[3], dz.shape[2]
         if not (self.precision == 'bf16' and self.grad_bf16 and spec['stride'] == 1 and k in (3, 5) and N % 8 == 0 and
@@ -431,9 +431,16 @@ class Engine:
                 x = a16
             if x.dtype == torch.bfloat16 and not ops.bf16_row_wgrad_ok(x, dy, gw.shape[0], spec['stride']):
                 x = ops.to_f32(x)      # (a layer shape outside the bf16 kernel-row weight gradient: it reads fp32)
+            # A conv bias in front of a BatchNorm has gradient sum(dy) = 0 identically (the backward above subtracts the mean);
+            # what the column sums of an fp32 dy return is rounding noise far below Adam's epsilon.  Sums of a bf16-STORED dy
+            # would be noise 1e4 times larger, which Adam normalises into full +-lr steps -- a random walk of a parameter that
+            # cannot change the output.  Such a layer gets its exact gradient instead: zero.
+            zero_bias = rec['bn'] and dy.dtype == torch.bfloat16
+            if zero_bias and si == 0:
+                self.G[f'{prefix}.conv.{ci}.bias'].zero_()
             with self._wgrad_side(x, dy):
                 ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], spec['stride'], bf16=self.precision == 'bf16',
-                                 dbias=self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None)
+                                 dbias=self.G[f'{prefix}.conv.{ci}.bias'] if (si == 0 and not zero_bias) else None)
             dxs.append(ops.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), spec['stride'], co, cs,
                                         bf16=self._bf16_unit(gw.shape[0], spec['stride'], cs),
                                         bank=self.bank if self.prep_batch else None) if need else None)

@@ -17,9 +17,9 @@ for sfx in ('', '_bf16'):
     json.dump(d, open(p, 'w'), indent=1)
     json.dump(d, open('profiles/r03_pmc_traffic%s.json' % sfx, 'w'), indent=1)      # (the box's copy: read by bench.py below)
 PY
-python bench.py --steps 8 --warmup 3 > gpurun_out/${tag}_f32_bench_line.json 2> gpurun_out/${tag}_f32_bench.err; tail -2 gpurun_out/${tag}_f32_bench.err
+python bench.py --steps 8 --warmup 3 --by-shape gpurun_out/${tag}_f32_by_shape.json > gpurun_out/${tag}_f32_bench_line.json 2> gpurun_out/${tag}_f32_bench.err; tail -2 gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bf16_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
-python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --no-infer --no-wgrad-overlap > gpurun_out/${tag}_bf16_inline_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
+python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --no-infer --no-wgrad-overlap --by-shape gpurun_out/${tag}_bf16_by_shape.json > gpurun_out/${tag}_bf16_inline_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16 --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bf16_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --hw 832 992 --batch 2 --unroll 16 --steps 2 --warmup 1 --no-bf16 --no-infer --no-cpu-baseline > gpurun_out/${tag}_f32_c4_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python - <<PY
@@ -38,3 +38,5 @@ for mode in fp32 bf16; do
 done
 cd $R && bash tools/gpu/r02_inf_prof.sh ${tag}_inf 2>&1 | grep "launches/frame"
 python tools/post_ab.py bf16 gpurun_out/${tag}_post_832x992.json 2>&1 | grep -v amdgpu | tail -9
+# bf16 vs fp32 training on the same stream (the bf16 accuracy contract: loss curves, held-out IoU, argmax agreement)
+python tools/train_compare.py 300 > gpurun_out/${tag}_bf16_vs_fp32_training.json 2> gpurun_out/${tag}_train_compare.err; tail -c 400 gpurun_out/${tag}_bf16_vs_fp32_training.json
