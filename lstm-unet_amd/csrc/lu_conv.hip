@@ -68,6 +68,7 @@ struct ConvArgs {
     int32_t gates_bf16;    // LSTM epilogue of the fragment kernel: gates_out is bf16
     unsigned short* h16_out;   // ... optional bf16 copy of h
     int64_t h16_fs;
+    int32_t out_vec4;      // fragment kernels, bias epilogue: dense 16-byte aligned output rows, N % 4 == 0 -> float4 stores through LDS
     int32_t dbg;           // ablation bits, honoured only in -DLU_ABLATION tool builds: 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
@@ -986,6 +987,45 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
         }
         return;
     }
+    if (EPI == LU_EPI_BIAS && a.out_vec4 && a.ksplit <= 1) {
+        // Bias epilogue with 16-byte stores.  A lane of an accumulator fragment holds ONE column of 16 pixels, so storing from the
+        // registers is 16 RW four-byte stores per lane, each with its own 64-bit address -- measured 36 us of a 16 x 32-pixel
+        // tile (tools/tile_fit.py: the per-tile constant of the 5x5 input gradients, 51 -> 15 us without the epilogue), a quarter
+        // of a 3x3 layer.  One patch row of every row group goes through the (dead) halo LDS per pass and comes back as
+        // (pixel, four consecutive columns) per thread: 4 float4 stores per thread and pass.
+        constexpr int NG = 8 / NFR, Q = BN / 4;            // row groups; column quads per pixel
+        float* Ex = reinterpret_cast<float*>(Ah);          // [NG][32 px][EX_LD]
+        static_assert(NG * TW * Q % 512 == 0, "whole items per thread");
+        constexpr int ITEMS = NG * TW * Q / 512;
+        float4 bq[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const int col = n0 + 4 * ((tid + 512 * q) % Q);
+            bq[q] = (a.bias && col < a.N) ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            __syncthreads();                                // pass 0: all halo reads finished; later: previous pass consumed
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pxr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Ex[(wm * TW + pxr) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const int j = tid + 512 * q;
+                const int pr = j / Q, cq = j - pr * Q;
+                const int g = pr / TW, px = pr - g * TW;
+                const int oy = y0 + RW * g + i, ox = x0 + px, col = n0 + 4 * cq;
+                if (oy >= a.Hin || ox >= a.Win || col >= a.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(&Ex[(g * TW + px) * EX_LD + 4 * cq]);
+                v.x += bq[q].x; v.y += bq[q].y; v.z += bq[q].z; v.w += bq[q].w;
+                *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_frame_stride + ((int64_t)oy * a.Win + ox) * a.out_pix_stride + col) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int oy = y0 + RW * wm + i;
@@ -1024,6 +1064,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     constexpr int AH_BYTES = HP * PITCH;               // one halo image; two of them live in dynamic LDS
     static_assert(HPASS + 2 <= K * K, "the next halo is fetched one piece per tap and stored two taps later");
     static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
+    static_assert(8 * TW * EX_LD * 4 <= 2 * AH_BYTES * (BN / 32), "bias-epilogue exchange (8 / NFR row groups) aliases the two halo images");
     LU_DYN_LDS(unsigned char, Ah);                     // [2][AH_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1331,6 +1372,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
     constexpr int D = K;                                // weight-fragment ring depth (stages)
     static_assert(HPASS + 2 <= KK, "the next halo is fetched one piece per tap and stored two taps later");
     static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
+    static_assert(8 * TW * EX_LD * 4 <= 2 * AH_BYTES * (BN / 32), "bias-epilogue exchange (8 / NFR row groups) aliases the two halo images");
     LU_DYN_LDS(unsigned char, Ah);                      // [2][AH_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2147,6 +2189,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.out = d->out;
     a.out_frame_stride = d->out_frame_stride;
     a.out_row_stride = d->out_row_stride;
+    a.out_vec4 = (d->out_row_stride == 0 && d->N % 4 == 0 && d->out_pix_stride % 4 == 0 && d->out_frame_stride % 4 == 0 &&
+                  aligned16(d->out) && (!d->bias || aligned16(d->bias))) ? 1 : 0;
     a.post_scale = d->post_scale;
     a.post_shift = d->post_shift;
     a.post_alpha = d->post_alpha;

@@ -320,6 +320,8 @@ def test_bf16_activations_stored_as_bf16_change_no_value(dev):
     res, n16, g16 = {}, {}, {}
     real, real_bwd = ops.bn_lrelu_apply, ops.bn_lrelu_bwd_apply
     modes = [(True, True), (True, False), (False, False)]       # (activations, BatchNorm-backward gradients) stored as bf16
+    if dev.type != 'cuda':
+        modes = [modes[0], modes[2]]       # (the emulator run keeps the CPU suite short: the mixed mode on the MI355X only)
     for mode in modes:
         count, countg = [0], [0]
 
@@ -346,13 +348,13 @@ def test_bf16_activations_stored_as_bf16_change_no_value(dev):
         n16[mode], g16[mode] = count[0], countg[0]
         res[mode] = (lg.cpu().numpy(), float(ops.wce_loss(sums).cpu()[0]), {k: v.cpu().numpy() for k, v in e.G.items()})
     assert n16[(True, True)] >= 6 and n16[(False, False)] == 0, n16          # the switches do something
-    assert g16[(True, True)] >= 6 and g16[(True, False)] == 0 and g16[(False, False)] == 0, g16
+    assert g16[(True, True)] >= 6 and g16.get((True, False), 0) == 0 and g16[(False, False)] == 0, g16
     lb, lossb, gb = res[(False, False)]
     # a conv bias in front of a BatchNorm: its true gradient is zero (the mean subtraction cancels it), what fp32 storage
     # computes is the rounding noise of a column sum
     bn_bias = {k for k in gb if k.endswith('.bias') and k.replace('.conv.', '.bn.').replace('.bias', '.gamma') in gb}
     assert len(bn_bias) >= 10
-    for mode in modes[:2]:
+    for mode in modes[:-1]:
         la, lossa, ga = res[mode]
         assert np.array_equal(la, lb) and lossa == lossb
         bad = [k for k in ga if not np.array_equal(ga[k], gb[k]) and not (mode[1] and k in bn_bias)]
@@ -621,14 +623,15 @@ def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precisi
         e.load_params(p)
         opt = Adam(e, lr=1e-3)
         got = []
-        for w in range(3):
+        n_win = 2 if (precision == 'bf16' and dev.type != 'cuda') else 3      # (emulator: keep the CPU suite short)
+        for w in range(n_win):
             lg = e.forward(torch.from_numpy(to_tb(xs[w])).to(dev), T, B, True)
             e.backward(torch.from_numpy(dl).to(dev))
             opt.apply_gradients()
             if not lazy:
                 e.bank = type(e.bank)()                        # fresh weight images every step instead of the batch refresh
                 assert len(e._alias) and e.states is not None and not e._alias      # reading `states` made them own tensors
-            if w < 2:
+            if w < n_win - 1:
                 e.reset_states_per_batch(keeps[w])
                 if lazy:
                     assert e._keep is not None and e._alias    # nothing applied yet
@@ -637,7 +640,7 @@ def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precisi
                     assert e._keep is None
             got.append(lg.cpu().numpy())
         if lazy:
-            assert e.bank.refreshes >= 2 and len(e.bank._flips) and (precision == 'fp32' or len(e.bank._packs))
+            assert e.bank.refreshes >= n_win - 1 and len(e.bank._flips) and (precision == 'fp32' or len(e.bank._packs))
         got.append(e.flat_params.cpu().numpy())
         st = e.get_states()
         got += [t for blk in st for l in blk for t in l]
