@@ -68,7 +68,8 @@ struct ConvArgs {
     int32_t gates_bf16;    // LSTM epilogue of the fragment kernel: gates_out is bf16
     unsigned short* h16_out;   // ... optional bf16 copy of h
     int64_t h16_fs;
-    int32_t out_vec4;      // fragment kernels, bias epilogue: dense 16-byte aligned output rows, N % 4 == 0 -> float4 stores through LDS
+    int32_t lstm_vec4;     // conv_halo_kernel, LSTM epilogue: every state / gate tensor 16-byte aligned -> float4 loads / stores through LDS
+    int32_t out_vec4;      // tile kernels, bias epilogue: dense 16-byte aligned output rows, N % 4 == 0 -> float4 stores through LDS
     int32_t dbg;           // ablation bits, honoured only in -DLU_ABLATION tool builds: 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
@@ -799,6 +800,91 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
 
     // ---- epilogue: wave = patch row, accumulator row = x ----
     const int oy = y0 + wave;
+    // 16-byte stores.  A lane holds ONE column of 16 pixels per fragment: storing from the registers is 64 four-byte stores per
+    // lane (96 + 16 scalar loads for the gate block), each with its own 64-bit address -- tools/tile_fit.py: ~90 us per round of
+    // tiles, 10 % of a fused step at the 256^2 level, and the two resident blocks of a CU reach it at the same time.  Each wave
+    // turns its fragments round in a PRIVATE slice of the (dead: the loop ended on a barrier) halo LDS, no block barrier: a
+    // lane then owns (pixel, four consecutive columns / channels).
+    if (EPI == LU_EPI_BIAS && a.out_vec4 && a.ksplit <= 1 && NF == 4) {
+        float* const Exw = Ah + wave * (16 * 36);          // [16 pixels][32 columns + 4]
+        const int cq = lane & 7;
+        float4 bq[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const int col = n0 + 32 * nf + 4 * cq;
+            bq[nf] = (a.bias && col < a.N) ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)          // pixel 16 half + (rr & 3) + 8 (rr >> 2) + 4 (lane >> 5) of the row
+                    Exw[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[nf][8 * half + rr];
+                LU_WAVE_SYNC();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int lp = (lane >> 3) + 8 * q;
+                    const int ox = x0 + 16 * half + lp, col = n0 + 32 * nf + 4 * cq;
+                    float4 v = *reinterpret_cast<const float4*>(&Exw[lp * 36 + 4 * cq]);
+                    v.x += bq[nf].x; v.y += bq[nf].y; v.z += bq[nf].z; v.w += bq[nf].w;
+                    if (oy < a.Hin && ox < a.Win && col < a.N)
+                        *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_frame_stride +
+                                                   ((int64_t)oy * a.Win + ox) * a.out_pix_stride + col) = v;
+                }
+                LU_WAVE_SYNC();
+            }
+        return;
+    }
+    if (EPI == LU_EPI_LSTM && a.lstm_vec4 && NF == 4 && HP * A_LD >= 8 * (8 * 132)) {
+        float* const Exw = Ah + wave * (8 * 132);          // [8 pixels][4 gates x 32 channels + 4]
+        const int F = a.F;
+        const int lp = lane >> 3, cq = lane & 7;
+        const int ch = nt * 32 + 4 * cq;                    // F % 32 == 0 is enforced by the host
+        const float* const bp = a.bias ? a.bias + ch : lu_zero16;      // (lu_zero16: 16 bytes of zeros)
+        const int bst = a.bias ? F : 0;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            // previous cell state and the gate biases of this pass: requested before the exchange, which covers part of their
+            // latency (held across the passes -- as in the fragment kernels -- they spill here: 128 VGPRs, two blocks per CU)
+            const bool okp = oy < a.Hin && x0 + 8 * qt + lp < a.Win;
+            const float4 cp = *reinterpret_cast<const float4*>(
+                okp ? a.c_prev + (int64_t)f * a.c_prev_fs + ((int64_t)oy * a.Win + x0 + 8 * qt + lp) * F + ch : lu_zero16);
+            const float4 bi = *reinterpret_cast<const float4*>(bp), bf = *reinterpret_cast<const float4*>(bp + bst),
+                         bg = *reinterpret_cast<const float4*>(bp + 2 * bst), bo = *reinterpret_cast<const float4*>(bp + 3 * bst);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)              // pixel 8 qt + rr + 4 (lane >> 5) of the row, gate nf
+                    Exw[(rr + 4 * (lane >> 5)) * 132 + 32 * nf + (lane & 31)] = acc[nf][4 * qt + rr];
+            LU_WAVE_SYNC();
+            // one gate at a time (read, activate, store): all four z vectors live at once cost two spilled registers
+            const float* ex = &Exw[lp * 132 + 4 * cq];
+            const int ox = x0 + 8 * qt + lp;
+            const int64_t pix = (int64_t)oy * a.Win + ox;
+            float* const gp = a.gates_out ? a.gates_out + (int64_t)f * a.gates_fs + pix * (4 * F) + ch : nullptr;
+            float4 z, gi, gf, gg, go, cn, hn;
+            z = *reinterpret_cast<const float4*>(ex);
+            gi.x = hard_sigmoid(z.x + bi.x); gi.y = hard_sigmoid(z.y + bi.y); gi.z = hard_sigmoid(z.z + bi.z); gi.w = hard_sigmoid(z.w + bi.w);
+            if (okp && gp) *reinterpret_cast<float4*>(gp) = gi;
+            z = *reinterpret_cast<const float4*>(ex + 32);
+            gf.x = hard_sigmoid(z.x + bf.x); gf.y = hard_sigmoid(z.y + bf.y); gf.z = hard_sigmoid(z.z + bf.z); gf.w = hard_sigmoid(z.w + bf.w);
+            if (okp && gp) *reinterpret_cast<float4*>(gp + F) = gf;
+            z = *reinterpret_cast<const float4*>(ex + 64);
+            gg.x = lu_tanh_fast(z.x + bg.x); gg.y = lu_tanh_fast(z.y + bg.y); gg.z = lu_tanh_fast(z.z + bg.z); gg.w = lu_tanh_fast(z.w + bg.w);
+            if (okp && gp) *reinterpret_cast<float4*>(gp + 2 * F) = gg;
+            cn.x = fmaf(gf.x, cp.x, gi.x * gg.x); cn.y = fmaf(gf.y, cp.y, gi.y * gg.y);      // explicit fmaf: every copy of the cell update contracts the same way
+            cn.z = fmaf(gf.z, cp.z, gi.z * gg.z); cn.w = fmaf(gf.w, cp.w, gi.w * gg.w);
+            if (okp) *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
+            z = *reinterpret_cast<const float4*>(ex + 96);
+            go.x = hard_sigmoid(z.x + bo.x); go.y = hard_sigmoid(z.y + bo.y); go.z = hard_sigmoid(z.z + bo.z); go.w = hard_sigmoid(z.w + bo.w);
+            if (okp && gp) *reinterpret_cast<float4*>(gp + 3 * F) = go;
+            hn.x = go.x * lu_tanh_fast(cn.x); hn.y = go.y * lu_tanh_fast(cn.y); hn.z = go.z * lu_tanh_fast(cn.z); hn.w = go.w * lu_tanh_fast(cn.w);
+            if (okp) *reinterpret_cast<float4*>(a.h_out + (int64_t)f * a.h_fs + pix * F + ch) = hn;
+            LU_WAVE_SYNC();
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -2290,6 +2376,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.h_fs = d->h_frame_stride;
         a.gates_fs = d->gates_frame_stride;
         a.gates_bf16 = (d->flags & LU_CONV_F_GATES_BF16) ? 1 : 0;
+        a.lstm_vec4 = (aligned16(d->c_prev) && aligned16(d->c_out) && aligned16(d->h_out) && (!d->bias || aligned16(d->bias)) &&
+                       (!d->gates_out || aligned16(d->gates_out)) && d->c_prev_frame_stride % 4 == 0 && d->c_out_frame_stride % 4 == 0 &&
+                       d->h_frame_stride % 4 == 0 && d->gates_frame_stride % 4 == 0) ? 1 : 0;
         a.h16_out = (unsigned short*)d->h16_out;
         a.h16_fs = d->h16_frame_stride;
         LU_REQUIRE((!a.gates_bf16 && !a.h16_out) || (d->precision == 1 && halo),

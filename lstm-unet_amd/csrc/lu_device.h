@@ -26,6 +26,7 @@ static inline void lu_glds16(const float* gptr, float* lds_wave_base) {
 #define LU_CHECK_LAUNCH() 0
 #define LU_SCHED_FENCE() ((void)0)
 #define LU_SCHED_GROUP(mask, n) ((void)0)
+#define LU_WAVE_SYNC() lu_emu::wave_barrier()      // lanes of a wave exchange data through LDS without a block barrier
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -81,6 +82,13 @@ __device__ __forceinline__ void lu_glds16(const float* gptr, float* lds_wave_bas
         __builtin_amdgcn_sched_barrier(0);    \
         asm volatile("" ::: "memory");        \
         __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+// The 64 lanes of a wave run in lockstep and a wave's LDS operations execute in order: an LDS exchange INSIDE a wave needs no
+// s_barrier, only the compiler kept from moving the reads above the writes.
+#define LU_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 int lu_check_launch();
 #endif
