@@ -713,17 +713,48 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     }
 
     float* slab = a.ws + (int64_t)z * a.slab;
+    if ((a.N & 3) == 0 && (a.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(a.ws) & 15) == 0) {
+        // 16-byte slab stores.  A lane holds ONE column of 16 channel rows per fragment: from the registers that is 16 K NFW
+        // four-byte stores per lane with a 64-bit address each -- on the 3x3 layers (64 stages per block) more time than the
+        // block's MFMAs.  Each wave turns its fragments round in a private slice of the operand LDS (dead: the loop ended on a
+        // barrier), no block barrier; a lane then owns (channel row, four consecutive columns).
+        float* const Exw = reinterpret_cast<float*>(smem) + wave * (16 * 36);      // [16 rows][32 columns + 4]
+        const int cq = lane & 7;
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-        const int tap = kh * K + t;
+        for (int t = 0; t < K; ++t) {
+            const int tap = kh * K + t;
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf)
+            for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = n0 + wn * 32 * NFW + 32 * nf + l31;
-                if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][nf][r];
-            }
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)      // row 16 half + (rr & 3) + 8 (rr >> 2) + 4 (lane >> 5) of the fragment
+                        Exw[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 36 + l31] = acc[t][nf][8 * half + rr];
+                    LU_WAVE_SYNC();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int lp = (lane >> 3) + 8 * q;
+                        const int c = c0 + wm * 32 + 16 * half + lp;
+                        const int n = n0 + wn * 32 * NFW + 32 * nf + 4 * cq;
+                        const float4 v = *reinterpret_cast<const float4*>(&Exw[lp * 36 + 4 * cq]);
+                        if (c < a.C && n < a.N) *reinterpret_cast<float4*>(&slab[((int64_t)tap * a.C + c) * a.N + n]) = v;
+                    }
+                    LU_WAVE_SYNC();
+                }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int tap = kh * K + t;
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int n = n0 + wn * 32 * NFW + 32 * nf + l31;
+                    if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][nf][r];
+                }
+        }
     }
     if (want_bias) {          // rows of a piece column live in different lanes / waves: shuffle, then 8 wave partials (fixed order)
         constexpr int RPW = 64 / PY;      // tile rows per wave and pass: 4 (bf16 dy) or 2 (fp32 dy)
