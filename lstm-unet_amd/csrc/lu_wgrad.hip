@@ -414,14 +414,37 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     }
 
     float* slab = a.ws + (int64_t)bz * a.slab;
+    if ((a.N & 3) == 0 && (a.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(a.ws) & 15) == 0) {
+        // 16-byte slab stores (see wgrad_row_bf16_kernel): each wave turns its fragments round, eight channel rows at a time, in
+        // a private slice of the dy tile's LDS (dead: the loop ended on a barrier); a lane then owns (row, four columns).
+        float* const Exw = &Ys[0][0] + wave * (8 * 36);      // [8 rows][32 columns + 4]
+        const int lp = lane >> 3, cq = lane & 7;
+        const int n = n0 + wn * 32 + 4 * cq;
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-        const int tap = kh * K + t;
+        for (int t = 0; t < K; ++t) {
+            const int tap = kh * K + t;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int n = n0 + wn * 32 + l31;
-            if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][r];
+            for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)      // row 8 qt + rr + 4 (lane >> 5) of the fragment
+                    Exw[(rr + 4 * (lane >> 5)) * 36 + l31] = acc[t][4 * qt + rr];
+                LU_WAVE_SYNC();
+                const float4 v = *reinterpret_cast<const float4*>(&Exw[lp * 36 + 4 * cq]);
+                const int c = c0 + wm * 32 + 8 * qt + lp;
+                if (c < a.C && n < a.N) *reinterpret_cast<float4*>(&slab[((int64_t)tap * a.C + c) * a.N + n]) = v;
+                LU_WAVE_SYNC();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int tap = kh * K + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 32 + l31;
+                if (c < a.C && n < a.N) slab[((int64_t)tap * a.C + c) * a.N + n] = acc[t][r];
+            }
         }
     }
     if (want_bias) {          // 16 row-threads per column group -> one sum per column (fixed order: deterministic)
