@@ -1077,37 +1077,33 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
         // Bias epilogue with 16-byte stores.  A lane of an accumulator fragment holds ONE column of 16 pixels, so storing from the
         // registers is 16 RW four-byte stores per lane, each with its own 64-bit address -- measured 36 us of a 16 x 32-pixel
         // tile (tools/tile_fit.py: the per-tile constant of the 5x5 input gradients, 51 -> 15 us without the epilogue), a quarter
-        // of a 3x3 layer.  One patch row of every row group goes through the (dead) halo LDS per pass and comes back as
-        // (pixel, four consecutive columns) per thread: 4 float4 stores per thread and pass.
-        constexpr int NG = 8 / NFR, Q = BN / 4;            // row groups; column quads per pixel
-        float* Ex = reinterpret_cast<float*>(Ah);          // [NG][32 px][EX_LD]
-        static_assert(NG * TW * Q % 512 == 0, "whole items per thread");
-        constexpr int ITEMS = NG * TW * Q / 512;
-        float4 bq[ITEMS];
-#pragma unroll
-        for (int q = 0; q < ITEMS; ++q) {
-            const int col = n0 + 4 * ((tid + 512 * q) % Q);
-            bq[q] = (a.bias && col < a.N) ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        // of a 3x3 layer.  Each wave turns its fragments round, 16 pixels at a time, in a private slice of the (dead) halo LDS --
+        // no block barrier after the first -- and a lane then owns (pixel, four consecutive columns).
+        float* const Exw = reinterpret_cast<float*>(Ah) + wave * (16 * 36);      // this wave's slice: [16 pixels][32 columns + 4]
+        const int cq = lane & 7;
+        const int col = n0 + 32 * wn + 4 * cq;
+        const float4 bq = (a.bias && col < a.N) ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();                                    // every wave is done with the halo images
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            __syncthreads();                                // pass 0: all halo reads finished; later: previous pass consumed
+            const int oy = y0 + RW * wm + i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pxr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ex[(wm * TW + pxr) * EX_LD + 32 * wn + (lane & 31)] = acc[i][r];
-            }
-            __syncthreads();
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int q = 0; q < ITEMS; ++q) {
-                const int j = tid + 512 * q;
-                const int pr = j / Q, cq = j - pr * Q;
-                const int g = pr / TW, px = pr - g * TW;
-                const int oy = y0 + RW * g + i, ox = x0 + px, col = n0 + 4 * cq;
-                if (oy >= a.Hin || ox >= a.Win || col >= a.N) continue;
-                float4 v = *reinterpret_cast<const float4*>(&Ex[(g * TW + px) * EX_LD + 4 * cq]);
-                v.x += bq[q].x; v.y += bq[q].y; v.z += bq[q].z; v.w += bq[q].w;
-                *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_frame_stride + ((int64_t)oy * a.Win + ox) * a.out_pix_stride + col) = v;
+                for (int rr = 0; rr < 8; ++rr)              // pixel 16 half + (rr & 3) + 8 (rr >> 2) + 4 (lane >> 5) of the row
+                    Exw[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[i][8 * half + rr];
+                LU_WAVE_SYNC();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int lp = (lane >> 3) + 8 * q;
+                    const int ox = x0 + 16 * half + lp;
+                    float4 v = *reinterpret_cast<const float4*>(&Exw[lp * 36 + 4 * cq]);
+                    v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                    if (oy < a.Hin && ox < a.Win && col < a.N)
+                        *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_frame_stride +
+                                                   ((int64_t)oy * a.Win + ox) * a.out_pix_stride + col) = v;
+                }
+                LU_WAVE_SYNC();
             }
         }
         return;
