@@ -11,7 +11,8 @@ dev = torch.device('cuda', 0)
 k, hw, B, N = 5, 256, 4, 128
 F32 = os.environ.get('TF_PREC', 'bf16') == 'fp32'      # fp32: conv_halo_kernel<5,BIAS>, 8 x 32 tiles, two per CU
 res = []
-for frames in (4, 2):
+FRAMES = tuple(int(v) for v in os.environ.get('TF_FRAMES', '4,2').split(','))
+for frames in FRAMES:
     for C in ((64, 128, 256, 512) if F32 else (128, 256, 512, 1024)):
         x = torch.randn(frames, hw, hw, C, device=dev)
         w = torch.randn(k, k, C, N, device=dev) * 0.02
@@ -34,7 +35,7 @@ for frames in (4, 2):
         print('frames %d C %4d: %8.1f us  tiles %d (%.1f per CU), %d stages per tile -> %.1f us per tile-round' % (
             frames, C, us, tiles, tiles / 256.0, stages, us / (tiles / 256.0)), flush=True)
         res.append((frames, C, us, stages, tiles / 256.0))
-for frames in (4, 2):
+for frames in FRAMES:
     pts = [(s, us / r) for f, c, us, s, r in res if f == frames]
     (s0, t0), (s1, t1) = pts[0], pts[-1]
     a_ = (t1 - t0) / (s1 - s0)
