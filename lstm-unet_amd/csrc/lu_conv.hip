@@ -69,6 +69,7 @@ struct ConvArgs {
     unsigned short* h16_out;   // ... optional bf16 copy of h
     int64_t h16_fs;
     int32_t lstm_vec4;     // conv_halo_kernel, LSTM epilogue: every state / gate tensor 16-byte aligned -> float4 loads / stores through LDS
+    int32_t out_vec4s;     // general kernel: as out_vec4, strided output rows (parity planes) allowed
     int32_t out_vec4;      // tile kernels, bias epilogue: dense 16-byte aligned output rows, N % 4 == 0 -> float4 stores through LDS
     int32_t dbg;           // ablation bits, honoured only in -DLU_ABLATION tool builds: 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
@@ -545,6 +546,46 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     }
 
     // ---- epilogue ----
+    if (EPI == LU_EPI_BIAS && a.out_vec4s && a.ksplit <= 1) {
+        // 16-byte stores (see conv_halo_kernel): each wave turns its fragments round, 16 rows at a time, in a private slice of
+        // the A tile's LDS (dead: the loop ended on a barrier); a lane then owns (row, four consecutive columns).
+        float* const Exw = &As[0][0] + wave * (16 * 36);
+        const int cq = lane & 7;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int64_t obase[2];
+                bool rok[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {      // the two rows this lane stores in every pass of this (mf, half)
+                    const int64_t m = m0 + wave * (32 * MF) + mf * 32 + 16 * half + (lane >> 3) + 8 * q;
+                    rok[q] = m < a.M;
+                    RowCursor rc;
+                    rc.set(a, rok[q] ? m : 0);
+                    obase[q] = (int64_t)rc.f * a.out_frame_stride +
+                               (a.out_row_stride ? (int64_t)rc.oy * a.out_row_stride + (int64_t)rc.ox * a.out_pix_stride
+                                                 : (int64_t)rc.pix * a.out_pix_stride);
+                }
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)      // row 16 half + (rr & 3) + 8 (rr >> 2) + 4 (lane >> 5) of the fragment
+                        Exw[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[mf][nf][8 * half + rr];
+                    LU_WAVE_SYNC();
+                    const int col = n0 + 32 * nf + 4 * cq;
+                    const float4 bq = (a.bias && col < a.N) ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float4 v = *reinterpret_cast<const float4*>(&Exw[((lane >> 3) + 8 * q) * 36 + 4 * cq]);
+                        v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                        if (rok[q] && col < a.N) *reinterpret_cast<float4*>(a.out + obase[q] + col) = v;
+                    }
+                    LU_WAVE_SYNC();
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int64_t mb = m0 + wave * (32 * MF) + mf * 32 + 4 * (lane >> 5);      // accumulator row r = 0 of this lane
@@ -2273,6 +2314,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     a.out_row_stride = d->out_row_stride;
     a.out_vec4 = (d->out_row_stride == 0 && d->N % 4 == 0 && d->out_pix_stride % 4 == 0 && d->out_frame_stride % 4 == 0 &&
                   aligned16(d->out) && (!d->bias || aligned16(d->bias))) ? 1 : 0;
+    a.out_vec4s = (d->N % 4 == 0 && d->out_pix_stride % 4 == 0 && d->out_frame_stride % 4 == 0 && d->out_row_stride % 4 == 0 &&
+                   aligned16(d->out) && (!d->bias || aligned16(d->bias))) ? 1 : 0;
     a.post_scale = d->post_scale;
     a.post_shift = d->post_shift;
     a.post_alpha = d->post_alpha;
