@@ -1578,14 +1578,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
     auto mma_stage = [&](int hb, int tapoff, const float4& b0, const float4& b1) {
         const unsigned char* ab = &Ah[hb * AH_BYTES + abase + tapoff];
         const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
-        if (LU_DBG(a, 2)) {      // ablation (tools only): no A-fragment LDS reads
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv1, bv0, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(bv0, bv1, acc[i]);
-            (void)ab;
-            return;
-        }
         lu_bf16x8 a0[RW], a1[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);

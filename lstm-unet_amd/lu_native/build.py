@@ -49,7 +49,12 @@ def build(force=False, verbose=True):
     from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     digest = source_hash()
-    with tempfile.TemporaryDirectory(prefix='lu_build_') as tmp:      # objects never land in the tree (nothing extra ships)
+    # objects never land in the tree (nothing extra ships).  The directory NAME is a function of the sources: hipcc leaves the
+    # object paths in the library, and a random name made two builds of the same sources differ in their build id
+    tmp = os.path.join(tempfile.gettempdir(), 'lu_build_' + digest[:16])
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    try:
         def compile_one(src):
             obj = os.path.join(tmp, src.replace('.hip', '.o'))
             cmd = [hipcc] + FLAGS + ['-c', '-x', 'hip', os.path.join(CSRC, src), '-o', obj]
@@ -63,6 +68,8 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     os.replace(LIB + '.tmp', LIB)
     with open(STAMP, 'w') as fh:
         fh.write(digest + '\n')
