@@ -872,3 +872,48 @@ def test_weight_prep_batch_equals_the_single_calls(be):
     calls.check(be.lib, be.lib.lu_weight_prep_batch(be.ptr(t), n, blocks, be.stream), 'prep packs')
     for out, ref in zip(outs, refs):
         assert np.array_equal(be.host(out).view(np.uint32), be.host(ref).view(np.uint32))
+
+
+def test_bn_lrelu_bwd_apply_bf16_result_and_state_begin(be):
+    """Two helper entry points of the bf16 / lazy-state paths at kernel level.
+    lu_bn_lrelu_bwd_apply_bf16: the fp32 backward rounded to nearest-even bf16 at the store -- exactly the bits a consumer that
+    rounds the fp32 tensor itself would see.  lu_state_begin: dst = src * keep[frame] (+ bf16 copy), zeros without a source, a
+    plain copy without a mask; 16-byte and scalar forms."""
+    rows, Cc = 256, 24
+    x, dy = rnd(rows, Cc, scale=2.0) + 0.5, rnd(rows, Cc)
+    gamma, beta = f32(1 + 0.2 * RNG.random(Cc)), rnd(Cc, scale=0.3)
+    xd, dyd, gd, bd = be.dev(x), be.dev(dy), be.dev(gamma), be.dev(beta)
+    ws = be.empty((be.lib.lu_colreduce_workspace_bytes(rows, Cc) // 8 + 1,), np.float64)
+    sums = be.empty((2 * Cc,), np.float64)
+    ck(be, be.lib.lu_bn_stats(be.ptr(xd), rows, Cc, be.ptr(sums), be.ptr(ws), be.stream), 'stats')
+    scale, shift, smean, sinv = [be.empty((Cc,)) for _ in range(4)]
+    ck(be, be.lib.lu_bn_finalize_train(be.ptr(sums), float(rows), be.ptr(gd), be.ptr(bd), 1e-3, 0.99, None, None,
+                                       be.ptr(scale), be.ptr(shift), be.ptr(smean), be.ptr(sinv), Cc, be.stream), 'fin')
+    bs = be.empty((2 * Cc,), np.float64)
+    ck(be, be.lib.lu_bn_lrelu_bwd_reduce(be.ptr(xd), be.ptr(dyd), be.ptr(scale), be.ptr(shift), be.ptr(smean),
+                                         be.ptr(sinv), 0.3, rows, Cc, be.ptr(bs), be.ptr(ws), be.stream), 'bwd_reduce')
+    dx, dg, db = be.empty(x.shape), be.empty((Cc,)), be.empty((Cc,))
+    ck(be, be.lib.lu_bn_lrelu_bwd_apply(be.ptr(xd), be.ptr(dyd), be.ptr(scale), be.ptr(shift), be.ptr(smean), be.ptr(sinv),
+                                        0.3, be.ptr(bs), float(rows), be.ptr(dx), be.ptr(dg), be.ptr(db), rows, Cc,
+                                        be.stream), 'bwd')
+    dx16, dg2, db2 = be.empty(x.shape, np.int16), be.empty((Cc,)), be.empty((Cc,))
+    ck(be, be.lib.lu_bn_lrelu_bwd_apply_bf16(be.ptr(xd), be.ptr(dyd), be.ptr(scale), be.ptr(shift), be.ptr(smean), be.ptr(sinv),
+                                             0.3, be.ptr(bs), float(rows), be.ptr(dx16), be.ptr(dg2), be.ptr(db2), rows, Cc,
+                                             be.stream), 'bwd16')
+    assert np.array_equal(be.host(dx16), KH.bf16_bits(be.host(dx)))
+    assert np.array_equal(be.host(dg2), be.host(dg)) and np.array_equal(be.host(db2), be.host(db))
+
+    for per_frame in (4 * 36, 7 * 5):          # float4 lanes / scalar tail form
+        frames = 3
+        src = rnd(frames, per_frame)
+        keep = f32([1.0, 0.0, 0.5])
+        sd, kd = be.dev(src), be.dev(keep)
+        for use_src, use_keep, use16 in ((True, True, True), (True, False, False), (False, True, True), (True, True, False)):
+            dst = be.empty((frames, per_frame))
+            d16 = be.empty((frames, per_frame), np.int16) if use16 else None
+            ck(be, be.lib.lu_state_begin(be.ptr(dst), be.ptr(d16), be.ptr(sd) if use_src else None,
+                                         be.ptr(kd) if use_keep else None, frames, per_frame, be.stream), 'state_begin')
+            want = (src * (keep[:, None] if use_keep else 1.0)) if use_src else np.zeros_like(src)
+            assert np.array_equal(be.host(dst), f32(want)), (per_frame, use_src, use_keep)
+            if use16:
+                assert np.array_equal(be.host(d16), KH.bf16_bits(f32(want)))
