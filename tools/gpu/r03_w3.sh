@@ -1,0 +1,6 @@
+python -m pytest tests/test_kernels.py tests/test_engine.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2; do
+for fl in 0 32; do
+python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-infer --no-wgrad-overlap --wgrad-flags $fl 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 flags $fl', d['ms_per_step'], d['value'], [(c['kernel'][:24], c['frac'], c['ms_per_step']) for c in d['roofline']['all_mfma_kernels'] if 'wgrad_row_bf16' in c['kernel']])"
+done
+done
