@@ -243,6 +243,7 @@ def main():
     ap.add_argument('--wgrad-flags', type=int, default=0, help='A/B: LU_WGRAD_F_* bits OR-ed into every weight-gradient descriptor')
     ap.add_argument('--conv-flags', type=int, default=0, help='A/B: LU_CONV_F_* bits OR-ed into every convolution descriptor')
     ap.add_argument('--ab-f32-act', action='store_true', help='A/B: bf16 mode with every activation stored as fp32 (round 2 / early round 3)')
+    ap.add_argument('--wgrad-rounds', type=int, default=0, help='A/B: rounds of blocks the bf16 kernel-row weight gradient is split into (default 5)')
     ap.add_argument('--ab-f32-grad', action='store_true', help='A/B: bf16 mode with the BatchNorm-backward gradients stored as fp32')
     ap.add_argument('--ab-no-prep', action='store_true',
                     help='A/B: derived weight images one launch at a time per step, recurrent state copied / masked eagerly (before round 3)')
@@ -291,6 +292,9 @@ def main():
         trainer.engine.grad_bf16 = False
     if args.ab_no_prep:
         trainer.engine.prep_batch = False
+    if args.wgrad_rounds:
+        from lu_native import calls as _calls
+        _calls.BF16_ROW_ROUNDS = args.wgrad_rounds
     if args.ab_f32_grad:
         trainer.engine.grad_bf16 = False
     ops.WGRAD_FLAGS |= args.wgrad_flags

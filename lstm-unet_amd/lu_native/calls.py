@@ -140,11 +140,15 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
     return d
 
 
-def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=5, cus=256):
+BF16_ROW_ROUNDS = 5      # (A/B: bench.py --wgrad-rounds)
+
+
+def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=None, cus=256):
     """Pixel-axis split of the bf16 kernel-row variant.  Its blocks are numbered XCD-aware (all tiles of a pixel slab on
     one XCD), one block per CU at 128-channel tiles (two at 64), all of equal length: pick a multiple of 8 slabs so that
     tiles x slabs is close to `rounds` full waves of the chip -- few fat slabs keep the slab write + re-read small
     (round 1: ~3000 blocks = 38 slabs of 26 MB at level 1 = 1 GB per launch; now 16 slabs)."""
+    rounds = BF16_ROW_ROUNDS if rounds is None else rounds
     inner = k * -(-Cin // ct) * -(-N // 128)
     per_round = cus * (1 if ct == 128 else 2)
     if inner <= 4 and Cin <= 64 and ct == 64:      # narrow layers (one channel tile, one column tile): 856 slabs of a 74 KB gradient made the slab REDUCE the
