@@ -2341,13 +2341,25 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     // bf16, N = 32 / 64 (the decoder tail): narrow blocks of the fragment kernel, always 8-row patches
     const bool narrow_n = d->precision == 1 && d->epilogue == LU_EPI_BIAS && (d->N == 32 || d->N == 64) &&
                           !(d->flags & LU_CONV_F_NO_NARROW);
-    if (d->precision != 0 && d->k == 5 && !narrow_n) {      // (the 3x3 instantiation of the tall patch spills registers: 8-row patches)
+    if (d->precision != 0 && d->k == 5 && !narrow_n) {      // (3x3: below)
         const int64_t nt_est = d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128;
         const int force = (d->flags & LU_CONV_F_PATCH16) ? 16 : (d->flags & LU_CONV_F_PATCH8) ? 8 : 0;      // tests and A/B runs
         const int64_t sp = d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits;
         if (force ? force == 16
                   : (d->precision == 1 && (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * nt_est * sp >= 256))
             th = 16;      // (fp32 fragment mode: 8-row patches, two blocks per CU, unless forced)
+    }
+    {   // 3x3 bf16 layers whose sources are all bf16 tensors (activations / BatchNorm-backward gradients stored as bf16): the
+        // second loop generation on 16-row patches as well -- 16 MFMAs per tap and wave and a three-deep weight-fragment ring
+        // instead of 8 and two.  (Round 2 measured this slower; the scalar epilogue, twice as long on the tall tile, was why.)
+        // fp32 sources stay on 8-row patches: their halo is twice the 16-byte pieces, more than one piece per tap.
+        bool all16 = d->n_src > 0;
+        for (int i = 0; i < d->n_src; ++i) all16 = all16 && d->src[i].dtype == LU_BF16;
+        const int force = (d->flags & LU_CONV_F_PATCH16) ? 16 : (d->flags & LU_CONV_F_PATCH8) ? 8 : 0;
+        if (d->precision == 1 && d->k == 3 && !narrow_n && d->epilogue == LU_EPI_BIAS && all16 && !(d->flags & LU_CONV_F_LOOP_GEN1) &&
+            d->splits <= 1 &&
+            (force ? force == 16 : (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * ((d->N + 127) / 128) >= 256))
+            th = 16;
     }
     const int64_t tiles_y = (d->Hout + th - 1) / th;
     const bool halo = d->stride == 1 && d->dil == 1 && k_h == d->k && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
@@ -2512,6 +2524,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && src16 && d->k == 5)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        else if (halo && !gen1 && src16 && d->k == 3 && th == 16)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<3, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(3, 8), stream, a);
         else if (halo && src16)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && d->k == 5 && th == 16)

@@ -917,3 +917,17 @@ def test_bn_lrelu_bwd_apply_bf16_result_and_state_begin(be):
             assert np.array_equal(be.host(dst), f32(want)), (per_frame, use_src, use_keep)
             if use16:
                 assert np.array_equal(be.host(d16), KH.bf16_bits(f32(want)))
+
+
+def test_conv3_bf16_sources_tall_patch_equals_the_8_row_kernel(be):
+    """3x3 bf16 layers on bf16 sources run the second loop generation on 16-row patches (conv_halo_frag2_kernel<3, BIAS, 8, true>)
+    when the launch has enough tiles; forced either way (LU_CONV_F_PATCH16 / PATCH8) the two kernels must give the same bits
+    (same taps, same channel order, same fp32 accumulation), ragged extents and a partial column tile included."""
+    for (H, W, Cc, N) in [(20, 40, 40, 136), (16, 32, 64, 128)]:
+        x = KH.bf16_round(rnd(2, H, W, Cc))
+        w, b = rnd(3, 3, Cc, N, scale=0.1), rnd(N)
+        o8 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH8, bf16_src=(0,))
+        o16 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16, bf16_src=(0,))
+        assert np.array_equal(o8, o16)
+        ref = npo.conv2d_same(x.astype(np.float64), KH.bf16_round(w).astype(np.float64), b.astype(np.float64), 1)
+        close(o16, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))

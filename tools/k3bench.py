@@ -8,6 +8,7 @@ from lu_native import ops
 if os.environ.get('KB_LIB'):
     ops.LIB_PATH = os.path.abspath(os.environ['KB_LIB'])
 dev = torch.device('cuda', 0)
+ops.CONV_FLAGS |= int(os.environ.get('KB_FLAGS', '0'))      # e.g. 2 = LU_CONV_F_PATCH16
 tag = sys.argv[1] if len(sys.argv) > 1 else 'product'
 frames = 32
 shapes = [(128, 128, 128), (64, 256, 256), (32, 512, 512), (64, 512, 128), (128, 256, 64), (256, 64, 32), (256, 32, 32)]
