@@ -314,12 +314,20 @@ class Engine:
             srcs = [(ops.to_f32(x) if x.dtype == torch.bfloat16 else x, co, cs) for (x, co, cs) in srcs]
             any16 = False
         fsrcs = srcs      # what the forward launch reads (the tape keeps `srcs`: the weight gradients see the real tensors)
+        if (bf and alt16 is not None and len(srcs) == 1 and spec['stride'] == 1 and w.shape[0] in (3, 5) and tape is not None and
+                srcs[0][0].dtype == torch.float32 and alt16.shape == srcs[0][0].shape and alt16.shape[3] % 8 == 0 and
+                srcs[0][1] == 0 and srcs[0][2] == alt16.shape[3]):
+            # the stride-1 convolution behind a ConvLSTM (last down block): read the bf16 copy of its output -- the bits the
+            # kernel would form from the fp32 tensor itself, half the bytes, and a bf16 source is what the tall 3x3 tile needs
+            fsrcs = [(alt16, 0, alt16.shape[3])]
+            any16 = True
+        base = fsrcs
         if bf and (any16 or any(x.shape[3] % 4 for (x, _, _) in srcs)):
             # thin sources (the 1-channel image skip of the last up block): the bf16 kernel reads 16-byte channel groups, so
             # they get zero pad channels (and zero weight rows) for this launch -- 33 MB at config-2, once per step; all sources
             # of a launch share one element type, so next to a bf16 tensor the others become bf16 as well
             fsrcs = []
-            for (x, co, cs) in srcs:
+            for (x, co, cs) in base:
                 if any16 and x.dtype != torch.bfloat16:
                     if x.shape[3] % 8:
                         xp = torch.zeros(x.shape[:3] + (-(-x.shape[3] // 8) * 8,), device=x.device, dtype=torch.bfloat16)
