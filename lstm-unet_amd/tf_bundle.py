@@ -343,10 +343,16 @@ def read_scalar_string(prefix, name, verify=True):
     return raw[pos + 4:pos + 4 + length]             # varint length | uint32 checksum of the lengths | bytes
 
 
+def _length_word(n):
+    """A string length as the running checksum sees it: the RESTORED integer, not its varint bytes -- a uint32 while it fits
+    (TensorFlow's tensor_bundle.cc keeps the checksum of pre-uint64 checkpoints valid that way), a uint64 above that."""
+    return struct.pack('<I', n) if n <= 0xFFFFFFFF else struct.pack('<Q', n)
+
+
 def _string_tensor_crc(raw):
     """Running checksum of a scalar string tensor as TensorFlow computes it (see _string_tensor_bytes)."""
     length, pos = get_varint(raw, 0)
-    crc = crc32c(struct.pack('<Q', length))
+    crc = crc32c(_length_word(length))
     crc = crc32c(raw[pos:pos + 4], crc)
     return crc32c(raw[pos + 4:pos + 4 + length], crc)
 
@@ -374,10 +380,15 @@ def resolve_through_object_graph(prefix, paths):
     """{attribute path: checkpoint key} for the variables reachable by walking the checkpoint's OWN object graph from the root
     along the attribute names (`DownLayers/0/ConvLSTM/0/cell/kernel`): whatever keys the writing TensorFlow chose -- attribute
     paths, `layer_with_weights-N/...` aliases at any depth -- the graph names them.  Paths it cannot reach are left out."""
-    blob = read_scalar_string(prefix, OBJECT_GRAPH_KEY)
-    if not blob:
+    try:      # best effort: the key-name scan of load_model_weights covers a graph this reader cannot take
+        blob = read_scalar_string(prefix, OBJECT_GRAPH_KEY)
+        nodes = parse_object_graph(blob) if blob else []
+    except (ValueError, IndexError, struct.error, UnicodeDecodeError) as exc:
+        import warnings
+        warnings.warn('%s: object graph unreadable (%s); falling back to the variable key names' % (prefix, exc))
         return {}
-    nodes = parse_object_graph(blob)
+    if not nodes:
+        return {}
     out = {}
     for path in paths:
         nid = 0
@@ -391,12 +402,13 @@ def resolve_through_object_graph(prefix, paths):
 
 
 def _string_tensor_bytes(items):
-    """On-disk form of a DT_STRING tensor: varint64 lengths | uint32 masked crc of the lengths (as uint64) | bytes; returns
-    (data, unmasked running crc over lengths-as-uint64, the length checksum, the string bytes)."""
+    """On-disk form of a DT_STRING tensor: varint64 lengths | uint32 masked crc of the lengths (each as uint32 while it fits,
+    else uint64: _length_word) | bytes; returns (data, unmasked running crc over the length words, the length checksum, the
+    string bytes)."""
     crc = 0
     data = bytearray()
     for it in items:
-        crc = crc32c(struct.pack('<Q', len(it)), crc)
+        crc = crc32c(_length_word(len(it)), crc)
         data += put_varint(len(it))
     lcs = struct.pack('<I', mask_crc(crc))
     crc = crc32c(lcs, crc)

@@ -147,6 +147,13 @@ def train(params):
     if dp.world_size > 1:                    # one run directory for the job: rank 0's (the time stamp is per process)
         dirs = [params.experiment_log_dir, params.experiment_save_dir]
         torch.distributed.broadcast_object_list(dirs, src=0)
+        for own, shared in zip((params.experiment_log_dir, params.experiment_save_dir), dirs):
+            # Params.__init__ has already created this rank's own time-stamped directories: drop the unused (empty) ones
+            if own != shared and os.path.isdir(own) and not os.listdir(own):
+                try:
+                    os.rmdir(own)
+                except OSError:
+                    pass
         params.experiment_log_dir, params.experiment_save_dir = dirs
     train_data_provider, val_data_provider = params.train_data_provider, params.val_data_provider
     train_data_provider.start_queues(None)
@@ -166,6 +173,7 @@ def train(params):
                 t.mul_(1.0 / dp.world_size)
 
     saved_states = []
+    bn_synced_at = [None]                    # step whose BatchNorm statistics are already the mean over the ranks
 
     def save_ckpt(collective=True):
         """collective=True: a regular save point that EVERY rank reaches at the same step (BN statistics are averaged over
@@ -176,6 +184,7 @@ def train(params):
             return None
         if collective:
             sync_bn_stats()
+            bn_synced_at[0] = trainer.step
         if dp.world_size > 1:                # recurrent states are rank-local clip streams: one small file per rank
             os.makedirs(ckpt_dir, exist_ok=True)
             own = os.path.join(ckpt_dir, 'states-%d.rank%d.pt' % (trainer.step, dp.rank))
@@ -283,8 +292,8 @@ def train(params):
             if local_err is None:
                 try:
                     image_sequence, seg_sequence, _, is_last_batch = train_data_provider.get_batch()
-                except ValueError as exc:
-                    local_err = exc
+                except Exception as exc:      # ValueError, but also the reader's RuntimeError (workers stopped / died) and a
+                    local_err = exc           # producer's own OSError / IndexError: every type must reach the flag all-reduce
             agree_on_failure(local_err)
             profiling = bool(params.profile) and is_main and not params.dry_run and \
                 (trainer.step + 1) % params.write_to_tb_interval == 0
@@ -327,7 +336,7 @@ def train(params):
                 local_err = None
                 try:
                     v_img, v_seg, _, v_last = val_data_provider.get_batch()
-                except ValueError as exc:
+                except Exception as exc:
                     local_err = exc
                 agree_on_failure(local_err)
                 v_sm, v_pred, v_loss = trainer.val_step(v_img, v_seg)
@@ -343,16 +352,24 @@ def train(params):
                 val_states = model.get_states()
                 model.set_states(train_states)
         in_step_with_peers = True                # the loop ran to its end on every rank
-    except (KeyboardInterrupt, ValueError, AWSError) as err:
+    except BaseException as err:
+        # the reference saves and closes on these three (train2D.py:222-227); a reader failure of any other type that
+        # agree_on_failure has spread to all ranks is checkpointed the same way and then re-raised
+        handled = isinstance(err, (KeyboardInterrupt, ValueError, AWSError))
+        agreed = bool(getattr(err, '_lu_agreed', False))
+        if not handled and not agreed:
+            raise
         # agree_on_failure raised on every rank at once; anything else (SIGINT to one pid, an error inside a step) may be
         # this rank's alone -- no collectives from here on in that case
-        in_step_with_peers = dp.world_size == 1 or (isinstance(err, (ValueError, AWSError)) and
-                                                    getattr(err, '_lu_agreed', False))
+        in_step_with_peers = dp.world_size == 1 or agreed
         if not params.dry_run:
             log_print('Saving Model Before closing due to error: {}'.format(str(err)))
-            save_ckpt(collective=False)
+            # all ranks in step: the resumable checkpoint gets the rank-averaged BatchNorm statistics like a regular one
+            save_ckpt(collective=in_step_with_peers and dp.world_size > 1)
+        if not handled:
+            raise
     finally:
-        if not params.dry_run and trainer.engine.plan is not None and in_step_with_peers:
+        if not params.dry_run and trainer.engine.plan is not None and in_step_with_peers and bn_synced_at[0] != trainer.step:
             sync_bn_stats()
         if not params.dry_run and is_main and trainer.engine.plan is not None:
             model_fname = os.path.join(params.experiment_save_dir, 'model.ckpt')

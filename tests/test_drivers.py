@@ -104,35 +104,48 @@ with engine_backend('emu'):
     def flaky():
         calls[0] += 1
         if rank == 1 and calls[0] == 5:
-            raise ValueError('non-finite values in frame 3 after augmentation')
+            if os.environ['LU_TEST_ERR'] == 'ValueError':
+                raise ValueError('non-finite values in frame 3 after augmentation')
+            raise RuntimeError('non-finite: the reader workers stopped')      # DataHandeling._next_item's type
         return real()
     prov.get_batch = flaky
     collectives = []
     orig = DataParallel.all_reduce_
     DataParallel.all_reduce_ = lambda self, t: (collectives.append(tuple(t.shape)), orig(self, t))[1]
-    trainer = train2D.train(params)
+    made = []
+    real_trainer = train2D.Trainer
+    train2D.Trainer = lambda *a, **k: (made.append(real_trainer(*a, **k)), made[-1])[1]
+    try:
+        train2D.train(params)
+        assert os.environ['LU_TEST_ERR'] == 'ValueError' or rank == 0      # (the peers leave with the agreed ValueError)
+    except RuntimeError as exc:       # not one of the reference's three: checkpointed like them, then re-raised on the failing rank
+        assert os.environ['LU_TEST_ERR'] == 'RuntimeError' and getattr(exc, '_lu_agreed', False), exc
+        print('re-raised:', exc, flush=True)
+    trainer = made[0]
     n_bn = len(trainer.engine.S)
-    # after the agreed failure: exactly one more round of BN-statistics averaging (the `finally` of a loop that every rank
-    # left together) and NONE from the error-path checkpoint
+    # after the agreed failure: exactly one more round of BN-statistics averaging -- by the error-path checkpoint, which is
+    # collective when (and only when) the failure was agreed on; the `finally` does not repeat it
     tail = collectives[-n_bn:]
     print('RANK', rank, 'steps', trainer.step, 'tail', len(tail), flush=True)
     np.save(os.path.join(%(tmp)r, 'done_%%d.npy' %% rank), np.array([trainer.step, len(collectives)]))
 '''
 
 
-def test_dp_loop_failure_on_one_rank_stops_all_ranks_without_hanging(tmp_path):
-    """A data error on ONE rank (reader ValueError) must end the loop on every rank at the same step, the error-path
-    checkpoint must not issue collectives (it may run on one rank only), and per-rank state files rotate with
-    save_checkpoint_max_to_keep (train2D.py:145-246 is single-device; SURVEY §8e)."""
+@pytest.mark.parametrize('err_kind', ['ValueError', 'RuntimeError'])
+def test_dp_loop_failure_on_one_rank_stops_all_ranks_without_hanging(tmp_path, err_kind):
+    """A data error on ONE rank -- the reader's ValueError, or the RuntimeError / OSError its worker threads hand over -- must
+    end the loop on every rank at the same step; the checkpoint of an AGREED failure averages the BatchNorm statistics like a
+    regular one (all ranks are in step), and per-rank state files rotate with save_checkpoint_max_to_keep (train2D.py:145-246
+    is single-device; SURVEY §8e)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'worker.py'
     script.write_text(DP_LOOP_WORKER % {'root': root, 'tmp': str(tmp_path)})
-    port = 29700 + os.getpid() % 1200
+    port = 29700 + os.getpid() % 1200 + (0 if err_kind == 'ValueError' else 1201)
     procs = [subprocess.Popen([sys.executable, str(script)],
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), LU_DP_BACKEND='gloo',
-                                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                                       LU_TEST_ERR=err_kind, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):

@@ -219,3 +219,36 @@ def test_object_graph_proto():
     keys = sorted(dict((n, v) for n, _, v in leaf)[3] for leaf in leaves)
     assert keys == [(p + tb.SUFFIX).encode() for p in ['DownLayers/0/Conv/0/bias', 'DownLayers/0/Conv/0/kernel',
                                                        'UpLayers/1/BN/0/gamma']]
+
+
+def test_string_tensor_checksum_uses_uint32_lengths(tmp_path):
+    """tensor_bundle.cc WriteStringTensor / ReadStringTensor: the running checksum extends with each string LENGTH as the
+    restored integer -- a uint32 while it fits (checkpoints from before the uint64 lengths stay valid), a uint64 only above
+    UINT32_MAX -- then with the masked length checksum, then with the bytes.  Assembled here by hand, independently of the
+    writer; a bundle whose string entry carries the uint64-width checksum (the round-3 writer) must be REJECTED by the verifying
+    reader and must not break load_model_weights (object graph = best effort, key names = fallback).  Unpinned against a real
+    TensorFlow string tensor (none available)."""
+    payload = b'\x0a\x02\x12\x00' * 5
+    crc = tb.crc32c(struct.pack('<I', len(payload)))
+    lcs = struct.pack('<I', tb.mask_crc(crc))
+    crc = tb.crc32c(payload, tb.crc32c(lcs, crc))
+    raw = tb.put_varint(len(payload)) + lcs + payload
+    data, got_crc = tb._string_tensor_bytes([payload])
+    assert data == raw and got_crc == crc and tb._string_tensor_crc(raw) == crc
+    wide = tb.crc32c(struct.pack('<Q', len(payload)))
+    assert wide != tb.crc32c(struct.pack('<I', len(payload)))
+    assert tb._length_word(2 ** 32) == struct.pack('<Q', 2 ** 32) and tb._length_word(2 ** 32 - 1) == b'\xff\xff\xff\xff'
+    prefix = str(tmp_path / 's.ckpt')
+    tb.write_bundle(prefix, {'v' + tb.SUFFIX: np.arange(3, dtype=np.float32)}, strings={tb.OBJECT_GRAPH_KEY: payload})
+    assert tb.read_scalar_string(prefix, tb.OBJECT_GRAPH_KEY) == payload
+    # the same bundle with a string entry checksummed the old (uint64-length) way
+    orig = tb._length_word
+    tb._length_word = lambda n: struct.pack('<Q', n)
+    try:
+        tb.write_bundle(prefix + '.old', {'v' + tb.SUFFIX: np.arange(3, dtype=np.float32)}, strings={tb.OBJECT_GRAPH_KEY: payload})
+    finally:
+        tb._length_word = orig
+    with pytest.raises(ValueError, match='checksum'):
+        tb.read_scalar_string(prefix + '.old', tb.OBJECT_GRAPH_KEY)
+    with pytest.warns(UserWarning, match='object graph unreadable'):
+        assert tb.resolve_through_object_graph(prefix + '.old', ['v']) == {}
