@@ -81,6 +81,61 @@ def lstm_step_flops(net, H, W, B, cin=1):
     return out
 
 
+NETS = ('params', 'default5', 'lstm3')
+
+
+def net_by_name(name):
+    """params   = Params.py:49-69, what train2D.py trains by default (3x3 convs, 5x5 ConvLSTM): the headline;
+    default5 = Networks.DEFAULT_NET_DOWN_PARAMS (Networks.py:12-32): 5x5 everywhere, 2 543.8 GFLOP/frame of training at 256^2;
+    lstm3    = north_star's wording, "one 3x3 conv producing i/f/o/g": 3x3 everywhere, 915.8 GFLOP/frame."""
+    import Params
+    import Networks
+    return {'params': Params.CTCParams.net_kernel_params, 'default5': Networks.DEFAULT_NET_DOWN_PARAMS,
+            'lstm3': Params.lstm_unet_kernels(3, 3)}[name]
+
+
+NET_WORDS = {'params': 'Params.py widths (5x5 ConvLSTM 128/256/256/512, 3x3 convs)',
+             'default5': 'Networks.DEFAULT_NET_DOWN_PARAMS (5x5 ConvLSTM AND 5x5 convs, same widths)',
+             'lstm3': '3x3-ConvLSTM variant of north_star (3x3 ConvLSTM 128/256/256/512, 3x3 convs)'}
+
+
+def measure_variant(net, precision, batches, B, T, H, W, dp, steps, warmup):
+    """One more trainer on the same resident batches: K timed steps + one step under per-class HIP events."""
+    import Params
+    import train2D
+    from lu_native import ops
+    from lu_native.profile import summarize_events
+    tr = train2D.Trainer(Params.CTCParams.net_model, net, 'NCHW', Params.CTCParams.class_weights,
+                         Params.CTCParams.learning_rate, dp=dp, seed=0, precision=precision)
+
+    def step(i):
+        img, seg, keep = batches[i % len(batches)]
+        tr.train_step(img, seg, want_outputs=True)
+        tr.model.reset_states_per_batch(keep)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    ops.EVENT_LOG = []
+    step(warmup + steps)
+    torch.cuda.synchronize()
+    ev, ops.EVENT_LOG = ops.EVENT_LOG, None
+    rows, _ = summarize_events(ev)
+    flops, fwd = step_flops(net, H, W, B, T)
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+    del tr
+    torch.cuda.empty_cache()
+    return {'ms_per_step': round(1e3 * sec, 3), 'frames_per_s': round(B * T / sec, 3),
+            'train_gflop_per_frame': round(flops / (B * T) / 1e9, 1), 'step_tflops_achieved': round(flops / 1e12 / sec, 2),
+            'frac_of_peak': round(flops / 1e12 / sec / peak, 4), 'peak': peak, 'steps': steps,
+            'mfma_kernels': [{k_: r_[k_] for k_ in ('kernel', 'achieved', 'frac', 'launches_per_step', 'ms_per_step')} for r_ in rows]}
+
+
 def synthetic_batches(n, B, T, H, W, rank, device):
     from DataHandeling import SyntheticSequence2D
     prov = SyntheticSequence2D(image_crop_size=(H, W), unroll_len=T, batch_size=B, data_format='NCHW',
@@ -103,6 +158,26 @@ def cpu_baseline(net, budget_s=60.0):
     from oracle import torch_oracle as tho
     host_cores = os.cpu_count() or 1
     t_start = time.time()
+    # PROBE, don't assert (SURVEY §8c last row): is there a TensorFlow on this box?  If so, pin the oracle
+    # (tools/tf_pin.py -> gpurun_out/tf_pin/) and time a build-owned tf.keras step beside the port; if not, say what the import
+    # actually raised.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('lu_tf_pin', os.path.join(ROOT, 'tools', 'tf_pin.py'))
+    tf_tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tf_tool)
+    tf_mod, tf_what = tf_tool.probe_tensorflow()
+    tf_line = None
+    if tf_mod is not None:
+        try:
+            rc = tf_tool.main(out=os.path.join(ROOT, 'gpurun_out', 'tf_pin'))
+            step_tf = tf_tool.keras_train_step_timer(tf_mod, net, 256, 256, 1, 2)
+            step_tf()                                             # trace + warm-up
+            t_tf = min(step_tf(), step_tf())
+            tf_line = {'value': round(2.0 / t_tf, 4), 'unit': 'frames/s', 'kind': 'tf', 'tensorflow': tf_what, 'tf_pin_rc': rc,
+                       'cores': host_cores, 'sample': 'tf.keras (build-owned model, NHWC) config-2 slice: 256x256, B=1, T=2, '
+                                                      'best of 2 steps after the trace: %.2f s/step' % t_tf}
+        except Exception as exc:
+            tf_line = {'value': None, 'kind': 'tf', 'tensorflow': tf_what, 'sample': 'failed: %r' % (exc,)}
 
     def make(net_, H, W, B, T):
         p = npo.init_params(net_, 1, seed=0)
@@ -145,8 +220,10 @@ def cpu_baseline(net, budget_s=60.0):
         n2 += 1
     t2 = e2 / n2
     return {'value': round(2.0 / t2, 4), 'unit': 'frames/s', 'cores': threads, 'host_cores': host_cores, 'kind': 'port',
+            'tensorflow_probe': tf_what if tf_mod is not None else '`import tensorflow` on this box raised %s' % tf_what,
+            'tf': tf_line,
             'sample': 'config-2 slice: Params.py-width net, 256x256 full frames, B=1, T=2, %d training step(s) after 1 warm-up: '
-                      '%.2f s/step; torch CPU fp32 restatement of the TF2 path (TF not installed), %d threads (best of a '
+                      '%.2f s/step; torch CPU fp32 restatement of the TF2 path, %d threads (best of a '
                       'walk-up probe) on a %d-core host' % (n2, t2, threads, host_cores),
             'config1': {'value': round(4.0 / t1, 3), 'unit': 'frames/s', 's_per_step': round(t1, 4),
                         'sample': 'BASELINE config-1 timed fully: 128x128, T=4, B=1, 32-channel 3x3 ConvLSTM-UNet, '
@@ -251,6 +328,11 @@ def main():
                     help='A/B: bf16 mode with the decoder tail on the kernels of round 2 (gather / fp32 tiles, fp32 all-taps weight gradients)')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else)")
+    ap.add_argument('--net', choices=list(NETS), default='params',
+                    help='kernel-size variant (SURVEY D1): params = train2D.py default = the headline; default5 = 5x5 everywhere; '
+                         'lstm3 = 3x3 ConvLSTM (north_star wording)')
+    ap.add_argument('--no-variants', action='store_true',
+                    help='skip the `variants` block (lstm3 / default5 in fp32 and bf16, N = 1, headline net only)')
     args = ap.parse_args()
     if args.gpus < 1:
         _die('--gpus must be >= 1')
@@ -276,7 +358,7 @@ def main():
     dev_index = dp.local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    net = Params.CTCParams.net_kernel_params
+    net = net_by_name(args.net)
     H = W = args.size
     if args.hw:
         H, W = args.hw
@@ -471,10 +553,23 @@ def main():
                  'what': 'same workload with --precision bf16: bf16 MFMA operands (v_mfma_f32_32x32x16_bf16) on the '
                          'convolutions and weight gradients, fp32 accumulate / master weights / state / optimiser'}
         del tr16
+    # ---- the kernel-size variants SURVEY D1 asks to report beside the headline net (N = 1, default headline run only) ----
+    variants = None
+    if dp.world_size == 1 and args.net == 'params' and not args.no_variants:
+        try:
+            del trainer
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        variants = {}
+        for vname in ('lstm3', 'default5'):
+            variants[vname] = {'net': NET_WORDS[vname]}
+            for prec in ('fp32', 'bf16'):
+                variants[vname][prec] = measure_variant(net_by_name(vname), prec, batches, B, T, H, W, dp, args.steps, args.warmup)
     cpu = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(net)
+            cpu = cpu_baseline(Params.CTCParams.net_kernel_params)
         except Exception as exc:  # the baseline is informational; never lose the GPU line over it
             cpu = {'value': None, 'unit': 'frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
     if dp.rank == 0:
@@ -483,13 +578,12 @@ def main():
             'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE config-2 per GPU: ' if (H, W, T, B) == (256, 256, 8, 4) else
+            'config': {'workload': ('BASELINE config-2 per GPU: ' if (H, W, T, B, args.net) == (256, 256, 8, 4, 'params') else
                                     ('BASELINE config-4: ' if (H, W, T, B) == (832, 992, 16, 2) else '')) +
-                                   '%dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet Params.py widths (5x5 ConvLSTM '
-                                   '128/256/256/512, 3x3 convs), %s, random-init' %
-                                   (H, W, T, B, 'fp32' if args.precision == 'fp32' else
+                                   '%dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet %s, %s, random-init' %
+                                   (H, W, T, B, NET_WORDS[args.net], 'fp32' if args.precision == 'fp32' else
                                     'bf16 MFMA operands on the wide stride-1 convs (fp32 master weights / accumulate / wgrad)'),
-                       'global_batch': B * dp.world_size, 'seq_len': T,
+                       'net': args.net, 'global_batch': B * dp.world_size, 'seq_len': T,
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
             'build_id': lu_build.build_id(),      # sha256[:16] of liblstmunet_hip.so
             'dp': dp_info,
@@ -498,6 +592,7 @@ def main():
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'inference': infer,
             'bf16_mode': mixed,
+            'variants': variants,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

@@ -124,13 +124,30 @@ def stream_softmax(model, frames, data_format='NCHW', pre_sequence_frames=0, on_
         yield t, (sm if on_device else sm.cpu().numpy())
 
 
+def resolve_resize(model_dict, asked=None):
+    """The bilinear convention the saved weights were trained under: model_params.pickle records it since round 4.
+    A pickle without it comes from the reference itself (or an older build): 'tf2.0' -- the TensorFlow release the reference
+    pins -- is assumed, loudly, because a model trained under the other convention runs without any error and segments worse.
+    `asked` (--resize) overrides; a contradiction with the record is a warning, not an error."""
+    recorded = model_dict.get('resize')
+    if recorded is None and asked is None:
+        log_print("WARNING: model_params.pickle does not record the bilinear resize convention (written by the reference or an "
+                  "older build): assuming 'tf2.0' (TensorFlow 2.0 / 2.1); pass --resize half_pixel for a model trained "
+                  "under a later TensorFlow")
+        return 'tf2.0'
+    if recorded is not None and asked is not None and asked != recorded:
+        log_print("WARNING: the model was trained with resize='{}', running it with --resize {}".format(recorded, asked))
+    return asked if asked is not None else recorded
+
+
 def inference(params):
     select_gpu(getattr(params, 'gpu_id', None))
     with open(os.path.join(params.model_path, 'model_params.pickle'), 'rb') as fobj:
         model_dict = pickle.load(fobj)
     model_cls = get_model(model_dict['name'])
     model = model_cls(*model_dict['params'], data_format=params.data_format, pad_image=True,
-                      precision=getattr(params, 'precision', 'fp32'))
+                      precision=getattr(params, 'precision', 'fp32'),
+                      resize=resolve_resize(model_dict, getattr(params, 'resize', None)))
     model.load_weights(os.path.join(params.model_path, 'model.ckpt'))
     log_print('Restored from {}'.format(os.path.join(params.model_path, 'model.ckpt')))
     dataset = params.data_reader(params.sequence_path, params.filename_format,
@@ -199,6 +216,8 @@ FLAGS = [
     (('--dry_run',), dict(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
     (('--precision',), dict(dest='precision', choices=['fp32', 'bf16'],
                             help='[MI355X] fp32 (default) or bf16 MFMA operands for the wide convolutions')),
+    (('--resize',), dict(dest='resize', choices=['tf2.0', 'half_pixel'],
+                         help='[MI355X] bilinear convention of the up blocks; default: what model_params.pickle recorded')),
     (('--graph',), dict(dest='graph', action='store_const', const=True,
                         help='[MI355X] replay the per-frame launch sequence from a captured hipGraph (bit-identical; measured '
                              'neutral to slightly slower: the frame is bound by the GPU, not by the host launches)')),

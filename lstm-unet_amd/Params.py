@@ -57,6 +57,7 @@ _TRAIN_DEFAULTS = dict(
     dry_run=False, profile=False,
     # MI355X options: pool BatchNorm statistics over all data-parallel ranks; MFMA operand precision
     sync_bn=False, precision='fp32', data_provider=None,
+    resize='tf2.0',        # bilinear convention of the up blocks (Networks.py:143): 'tf2.0' = TensorFlow 2.0 / 2.1, 'half_pixel' = later
 )
 
 _INFER_DEFAULTS = dict(
@@ -66,6 +67,7 @@ _INFER_DEFAULTS = dict(
     FOV=0, min_cell_size=10, max_cell_size=100, edge_dist=2, pre_sequence_frames=4,
     dry_run=False, save_intermediate=True, save_intermediate_path='./tmp/output/PhC-C2DL-PSC/01',
     precision='fp32',      # MI355X option: 'bf16' = bf16 MFMA operands
+    resize=None,           # bilinear convention: None = what model_params.pickle recorded (else 'tf2.0'); 'tf2.0' / 'half_pixel' override
     fov_fix=False,         # MI355X option: True masks columns [0, FOV) instead of the reference's single column (Inference2D.py:97)
     graph=False,           # MI355X option: True replays the per-frame launch sequence from a captured hipGraph
 )

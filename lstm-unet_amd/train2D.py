@@ -35,11 +35,11 @@ class Trainer(object):
     """Owns model + optimiser + DP plumbing; exposes train_step / val_step."""
 
     def __init__(self, net_model, net_kernel_params, data_format='NCHW', class_weights=(0.15, 0.25, 0.6),
-                 learning_rate=1e-5, dp=None, sync_bn=False, seed=0, precision='fp32'):
+                 learning_rate=1e-5, dp=None, sync_bn=False, seed=0, precision='fp32', resize='tf2.0'):
         self.dp = dp if dp is not None else DataParallel()
         self.data_format = data_format
         self.model = net_model(net_kernel_params, data_format, False, seed=seed, dp=self.dp, sync_bn=sync_bn,
-                               precision=precision)
+                               precision=precision, resize=resize)
         self.engine = self.model.engine
         self.optimizer = Adam(self.engine, lr=learning_rate)
         self.class_weights = list(class_weights)
@@ -142,7 +142,7 @@ def train(params):
     is_main = dp.rank == 0
     trainer = Trainer(params.net_model, params.net_kernel_params, params.data_format, params.class_weights,
                       params.learning_rate, dp=dp, sync_bn=getattr(params, 'sync_bn', False),
-                      precision=getattr(params, 'precision', 'fp32'))
+                      precision=getattr(params, 'precision', 'fp32'), resize=getattr(params, 'resize', 'tf2.0'))
     model = trainer.model
     if dp.world_size > 1:                    # one run directory for the job: rank 0's (the time stamp is per process)
         dirs = [params.experiment_log_dir, params.experiment_save_dir]
@@ -377,7 +377,10 @@ def train(params):
             # the reference's own Inference2D.py (and ours) loads; params.save_format = 'pt' writes a torch blob instead
             model.save_weights(model_fname, save_format=getattr(params, 'save_format', 'tf'))
             with open(os.path.join(params.experiment_save_dir, 'model_params.pickle'), 'wb') as fobj:
-                pickle.dump({'name': model.__class__.__name__, 'params': (params.net_kernel_params,)}, fobj,
+                # 'name' / 'params' are the reference's contract (train2D.py:236-239); 'resize' / 'precision' record what the
+                # weights were trained under -- the bilinear convention is part of the function they encode
+                pickle.dump({'name': model.__class__.__name__, 'params': (params.net_kernel_params,),
+                             'resize': trainer.engine.resize, 'precision': trainer.engine.precision}, fobj,
                             protocol=pickle.HIGHEST_PROTOCOL)
             log_print('Saved Model to file: {}'.format(model_fname))
         elif params.dry_run:
@@ -471,6 +474,9 @@ def build_arg_parser():
                              '--root_data_dir / --train_sequence_list (needs the metadata_<seq>.pickle files)')
     parser.add_argument('--precision', dest='precision', choices=['fp32', 'bf16'],
                         help='[MI355X] fp32 (default) or bf16-MFMA operands for the wide stride-1 convolutions')
+    parser.add_argument('--resize', dest='resize', choices=['tf2.0', 'half_pixel'],
+                        help="[MI355X] bilinear convention of the up blocks: 'tf2.0' (default; TensorFlow 2.0 / 2.1, the release the "
+                             "reference pins) or 'half_pixel' (later releases); recorded in model_params.pickle")
     return parser
 
 

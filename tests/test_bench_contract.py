@@ -27,6 +27,13 @@ def test_algorithmic_flops_match_survey():
     per_launch = b.lstm_step_flops(net, 256, 256, 4)
     assert [round(x / 1e9) for x in per_launch] == [866, 1288, 429, 322]
     assert b.PEAK_FP32_MFMA_TFLOPS == 157.3
+    # the kernel-size variants of SURVEY D1 / §8d ("Variants at C2: all-5x5 -> 2 543.8; 3x3-LSTM -> 915.8 GFLOP/frame"; forward
+    # 870.9 / 313.5) that `bench.py --net` and the `variants` block of the default line report
+    t5, f5 = b.step_flops(b.net_by_name('default5'), 256, 256, 4, 8)
+    t3, f3 = b.step_flops(b.net_by_name('lstm3'), 256, 256, 4, 8)
+    assert abs(f5 / 1e9 - 870.9) < 0.1 and abs(t5 / 32 / 1e9 - 2543.8) < 0.2
+    assert abs(f3 / 1e9 - 313.5) < 0.1 and abs(t3 / 32 / 1e9 - 915.8) < 0.2
+    assert b.net_by_name('params') is Params.CTCParams.net_kernel_params
 
 
 def _run_bench(extra, env_extra, timeout=900):

@@ -33,7 +33,7 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     args = dict(experiment_name='t', crop_size=(size, size), batch_size=2, unroll_len=2, num_iterations=3,
                 validation_interval=2, print_to_console_interval=1, save_checkpoint_iteration=2,
                 save_checkpoint_dir=str(tmp_path), save_log_dir=str(tmp_path), data_format='NCHW',
-                learning_rate=1e-3, write_to_tb_interval=2)
+                learning_rate=1e-3, write_to_tb_interval=2, resize='half_pixel')
     params = Params.CTCParams(args)
     assert isinstance(params.train_data_provider, DataHandeling.SyntheticSequence2D) and params.channel_axis == 1
     trainer = train2D.train(params)
@@ -43,6 +43,16 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     with open(os.path.join(save_dir, 'model_params.pickle'), 'rb') as f:
         meta = pickle.load(f)
     assert meta['name'] == 'ULSTMnet2D' and meta['params'][0] == net
+    # the bilinear convention the weights were trained under travels with them ...
+    assert meta['resize'] == 'half_pixel' == trainer.engine.resize and meta['precision'] == 'fp32'
+    logged = []
+    monkeypatch.setattr(Inference2D, 'log_print', lambda *a: logged.append(' '.join(map(str, a))))
+    assert Inference2D.resolve_resize(meta) == 'half_pixel' and not logged
+    assert Inference2D.resolve_resize(meta, 'tf2.0') == 'tf2.0' and 'trained with' in logged[-1]
+    # ... and a pickle without the record (the reference's own, train2D.py:236-239) is run under 'tf2.0', loudly
+    assert Inference2D.resolve_resize({'name': 'ULSTMnet2D', 'params': (net,)}) == 'tf2.0' and 'does not record' in logged[-1]
+    monkeypatch.undo()
+    monkeypatch.setattr(Params.CTCParams, 'net_kernel_params', net)
     ckpts = sorted(os.listdir(os.path.join(save_dir, 'tf_ckpts')))
     assert ckpts, 'no periodic checkpoint written'
     # TensorBoard event files: Loss / SEG scalars and Image / GT / Output images at steps 2 and 4, train and val

@@ -591,8 +591,11 @@ def test_config4_frame_vs_fp64_oracle(full_engine):
     assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-3
 
 
-# Full-width gradients, MEASURED on the MI355X (profiles/r04_gpu_tests_tail.log); tolerances = 2x the measured worst tensor.
-FULL_GRAD_TOL = {'fp32': (None, None), 'bf16': (None, None)}      # (max-abs / tensor-max, L2-relative); filled from the measurement
+# Full-width gradients, MEASURED on the MI355X (profiles/r04_fullsize_oracle_tests.log): fp32 worst max-abs / tensor-max 1.74e-2
+# (up.0.bn.0.beta; 75 of the 78 tensors <= 2.1e-3 -- the three above sit behind the 8x8-pixel level, whose BatchNorm pools 512
+# samples: kink flips), worst L2-relative 3.6e-3; bf16 mode against the rounded-forward / exact-backward oracle 0.186 /
+# 0.099 (the engine's backward rounds dy and the saved gates to bf16 as well).  Tolerances = 2x the measured worst tensor.
+FULL_GRAD_TOL = {'fp32': (0.035, 0.0075), 'bf16': (0.4, 0.2)}      # (max-abs / tensor-max, L2-relative)
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
@@ -638,5 +641,4 @@ def test_full_width_every_gradient_tensor_vs_oracle_autograd(full_engine, precis
     assert abs(loss - float(loss_ref)) <= (1e-4 if precision == 'fp32' else 2e-2) * max(1.0, abs(float(loss_ref)))
     assert len(rows) == len(e.G)
     tol_mr, tol_l2 = FULL_GRAD_TOL[precision]
-    assert worst_mr <= (tol_mr or (0.1 if precision == 'fp32' else 0.5))
-    assert worst_l2 <= (tol_l2 or (0.05 if precision == 'fp32' else 0.25))
+    assert worst_mr <= tol_mr and worst_l2 <= tol_l2

@@ -36,11 +36,115 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
-def main():
+def probe_tensorflow():
+    """-> (module or None, version string or the text of the exception `import tensorflow` actually raised here)."""
     try:
         import tensorflow as tf
+        return tf, getattr(tf, '__version__', '?')
+    except Exception as exc:      # ImportError normally; a broken install raises other things
+        return None, '%s: %s' % (type(exc).__name__, exc)
+
+
+def keras_train_step_timer(tf, net, H, W, B, T, class_weights=(0.15, 0.25, 0.6), lr=1e-5):
+    """Build-owned tf.keras model (no reference file is read) with the layers constructed as the reference constructs them
+    (Networks.py:44-58,130-139,195-205; channels_last: stock CPU builds of TensorFlow run Conv2D in NHWC only), the loss of
+    losses.py:13-27 and the step of train2D.py:87-95 -> a callable that runs ONE optimiser step on seeded synthetic data and
+    returns its wall time.  Used by bench.py's cpu_baseline when TensorFlow is importable on the GPU box (kind "tf")."""
+    import time
+    try:
+        from tensorflow.python import keras as k
     except ImportError:
-        print('tf_pin: TensorFlow is not importable here -- nothing written; the oracle stays "parity unpinned".')
+        from tensorflow import keras as k
+    L = k.layers
+
+    class Down(k.Model):
+        def __init__(self, convs, lstms, stride):
+            super().__init__()
+            self.ConvLSTM = [L.ConvLSTM2D(filters=f, kernel_size=ks, strides=1, padding='same', data_format='channels_last',
+                                          return_sequences=True, stateful=True) for ks, f in lstms]
+            self.Conv = [L.Conv2D(filters=f, kernel_size=ks, strides=(stride if i == 0 else 1), use_bias=True,
+                                  data_format='channels_last', padding='same') for i, (ks, f) in enumerate(convs)]
+            self.BN = [L.BatchNormalization(axis=-1) for _ in convs]
+            self.LReLU = [L.LeakyReLU() for _ in convs]
+
+        def call(self, x, training=None):
+            for layer in self.ConvLSTM:
+                x = layer(x)
+            bt = x.shape[0] * x.shape[1]
+            y = tf.reshape(x, [bt] + x.shape[2:].as_list())
+            for c, b, a in zip(self.Conv, self.BN, self.LReLU):
+                y = a(b(c(y), training=training))
+            return tf.reshape(y, [x.shape[0], x.shape[1]] + y.shape[1:].as_list()), y
+
+    class Up(k.Model):
+        def __init__(self, convs, factor, logits):
+            super().__init__()
+            self.factor, self.logits = factor, logits
+            self.Conv = [L.Conv2D(filters=f, kernel_size=ks, strides=1, use_bias=True, data_format='channels_last',
+                                  padding='same') for ks, f in convs]
+            self.BN = [L.BatchNormalization(axis=-1) for _ in convs]
+            self.LReLU = [L.LeakyReLU() for _ in convs]
+
+        def call(self, xs, training=None):
+            x, skip = xs
+            x = k.backend.resize_images(x, self.factor, self.factor, 'channels_last', interpolation='bilinear')
+            y = tf.concat([x, skip], -1)
+            for i, (c, b, a) in enumerate(zip(self.Conv, self.BN, self.LReLU)):
+                y = c(y)
+                if not (self.logits and i == len(self.Conv) - 1):
+                    y = a(b(y, training=training))
+            return y
+
+    n = len(net['down_conv_kernels'])
+    downs = [Down(net['down_conv_kernels'][i], net['lstm_kernels'][i], 2 if i < n - 1 else 1) for i in range(n)]
+    ups = [Up(net['up_conv_kernels'][j], 1 if j == 0 else 2, j == n - 1) for j in range(n)]
+    opt = k.optimizers.Adam(lr)
+    cw = tf.constant(np.asarray(class_weights, np.float32))
+    rng = np.random.default_rng(0)
+    x = tf.constant(rng.standard_normal((B, T, H, W, 1)).astype(np.float32))
+    gt = tf.constant(rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32))
+
+    def forward(training):
+        skips, seq = [], x
+        flat = tf.reshape(x, [B * T, H, W, 1])
+        for d in downs:
+            skips.append(flat)
+            seq, flat = d(seq, training=training)
+        y = flat
+        for u, sk in zip(ups, skips[::-1]):
+            y = u((y, sk), training=training)
+        return tf.reshape(y, [B, T, H, W, 3])
+
+    @tf.function
+    def step():
+        with tf.GradientTape() as tape:
+            logits = forward(True)
+            valid = tf.cast(tf.greater(gt, -1), tf.float32)
+            pix_w = tf.reduce_sum(tf.one_hot(tf.cast(gt, tf.int32), 3) * cw, -1)
+            ce = tf.nn.sparse_softmax_cross_entropy_with_logits(tf.cast(tf.maximum(gt, 0), tf.int32), logits)
+            loss = tf.reduce_sum(ce * pix_w * valid) / (tf.reduce_sum(valid) + 0.00001)
+        variables = [v for m in downs + ups for v in m.trainable_variables]
+        opt.apply_gradients(zip(tape.gradient(loss, variables), variables))
+        return loss
+
+    def timed():
+        t0 = time.time()
+        float(step().numpy())
+        return time.time() - t0
+    return timed
+
+
+def main(out=None):
+    global GOLDEN
+    if out is None and '--out' in sys.argv:
+        out = sys.argv[sys.argv.index('--out') + 1]
+    if out:
+        os.makedirs(out, exist_ok=True)
+        GOLDEN = out
+    tf, why = probe_tensorflow()
+    if tf is None:
+        print('tf_pin: TensorFlow is not importable here (%s) -- nothing written; the oracle stays "parity unpinned".' % why)
+        print('tf_pin: python %s, executable %s' % (sys.version.split()[0], sys.executable))
         return 1
     if int(tf.__version__.split('.')[0]) != 2:
         print('tf_pin: the reference requires TensorFlow 2.x (train2D.py:25-26), found', tf.__version__)
