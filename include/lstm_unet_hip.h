@@ -76,8 +76,10 @@ enum {
                                   * numbering instead of the balanced one (equal runs of work items per XCD) -- A/B */
     LU_CONV_F_SLABS_ONLY = 2048, /* LU_EPI_BIAS, splits > 1: stop after the partial slabs -- workspace[s][frames*Hout*Wout][N],
                                   * bias NOT added, `out` unused; the consumer sums them (lu_lstm_gates_fwd_slabs) */
-    LU_CONV_F_NO_NARROW = 4096   /* precision 1, stride-1 3x3 / 5x5 with N = 32 / 64: take the gather kernel instead of the narrow
+    LU_CONV_F_NO_NARROW = 4096,  /* precision 1, stride-1 3x3 / 5x5 with N = 32 / 64: take the gather kernel instead of the narrow
                                   * blocks of the halo kernel (A/B runs and tests: the two must agree) */
+    LU_CONV_F_HALF_BLOCK = 8192  /* precision 1 halo kernel, N > 64 (5x5; 3x3 on bf16 sources): 4-wave blocks on 8 x 32 patches, two
+                                  * independent blocks per CU, instead of one 8-wave block on a 16 x 32 patch (bit-identical) */
 };
 
 typedef struct lu_conv_desc {
@@ -236,7 +238,11 @@ enum {
     LU_WGRAD_F_NO_RAGGED = 64,   /* fp32 kernel-row variant: only for W % 16 == 0 (other widths: the one-tap-per-block kernel) -- A/B */
     LU_WGRAD_F_NO_SLIDE = 512,   /* fp32 kernel-row variant: every k-pair re-reads its K x rows from LDS (the instance of rounds 1-2; A/B) */
     LU_WGRAD_F_KP32 = 256,       /* fp32 kernel-row variant, 5x5, W % 32 == 0: 32-pixel stages (A/B: measured slower than 16) */
-    LU_WGRAD_F_NO_NARROW_BF16 = 128  /* precision 1: keep the narrow layers (C < 64) on the fp32 all-taps / general kernels -- A/B */
+    LU_WGRAD_F_NO_NARROW_BF16 = 128, /* precision 1: keep the narrow layers (C < 64) on the fp32 all-taps / general kernels -- A/B */
+    LU_WGRAD_F_TAPS9 = 1024,     /* precision 1, stride-1 3x3, C >= 64 (the all-taps form: one block = nine taps of a 64-channel x
+                                  * 128-column tile, the library's own choice on 8 waves): 4 fat waves instead, one per SIMD,
+                                  * accumulators in AGPRs (bf16 operands; measured slower -- A/B, tests) */
+    LU_WGRAD_F_NO_TAPS9 = 2048   /* ... keep the kernel-row form (one block = three taps of a kernel row) -- A/B, tests */
 };
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

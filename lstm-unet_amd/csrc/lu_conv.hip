@@ -1479,9 +1479,15 @@ struct ChunkDesc {
     int single;                  // 1: the centre-tap-only chunk (its packed image holds ONE tap)
 };
 
-template <int K, int EPI, int RW, bool B16>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
-__global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
-    constexpr int BN = 128, NT = 512, TH = 2 * RW, TW = 32, KK = K * K;
+// WM = row groups of waves per block.  2: 8 waves, a (2 RW) x 32 patch -- with RW = 8 (237 VGPRs) ONE block per CU, whose 8 waves
+// meet at the chunk barriers, start together and reach the epilogue together: nothing covers a tile's prologue (first halo: a
+// global-memory latency + LDS store + barrier), its epilogue (fragment exchange, gate math, stores) or the skew at a barrier.
+// 1 ("half blocks", round 4): 4 waves = ONE row group x 4 column fragments, an RW x 32 patch, 256 threads -- the same RW MFMAs
+// per weight fragment and the same registers per wave, but TWO INDEPENDENT blocks per CU (2 x 2 halo images of 8 + K - 1 rows:
+// 138 KB at K = 5): one block's prologue / epilogue / barrier wait runs under the other block's MFMAs.
+template <int K, int EPI, int RW, bool B16, int WM = 2>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
+__global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a) {
+    constexpr int BN = 128, NT = 256 * WM, TH = WM * RW, TW = 32, KK = K * K;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
     constexpr int CKS = CKB;                            // channels per stage
     constexpr int PC = B16 ? 8 : 4;                     // channels per 16-byte piece
@@ -1494,8 +1500,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_frag2_kernel(ConvArgs a) {
     constexpr int AH_BYTES = HP * PITCH;
     constexpr int D = K;                                // weight-fragment ring depth (stages)
     static_assert(HPASS + 2 <= KK, "the next halo is fetched one piece per tap and stored two taps later");
-    static_assert(EPI != LU_EPI_LSTM || 2 * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
-    static_assert(8 * TW * EX_LD * 4 <= 2 * AH_BYTES * (BN / 32), "bias-epilogue exchange (8 / NFR row groups) aliases the two halo images");
+    static_assert(WM == 1 || WM == 2, "one or two row groups of waves");
+    static_assert(EPI != LU_EPI_LSTM || WM * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
+    static_assert(4 * WM * 16 * 36 * 4 <= 2 * AH_BYTES, "bias-epilogue exchange (a 16 x 36 slice per wave) aliases the two halo images");
     LU_DYN_LDS(unsigned char, Ah);                      // [2][AH_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2361,6 +2368,22 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
             (force ? force == 16 : (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * ((d->N + 127) / 128) >= 256))
             th = 16;
     }
+    // half blocks (conv_halo_frag2_kernel<..., WM = 1>): 8 x 32 patches, 4 waves of 8 rows each, two independent blocks per CU
+    bool half_blk = false;
+    {
+        bool all16 = d->n_src > 0;
+        for (int i = 0; i < d->n_src; ++i) all16 = all16 && d->src[i].dtype == LU_BF16;
+        // Measured (round 4, same-box A/B on the config-2 shapes): the 3x3 fused step 0.33 -> 0.42 of peak (it leaves the first loop
+        // generation), the 5x5 fused step +2 %, 3x3 bias layers +3 %, 5x5 bias layers (the recurrent / input gradients) -0.5 %:
+        // the library's own choice is half blocks for the ConvLSTM epilogue and for 3x3 layers, given two blocks per CU of work.
+        const int64_t blocks8 = (int64_t)d->frames * ((d->Hout + 7) / 8) * tiles_x *
+                                (d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128) * (d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits);
+        const bool forced = (d->flags & (LU_CONV_F_PATCH8 | LU_CONV_F_PATCH16)) != 0;
+        const bool own_choice = !forced && blocks8 >= 512 && (d->epilogue == LU_EPI_LSTM || d->k == 3);
+        half_blk = d->precision == 1 && !narrow_n && !(d->flags & LU_CONV_F_LOOP_GEN1) && (d->k == 5 || (d->k == 3 && all16)) &&
+                   ((d->flags & LU_CONV_F_HALF_BLOCK) || own_choice);
+        if (half_blk) th = 8;
+    }
     const int64_t tiles_y = (d->Hout + th - 1) / th;
     const bool halo = d->stride == 1 && d->dil == 1 && k_h == d->k && (d->k == 3 || d->k == 5) && d->pad_t == (d->k - 1) / 2 &&
                       d->pad_l == (d->k - 1) / 2 && d->Hout == d->Hin && d->Wout == d->Win && bvec &&
@@ -2444,7 +2467,10 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         const dim3 grid = tile_grid();
         LU_REQUIRE(d->dil == 1 && d->stride == 1 && k_h == d->k, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1, a square kernel");
         // (3x3: the first loop generation -- its 8-row-patch instance fits 4 waves per SIMD, the unrolled one does not: measured)
-        if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
+        if (half_blk && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true, 1>), grid, dim3(256), halo_bf16_lds(5, 4), stream, a);
+        else if (half_blk && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, false, 1>), grid, dim3(256), halo_bf16_lds(5, 4), stream, a);
+        else if (half_blk) LU_LAUNCH_DYN((conv_halo_frag2_kernel<3, LU_EPI_LSTM, 8, true, 1>), grid, dim3(256), halo_bf16_lds(3, 4), stream, a);
+        else if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->precision == 1 && !gen1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (d->precision == 1 && !gen1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->precision == 1 && !gen1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
@@ -2512,6 +2538,12 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
             LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, true, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (narrow)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, false, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (halo && half_blk && src16 && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true, 1>), gridb, dim3(256), halo_bf16_lds(5, 4), stream, a);
+        else if (halo && half_blk && d->k == 5)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, false, 1>), gridb, dim3(256), halo_bf16_lds(5, 4), stream, a);
+        else if (halo && half_blk)
+            LU_LAUNCH_DYN((conv_halo_frag2_kernel<3, LU_EPI_BIAS, 8, true, 1>), gridb, dim3(256), halo_bf16_lds(3, 4), stream, a);
         else if (halo && !gen1 && src16 && d->k == 5 && th == 16)
             LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && !gen1 && src16 && d->k == 5)

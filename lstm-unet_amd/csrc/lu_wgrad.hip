@@ -482,16 +482,27 @@ constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 //   PRBT = 64 (W % 64 == 0): 64-pixel stages.  All eight waves meet at a barrier per stage, so whatever a stage spends on
 //   loads, LDS stores and cursor arithmetic (about as many issue cycles as 20 MFMAs take) is exposed once per stage;
 //   twice the MFMAs per stage halves that share.  One register set then suffices (a load has a whole 2600-cycle stage to land).
-template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
-__global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
+//   R = K ("all taps", round 4; 3x3 only): the block owns ALL K x K taps of its (c, n) tile -- the x tile holds the K input rows
+//   under the 32-pixel run, the dy tile is shared by K * K taps instead of K: 1.5x the MFMAs per staged byte and per stage
+//   barrier, x and dy fetched once instead of K times per 128 columns.  The K * K * NFW accumulator tiles do not fit beside a
+//   second wave on the SIMD, so the block is 64 channels x 128 columns on either
+//     NWV = 8 waves (2 x 4, 32c x 32n x 9 taps = 144 accumulator registers each, two waves per SIMD), or
+//     NWV = 4 "fat" waves (2 x 2, 32c x 64n x 9 taps = 288 accumulator registers -- the accumulators live in AGPRs, ONE wave per
+//     SIMD with the whole 512-entry register file): every x fragment feeds two column fragments, i.e. half the LDS fragment
+//     reads, funnel shifts and per-stage bookkeeping instructions per MFMA of the 8-wave form.
+template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+__global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
     constexpr int PRB = PRBT;      // (shadows the file-level default inside this kernel)
-    constexpr int BMw = CT, BNw = 128, XP = S * (PRB - 1) + K, NT = 512;
-    constexpr int WMC = CT / 32, WNN = 8 / WMC, NFW = BNw / (32 * WNN);
+    constexpr int BMw = CT, BNw = 128, XP = S * (PRB - 1) + K, NT = 64 * NWV;
+    constexpr int WMC = CT / 32, WNN = NWV / WMC, NFW = BNw / (32 * WNN);
     constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 per LDS row: pitch = 64 B (mod 256 B)
     constexpr int XE = XB ? 8 : 4, YE = YB ? 8 : 4;     // elements per 16-byte piece
     constexpr int PX = BMw / XE, PY = BNw / YE;         // pieces per tile row
-    constexpr int XPASS = (XP * PX + NT - 1) / NT, YPASS = PRB * PY / NT;
+    constexpr int XROWS = R * XP;                       // rows of the x tile: the R input rows back to back
+    constexpr int XPASS = (XROWS * PX + NT - 1) / NT, YPASS = PRB * PY / NT;
     static_assert(PRB * PY % NT == 0, "dy tile: whole passes");
+    static_assert(R == 1 || (R == K && S == 1), "all-taps form: stride 1, every kernel row");
+    static_assert(WMC * WNN == NWV && NFW * WNN * 32 == BNw, "wave grid");
     constexpr int XPA = XPASS * NT / PX;   // x-tile rows ALLOCATED: every (thread, pass) owns a slot, so the stores need no guard
     LU_DYN_LDS(unsigned short, smem);      // Xs[2][XPA * XLD] | Ys[2][PRB * YLD] | Bred[8 * 128] floats (wgrad_row_bf16_lds)
     unsigned short* const Xs = smem;
@@ -507,10 +518,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     // that per slab (L1: 5 x 2 x 8 = 80) the concurrent set should share dy columns -- every "round" then reads all of x
     // (the small operand) but a DISJOINT part of dy, instead of all of dy every round (PMC: 3.3x -> see profiles/)
     int tl = jb % a.inner;
-    const int rc = a.inner / a.n_tiles;          // K * c_tiles
+    const int rc = a.inner / a.n_tiles;          // K * c_tiles (all-taps form: c_tiles)
     const int n0 = (tl / rc) * BNw;
     tl -= (tl / rc) * rc;
-    const int kh = tl / a.c_tiles;
+    const int kh = R == 1 ? tl / a.c_tiles : 0;  // first kernel row of this block
     const int c0 = (tl - kh * a.c_tiles) * BMw;
     const int64_t p_begin = (int64_t)z * a.chunk;
     int64_t p_end = p_begin + a.chunk;
@@ -540,16 +551,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
 
     auto load_stage = [&](lu_u4 (&rx)[XPASS], lu_u4 (&ry)[YPASS]) {
         const bool live = ls < n_it;
-        const int iy = S * oy + kh - a.pad_t;
-        const bool rowok = live && iy >= 0 && iy < a.Hin;
-        const int64_t xrow = pf * a.x_fs + ((int64_t)iy * a.Win + (S * ox0 - a.pad_l)) * a.x_ps + c0;
+        const int iy0 = S * oy + kh - a.pad_t;
+        const int64_t xrow = pf * a.x_fs + ((int64_t)iy0 * a.Win + (S * ox0 - a.pad_l)) * a.x_ps + c0;
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) {
             const int item = tid + NT * i;
-            const int xr = item / PX, q = item - xr * PX;
-            const int ix = S * ox0 - a.pad_l + xr;
-            const bool ok = rowok && xr < XP && ix >= 0 && ix < a.Win && c0 + XE * q < a.C;
-            const int64_t off = xrow + (int64_t)xr * a.x_ps + XE * q;
+            const int rr = item / PX, q = item - rr * PX;      // (functions of the thread index only: hoisted out of the loop)
+            const int r = R == 1 ? 0 : rr / XP, xr = rr - r * XP;
+            const int iy = iy0 + r, ix = S * ox0 - a.pad_l + xr;
+            const bool ok = live && iy >= 0 && iy < a.Hin && rr < XROWS && ix >= 0 && ix < a.Win && c0 + XE * q < a.C;
+            const int64_t off = xrow + ((int64_t)r * a.Win + xr) * a.x_ps + XE * q;
             const lu_u4* pp = XB ? reinterpret_cast<const lu_u4*>(reinterpret_cast<const unsigned short*>(a.x) + off)
                                  : reinterpret_cast<const lu_u4*>(a.x + off);
             rx[i] = *(ok ? pp : zp);
@@ -621,9 +632,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         }
     };
 
-    f32x16 acc[K][NFW];
+    f32x16 acc[R * K][NFW];      // [kernel row r of this block][tap t][column fragment]
 #pragma unroll
-    for (int t = 0; t < K; ++t)
+    for (int t = 0; t < R * K; ++t)
 #pragma unroll
         for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
@@ -651,19 +662,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
 #pragma unroll
         for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf * (PRB * YLD) + yoff + 16 * j * YLD + 32 * nf], YLD);
         if constexpr (S == 1) {
-            short xw[4 * NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf * (XPA * XLD) + xoff + (16 * j + 4 * r) * XLD]);
-                xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
-            }
+            for (int kr = 0; kr < R; ++kr) {      // the R input rows of the tile (all-taps form) -- one for the kernel-row form
+                short xw[4 * NR];
 #pragma unroll
-            for (int t = 0; t < K; ++t) {
-                lu_bf16x8 av;
+                for (int r = 0; r < NR; ++r) {
+                    const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf * (XPA * XLD) + xoff + (kr * XP + 16 * j + 4 * r) * XLD]);
+                    xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
+                for (int t = 0; t < K; ++t) {
+                    lu_bf16x8 av;
 #pragma unroll
-                for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
+                    for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
+#pragma unroll
+                    for (int nf = 0; nf < NFW; ++nf) acc[kr * K + t][nf] = lu_mfma_bf16(av, bv[nf], acc[kr * K + t][nf]);
+                }
             }
         } else {      // strided rows: consecutive k are S tile rows apart -- one pair of reads per tap
 #pragma unroll
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
 #pragma unroll
             for (int j = 1; j < PRB / 16; ++j) mma_half(buf, j);
 #pragma unroll
-            for (int g = 0; g < (PRB / 16 - 1) * K * NFW; ++g) {
+            for (int g = 0; g < (PRB / 16 - 1) * R * K * NFW; ++g) {
                 LU_SCHED_GROUP(0x008, 1);        // one MFMA ...
                 LU_SCHED_GROUP(0x366, 8);        // ... then up to 8 non-MFMA instructions (VALU / SALU / VMEM / DS)
             }
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         float* const Exw = reinterpret_cast<float*>(smem) + wave * (16 * 36);      // [16 rows][32 columns + 4]
         const int cq = lane & 7;
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
+        for (int t = 0; t < R * K; ++t) {
             const int tap = kh * K + t;
 #pragma unroll
             for (int nf = 0; nf < NFW; ++nf)
@@ -767,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
+        for (int t = 0; t < R * K; ++t) {
             const int tap = kh * K + t;
 #pragma unroll
             for (int nf = 0; nf < NFW; ++nf)
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
         if (tid < BNw) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += Bred[w * BNw + tid];
+            for (int w = 0; w < NWV; ++w) s += Bred[w * BNw + tid];
             if (n0 + tid < a.N) a.bias_ws[((int64_t)z * brc + bslot) * a.N + n0 + tid] = s;
         }
     }
@@ -1051,9 +1065,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // dynamic LDS of wgrad_row_bf16_kernel<K, CT, *, *, S, PRBT>
-size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb, bool xb) {
+size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb, bool xb, int R = 1, int NT = 512) {
     const int XP = S * (prb - 1) + K, XLD = CT + 32, YLD = 128 + 32, PX = CT / (xb ? 8 : 4);
-    const int XPA = (XP * PX + 511) / 512 * 512 / PX;      // rows allocated = pass coverage (see the kernel)
+    const int XPA = (R * XP * PX + NT - 1) / NT * NT / PX;      // rows allocated = pass coverage (see the kernel)
     return (size_t)(2 * XPA * XLD + 2 * prb * YLD) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
 }
 
@@ -1138,7 +1152,15 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     // bf16 kernel-row variant: channel tile, and the bias rows per split that go with it (also needed by a phase-2 call)
     const int ct_bf16 = d->k == 1 ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
                                                                                           : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
-    const int bias_rows_per_split = small3 ? 1 : row_bf16 ? d->k * ((d->C + ct_bf16 - 1) / ct_bf16)
+    // all-taps form of the 3x3 layers (one block = all nine taps of a 64-channel x 128-column tile): 4 fat waves, or 8 thin ones
+    // Measured (round 4, same-box A/B, config-2 shapes): 8 waves 0.196 -> 0.215 of peak on the Params-net 3x3 layers, 0.295 -> 0.345 on
+    // the 3x3 ConvLSTM kernels (64-pixel stages where W % 64 == 0: +1 %); 4 fat waves 0.155 / 0.218 -- one wave per SIMD leaves the
+    // compiler-scheduled stage nothing to hide its LDS / global latencies behind.  The library's own choice is the 8-wave form;
+    // LU_WGRAD_F_NO_TAPS9 keeps the kernel-row form (A/B, tests), LU_WGRAD_F_TAPS9 selects the fat waves.
+    const bool taps9 = row_bf16 && row_variant && d->k == 3 && d->stride == 1 && d->C >= 64 && !(d->flags & LU_WGRAD_F_NO_TAPS9) &&
+                       !(d->flags & (LU_WGRAD_F_CT64 | LU_WGRAD_F_CT128));
+    const int bias_rows_per_split = small3 ? 1 : taps9 ? (d->C + 63) / 64
+                                                : row_bf16 ? d->k * ((d->C + ct_bf16 - 1) / ct_bf16)
                                                 : row_variant ? d->k * ((d->C + 63) / 64) : 1;      // (blocks sharing a dy tile)
     if (d->phase == 2) {
         // reduce only: the slabs were produced by an earlier phase-1 call with the same descriptor
@@ -1148,6 +1170,26 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         if (tiles <= 16) LU_LAUNCH((wgrad_small3_kernel<2>), grid, dim3(512), stream, a);
         else if (tiles <= 24) LU_LAUNCH((wgrad_small3_kernel<3>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_small3_kernel<5>), grid, dim3(512), stream, a);
+    } else if (taps9) {
+        a.c_tiles = (d->C + 63) / 64;
+        a.n_tiles = (d->N + 127) / 128;
+        a.inner = a.n_tiles * a.c_tiles;
+        a.splits = splits;
+        dim3 grid((unsigned)(8 * a.inner * ((splits + 7) / 8)));
+#define LU_WG9(NWV_)                                                                                                                   \
+    do {                                                                                                                               \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 32, 3, NWV_>), grid, dim3(64 * NWV_), wgrad_row_bf16_lds(3, 64, 1, 32, true, 3, 64 * NWV_), stream, a);     \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, false, true, 1, 32, 3, NWV_>), grid, dim3(64 * NWV_), wgrad_row_bf16_lds(3, 64, 1, 32, false, 3, 64 * NWV_), stream, a);    \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, false, 1, 32, 3, NWV_>), grid, dim3(64 * NWV_), wgrad_row_bf16_lds(3, 64, 1, 32, true, 3, 64 * NWV_), stream, a);    \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, false, false, 1, 32, 3, NWV_>), grid, dim3(64 * NWV_), wgrad_row_bf16_lds(3, 64, 1, 32, false, 3, 64 * NWV_), stream, a);           \
+    } while (0)
+        // (fat waves: bf16 operands only -- an fp32 operand's conversion registers do not fit beside 288 accumulators)
+        const bool p64 = d->Wout % 64 == 0 && xb && yb && !(d->flags & LU_WGRAD_F_PRB32);      // 64-pixel stages (bf16 operands)
+        if (p64 && !(d->flags & LU_WGRAD_F_TAPS9))
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 64, 3, 8>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 64, true, 3, 512), stream, a);
+        else if (!(d->flags & LU_WGRAD_F_TAPS9) || !(xb && yb)) LU_WG9(8);
+        else LU_WG9(4);
+#undef LU_WG9
     } else if (row_bf16) {
         const int ct = ct_bf16;
         a.c_tiles = (d->C + ct - 1) / ct;

@@ -14,11 +14,14 @@ LU_CONV_F_LDS_DMA, LU_CONV_F_MF2, LU_CONV_F_GENERAL = 16, 32, 64
 LU_CONV_F_LOOP_GEN1, LU_CONV_F_GATES_BF16, LU_CONV_F_SRC1_CENTER, LU_CONV_F_NO_BALANCE = 128, 256, 512, 1024
 LU_CONV_F_SLABS_ONLY = 2048
 LU_CONV_F_NO_NARROW = 4096
+LU_CONV_F_HALF_BLOCK = 8192
 LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE, LU_WGRAD_F_PRB32 = 1, 2, 4, 8, 16, 32
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128
 LU_WGRAD_F_KP32 = 256
 LU_WGRAD_F_NO_SLIDE = 512
+LU_WGRAD_F_TAPS9 = 1024
+LU_WGRAD_F_NO_TAPS9 = 2048
 
 
 class ConvSrc(C.Structure):

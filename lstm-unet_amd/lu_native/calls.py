@@ -143,7 +143,7 @@ def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, 
 BF16_ROW_ROUNDS = 5      # (A/B: bench.py --wgrad-rounds)
 
 
-def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=None, cus=256):
+def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=None, cus=256, all_taps=False):
     """Pixel-axis split of the bf16 kernel-row variant.  Its blocks are numbered XCD-aware (all tiles of a pixel slab on
     one XCD), one block per CU at 128-channel tiles (two at 64), all of equal length: pick a multiple of 8 slabs so that
     tiles x slabs is close to `rounds` full waves of the chip -- few fat slabs keep the slab write + re-read small
@@ -151,7 +151,10 @@ def wgrad_splits_bf16_row(pixels, k, Cin, N, ct, rounds=None, cus=256):
     rounds = BF16_ROW_ROUNDS if rounds is None else rounds
     inner = k * -(-Cin // ct) * -(-N // 128)
     per_round = cus * (1 if ct == 128 else 2)
-    if inner <= 4 and Cin <= 64 and ct == 64:      # narrow layers (one channel tile, one column tile): 856 slabs of a 74 KB gradient made the slab REDUCE the
+    if all_taps:         # all-taps form of the 3x3 layers: (64-channel tiles) x (128-column tiles) blocks per slab, one block per CU
+        inner = -(-Cin // 64) * -(-N // 128)
+        per_round = cus
+    if inner <= 4 and Cin <= 64 and (ct == 64 or all_taps):      # narrow layers (one channel tile, one column tile): 856 slabs of a 74 KB gradient made the slab REDUCE the
         rounds = 1       # long pole (74 blocks streaming 63 MB: 0.29 ms); one round of blocks = 170 slabs
     s = max(8, int(round(rounds * per_round / float(inner) / 8.0)) * 8)
     while s > 8 and pixels // s < 2048:

@@ -349,7 +349,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     if bf16_row:
         ct = 64 if (k == 1 or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
             (128 if (Cin % 128 == 0 or Cin > 256) else 64)
-        splits = calls.wgrad_splits_bf16_row(frames * Hout * Wout, k, Cin, N, ct)
+        all_taps = (k == 3 and stride == 1 and Cin >= 64 and      # mirrors lu_conv2d_wgrad: the all-taps form of the 3x3 layers
+                    not (WGRAD_FLAGS & (cabi.LU_WGRAD_F_NO_TAPS9 | cabi.LU_WGRAD_F_CT64 | cabi.LU_WGRAD_F_CT128)))
+        splits = calls.wgrad_splits_bf16_row(frames * Hout * Wout, k, Cin, N, ct, all_taps=all_taps)
     else:
         splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
                                     target_blocks=3072)      # re-measured after the kernel-row variants: ~3000 blocks >= 6000

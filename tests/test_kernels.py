@@ -158,10 +158,46 @@ def test_conv_halo_variant(be):
     close(gates[..., F:2 * F], npo.hard_sigmoid(z[..., F:2 * F]), 2e-5)
 
 
-@pytest.mark.parametrize('patch', ['8', '16'])
+@pytest.mark.parametrize('patch', ['8', '16', 'half'])
 def test_conv_bf16_mfma_variant(be, patch):
-    # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks) forced through lu_conv_desc.flags
-    _conv_bf16_cases(be, cabi.LU_CONV_F_PATCH16 if patch == '16' else cabi.LU_CONV_F_PATCH8)
+    # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks) forced through lu_conv_desc.flags; 'half': 4-wave blocks
+    # on 8 x 32 patches (conv_halo_frag2_kernel<..., WM = 1>, two independent blocks per CU)
+    _conv_bf16_cases(be, {'16': cabi.LU_CONV_F_PATCH16, '8': cabi.LU_CONV_F_PATCH8, 'half': cabi.LU_CONV_F_HALF_BLOCK}[patch])
+
+
+def test_conv_bf16_half_blocks_are_bitwise_equal_to_the_full_blocks(be):
+    """LU_CONV_F_HALF_BLOCK only changes which waves own which patch rows: same taps, same channel order, same fp32 accumulation
+    per output -- bias layers (3x3 / 5x5 on bf16 sources, two sources, ragged extents, a partial column tile, a K split) and the
+    fused ConvLSTM step on the bf16 tape (5x5, and 3x3 -- which half blocks move from the first loop generation to the second)
+    must give the same bits as the library's default kernels."""
+    HB = cabi.LU_CONV_F_HALF_BLOCK
+    for (fr, H, W, Cc, N, k, sp) in [(2, 20, 40, 40, 136, 3, 1), (1, 16, 32, 64, 128, 3, 1), (2, 19, 33, 72, 160, 5, 1),
+                                     (1, 9, 33, 96, 72, 5, 2)]:
+        x = KH.bf16_round(rnd(fr, H, W, Cc))
+        w, b = rnd(k, k, Cc, N, scale=0.1), rnd(N)
+        for f0 in (cabi.LU_CONV_F_PATCH8, cabi.LU_CONV_F_PATCH16):
+            want = KH.conv2d(be, [x], [w], b, k, splits=sp, precision=1, flags=f0, bf16_src=(0,))
+            assert np.array_equal(KH.conv2d(be, [x], [w], b, k, splits=sp, precision=1, flags=HB, bf16_src=(0,)), want)
+    xa, xb = KH.bf16_round(rnd(1, 17, 32, 40)), KH.bf16_round(rnd(1, 17, 32, 24))
+    wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
+    assert np.array_equal(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=HB, bf16_src=(0, 1)),
+                          KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, bf16_src=(0, 1)))
+    x5 = rnd(1, 16, 34, 36)                                      # fp32 sources: 5x5 only (the 3x3 halo needs bf16 pieces)
+    w5, b5 = rnd(5, 5, 36, 128, scale=0.1), rnd(128)
+    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=HB), KH.conv2d(be, [x5], [w5], b5, 5, precision=1))
+    F = 32
+    for (k, cin, center) in [(5, 8, False), (3, 8, False), (3, 1, True), (5, 1, True)]:
+        x, h, c = rnd(2, 18, 40, cin), rnd(2, 18, 40, F, scale=0.5), rnd(2, 18, 40, F)
+        ker, rec, b = rnd(k, k, cin, 4 * F, scale=0.3), rnd(k, k, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+        want = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center)
+        got = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=HB)
+        for a_, b_ in zip(got, want):
+            assert np.array_equal(a_, b_), (k, cin, center)
+    x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)      # fp32 sources, fp32 gates out
+    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+    for a_, b_ in zip(KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=HB),
+                      KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1)):
+        assert np.array_equal(a_, b_)
 
 
 def _conv_bf16_cases(be, flags=0):
@@ -566,6 +602,33 @@ def _wgrad_bf16_cases(be, flags=0):
             close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_WGRAD_F_NO_NARROW_BF16), gfull, 2e-4)
     with pytest.raises(RuntimeError):                         # bf16 operands need the bf16 kernel-row variant
         KH.conv2d_wgrad(be, rnd(1, 4, 16, 64), rnd(1, 4, 16, 128), 3, 1, precision=1, dy_bf16=True)
+
+
+@pytest.mark.parametrize('form', ['fat4', 'w8'])
+def test_wgrad_bf16_all_taps_form_equals_the_kernel_row_form(be, form):
+    """The all-taps form of the 3x3 layers (round 4; LU_WGRAD_F_TAPS9: its fat-wave instance): one block accumulates all nine taps of a 64-channel x 128-column tile (x tile = three
+    input rows, dy tile shared by nine taps) on 4 fat waves (accumulators in AGPRs) or 8 waves.  Every (tap, c, n) sum still
+    walks the pixels of its slab in the same 16-pixel MFMA steps: bit-identical to the kernel-row form, bias gradient included;
+    operand types, ragged channel / column counts, top / bottom image rows, odd stage and slab counts."""
+    fl = cabi.LU_WGRAD_F_TAPS9 if form == 'fat4' else 0      # (0: the library's own choice = the 8-wave all-taps form)
+    R = KH.bf16_round
+    for (fr, H, W, Cc, N, sp, xb, yb) in [(2, 5, 32, 72, 136, 3, True, True), (1, 4, 64, 64, 128, 1, True, True),
+                                          (3, 3, 32, 128, 64, 9, True, True), (1, 6, 32, 136, 264, 2, True, False),
+                                          (2, 5, 128, 72, 136, 3, True, True),
+                                          (2, 3, 64, 64, 72, 2, False, True), (1, 5, 32, 96, 128, 1, False, False)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        want, db0 = KH.conv2d_wgrad(be, x, dy, 3, 1, splits=sp, precision=1, x_bf16=xb, dy_bf16=yb, dbias0=np.zeros(N, np.float32),
+                                    flags=cabi.LU_WGRAD_F_CT64)
+        got, db = KH.conv2d_wgrad(be, x, dy, 3, 1, splits=sp, precision=1, x_bf16=xb, dy_bf16=yb, dbias0=np.zeros(N, np.float32),
+                                  flags=fl)
+        assert np.array_equal(got, want), (form, Cc, N, sp)
+        if W % 64 == 0:      # (64-pixel stages where the width allows: the same pixels in the same 16-pixel steps)
+            assert np.array_equal(KH.conv2d_wgrad(be, x, dy, 3, 1, splits=sp, precision=1, x_bf16=xb, dy_bf16=yb,
+                                                  flags=fl | cabi.LU_WGRAD_F_PRB32), want)
+        close(db, db0, 1e-5)
+        _, gw = _torch_conv_grads(R(x), rnd(3, 3, Cc, N), R(dy), 1)
+        close(got, gw, 2e-4)
+        close(db, (R(dy) if yb else dy).reshape(-1, N).sum(0), 2e-4)
 
 
 @pytest.mark.parametrize('k,cin', [(3, 8), (5, 1)])
