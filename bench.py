@@ -254,6 +254,44 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
 
 
+def dp_self_check(dp, dev):
+    """`--check` (N > 1): before anything is timed, one data-parallel training step with SyncBN on N ranks x 1 slot must equal the
+    single-process step on the N-slot batch -- loss to 1e-5, the all-reduced PRE-ADAM gradients to 2e-6 of the largest gradient
+    (the comparison of tests/test_dp_equivalence.py::test_dpN_syncbn_over_rccl_equals_single_process, inline).  Every rank
+    learns the verdict (one flag all-reduce); a failure ends the run with exit code 2 and no JSON line."""
+    import Networks
+    import train2D
+    from lu_native.dp import DataParallel
+    n = dp.world_size
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 3, 1, 24, 32)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(n, 3, 1, 24, 32)).astype(np.float32)
+    net = {'down_conv_kernels': [[(3, w), (3, w)] for w in (32, 16, 16, 32)], 'lstm_kernels': [[(3, w)] for w in (32, 16, 16, 32)],
+           'up_conv_kernels': [[(3, 16), (3, 16)], [(3, 8), (3, 8)], [(3, 8), (3, 8)], [(3, 8), (3, 8), (1, 3)]]}
+    tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3)
+    sl = slice(dp.rank, dp.rank + 1)
+    _, _, loss = tr.train_step(x[sl], gt[sl])
+    grads = tr.engine.flat_grads.clone()
+    res = {'ranks': n, 'slots': n, 'loss_err': None, 'grad_err_over_max': None, 'ok': False}
+    flag = torch.zeros(1, device=dev)
+    if dp.rank == 0:
+        ref = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=DataParallel.solo(), seed=3)
+        _, _, loss_ref = ref.train_step(x, gt)
+        g_ref = ref.engine.flat_grads
+        res['loss_err'] = abs(float(loss) - float(loss_ref))
+        res['grad_err_over_max'] = float((grads - g_ref).abs().max() / g_ref.abs().max())
+        res['ok'] = res['loss_err'] <= 1e-5 and res['grad_err_over_max'] <= 2e-6
+        flag += 0.0 if res['ok'] else 1.0
+        print('bench.py --check: dp%d + SyncBN vs single process: loss err %.3e, pre-Adam gradient err / max|g| %.3e -> %s' %
+              (n, res['loss_err'], res['grad_err_over_max'], 'OK' if res['ok'] else 'FAILED'), file=sys.stderr, flush=True)
+    torch.distributed.all_reduce(flag)
+    if float(flag.item()) > 0:
+        _die('--check failed: the data-parallel step does not reproduce the single-process step; nothing was timed')
+    del tr
+    torch.cuda.empty_cache()
+    return res
+
+
 def dp_report(dp, dev_index, engine, steps, launched, sync_bn):
     """What the collective layer saw, measured on the live process group (every rank calls this): backend, group size, the
     device of each rank, gradient all-reduce launches per step, and -- timed stand-alone after the timed region with HIP
@@ -331,6 +369,8 @@ def main():
     ap.add_argument('--net', choices=list(NETS), default='params',
                     help='kernel-size variant (SURVEY D1): params = train2D.py default = the headline; default5 = 5x5 everywhere; '
                          'lstm3 = 3x3 ConvLSTM (north_star wording)')
+    ap.add_argument('--check', action='store_true',
+                    help='N > 1: run the DP + SyncBN == single-process comparison inline first; refuse to print a line if it fails')
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the `variants` block (lstm3 / default5 in fp32 and bf16, N = 1, headline net only)')
     args = ap.parse_args()
@@ -358,6 +398,7 @@ def main():
     dev_index = dp.local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
+    self_check = dp_self_check(dp, dev) if (args.check and dp.world_size > 1) else None
     net = net_by_name(args.net)
     H = W = args.size
     if args.hw:
@@ -415,6 +456,21 @@ def main():
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     dp_info = dp_report(dp, dev_index, trainer.engine, args.steps, dp.launched - launched0, args.sync_bn)
+    if dp.world_size > 1:
+        # proof of overlap: two more steps with per-bucket time stamps (outside the timed region: the stamps are device events,
+        # but a traced step is not the step that is reported)
+        dp.trace = []
+        one_step(args.warmup + args.steps)
+        one_step(args.warmup + args.steps + 1)
+        torch.cuda.synchronize()
+        traced = dp.trace_report()
+        dp.trace = None
+        dp_info['bucket_trace'] = traced[-1] if traced else None
+        dp_info['bucket_trace_what'] = ('per gradient bucket of one step, rank 0: handed to the collective layer this long BEFORE '
+                                        'backward ended (the remaining backward hides it), compute stream free again this long '
+                                        'AFTER backward ended (the exposed part; compare allreduce_ms_per_step = stand-alone)')
+        dp_info['exposed_allreduce_ms'] = traced[-1][-1]['done_ms_after_backward_end'] if traced and traced[-1] else None
+        dp_info['self_check'] = self_check
     ms_per_step = 1e3 * elapsed / args.steps
     frames_per_s = dp.world_size * B * T * args.steps / elapsed
 
@@ -432,7 +488,7 @@ def main():
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only): a STATIC table
             if (H, W, T, B) == (256, 256, 8, 4):      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
                 sfx = '' if args.precision == 'fp32' else '_bf16'
-                name = next(n for n in ('r03_pmc_traffic%s.json' % sfx, 'r02_pmc_traffic%s.json' % sfx, 'r01_pmc_traffic%s.json' % sfx)
+                name = next(n for n in ('r04_pmc_traffic%s.json' % sfx, 'r03_pmc_traffic%s.json' % sfx, 'r02_pmc_traffic%s.json' % sfx, 'r01_pmc_traffic%s.json' % sfx)
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     blob = json.load(fh)
@@ -443,25 +499,52 @@ def main():
         except (OSError, KeyError, ValueError, StopIteration):
             traffic_db = {}
 
-        def traffic_of(kind):
-            """launch-weighted mean over the rocprof kernel names of this event class, e.g. the class
+        def class_pattern(kind):
+            """event class -> regular expression over rocprof's kernel names, e.g. the class
             conv_halo_frag_kernel<5,LU_EPI_LSTM,*,bf16> covers rocprof's conv_halo_frag2_kernel<5, 1, 8, true> and <5, 1, 4, true>
             (and the first-generation conv_halo_frag_kernel<5, 1, 8, false, ...> of older tables)."""
             name = kind.split(' ')[0]
             m = re.match(r'(\w+)<(\d)(?:,LU_EPI_(LSTM|BIAS))?', name)
             if name.startswith('conv_halo_frag_kernel<') and m:
-                pat = r'conv_halo_frag2?_kernel<%s, %d, ' % (m.group(2), 1 if m.group(3) == 'LSTM' else 0)
-            elif name.startswith('wgrad_row_bf16_kernel<') and m:      # rocprof: wgrad_row_bf16_kernel<5, 128, true, true, 1, 64>
-                pat = r'wgrad_row_bf16_kernel<%s, ' % m.group(2)
-            elif name.startswith('wgrad_row_kernel<') and m:           # rocprof: wgrad_row_kernel<5> (older tables) or <5, false>
-                pat = r'wgrad_row_kernel<%s[,>]' % m.group(2)
-            elif m and m.group(3):                                     # conv_halo_kernel<5,LU_EPI_LSTM> -> <5, 1>
-                pat = re.escape('%s<%s, %d>' % (m.group(1), m.group(2), 1 if m.group(3) == 'LSTM' else 0))
-            else:
-                pat = re.escape(name) + (r'[<(]' if '<' not in name else '')
+                return r'conv_halo_frag2?_kernel<%s, %d, ' % (m.group(2), 1 if m.group(3) == 'LSTM' else 0)
+            if name.startswith('wgrad_row_bf16_kernel<') and m:      # rocprof: wgrad_row_bf16_kernel<5, 128, true, true, 1, 64>
+                return r'wgrad_row_bf16_kernel<%s, ' % m.group(2)
+            if name.startswith('wgrad_row_kernel<') and m:           # rocprof: wgrad_row_kernel<5> (older tables) or <5, false>
+                return r'wgrad_row_kernel<%s[,>]' % m.group(2)
+            if m and m.group(3):                                     # conv_halo_kernel<5,LU_EPI_LSTM> -> <5, 1>
+                return re.escape('%s<%s, %d>' % (m.group(1), m.group(2), 1 if m.group(3) == 'LSTM' else 0))
+            return re.escape(name) + (r'[<(]' if '<' not in name else '')
+
+        def traffic_of(kind):
+            """launch-weighted mean over the rocprof kernel names of this event class"""
+            pat = class_pattern(kind)
             hit = [v for k_, v in traffic_db.items() if re.search(pat, k_)]
             n = sum(v['launches'] for v in hit)
             return round(sum(v['traffic_bytes_per_launch'] * v['launches'] for v in hit) / n) if n else None
+
+        # shader clock and MFMA-busy share per kernel class: a STATIC table as well (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+        # GRBM_GUI_ACTIVE, tools/pmc_mfma.py), time-weighted over the class -- so that a power-throttled kernel is visible on the line
+        # itself: frac_of_clocked_peak = achieved / (peak x clock / 2400 MHz)
+        util_db, util_src, util_build = {}, None, None
+        try:
+            if (H, W, T, B, args.net) == (256, 256, 8, 4, 'params'):
+                name = next(n for n in ('r04_pmc_mfma_util.json', 'r03_pmc_mfma_util.json', 'r02_pmc_mfma_util.json')
+                            if os.path.exists(os.path.join(ROOT, 'profiles', n)))
+                with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                    blob = json.load(fh)
+                util_db, util_build, util_src = blob.get(args.precision, {}), blob.get('build_id'), 'profiles/' + name
+        except (OSError, KeyError, ValueError, StopIteration):
+            util_db = {}
+
+        def clock_of(kind):
+            pat = class_pattern(kind)
+            hit = [v for k_, v in util_db.items() if re.search(pat, k_)]
+            wt = sum(v['launches'] * v['avg_duration_us'] for v in hit)
+            if not wt:
+                return None, None
+            clk = sum(v['shader_clock_ghz'] * v['launches'] * v['avg_duration_us'] for v in hit) / wt
+            busy = sum(v['mfma_utilisation'] * v['launches'] * v['avg_duration_us'] for v in hit) / wt
+            return clk, busy
 
         from lu_native.profile import summarize_events
         rows, hbm_rows = summarize_events(ev)
@@ -471,6 +554,11 @@ def main():
                 json.dump({'build_id': build_id, 'precision': args.precision, 'rows': by_shape(ev)}, fh, indent=1)
         for r_ in rows:
             r_['traffic'] = traffic_of(r_['kernel'])
+            clk, busy = clock_of(r_['kernel'])
+            if clk:
+                r_['clock_mhz'] = round(1e3 * clk)
+                r_['mfma_busy'] = round(busy, 4)
+                r_['frac_of_clocked_peak'] = round(r_['achieved'] / (r_['peak'] * clk / 2.4), 4)
         if rows:
             roofline = dict(rows[0])            # the dominant kernel class = largest share of the step
             roofline['traffic_unit'] = ('L2-fabric bytes per launch INCLUDING Infinity-Cache hits (an upper bound on HBM bytes): '
@@ -478,6 +566,10 @@ def main():
             roofline['traffic_source'] = traffic_src
             roofline['traffic_build_id'] = traffic_build
             roofline['traffic_stale'] = bool(traffic_db) and traffic_build != build_id      # table from another binary
+            roofline['clock_source'] = util_src and ('%s (static table from a separate rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES '
+                                                     'GRBM_GUI_ACTIVE pass; peak quoted at 2.4 GHz)' % util_src)
+            roofline['clock_build_id'] = util_build
+            roofline['clock_stale'] = bool(util_db) and util_build != build_id
             roofline['all_mfma_kernels'] = rows
             roofline['hbm_kernels'] = hbm_rows
     # ---- secondary metric: streaming inference (Inference2D.py:45-62: B=1, T=1, pad_image=True, stateful) ----

@@ -1,6 +1,7 @@
 """Thin, pointer-level call helpers over the C ABI (descriptor packing + error checks).
 Everything here works on raw addresses; ops.py feeds it torch device pointers."""
 import ctypes as C
+import functools
 
 from . import cabi
 
@@ -66,6 +67,7 @@ def conv_cost_us(frames, Hout, Wout, N, k, channels, splits, halo=True):
     return t
 
 
+@functools.lru_cache(maxsize=4096)      # pure functions of the launch shape: the streaming frame asks ~200 times per frame
 def conv_splits(frames, Hout, Wout, N, k, channels, halo=True):
     """K-axis split for launches with too few 256x128 output tiles to fill 256 CUs: the split count with the smallest
     modelled duration (whole rounds of resident blocks matter more than the count itself: 152 tiles x 3 = 456 blocks is one
@@ -77,6 +79,7 @@ def conv_splits(frames, Hout, Wout, N, k, channels, halo=True):
     return min(cands, key=lambda s: (conv_cost_us(frames, Hout, Wout, N, k, channels, s, halo), s))
 
 
+@functools.lru_cache(maxsize=4096)      # pure functions of the launch shape: the streaming frame asks ~200 times per frame
 def conv_plan(frames, Hout, Wout, N, k, channels, halo_ok=True):
     """(splits, use_halo, modelled microseconds) of an fp32 LU_EPI_BIAS launch.  Where the halo kernel applies, its 8 x 32
     patches may hang over the image (136-pixel rows: 15 %); the general kernel tiles flattened pixel rows without waste
@@ -93,6 +96,7 @@ def conv_plan(frames, Hout, Wout, N, k, channels, halo_ok=True):
     return s_h, True, c_h
 
 
+@functools.lru_cache(maxsize=4096)      # pure functions of the launch shape: the streaming frame asks ~200 times per frame
 def fused_step_cost_us(frames, H, W, F, k, channels):
     """Modelled duration of the fused fp32 ConvLSTM step (8 x 32-pixel patches x 32 hidden channels x 4 gates per block)."""
     blocks = conv_tiles(frames, H, W, 4 * F, k)

@@ -24,6 +24,10 @@ class DataParallel(object):
         self.last_ranges = []  # bucket ranges of the most recent step (bench.py times all-reduces of these sizes)
         self._ranges = []
         self.flat = None
+        # trace = [] switches per-bucket time stamps on (bench.py's overlap proof): device events on the compute stream when a
+        # bucket is handed to the collective layer, when backward has ended (finish()) and when each all-reduce has been waited for
+        self.trace = None
+        self._trace_cur = []
         if self.world_size > 1 and not dist.is_initialized():
             if backend is None:
                 # LU_DP_BACKEND=gloo lets several ranks share ONE GPU (control-flow checks on a 1-GPU box)
@@ -70,21 +74,56 @@ class DataParallel(object):
             self._launch(start, end)
             self._carry = None
 
+    @classmethod
+    def solo(cls):
+        """A world of one inside a multi-rank process (bench.py --check: the single-process reference step): no collectives."""
+        self = cls.__new__(cls)
+        self.rank, self.world_size, self.local_rank = 0, 1, 0
+        self.bucket_bytes, self._pending, self.launched, self._carry = 64 << 20, [], 0, None
+        self.last_ranges, self._ranges, self.flat, self.trace, self._trace_cur = [], [], None, None, []
+        return self
+
+    def _stamp(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
     def _launch(self, start, end):
         self.launched += 1
         self._ranges.append((start, end))
+        tracing = self.trace is not None and self.flat.is_cuda
+        if tracing:
+            self._trace_cur.append({'bytes': 4 * (end - start), 'issue': self._stamp()})
         self._pending.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """Flush the tail bucket and make the current stream wait for every outstanding all-reduce."""
+        tracing = self.trace is not None and self.flat is not None and self.flat.is_cuda
+        end_of_backward = self._stamp() if tracing else None
         if self._carry is not None:
             self._launch(*self._carry)
             self._carry = None
-        for w in self._pending:
+        for i, w in enumerate(self._pending):
             w.wait()
+            if tracing:
+                self._trace_cur[i]['done'] = self._stamp()
         self._pending = []
+        if tracing:
+            self.trace.append({'backward_end': end_of_backward, 'buckets': self._trace_cur})
+            self._trace_cur = []
         if self._ranges:
             self.last_ranges, self._ranges = self._ranges, []
+
+    def trace_report(self):
+        """Per traced step, per bucket (after a device synchronize): how long before the end of backward the bucket was handed
+        over (> 0: its all-reduce had that much of the remaining backward to hide behind), and how long after the end of
+        backward the compute stream could continue past it (the EXPOSED part; the last bucket's value is the step's)."""
+        out = []
+        for st in self.trace or []:
+            e0 = st['backward_end']
+            out.append([{'bytes': b['bytes'], 'issued_ms_before_backward_end': round(b['issue'].elapsed_time(e0), 3),
+                         'done_ms_after_backward_end': round(e0.elapsed_time(b['done']), 3)} for b in st['buckets']])
+        return out
 
     def shard_slots(self, n_slots):
         """Batch slots owned by this rank: [rank*n/W, (rank+1)*n/W)."""

@@ -57,7 +57,14 @@ def lib():
     return _lib
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """Raw handle of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object through
+    three Python layers (~10 us; 31 launches per streaming frame = 0.3 ms of a 1.5 ms bf16 frame): ask the C layer directly."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

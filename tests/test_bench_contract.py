@@ -73,8 +73,14 @@ def test_bench_self_launches_n_ranks(backend):
         rc, line, err = _run_bench(['--gpus', '2'] + SMALL, {'LU_DP_BACKEND': 'nccl'})
         assert rc == 2 and line is None and 'needs 2 visible GPUs' in err      # refuses instead of measuring one GPU
         pytest.skip('RCCL needs one device per rank: %d visible' % torch.cuda.device_count())
-    rc, line, err = _run_bench(['--gpus', '2', '--sync-bn'] + SMALL, {'LU_DP_BACKEND': backend})
+    rc, line, err = _run_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': backend})
     assert rc == 0 and line is not None, err
+    # --check: the DP == single-process comparison ran inline before the timing, and the overlap proof is on the line
+    assert 'vs single process' in err and line['dp']['self_check']['ok'] and line['dp']['self_check']['grad_err_over_max'] <= 2e-6
+    tr = line['dp']['bucket_trace']
+    assert tr and all(b['bytes'] > 0 for b in tr) and sum(b['bytes'] for b in tr) == sum(line['dp']['gradient_bucket_bytes'])
+    assert tr[0]['issued_ms_before_backward_end'] > 0      # the first bucket leaves while backward is still running
+    assert line['dp']['exposed_allreduce_ms'] is not None
     assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['config']['global_batch'] == 2
     dp = line['dp']
     assert dp['world_size'] == 2 and dp['backend'] == backend and [d['rank'] for d in dp['devices']] == [0, 1]
