@@ -242,7 +242,11 @@ enum {
     LU_WGRAD_F_TAPS9 = 1024,     /* precision 1, stride-1 3x3, C >= 64 (the all-taps form: one block = nine taps of a 64-channel x
                                   * 128-column tile, the library's own choice on 8 waves): 4 fat waves instead, one per SIMD,
                                   * accumulators in AGPRs (bf16 operands; measured slower -- A/B, tests) */
-    LU_WGRAD_F_NO_TAPS9 = 2048   /* ... keep the kernel-row form (one block = three taps of a kernel row) -- A/B, tests */
+    LU_WGRAD_F_NO_TAPS9 = 2048,  /* ... keep the kernel-row form (one block = three taps of a kernel row) -- A/B, tests */
+    LU_WGRAD_F_DMA = 4096,       /* precision 1, bf16 operands, stride 1: tiles by global_load_lds straight into swizzled LDS rows (three stage
+                                  * buffers, counted vmcnt waits) instead of staging registers + ds_write -- bit-identical; the library's own
+                                  * choice for the all-taps 3x3 form (+3.5 %), opt-in for the 5x5 kernel-row form (measured -3 %) */
+    LU_WGRAD_F_NO_DMA = 8192     /* ... never (A/B, tests) */
 };
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

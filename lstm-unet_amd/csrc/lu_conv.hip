@@ -71,6 +71,8 @@ struct ConvArgs {
     int32_t lstm_vec4;     // conv_halo_kernel, LSTM epilogue: every state / gate tensor 16-byte aligned -> float4 loads / stores through LDS
     int32_t out_vec4s;     // general kernel: as out_vec4, strided output rows (parity planes) allowed
     int32_t out_vec4;      // tile kernels, bias epilogue: dense 16-byte aligned output rows, N % 4 == 0 -> float4 stores through LDS
+    const float* zero16;   // device address of lu_zero16: as a kernel ARGUMENT it lives in SGPRs -- through the symbol every use in a
+                           // loop costs s_getpc + s_load + s_waitcnt lgkmcnt(0), and that wait also drains the LDS reads in flight
     int32_t dbg;           // ablation bits, honoured only in -DLU_ABLATION tool builds: 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
@@ -236,6 +238,7 @@ struct RowCursor {
 // index XOR-swizzled by (row >> 2) & 3 (the swizzle is applied on the SOURCE channel group; LDS stays lane-linear).
 template <int NF, bool BVEC, int EPI, bool GEN, int MF, bool DMA>
 __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(ConvArgs a) {
+    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
     constexpr int NT = 64 * (8 / MF);    // threads per block
     constexpr int RA = 1024 / NT;        // A rows (16-byte column groups) gathered per thread per stage
     constexpr int BN = 32 * NF;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     // Guarding the load (`if (ok) v = *p`) makes hipcc branch around each load with `s_waitcnt vmcnt(0)`
     // in between -- six serialized memory round trips per stage; zeroing AFTER the load drags the wait
     // up to the issue point.  Selecting the POINTER keeps all loads of a stage in flight across the MFMAs.
-    const float* const zp = lu_zero16;
+    const float* const zp = lu_z16;
     auto load_w = [&](const SrcInfo& si, bool thin, int tap_v, int chunk, int p) -> float4 {
         const int row = brow0 + RPP * p;
         int tap, c;
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
 // ---------------------------------------------------------------------------------------------------------
 template <int K, int EPI>
 __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
+    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
     constexpr int NF = 4, BN = 128, NT = 512, TH = 8, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;    // halo width / height / pixels
     constexpr int HPASS = (HP * 4 + NT - 1) / NT;                        // 16-byte loads per thread per halo
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     const int t2 = tile - f * a.tiles_pf;
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
-    const float* const zp = lu_zero16;
+    const float* const zp = lu_z16;
     // Per-source fields live in registers and are picked with selects: indexing a.src[st.s] inside the tap loop costs a
     // scalar kernarg load + s_waitcnt lgkmcnt(0) per use, and that wait also drains the LDS fragment reads in flight.
     const float* const x_s0 = a.src[0].x + (int64_t)f * a.src[0].frame_stride;
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         const int F = a.F;
         const int lp = lane >> 3, cq = lane & 7;
         const int ch = nt * 32 + 4 * cq;                    // F % 32 == 0 is enforced by the host
-        const float* const bp = a.bias ? a.bias + ch : lu_zero16;      // (lu_zero16: 16 bytes of zeros)
+        const float* const bp = a.bias ? a.bias + ch : lu_z16;      // (lu_z16: 16 bytes of zeros)
         const int bst = a.bias ? F : 0;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             // latency (held across the passes -- as in the fragment kernels -- they spill here: 128 VGPRs, two blocks per CU)
             const bool okp = oy < a.Hin && x0 + 8 * qt + lp < a.Win;
             const float4 cp = *reinterpret_cast<const float4*>(
-                okp ? a.c_prev + (int64_t)f * a.c_prev_fs + ((int64_t)oy * a.Win + x0 + 8 * qt + lp) * F + ch : lu_zero16);
+                okp ? a.c_prev + (int64_t)f * a.c_prev_fs + ((int64_t)oy * a.Win + x0 + 8 * qt + lp) * F + ch : lu_z16);
             const float4 bi = *reinterpret_cast<const float4*>(bp), bf = *reinterpret_cast<const float4*>(bp + bst),
                          bg = *reinterpret_cast<const float4*>(bp + 2 * bst), bo = *reinterpret_cast<const float4*>(bp + 3 * bst);
 #pragma unroll
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
             const int oy = y0 + RW * g + i, ox = x0 + px;
             const bool ok = oy < a.Hin && ox < a.Win;
             cpv[i] = *reinterpret_cast<const float4*>(ok ? a.c_prev + (int64_t)f * a.c_prev_fs + ((int64_t)oy * a.Win + ox) * F + ch
-                                                         : lu_zero16);
+                                                         : (a.zero16 ? a.zero16 : lu_zero16));
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
@@ -1172,6 +1176,7 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 // HBM, not by the matrix pipe, and all they need is the halo staged once and every wave busy on its own rows.
 template <int K, int EPI, int RW, bool F32, bool B16, int NFR = 4>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
 __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_frag_kernel(ConvArgs a) {
+    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
     static_assert(!(F32 && B16), "bf16 tensors feed the bf16 MFMA only");
     static_assert(NFR == 4 || (EPI == LU_EPI_BIAS && (NFR == 1 || NFR == 2)), "narrow blocks: bias epilogue only");
     constexpr int BN = 32 * NFR, NT = 512, TH = (8 / NFR) * RW, TW = 32;
@@ -1198,7 +1203,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     const int t2 = tile - f * a.tiles_pf;
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
-    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_z16);
     const int q = tid % G;                 // channel group inside the chunk
     // this wave's column fragment (32 output columns): gate wn of channels [32 nt, 32 nt + 32) / plain columns
     const int nfr = (a.N + 31) >> 5;
@@ -1265,8 +1270,8 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     auto load_b = [&](const IterState& st, float4& b0, float4& b1) {
         const unsigned char* wp = (st.s ? w_s1 : w_s0) +
                                   ((int64_t)st.tap * (st.s ? nch_s1 : nch_s0) + st.chunk) * nfr * 2048;
-        const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : lu_zero16;
-        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_zero16;
+        const float* p0 = frag_ok ? reinterpret_cast<const float*>(wp) : lu_z16;
+        const float* p1 = frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_z16;
         b0 = *reinterpret_cast<const float4*>(p0);
         b1 = *reinterpret_cast<const float4*>(p1);
     };
@@ -1487,6 +1492,7 @@ struct ChunkDesc {
 // 138 KB at K = 5): one block's prologue / epilogue / barrier wait runs under the other block's MFMAs.
 template <int K, int EPI, int RW, bool B16, int WM = 2>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
 __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a) {
+    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
     constexpr int BN = 128, NT = 256 * WM, TH = WM * RW, TW = 32, KK = K * K;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
     constexpr int CKS = CKB;                            // channels per stage
@@ -1513,7 +1519,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
     const int t2 = tile - f * a.tiles_pf;
     const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
     const int n0 = nt * BN;
-    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_z16);
     const int q = tid % G;
     const int nfr = (a.N + 31) >> 5;
     const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
@@ -1570,8 +1576,8 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
     };
     auto load_b = [&](const ChunkDesc& d, int tap, float4& b0, float4& b1) {
         const unsigned char* wp = d.w + (d.single ? 0 : tap) * d.wts;
-        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : lu_zero16);
-        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_zero16);
+        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : lu_z16);
+        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_z16);
     };
 
     f32x16 acc[RW];
@@ -1938,6 +1944,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_fwd_bf16_kernel(S2FwdArgs a) {
 // MFMA-fragment order exactly as in conv_halo_frag_kernel.  Waves: 2 (groups of 128 pixels) x 4 (column fragments).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
+    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
     constexpr int NT = 512, RA = 4, MFW = 4;           // RA pixel rows gathered per thread; MFW 32-pixel fragments per wave
     __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1946,7 +1953,7 @@ __global__ __launch_bounds__(512, 2) void conv_gather_bf16_kernel(ConvArgs a) {
     if (!lu_block_tile(a, mt, nt, ks)) return;
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * 128;
-    const float* const zp = lu_zero16;
+    const float* const zp = lu_z16;
     const int nfr = (a.N + 31) >> 5;
     const int frag = nt * 4 + wn;
     const bool frag_ok = frag < nfr;
@@ -2246,6 +2253,22 @@ __global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __re
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// device address of this translation unit's lu_zero16 (looked up once; null on failure: the kernels then take the symbol itself)
+const void* conv_zero16_address() {
+#ifdef LU_EMU
+    return lu_zero16;
+#else
+    static const void* addr = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lu_zero16)) == hipSuccess) addr = p;
+        tried = true;
+    }
+    return addr;
+#endif
+}
+
 // dynamic LDS of conv_halo_frag_kernel<K, *, RW, *>: two halo images of 80 bytes per pixel
 size_t halo_bf16_lds(int K, int RW) { return (size_t)2 * (2 * RW + K - 1) * (32 + K - 1) * LDB * sizeof(unsigned short); }
 // (narrow blocks, NFR = 1 / 2: 8 / NFR row groups of RW = NFR rows -- the 8-row patch, same bytes as RW = 4)
@@ -2261,6 +2284,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     LU_REQUIRE(d->frames > 0 && d->Hout > 0 && d->Wout > 0 && d->N > 0, "lu_conv2d_fwd: empty problem");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    a.zero16 = reinterpret_cast<const float*>(conv_zero16_address());
     const int k_h = d->k_h ? d->k_h : d->k;      // rectangular tap window k_h x k (parity planes of stride-2 gradients)
     LU_REQUIRE(k_h >= 1 && k_h <= 7, "lu_conv2d_fwd: unsupported kernel height %d", k_h);
     a.k = d->k;                                   // taps per kernel row

@@ -34,6 +34,8 @@ struct WgradArgs {
     float* bias_ws;     // [splits][N] column sums of dy (bias gradient), or null; kernel-row variants only
     int32_t xfold;      // fp32 kernel-row variant: pixel slabs folded into grid.x (8 / column tiles; 0 / 1 = none)
     int32_t ragged, wst, rows_per;      // fp32 kernel-row variant, W % 16 != 0: slabs of whole rows, ceil(W / 16) runs per row
+    const void* zero16; // device address of lu_zero16 (bf16 kernel-row variant: a kernel ARGUMENT lives in SGPRs; taken through the
+                        // symbol it costs s_getpc + s_load + s_waitcnt lgkmcnt(0) -- which also drains the LDS reads -- per use)
 };
 
 template <int MF, int NF, int WM, int WN, bool THIN, bool YVEC>
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     float rat0 = 0.f, rat1 = 0.f;
 
     // All global loads are unconditional; masked lanes read lu_zero16 (see lu_conv.hip for why).
-    const float* const zp = lu_zero16;
+    const float* const zp = a.zero16 ? reinterpret_cast<const float*>(a.zero16) : lu_zero16;
     // Per-row pixel cursors (frame, oy, ox), advanced by KP pixels per stage with adds/compares only: the
     // per-stage integer divisions of a naive decode cost more VALU issue slots than the stage's MFMAs leave free.
     struct Pix {
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     int64_t p_end = p_begin + a.chunk;
     if (p_end > a.M) p_end = a.M;
     int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
-    const float* const zp = lu_zero16;
+    const float* const zp = a.zero16 ? reinterpret_cast<const float*>(a.zero16) : lu_zero16;
 
     // the pixel run of a stage is uniform over the block: (frame, row, first column) advance by 16 pixels per stage
     int64_t pf = 0;          // frame index
@@ -475,6 +477,11 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
 //   and run back to back there: x and dy come from HBM once per slab and from that XCD's L2 for the other tiles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
+#ifdef LU_WG_ABL      // tools-only builds (tools/gpu/r04_wg_ablate.sh): parts of the 64-pixel-stage loop compiled out, to see what bounds it
+#define LU_WGA(bit) ((LU_WG_ABL) & (bit))      // 1 global loads, 2 LDS stores, 4 stage barrier, 8 bias sums, 16 LDS fragment reads
+#else
+#define LU_WGA(bit) 0
+#endif
 
 //   S = 2: the stride-2 3x3 layers (first convolution of a down block).  A stage is still 32 OUTPUT pixels of one output
 //   row; the x tile holds the 2 * 31 + K input pixels under them and a tap-t fragment reads every second tile row
@@ -490,12 +497,21 @@ constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 //     NWV = 4 "fat" waves (2 x 2, 32c x 64n x 9 taps = 288 accumulator registers -- the accumulators live in AGPRs, ONE wave per
 //     SIMD with the whole 512-entry register file): every x fragment feeds two column fragments, i.e. half the LDS fragment
 //     reads, funnel shifts and per-stage bookkeeping instructions per MFMA of the 8-wave form.
-template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+//   DMA (round 4; bf16 operands, stride 1; opt-in, measured SLOWER -- see the loop): the tiles go from global memory STRAIGHT into LDS (global_load_lds_dwordx4: a wave
+//   instruction copies 64 x 16 bytes to 1 KB of consecutive LDS) -- no staging registers, no ds_write_b128 (13 issue cycles
+//   each, 5 per thread and 64-pixel stage), no load -> store dependency inside the stage.  Compile-time ablations of the
+//   register-staged loop (tools/gpu/r04_wg_ablate.sh, L1 5x5: 5.34 ms): without the global loads 4.06, without the LDS stores
+//   4.35, without both 3.76 ms -- a third of the kernel was moving operands through registers.  A DMA'd row cannot be padded
+//   (the 1 KB of an instruction is contiguous), so bank conflicts of the transposing fragment reads are avoided by a swizzle
+//   applied to the SOURCE address instead: the 64-byte column segment s of row r is stored at segment s ^ (r & 3) (256-byte
+//   rows: four rows of a fragment read land on four different bank quarters) resp. s ^ ((r >> 1) & 1) (128-byte rows).
+template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8, bool DMA = false>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
 __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
     constexpr int PRB = PRBT;      // (shadows the file-level default inside this kernel)
     constexpr int BMw = CT, BNw = 128, XP = S * (PRB - 1) + K, NT = 64 * NWV;
     constexpr int WMC = CT / 32, WNN = NWV / WMC, NFW = BNw / (32 * WNN);
-    constexpr int XLD = BMw + 32, YLD = BNw + 32;      // bf16 per LDS row: pitch = 64 B (mod 256 B)
+    static_assert(!DMA || (XB && YB && S == 1), "LDS-DMA staging: raw bf16 copies of stride-1 tiles");
+    constexpr int XLD = DMA ? BMw : BMw + 32, YLD = DMA ? BNw : BNw + 32;      // bf16 per LDS row: pitch = 64 B (mod 256 B); DMA: dense, swizzled
     constexpr int XE = XB ? 8 : 4, YE = YB ? 8 : 4;     // elements per 16-byte piece
     constexpr int PX = BMw / XE, PY = BNw / YE;         // pieces per tile row
     constexpr int XROWS = R * XP;                       // rows of the x tile: the R input rows back to back
@@ -503,11 +519,14 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
     static_assert(PRB * PY % NT == 0, "dy tile: whole passes");
     static_assert(R == 1 || (R == K && S == 1), "all-taps form: stride 1, every kernel row");
     static_assert(WMC * WNN == NWV && NFW * WNN * 32 == BNw, "wave grid");
-    constexpr int XPA = XPASS * NT / PX;   // x-tile rows ALLOCATED: every (thread, pass) owns a slot, so the stores need no guard
+    constexpr int XRPI = 64 / PX, YRPI = 64 / PY;       // DMA: tile rows per wave instruction (64 lanes x 16 bytes)
+    constexpr int XI = (XROWS + XRPI - 1) / XRPI, YI = PRB / YRPI;      // ... instructions per x / dy tile
+    constexpr int XPA = DMA ? XI * XRPI : XPASS * NT / PX;   // x-tile rows ALLOCATED: every (thread, pass) owns a slot, so the stores need no guard
     LU_DYN_LDS(unsigned short, smem);      // Xs[2][XPA * XLD] | Ys[2][PRB * YLD] | Bred[8 * 128] floats (wgrad_row_bf16_lds)
+    constexpr int NBUF = DMA ? 3 : 2;
     unsigned short* const Xs = smem;
-    unsigned short* const Ys = smem + 2 * XPA * XLD;
-    float* const Bred = reinterpret_cast<float*>(Ys + 2 * PRB * YLD);
+    unsigned short* const Ys = smem + NBUF * XPA * XLD;
+    float* const Bred = reinterpret_cast<float*>(Ys + NBUF * PRB * YLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WMC, wn = wave / WMC;
     // XCD-aware numbering: block b runs on XCD b % 8; the `inner` tiles of a pixel slab are consecutive on one XCD
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
     int64_t p_end = p_begin + a.chunk;
     if (p_end > a.M) p_end = a.M;
     const int n_it = p_end > p_begin ? (int)((p_end - p_begin + PRB - 1) / PRB) : 0;
-    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_zero16);
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(a.zero16 ? a.zero16 : (const void*)lu_zero16);
 
     // cursor of the NEXT stage to fetch: (frame, row, first column), stage index
     int64_t pf = 0;
@@ -549,7 +568,75 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
 #pragma unroll
     for (int e = 0; e < YE; ++e) bsum[e] = 0.f;
 
+    // ---- stride 1: lean stage loads (round 4).  The first version recomputed every piece's address and bounds from (frame, row,
+    // column) each stage: ~110 scalar and ~60 vector instructions per 40 MFMAs, short-circuit branches around the loads and two
+    // GOT look-ups of the zero block with s_waitcnt lgkmcnt(0) behind them (which also wait for the LDS fragment reads in flight).
+    // Now: one 64-bit element cursor per operand advanced by a constant per stage (S == 1 and Wout == Win: consecutive runs are
+    // consecutive in memory; a frame wrap adds the frame gap), per-thread piece offsets and validity BITS computed once, and the
+    // per-stage test is bit arithmetic: valid & row-inside(r) & not(left edge & lo) & not(right edge & hi).
+    int xvo[XPASS], yvo[YPASS];            // element offset of piece i from the stage cursor
+    unsigned xbits[XPASS], ybits = 0;      // bit 0 valid, 1 "left of the run" (xr < pad_l), 2 "right of it", 4.. kernel row r
+    int64_t xcur = 0, ycur = 0;
+    if constexpr (S == 1) {
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int item = tid + NT * i;
+            const int rr = item / PX, q = item - rr * PX;
+            const int r = R == 1 ? 0 : rr / XP, xr = rr - r * XP;
+            xvo[i] = (r * a.Win + xr) * a.x_ps + XE * q;
+            xbits[i] = ((rr < XROWS && c0 + XE * q < a.C) ? 1u : 0u) | (xr < a.pad_l ? 2u : 0u) | (xr >= PRB + a.pad_l ? 4u : 0u) |
+                       ((unsigned)r << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) {
+            const int item = tid + NT * i;
+            const int yr = item / PY, q = item - yr * PY;
+            yvo[i] = yr * a.dy_ps + YE * q;
+            ybits |= (n0 + YE * q < a.N ? 1u : 0u) << i;
+        }
+        xcur = pf * a.x_fs + ((int64_t)(oy + kh - a.pad_t) * a.Win + (ox0 - a.pad_l)) * a.x_ps + c0;
+        ycur = pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n0;
+    }
+    const int64_t x_gap = a.x_fs - (int64_t)a.HWo * a.x_ps, y_gap = a.dy_fs - (int64_t)a.HWo * a.dy_ps;      // (S == 1: Hin * Win == HWo)
+    const lu_u4* const zpa = zp;
     auto load_stage = [&](lu_u4 (&rx)[XPASS], lu_u4 (&ry)[YPASS]) {
+        if constexpr (S == 1) {
+            const unsigned live = ls < n_it ? 1u : 0u;
+            const int iy0 = oy + kh - a.pad_t;
+            unsigned rowbits = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rowbits |= ((unsigned)(iy0 + r) < (unsigned)a.Hin ? live : 0u) << r;
+            const unsigned edge = (ox0 == 0 ? 2u : 0u) | (ox0 + PRB >= a.Wout ? 4u : 0u);
+            const unsigned short* const xb = reinterpret_cast<const unsigned short*>(a.x);
+            const float* const xf = a.x;
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const unsigned ok = xbits[i] & (rowbits >> (xbits[i] >> 4)) & ((xbits[i] & edge) == 0u ? 1u : 0u);
+                const lu_u4* pp = XB ? reinterpret_cast<const lu_u4*>(xb + xcur + xvo[i]) : reinterpret_cast<const lu_u4*>(xf + xcur + xvo[i]);
+                rx[i] = *((ok & 1u) ? pp : zpa);
+            }
+            const unsigned short* const yb = reinterpret_cast<const unsigned short*>(a.dy);
+#pragma unroll
+            for (int i = 0; i < YPASS; ++i) {
+                const unsigned ok = (ybits >> i) & live;
+                const lu_u4* pp = YB ? reinterpret_cast<const lu_u4*>(yb + ycur + yvo[i]) : reinterpret_cast<const lu_u4*>(a.dy + ycur + yvo[i]);
+                ry[i] = *((ok & 1u) ? pp : zpa);
+            }
+            ++ls;
+            ox0 += PRB;
+            xcur += PRB * a.x_ps;
+            ycur += PRB * a.dy_ps;
+            if (ox0 >= a.Wout) {          // W % 32 == 0: a run never straddles two rows
+                ox0 = 0;
+                if (++oy == a.Hout) {
+                    oy = 0;
+                    ++pf;
+                    xcur += x_gap;
+                    ycur += y_gap;
+                }
+            }
+            return;
+        }
         const bool live = ls < n_it;
         const int iy0 = S * oy + kh - a.pad_t;
         const int64_t xrow = pf * a.x_fs + ((int64_t)iy0 * a.Win + (S * ox0 - a.pad_l)) * a.x_ps + c0;
@@ -644,8 +731,22 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
     // columns 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
     const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    // DMA: 64-byte column segment g of tile row r lives at segment g ^ swz(r); every row a lane reads is r0 + frow + (multiple of
+    // 4), so the swizzle term is a per-lane constant (per kernel row kr of the all-taps form: XP need not be a multiple of 4)
+    auto swz = [](int row, int row_bytes) { return row_bytes == 256 ? (row & 3) : ((row >> 1) & 1); };
+    int xseg[R], yseg[NFW];
+#pragma unroll
+    for (int kr = 0; kr < R; ++kr) xseg[kr] = DMA ? ((wm ^ swz(kr * XP + frow, 2 * BMw)) - wm) * 32 : 0;
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) yseg[nf] = DMA ? (((wn * NFW + nf) ^ swz(frow, 2 * BNw)) - (wn * NFW + nf)) * 32 : 0;
     const int xoff = S * frow * XLD + wm * 32 + fcol, yoff = frow * YLD + wn * 32 * NFW + fcol;
     auto frag = [&](const unsigned short* base, int ld) {      // 8 consecutive k (rows) of this lane's column
+        if (LU_WGA(16)) {
+            lu_bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)(lane + e);
+            return v;
+        }
         const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + 4 * ld);
         lu_bf16x8 v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
@@ -660,14 +761,16 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
     auto mma_half = [&](int buf, int j) {
         lu_bf16x8 bv[NFW];
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf * (PRB * YLD) + yoff + 16 * j * YLD + 32 * nf], YLD);
+        for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf * (PRB * YLD) + yoff + 16 * j * YLD + 32 * nf + yseg[nf]], YLD);
         if constexpr (S == 1) {
 #pragma unroll
             for (int kr = 0; kr < R; ++kr) {      // the R input rows of the tile (all-taps form) -- one for the kernel-row form
                 short xw[4 * NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const lu_bf16x4 q4 = lu_lds_tr16(&Xs[buf * (XPA * XLD) + xoff + (kr * XP + 16 * j + 4 * r) * XLD]);
+                    lu_bf16x4 q4;
+                    if (LU_WGA(16)) { q4[0] = (short)lane; q4[1] = (short)(lane + r); q4[2] = (short)j; q4[3] = (short)kr; }
+                    else q4 = lu_lds_tr16(&Xs[buf * (XPA * XLD) + xoff + xseg[kr] + (kr * XP + 16 * j + 4 * r) * XLD]);
                     xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
                 }
 #pragma unroll
@@ -693,8 +796,157 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
         }
     };
 
+    // ---- DMA staging: wave w issues tile instructions w, w + NWV, ... (x rows first, then dy rows) of the stage under the cursor.
+    // Branch-free: per slot the piece offset, validity bits and LDS destination are per-thread constants; x and dy slots differ
+    // only in which cursor / base they select (wave-uniform). ----
+    constexpr int DSLOTS = (XI + YI + NWV - 1) / NWV;
+    int dvo[DSLOTS], dlds[DSLOTS];
+    unsigned dbits[DSLOTS];      // bit 0 valid, 1 lo, 2 hi, 4..7 row-bit index (kernel row r; R for a dy slot), 8 x slot
+    if constexpr (DMA) {
+#pragma unroll
+        for (int k2 = 0; k2 < DSLOTS; ++k2) {
+            const int ii = wave + NWV * k2;
+            if (ii < XI) {
+                const int rr = XRPI * ii + lane / PX;
+                const int pc = (lane % PX) ^ (4 * swz(rr, 2 * BMw));      // source piece: the swizzle is applied on the way in
+                const int r = R == 1 ? 0 : rr / XP, xr = rr - r * XP;
+                dvo[k2] = (r * a.Win + xr) * a.x_ps + 8 * pc;
+                dbits[k2] = ((rr < XROWS && c0 + 8 * pc < a.C) ? 1u : 0u) | (xr < a.pad_l ? 2u : 0u) | (xr >= PRB + a.pad_l ? 4u : 0u) |
+                            ((unsigned)(rr < XROWS ? r : 0) << 4) | 256u;
+                dlds[k2] = XRPI * ii * XLD;
+            } else {
+                const int yi = ii - XI;
+                const int yr = YRPI * yi + lane / PY;
+                const int pc = (lane % PY) ^ (4 * swz(yr, 2 * BNw));
+                dvo[k2] = yr * a.dy_ps + 8 * pc;
+                dbits[k2] = ((yi < YI && n0 + 8 * pc < a.N) ? 1u : 0u) | ((unsigned)R << 4);
+                dlds[k2] = (yi < YI ? YRPI * yi : 0) * YLD;
+            }
+        }
+    }
+    auto dma_stage = [&](unsigned short* Xd, unsigned short* Yd) {
+        const unsigned live = ls < n_it ? 1u : 0u;
+        const int iy0 = oy + kh - a.pad_t;
+        unsigned rowbits = live << R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) rowbits |= ((unsigned)(iy0 + r) < (unsigned)a.Hin ? live : 0u) << r;
+        const unsigned edge = (ox0 == 0 ? 2u : 0u) | (ox0 + PRB >= a.Wout ? 4u : 0u);
+        const unsigned short* const xb = reinterpret_cast<const unsigned short*>(a.x) + xcur;
+        const unsigned short* const yb = reinterpret_cast<const unsigned short*>(a.dy) + ycur;
+        const unsigned short* const zs = reinterpret_cast<const unsigned short*>(a.zero16 ? a.zero16 : (const void*)lu_zero16);
+#pragma unroll
+        for (int k2 = 0; k2 < DSLOTS; ++k2) {
+            const bool isx = wave + NWV * k2 < XI;           // (wave-uniform)
+            if (wave + NWV * k2 < XI + YI) {                  // (wave-uniform; only the last slot can be empty)
+                const unsigned ok = dbits[k2] & (rowbits >> ((dbits[k2] >> 4) & 15u)) & ((dbits[k2] & edge) == 0u ? 1u : 0u);
+                const unsigned short* sp = (isx ? xb : yb) + dvo[k2];
+                lu_glds16(reinterpret_cast<const float*>((ok & 1u) ? sp : zs), reinterpret_cast<float*>((isx ? Xd : Yd) + dlds[k2]));
+            }
+        }
+        ++ls;
+        ox0 += PRB;
+        xcur += PRB * a.x_ps;
+        ycur += PRB * a.dy_ps;
+        if (ox0 >= a.Wout) {
+            ox0 = 0;
+            if (++oy == a.Hout) {
+                oy = 0;
+                ++pf;
+                xcur += x_gap;
+                ycur += y_gap;
+            }
+        }
+    };
+    // bias gradient of a DMA'd stage: column sums of its dy tile read back from LDS, by the same (row, piece) -> thread map and in
+    // the same stage order as the register-staged form sums its pieces (bit-identical partial sums)
+    auto bias_stage_lds = [&](const unsigned short* Yr) {
+        const bool mine = want_bias && bphase == bslot;      // (uniform)
+        bphase = bphase + 1 == brc ? 0 : bphase + 1;
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < YPASS; ++i) {
+                const int item = tid + NT * i;
+                const int yr = item / PY, q = item - yr * PY;
+                const lu_u4 v = *reinterpret_cast<const lu_u4*>(&Yr[yr * YLD + 8 * (q ^ (4 * swz(yr, 2 * BNw)))]);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[(2 * e) % YE] += lu_bits2f(w4[e] << 16);
+                    bsum[(2 * e + 1) % YE] += lu_bits2f(w4[e] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    // One stage of the DMA loop.  hipcc drains the DMA counter (s_waitcnt vmcnt(0)) in front of every transposing LDS read that
+    // MAY alias a transfer in flight -- and with one dynamic LDS array everything may.  As __restrict__ PARAMETERS of an inlined
+    // function the buffer being filled (Xd / Yd) and the buffer being read (Xr / Yr) carry scoped-noalias metadata, the waits
+    // disappear (checked in the ISA: the only vmcnt wait left is the one in front of the stage barrier), and the transfers of
+    // stage it + 1 run under the MFMAs of stage it.  The sched_barrier keeps their issue in front of the stage.
+    auto dma_iter = [&](unsigned short* __restrict__ Xd, unsigned short* __restrict__ Yd, const unsigned short* __restrict__ Xr,
+                        const unsigned short* __restrict__ Yr) {
+        dma_stage(Xd, Yd);
+#ifndef LU_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        bias_stage_lds(Yr);
+#pragma unroll
+        for (int j = 0; j < PRB / 16; ++j) {
+            lu_bf16x8 bv[NFW];
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Yr[yoff + 16 * j * YLD + 32 * nf + yseg[nf]], YLD);
+#pragma unroll
+            for (int kr = 0; kr < R; ++kr) {
+                short xw[4 * NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const lu_bf16x4 q4 = lu_lds_tr16(&Xr[xoff + xseg[kr] + (kr * XP + 16 * j + 4 * r) * XLD]);
+                    xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
+                }
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    lu_bf16x8 av;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
+#pragma unroll
+                    for (int nf = 0; nf < NFW; ++nf) acc[kr * K + t][nf] = lu_mfma_bf16(av, bv[nf], acc[kr * K + t][nf]);
+                }
+            }
+        }
+    };
+
     const int l31 = lane & 31;
-    if constexpr (PRB == 32) {
+    if constexpr (DMA) {
+        // THREE stage buffers, the transfers of two stages in flight: at 60 % of the bf16 peak a 64-pixel stage lasts ~1.5 us, less
+        // than a loaded memory round trip -- one stage of look-ahead (what the staging registers can afford) exposes part of every
+        // fetch.  The wait in front of the stage barrier is COUNTED: this wave's transfers of stage it + 2 may still be in flight,
+        // those of stage it + 1 must have landed (raw s_barrier: __syncthreads' fence would drain the counter).
+        constexpr int XB3 = XPA * XLD, YB3 = PRB * YLD;
+        auto stage_sync = [&]() {
+#ifdef LU_EMU
+            __syncthreads();
+#else
+            constexpr int REM = (XI + YI) % NWV;             // waves below REM issue DSLOTS transfers per stage, the others one fewer
+            if (REM == 0 || wave < REM) __builtin_amdgcn_s_waitcnt(0x0070 | DSLOTS);      // vmcnt(DSLOTS) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070 | (DSLOTS - 1));
+            __builtin_amdgcn_s_barrier();
+#endif
+        };
+        dma_stage(Xs, Ys);                 // stage 0
+        dma_stage(Xs + XB3, Ys + YB3);     // stage 1
+        stage_sync();
+        int b0 = 0, b2 = 2;
+        for (int it = 0; it < n_it; ++it) {
+            // stage it + 2 goes to buffer b2, which every wave left behind at the last barrier (it held stage it - 1)
+            dma_iter(Xs + b2 * XB3, Ys + b2 * YB3, Xs + b0 * XB3, Ys + b0 * YB3);
+            stage_sync();
+            b0 = b0 == 2 ? 0 : b0 + 1;
+            b2 = b2 == 2 ? 0 : b2 + 1;
+        }
+#ifndef LU_EMU
+        __builtin_amdgcn_s_waitcnt(0x0070);      // nothing of the zero-filled tail stages may land in the epilogue's exchange area
+        __builtin_amdgcn_s_barrier();
+#endif
+    } else if constexpr (PRB == 32) {
         lu_u4 rxA[XPASS], ryA[YPASS], rxB[XPASS], ryB[YPASS];
         load_stage(rxA, ryA);              // stage 0
         bias_stage(ryA);
@@ -730,13 +982,13 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
         for (int it = 0; it < n_it; ++it) {
             const int buf = it & 1;
             mma_half(buf, 0);
-            bias_stage(ryA);
+            if (!LU_WGA(8)) bias_stage(ryA);
             LU_SCHED_FENCE();
             // One branch-free scheduling region: the LDS stores of stage it + 1, the loads of stage it + 2 and the remaining
             // MFMAs of this stage are independent of each other -- spread the bookkeeping BETWEEN the MFMAs (an in-order
             // wave cannot hide it behind its own MFMAs otherwise, and the barrier keeps all waves in the same phase)
-            store_stage(buf ^ 1, rxA, ryA);      // stage it + 1 (requested one whole stage ago)
-            load_stage(rxA, ryA);                // stage it + 2
+            if (!LU_WGA(2)) store_stage(buf ^ 1, rxA, ryA);      // stage it + 1 (requested one whole stage ago)
+            if (!LU_WGA(1)) load_stage(rxA, ryA);                // stage it + 2
 #pragma unroll
             for (int j = 1; j < PRB / 16; ++j) mma_half(buf, j);
 #pragma unroll
@@ -745,7 +997,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
                 LU_SCHED_GROUP(0x366, 8);        // ... then up to 8 non-MFMA instructions (VALU / SALU / VMEM / DS)
             }
             LU_SCHED_FENCE();
-            __syncthreads();
+            if (!LU_WGA(4)) __syncthreads();
         }
     }
 
@@ -836,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_small3_kernel(WgradArgs a) {
     int64_t p_end = p_begin + a.chunk;
     if (p_end > a.M) p_end = a.M;
     const int n_it = p_end > p_begin ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
-    const float* const zp = lu_zero16;
+    const float* const zp = a.zero16 ? reinterpret_cast<const float*>(a.zero16) : lu_zero16;
 
     int64_t pf = 0;
     int oy = 0, ox0 = 0;
@@ -1064,11 +1316,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// device address of this translation unit's lu_zero16 (looked up once; null on failure: the kernel then takes the symbol itself)
+const void* zero16_address() {
+#ifdef LU_EMU
+    return lu_zero16;
+#else
+    static const void* addr = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lu_zero16)) == hipSuccess) addr = p;
+        tried = true;
+    }
+    return addr;
+#endif
+}
+
 // dynamic LDS of wgrad_row_bf16_kernel<K, CT, *, *, S, PRBT>
-size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb, bool xb, int R = 1, int NT = 512) {
-    const int XP = S * (prb - 1) + K, XLD = CT + 32, YLD = 128 + 32, PX = CT / (xb ? 8 : 4);
-    const int XPA = (R * XP * PX + NT - 1) / NT * NT / PX;      // rows allocated = pass coverage (see the kernel)
-    return (size_t)(2 * XPA * XLD + 2 * prb * YLD) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
+size_t wgrad_row_bf16_lds(int K, int CT, int S, int prb, bool xb, int R = 1, int NT = 512, bool dma = false) {
+    const int XP = S * (prb - 1) + K, XLD = dma ? CT : CT + 32, YLD = dma ? 128 : 128 + 32, PX = CT / (xb ? 8 : 4);
+    const int XPA = dma ? (R * XP + 64 / PX - 1) / (64 / PX) * (64 / PX)      // whole wave instructions of 64 / PX rows
+                        : (R * XP * PX + NT - 1) / NT * NT / PX;              // rows allocated = pass coverage (see the kernel)
+    const int nbuf = dma ? 3 : 2;
+    return (size_t)(nbuf * XPA * XLD + nbuf * prb * YLD) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
 }
 
 }  // namespace
@@ -1111,6 +1381,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.ws = (float*)d->workspace;
     a.slab = (int64_t)a.kk * d->C * d->N;
     a.bias_ws = d->dbias ? a.ws + (int64_t)splits * a.slab : nullptr;
+    a.zero16 = zero16_address();
     const bool xvec32 = d->x_dtype == LU_F32 && (d->C % 4 == 0) && (d->x_pix_stride % 4 == 0) && (d->x_frame_stride % 4 == 0) && aligned16(d->x);
     const bool yvec32 = d->dy_dtype == LU_F32 && (d->N % 4 == 0) && (d->dy_pix_stride % 4 == 0) && (d->dy_frame_stride % 4 == 0) && aligned16(d->dy);
     dim3 block(256);
@@ -1140,7 +1411,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     const bool row_k1 = xvec && yvec && d->stride == 1 && d->k == 1 && d->precision == 1 && d->C >= 32 && d->Wout == d->Win &&
                         d->Hout == d->Hin && !d->dbias && !(d->flags & LU_WGRAD_F_NO_ROW);
     // ... and the stride-2 3x3 layers (x rows read with a stride; the general fp32 kernel ran them at 73 TFLOP/s in bf16 mode)
-    const bool row_s2 = xvec && yvec && d->stride == 2 && d->k == 3 && d->precision == 1 && d->C >= 64 &&
+    // (round 4: 5x5 as well -- Networks.DEFAULT_NET_DOWN_PARAMS' down blocks; 64-channel tiles: five accumulator tiles per wave)
+    const bool row_s2 = xvec && yvec && d->stride == 2 && (d->k == 3 || d->k == 5) && d->precision == 1 && d->C >= 64 &&
                         d->Hout == (d->Hin + 1) / 2 && d->Wout == (d->Win + 1) / 2 && !(d->flags & LU_WGRAD_F_NO_ROW);
     const bool row_bf16 = ((row_variant && !small3) || row_k1 || row_s2) && d->precision == 1 && d->Wout % PRB == 0;
     LU_REQUIRE((!xb && !yb) || row_bf16,
@@ -1150,7 +1422,7 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
     // bf16 kernel-row variant: channel tile, and the bias rows per split that go with it (also needed by a phase-2 call)
-    const int ct_bf16 = d->k == 1 ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
+    const int ct_bf16 = (d->k == 1 || (d->stride == 2 && d->k == 5)) ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
                                                                                           : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
     // all-taps form of the 3x3 layers (one block = all nine taps of a 64-channel x 128-column tile): 4 fat waves, or 8 thin ones
     // Measured (round 4, same-box A/B, config-2 shapes): 8 waves 0.196 -> 0.215 of peak on the Params-net 3x3 layers, 0.295 -> 0.345 on
@@ -1185,7 +1457,14 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     } while (0)
         // (fat waves: bf16 operands only -- an fp32 operand's conversion registers do not fit beside 288 accumulators)
         const bool p64 = d->Wout % 64 == 0 && xb && yb && !(d->flags & LU_WGRAD_F_PRB32);      // 64-pixel stages (bf16 operands)
-        if (p64 && !(d->flags & LU_WGRAD_F_TAPS9))
+        // LDS-DMA staging (bf16 operands): measured +3.5 % on the all-taps 3x3 form (three stage buffers, counted waits), -3 % on the 5x5
+        // kernel-row form, which keeps its staging registers unless LU_WGRAD_F_DMA asks
+        const bool dma9 = xb && yb && !(d->flags & (LU_WGRAD_F_NO_DMA | LU_WGRAD_F_TAPS9));
+        if (p64 && dma9)
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 64, 3, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 64, true, 3, 512, true), stream, a);
+        else if (dma9)
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 32, 3, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 32, true, 3, 512, true), stream, a);
+        else if (p64 && !(d->flags & LU_WGRAD_F_TAPS9))
             LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 64, 3, 8>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 64, true, 3, 512), stream, a);
         else if (!(d->flags & LU_WGRAD_F_TAPS9) || !(xb && yb)) LU_WG9(8);
         else LU_WG9(4);
@@ -1211,15 +1490,23 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, true, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64, true), stream, a);     \
         else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, 128, false, false, 1, 64>), grid, dim3(512), wgrad_row_bf16_lds(K_, 128, 1, 64, false), stream, a);            \
     } while (0)
-#define LU_WGB2(CT_)                                                                                                  \
+#define LU_WGB2(K_, CT_)                                                                                             \
     do {                                                                                                             \
-        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, true), stream, a);          \
-        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, false), stream, a);          \
-        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, true, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, true), stream, a);          \
-        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, CT_, false, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(3, CT_, 2, 32, false), stream, a);                 \
+        if (xb && yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 2, 32, true), stream, a);          \
+        else if (yb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, true, 2>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 2, 32, false), stream, a);          \
+        else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 2, 32, true), stream, a);          \
+        else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 2, 32, false), stream, a);                 \
     } while (0)
-        if (d->stride == 2 && ct == 128) LU_WGB2(128);
-        else if (d->stride == 2) LU_WGB2(64);
+        const bool dma = xb && yb && d->stride == 1 && (d->flags & LU_WGRAD_F_DMA);      // LDS-DMA staging (bf16 operands; opt-in: measured slower)
+        if (dma && d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32))
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 64, 1, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 64, true, 1, 512, true), stream, a);
+        else if (dma && d->k == 5 && ct == 128)
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 32, 1, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 32, true, 1, 512, true), stream, a);
+        else if (dma && d->k == 5)
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 64, true, true, 1, 32, 1, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(5, 64, 1, 32, true, 1, 512, true), stream, a);
+        else if (d->stride == 2 && d->k == 5) LU_WGB2(5, 64);
+        else if (d->stride == 2 && ct == 128) LU_WGB2(3, 128);
+        else if (d->stride == 2) LU_WGB2(3, 64);
         else if (d->k == 1) LU_WGB(1, 64);
         else if (d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32)) LU_WGB64(5);
         else if (d->k == 5 && ct == 128) LU_WGB(5, 128);

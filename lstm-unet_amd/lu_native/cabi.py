@@ -22,6 +22,8 @@ LU_WGRAD_F_KP32 = 256
 LU_WGRAD_F_NO_SLIDE = 512
 LU_WGRAD_F_TAPS9 = 1024
 LU_WGRAD_F_NO_TAPS9 = 2048
+LU_WGRAD_F_DMA = 4096
+LU_WGRAD_F_NO_DMA = 8192
 
 
 class ConvSrc(C.Structure):

@@ -319,7 +319,7 @@ def bf16_row_wgrad_ok(x, dy, k, stride):
     small3 = k == 3 and Cin <= 64 and N <= 64 and x.dtype == torch.float32 and dy.dtype == torch.float32 and not narrow
     shape_ok = (k in (3, 5) and Cin >= (32 if narrow else 64) and not small3) or (k == 1 and Cin >= 32)
     if stride == 2:      # the stride-2 3x3 layers (first convolution of a down block)
-        return (k == 3 and Cin >= 64 and Wout % 32 == 0 and vec(x, Cin) and vec(dy, N) and Hout == (Hin + 1) // 2 and
+        return (k in (3, 5) and Cin >= 64 and Wout % 32 == 0 and vec(x, Cin) and vec(dy, N) and Hout == (Hin + 1) // 2 and
                 Wout == (Win + 1) // 2 and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
     return (stride == 1 and shape_ok and Wout % 32 == 0 and vec(x, Cin) and vec(dy, N) and
             Hout == Hin and Wout == Win and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
@@ -354,7 +354,7 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     if bf16_row and stride == 2:
         row_variant = True           # (the bias gradient rides on this launch as well)
     if bf16_row:
-        ct = 64 if (k == 1 or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
+        ct = 64 if (k == 1 or (stride == 2 and k == 5) or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
             (128 if (Cin % 128 == 0 or Cin > 256) else 64)
         all_taps = (k == 3 and stride == 1 and Cin >= 64 and      # mirrors lu_conv2d_wgrad: the all-taps form of the 3x3 layers
                     not (WGRAD_FLAGS & (cabi.LU_WGRAD_F_NO_TAPS9 | cabi.LU_WGRAD_F_CT64 | cabi.LU_WGRAD_F_CT128)))

@@ -577,11 +577,12 @@ def _wgrad_bf16_cases(be, flags=0):
         assert np.array_equal(got, base)
         close(db, (R(dy) if yb else dy).reshape(-1, N).sum(0), 2e-4)
         close(db0, dy.reshape(-1, N).sum(0), 2e-4)
-    for (fr, H, W, Cc, N, sp, xb, yb) in [(2, 6, 64, 72, 136, 2, True, False), (1, 5, 64, 64, 64, 1, False, False),
-                                          (1, 8, 128, 128, 72, 3, True, True)]:      # stride-2 3x3 (TF-SAME: odd H too)
+    for (fr, H, W, Cc, N, sp, xb, yb, k2) in [(2, 6, 64, 72, 136, 2, True, False, 3), (1, 5, 64, 64, 64, 1, False, False, 3),
+                                              (1, 8, 128, 128, 72, 3, True, True, 3), (2, 6, 64, 72, 136, 2, True, True, 5),
+                                              (1, 7, 64, 128, 64, 1, False, True, 5)]:      # stride-2 3x3 / 5x5 (TF-SAME: odd H too)
         x, dy = rnd(fr, H, W, Cc), rnd(fr, (H + 1) // 2, W // 2, N)
-        _, gw = _torch_conv_grads(R(x), rnd(3, 3, Cc, N), R(dy), 2)
-        got, db = KH.conv2d_wgrad(be, x, dy, 3, 2, splits=sp, precision=1, flags=flags, x_bf16=xb, dy_bf16=yb,
+        _, gw = _torch_conv_grads(R(x), rnd(k2, k2, Cc, N), R(dy), 2)
+        got, db = KH.conv2d_wgrad(be, x, dy, k2, 2, splits=sp, precision=1, flags=flags, x_bf16=xb, dy_bf16=yb,
                                   dbias0=np.zeros(N, np.float32))
         close(got, gw, 2e-4)
         close(db, (R(dy) if yb else dy).reshape(-1, N).sum(0), 2e-4)
@@ -602,6 +603,26 @@ def _wgrad_bf16_cases(be, flags=0):
             close(KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_WGRAD_F_NO_NARROW_BF16), gfull, 2e-4)
     with pytest.raises(RuntimeError):                         # bf16 operands need the bf16 kernel-row variant
         KH.conv2d_wgrad(be, rnd(1, 4, 16, 64), rnd(1, 4, 16, 128), 3, 1, precision=1, dy_bf16=True)
+
+
+def test_wgrad_bf16_lds_dma_equals_register_staging(be):
+    """bf16 operands reach LDS by global_load_lds (dense rows, 64-byte column segments XOR-swizzled by the row; three stage buffers,
+    counted vmcnt waits) instead of through staging registers and ds_write: same tiles, same fragments, same MFMA order --
+    bit-identical weight AND bias gradients.  The library's own choice for the all-taps 3x3 form (measured +3.5 %), opt-in
+    (LU_WGRAD_F_DMA) for the 5x5 kernel-row form (measured -3 %); LU_WGRAD_F_NO_DMA keeps the registers everywhere.  5x5 on 128- /
+    64-channel tiles with 64- / 32-pixel stages, the all-taps 3x3 form (198- / 102-row x tiles: the swizzle term changes with the
+    kernel row), masked channel / column tails, image borders, odd slab counts."""
+    for (fr, H, W, Cc, N, k, sp) in [(1, 5, 64, 128, 136, 5, 2), (2, 4, 32, 128, 128, 5, 3), (1, 6, 64, 72, 264, 5, 1),
+                                     (2, 5, 64, 136, 72, 3, 3), (1, 7, 32, 64, 128, 3, 1), (3, 3, 96, 200, 136, 5, 2)]:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        want, db0 = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True,
+                                    dbias0=np.zeros(N, np.float32), flags=cabi.LU_WGRAD_F_NO_DMA)
+        got, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
+                                  flags=cabi.LU_WGRAD_F_DMA)
+        assert np.array_equal(got, want), (Cc, N, k, sp)
+        assert np.array_equal(db, db0), (Cc, N, k, sp)
+        _, gw = _torch_conv_grads(KH.bf16_round(x), rnd(k, k, Cc, N), KH.bf16_round(dy), 1)
+        close(got, gw, 2e-4)
 
 
 @pytest.mark.parametrize('form', ['fat4', 'w8'])
