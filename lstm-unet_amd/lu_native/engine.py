@@ -246,6 +246,30 @@ class Engine:
         the halo kernel; oracle/torch_oracle.py restates the same rule)."""
         return self.precision == 'bf16' and (n_out >= 64 or (self.narrow_bf16 and n_out == 32 and stride == 1 and k in (3, 5)))
 
+    def _down_consumers_bf16(self, plan, bi, ci, B, H, W):
+        """True when every consumer of conv unit `ci` of down block `bi` ([.., H, W, cout]) reads it as a bf16 MFMA operand, i.e. when
+        storing it as bf16 changes no value anywhere: the block's next convolution; after the last one the next block's first
+        ConvLSTM (its fused bf16 step on bf16 tensors -- narrow layers with 4F <= 64 run the fp32 kernels and read fp32), the
+        decoder's skip convolution of that level, and -- last block -- the first up block (a bilinear resize reads fp32)."""
+        if self.precision != 'bf16':
+            return False
+        down, up = plan['down'], plan['up']
+        blk = down[bi]
+        if ci + 1 < len(blk['conv']):
+            nxt = blk['conv'][ci + 1]
+            return self._bf16_unit(nxt['k'], nxt['stride'], nxt['cout'])
+        cout = blk['conv'][ci]['cout']
+        if bi + 1 < len(down):
+            l = down[bi + 1]['lstm'][0]      # next block's first ConvLSTM: the conditions of _lstm_forward's bf16-tensor route
+            if not (self._bf16_conv(l['k'], 1, 4 * l['f']) and ops.fused_step_applies(B, H, W, l['f'], True) and cout % 8 == 0):
+                return False
+            c0 = up[len(down) - 2 - bi]['conv'][0]      # skips = [image, D0, D1, D2] reversed: D_bi feeds up block n - 2 - bi
+            return self._bf16_unit(c0['k'], c0['stride'], c0['cout'])
+        if up[0]['up_factor'] == 2:
+            return False
+        c0 = up[0]['conv'][0]
+        return self._bf16_unit(c0['k'], c0['stride'], c0['cout'])
+
     def _sync_weight_images(self):
         """Before any use of a derived weight image: drop the per-step cache and refresh the bank if the parameters changed."""
         ver = self.flat_params._version       # in-place torch updates (copy_, torch optimisers) bump it; the raw-pointer
@@ -654,9 +678,8 @@ class Engine:
                 seq = self._lstm_forward(bi, li, l, seq, T, B, tape)
             n_dc = len(blk['conv'])
             for ci, l in enumerate(blk['conv']):
-                # consumers of this activation: the block's next convolution; after the last one the next block's ConvLSTM, the
-                # decoder's skip convolution and -- last block -- the first up block (a bilinear resize needs the fp32 tensor)
-                z16 = not (bi == len(plan['down']) - 1 and ci == n_dc - 1 and plan['up'][0]['up_factor'] == 2)
+                # bf16 storage only if EVERY consumer of this activation rounds it to a bf16 MFMA operand anyway (_down_consumers_bf16)
+                z16 = self._down_consumers_bf16(plan, bi, ci, B, -(-seq.shape[1] // l['stride']), -(-seq.shape[2] // l['stride']))
                 seq = self._conv_unit(f'down.{bi}', ci, l, [(seq, 0, l['cin'])], True, training, tape,
                                       alt16=self._h16_seq if ci == 0 else None, z16=z16)
             self._h16_seq = None
