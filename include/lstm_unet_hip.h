@@ -376,6 +376,8 @@ int lu_softmax_wce_bwd(const float* logits, const float* gt, const float* class_
                        float grad_scale, float* dlogits, int64_t rows, lu_stream_t stream);
 /* k.layers.Softmax over the 3 classes (Networks.py:206,252): out[r,:] = softmax(logits[r,:]) */
 int lu_softmax3(const float* logits, float* out, int64_t rows, lu_stream_t stream);
+/* ... for any class count (reference Networks.py:205-206: `last_depth` = filters of the last up-block kernel; ABI v8) */
+int lu_softmax_rows(const float* logits, float* out, int64_t rows, int32_t classes, lu_stream_t stream);
 /* loss[0] = sums[0] / (sums[1] + 1e-5) */
 int lu_wce_finalize(const double* sums, float* loss, lu_stream_t stream);
 

@@ -50,8 +50,9 @@ class PostPipeline(object):
     frames/s measured).  Two processors alternate; frame t - 2's buffers are collected before frame t re-uses them.
     Results are those of postprocess(): same kernels, same order per frame."""
 
-    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=False):
+    def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=False, depth=2):
         self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
+        self.depth = int(depth)      # frames in flight behind the forward (>= 2: see the class comment)
         self.stream = None
         self.pending = []
         self._procs = None
@@ -72,12 +73,12 @@ class PostPipeline(object):
         if self.stream is None:
             from lu_native.post import PostProcessor
             self.stream = torch.cuda.Stream()
-            self._procs = [PostProcessor(graph=self.graph), PostProcessor(graph=self.graph)]
-        done = self._finish() if len(self.pending) == 2 else []      # frame t - 2 (its processor is the one re-used now)
+            self._procs = [PostProcessor(graph=self.graph) for _ in range(self.depth)]
+        done = self._finish() if len(self.pending) == self.depth else []      # frame t - depth (its processor is the one re-used now)
         ready = torch.cuda.Event()
         ready.record()                                # after the forward that produced softmax_chw (current stream)
         softmax_chw.record_stream(self.stream)
-        proc = self._procs[self._n & 1]
+        proc = self._procs[self._n % self.depth]
         self._n += 1
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)

@@ -447,9 +447,7 @@ class ULSTMnet2D(object):
             sm_src = logits
         # softmax over the class axis
         cl = sm_src.permute(0, 1, 3, 4, 2).contiguous() if self._nchw else sm_src.contiguous()
-        if cl.shape[-1] != 3:
-            raise NotImplementedError('the softmax / loss kernels are written for the 3-class (bg, cell, edge) head')
-        sm = ops.softmax3(cl)
+        sm = ops.softmax_last(cl)      # (any head depth, Networks.py:205-206; losses.WeightedCELoss is 3-class like the reference's)
         sm = sm.permute(0, 1, 4, 2, 3).contiguous() if self._nchw else sm
         return logits, sm
 

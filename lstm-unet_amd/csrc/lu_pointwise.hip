@@ -1221,6 +1221,26 @@ extern "C" int lu_softmax_wce_bwd(const float* logits, const float* gt, const fl
     return LU_CHECK_LAUNCH();
 }
 
+// softmax over the last axis for any class count (Networks.py:205-206: the head's depth is whatever the last up-block kernel says;
+// the 3-class kernel above is the reference's own configuration and stays the fast path)
+__global__ void softmax_rows_kernel(const float* __restrict__ logits, float* __restrict__ out, int64_t rows, int C) {
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+        const float* l = logits + r * C;
+        float m = l[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(l[c] - m);
+        const float inv = 1.f / sum;
+        for (int c = 0; c < C; ++c) out[r * C + c] = expf(l[c] - m) * inv;
+    }
+}
+
+extern "C" int lu_softmax_rows(const float* logits, float* out, int64_t rows, int32_t classes, lu_stream_t stream) {
+    LU_REQUIRE(logits && out && rows > 0 && classes >= 1, "lu_softmax_rows: bad arguments");
+    LU_LAUNCH(softmax_rows_kernel, dim3(grid_for(rows)), dim3(NT), stream, logits, out, rows, (int)classes);
+    return LU_CHECK_LAUNCH();
+}
+
 extern "C" int lu_softmax3(const float* logits, float* out, int64_t rows, lu_stream_t stream) {
     LU_REQUIRE(logits && out && rows > 0, "lu_softmax3: bad arguments");
     LU_LAUNCH(softmax3_kernel, dim3(grid_for(rows)), dim3(NT), stream, logits, out, rows);

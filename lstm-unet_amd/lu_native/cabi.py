@@ -99,6 +99,7 @@ PROTOTYPES = {
     'lu_softmax_wce_bwd': (C.c_int, [P, P, P, P, f32, P, i64, S]),
     'lu_wce_finalize': (C.c_int, [P, P, S]),
     'lu_softmax3': (C.c_int, [P, P, i64, S]),
+    'lu_softmax_rows': (C.c_int, [P, P, i64, C.c_int32, S]),
     'lu_adam_step': (C.c_int, [P, P, P, P, i64, f32, f32, f32, f32, f32, S]),
     'lu_scale_frames': (C.c_int, [P, P, i32, i64, S]),
     'lu_state_begin': (C.c_int, [P, P, P, P, i32, i64, S]),

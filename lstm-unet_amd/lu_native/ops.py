@@ -706,6 +706,19 @@ def softmax3(logits):
     return out
 
 
+def softmax_last(logits):
+    """Softmax over the last (class) axis for any head depth (Networks.py:205-206); 3 classes take the dedicated kernel."""
+    if logits.shape[-1] == 3:
+        return softmax3(logits)
+    _chk(logits)
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    out = torch.empty_like(logits)
+    c = int(logits.shape[-1])
+    calls.check(lib(), lib().lu_softmax_rows(logits.data_ptr(), out.data_ptr(), logits.numel() // c, c, _stream()),
+                'lu_softmax_rows')
+    return out
+
+
 def wce_loss(sums):
     loss = torch.empty(1, device=sums.device, dtype=torch.float32)
     calls.check(lib(), lib().lu_wce_finalize(sums.data_ptr(), loss.data_ptr(), _stream()), 'lu_wce_finalize')

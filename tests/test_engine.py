@@ -197,6 +197,27 @@ def test_train_step_parity(dev):
                 tm.P[k] = torch.tensor(e.P[k].cpu().numpy(), dtype=torch.float64)
 
 
+def test_head_depth_other_than_three(dev):
+    """Networks.py:201-206: `last_depth` is whatever the last up-block kernel says and the model's second output is the softmax
+    over that many classes (the reference's loss hard-codes 3 classes; the model does not)."""
+    import Networks
+    net = tiny_net(3)
+    net['up_conv_kernels'][-1][-1] = (1, 5)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((1, 2, 1, 16, 16)).astype(np.float32)
+    m = Networks.ULSTMnet2D(net, 'NCHW', False, seed=2)
+    assert m.last_depth == 5
+    logits, sm = m(x, training=False)
+    assert tuple(logits.shape) == (1, 2, 5, 16, 16) and tuple(sm.shape) == (1, 2, 5, 16, 16)
+    lg = logits.cpu().numpy().astype(np.float64)
+    want = np.exp(lg - lg.max(2, keepdims=True))
+    want /= want.sum(2, keepdims=True)
+    assert np.abs(sm.cpu().numpy() - want).max() <= 1e-6
+    p = m.engine.export_params()
+    ref = npo.model_forward(net, p, np.transpose(x, (0, 1, 3, 4, 2)), training=False, pad_image=False)
+    assert np.abs(np.transpose(lg, (0, 1, 3, 4, 2)) - ref['logits']).max() <= 1e-3 * max(1.0, np.abs(ref['logits']).max())
+
+
 def test_public_api_and_autograd_path(dev):
     import Networks
     import losses

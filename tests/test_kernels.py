@@ -835,6 +835,11 @@ def test_softmax_wce(be):
     sm2 = be.empty(lg.shape)
     ck(be, be.lib.lu_softmax3(be.ptr(lgd), be.ptr(sm2), rows, be.stream), 'softmax3')
     close(be.host(sm2), npo.softmax(lg.astype(np.float64)), 1e-6)
+    for classes in (1, 2, 3, 5, 11):          # any head depth (Networks.py:205-206: last_depth = filters of the last up-block kernel)
+        lgc = rnd(257, classes, scale=3.0)
+        lgcd, smc = be.dev(lgc), be.empty(lgc.shape)
+        ck(be, be.lib.lu_softmax_rows(be.ptr(lgcd), be.ptr(smc), 257, classes, be.stream), 'softmax_rows')
+        close(be.host(smc), npo.softmax(lgc.astype(np.float64)), 1e-6)
     lt = torch.tensor(lg, dtype=torch.float64, requires_grad=True)
     (gl,) = torch.autograd.grad(tho.weighted_ce(torch.tensor(gt, dtype=torch.float64), lt, cw.tolist()), [lt])
     dl = be.empty(lg.shape)

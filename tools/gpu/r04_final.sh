@@ -43,7 +43,7 @@ PY
 for prec in fp32 bf16; do for i in 1 2 3 4 5; do
 python bench.py --precision $prec --steps 1 --warmup 1 --no-cpu-baseline --no-variants --no-bf16 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stream $prec run $i', d['inference']['frames_per_s'], d['inference']['frames_per_s_with_postprocess'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stream $prec run $i', d['inference']['frames_per_s'], d['inference']['frames_per_s_with_postprocess'], d['inference']['frames_per_s_with_postprocess_runs'])"
 done; done | tee gpurun_out/${tag}_streaming_5runs.log
 cd /tmp && export TMPDIR=/tmp
 for mode in fp32 bf16; do
