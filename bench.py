@@ -373,6 +373,8 @@ def main():
                     help='N > 1: run the DP + SyncBN == single-process comparison inline first; refuse to print a line if it fails')
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the `variants` block (lstm3 / default5 in fp32 and bf16, N = 1, headline net only)')
+    ap.add_argument('--lib', default=None, metavar='SO',
+                    help='A/B: another build of the kernel library (same ABI), e.g. the previous commit\'s for a same-box comparison')
     args = ap.parse_args()
     if args.gpus < 1:
         _die('--gpus must be >= 1')
@@ -392,6 +394,8 @@ def main():
     from lu_native.dp import DataParallel
     import train2D
 
+    if args.lib:
+        ops.LIB_PATH = lu_build.LIB = os.path.abspath(args.lib)      # (build_id on the line is then this file's)
     dp = DataParallel()
     if dp.world_size > 1 and torch.distributed.get_world_size() != args.gpus:
         _die('process group has %d ranks, --gpus %d' % (torch.distributed.get_world_size(), args.gpus))

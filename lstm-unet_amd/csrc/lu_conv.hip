@@ -623,7 +623,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     constexpr int PAD = (K - 1) / 2;
     static_assert(HP * A_LD >= BM * A_LD, "halo buffer doubles as the [256][20] tile of the thin-source prologue");
     __shared__ __attribute__((aligned(16))) float Ah[HP * A_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[3][CK * BN];      // weight tiles [16 k][128 columns]: three stages (LDS-DMA, see the loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = blockIdx.x;
@@ -657,20 +657,6 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
     const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
     const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
-    auto tap_advance = [&](IterState& st) {          // iter_advance without the kernarg look-ups
-        ++st.tap;
-        if (++st.kw == K) {
-            st.kw = 0;
-            ++st.kh;
-        }
-        if (st.tap < K * K) return;
-        st.tap = st.kh = st.kw = 0;
-        if (++st.chunk == (st.s ? nch_s1 : nch_s0)) {
-            st.chunk = 0;
-            ++st.s;
-        }
-    };
-
     // ---- halo gather: piece i of a thread is 4 channels of halo pixel (tid + 512 i) / 4.  The staging registers are a NATIVE
     // vector type and the pixel offsets are recomputed per chunk (a handful of integer ops every K*K stages): as `float4 rh[]` +
     // `int hoff[]` captured by the lambdas the arrays lived in SCRATCH memory (80 bytes per thread, rounds 1-2) -- every chunk the
@@ -683,11 +669,11 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
 
     lu_u4 rh[HPASS];
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_halo = [&](const IterState& st) {
-        const int c = st.chunk * CK + 4 * q;
-        const float* base = (st.s ? x_s1 : x_s0) + c;
-        const int ps = st.s ? ps_s1 : ps_s0;
-        const bool cok = c < (st.s ? C_s1 : C_s0);
+    auto load_halo = [&](int src, int chunk) {
+        const int c = chunk * CK + 4 * q;
+        const float* base = (src ? x_s1 : x_s0) + c;
+        const int ps = src ? ps_s1 : ps_s0;
+        const bool cok = c < (src ? C_s1 : C_s0);
 #pragma unroll
         for (int i = 0; i < HPASS; ++i) {
             const int hp = (tid + NT * i) >> 2;
@@ -722,14 +708,34 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         const bool ok = rok && ((EPI == LU_EPI_LSTM) || bcol < a.N);
         rb = *reinterpret_cast<const float4*>(ok ? wp : zp);
     };
-    auto load_bv = [&](const IterState& st) {          // vector sources: weight row (tap, 16 chunk + brow)
-        const int c = st.chunk * CK + brow;
-        const float* wp = (st.s ? w_s1 : w_s0) + (int64_t)st.tap * (st.s ? wts_s1 : wts_s0) +
-                          (int64_t)c * (st.s ? wrs_s1 : wrs_s0) + bcol;
-        const bool ok = c < (st.s ? C_s1 : C_s0) && ((EPI == LU_EPI_LSTM) || bcol < a.N);
-        rb = *reinterpret_cast<const float4*>(ok ? wp : zp);
+    // Weight tile of a stage by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): thread (brow, bq) owns the
+    // 16 bytes of row brow, columns 4 bq .. 4 bq + 3 = float tid * 4 of the [16][128] image, i.e. a wave's 64 lanes fill 1 KB.
+    // The stream of weight tiles is walked by a RUNNING per-thread pointer (round 4): one 64-bit add per stage, a handful of scalar
+    // instructions at a chunk change -- the (tap, chunk, source) -> address arithmetic redone every stage (64-bit multiplies,
+    // selects between the two sources' fields) was most of the ~0.3 us per stage that the loads cost the loop besides their data.
+    int d_s = 0, d_chunk = 0, d_tap = 0;      // (source, chunk, tap) of the NEXT tile to request
+    const float* wq = nullptr;                 // ... its 16 bytes for this thread
+    bool wok = false;                          // ... inside the kernel (row c < C, column < N)
+    const bool colok = (EPI == LU_EPI_LSTM) || bcol < a.N;
+    auto dma_seek = [&](int src, int chunk, int tap) {
+        d_s = src;
+        d_chunk = chunk;
+        d_tap = tap;
+        const int c = chunk * CK + brow;
+        wq = (src ? w_s1 : w_s0) + (int64_t)tap * (src ? wts_s1 : wts_s0) + (int64_t)c * (src ? wrs_s1 : wrs_s0) + bcol;
+        wok = c < (src ? C_s1 : C_s0) && colok;
     };
-    auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][brow * BN + 4 * bq]) = rb; };
+    auto dma_next = [&](float* Bd) {           // request the tile, step to the one after it
+        lu_glds16(wok ? wq : zp, Bd + wave * 256);
+        if (++d_tap < K * K) {
+            wq += d_s ? wts_s1 : wts_s0;
+        } else if (d_chunk + 1 < (d_s ? nch_s1 : nch_s0)) {
+            dma_seek(d_s, d_chunk + 1, 0);
+        } else {
+            dma_seek(d_s + 1, 0, 0);           // (past the last source: never requested -- the callers count stages)
+        }
+    };
+    auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][brow * BN + 4 * bq]) = rb; };      // (thin-source prologue)
 
     f32x16 acc[NF];
 #pragma unroll
@@ -738,22 +744,42 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
 
     const int khalf = 4 * (lane >> 5);
-    float af[4];
-    // group g of a stage: k = 8*(g/4) + {g%4, 4 + g%4}; the A fragment row is the halo pixel (wave + kh, x + kw)
-    auto mma_group = [&](int buf, int g, int arow) {
-        const int s = g >> 2, j = g & 3;
-        if (j == 0) {
-            float4 t = *reinterpret_cast<const float4*>(&Ah[arow * A_LD + 8 * s + khalf]);
-            af[0] = t.x;
-            af[1] = t.y;
-            af[2] = t.z;
-            af[3] = t.w;
-        }
-        float bv[NF];
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[nf] = lu_mfma(af[j], bv[nf], acc[nf]);
+    // One stage = 8 groups g = (s, j) of four MFMAs: k = 8 s + {j, 4 + j}; the A fragment row is the halo pixel (wave + kh,
+    // x + kw).  The LDS reads run AHEAD of the MFMAs (round 4): both A fragments of the stage and a ring of three B value sets,
+    // group g + 2 requested before group g is issued, so the waits the compiler places are counted, never drains (rounds 1-3:
+    // ds_read2_b32 -> s_waitcnt lgkmcnt(0) -> two MFMAs).  Same values, same MFMA order as before: bit-identical results.
+    const int boff = khalf * BN + (lane & 31);
+    struct B4 {
+        float x, y, z, w;
+    };
+    auto rd_b = [&](const float* Br, int g) {
+        const float* p = Br + boff + (8 * (g >> 2) + (g & 3)) * BN;
+        return B4{p[0], p[32], p[64], p[96]};
+    };
+    auto rd_a = [&](int arow, int s) { return *reinterpret_cast<const float4*>(&Ah[arow * A_LD + 8 * s + khalf]); };
+    auto mma4 = [&](float av, const B4& b) {
+        acc[0] = lu_mfma(av, b.x, acc[0]);
+        acc[1] = lu_mfma(av, b.y, acc[1]);
+        acc[2] = lu_mfma(av, b.z, acc[2]);
+        acc[3] = lu_mfma(av, b.w, acc[3]);
+    };
+    float4 fa0, fa1;
+    B4 fb[3];
+    if (LU_DBG(a, 32)) {      // (tool builds: operands from registers)
+        fa0 = fa1 = *reinterpret_cast<const float4*>(lu_z16);
+        fb[0] = fb[1] = fb[2] = B4{fa0.x, fa0.y, fa0.z, fa0.w};
+    }
+    auto stage_begin = [&](const float* Br, int arow) {      // requests of the stage's first reads (right behind the barrier)
+        fa0 = rd_a(arow, 0);
+        fb[0] = rd_b(Br, 0);
+        fb[1] = rd_b(Br, 1);
+        fa1 = rd_a(arow, 1);
+    };
+    auto stage_group = [&](const float* Br, int g) {
+        if (g + 2 < 8 && !LU_DBG(a, 32)) fb[(g + 2) % 3] = rd_b(Br, g + 2);
+        const float4& fa = (g >> 2) ? fa1 : fa0;
+        const int j = g & 3;
+        mma4(j == 0 ? fa.x : j == 1 ? fa.y : j == 2 ? fa.z : fa.w, fb[g % 3]);
     };
 
     // ---- thin sources (e.g. the 1-channel image): per-tap gather into the buffer used as a [256][20] tile ----
@@ -787,8 +813,9 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
                     *reinterpret_cast<float4*>(&Ah[((tid >> 2) + 128 * i) * A_LD + 4 * q]) = rt[i];
                 store_b(0);
                 __syncthreads();
+                stage_begin(&Bs[0][0], wave * 32 + (lane & 31));
 #pragma unroll
-                for (int g = 0; g < 8; ++g) mma_group(0, g, wave * 32 + (lane & 31));
+                for (int g = 0; g < 8; ++g) stage_group(&Bs[0][0], g);
                 __syncthreads();
             }
         }
@@ -814,32 +841,104 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             st.kh = st.tap / K;
             st.kw = st.tap - st.kh * K;
         }
-        load_halo(st);
-        load_bv(st);
+        // Pipeline (round 4).  The weight tile of stage it + 2 is requested by LDS-DMA during stage it into the third buffer -- a
+        // tile has two stages (~7 us) to land, where the register-staged form (load after the first group of stage it, s_waitcnt
+        // vmcnt(0) + ds_write at its end) left the fetch less than one and measurably waited for it: compiled out, the loads alone
+        // were 7.8 % of the 5x5 input gradients (tools/gpu/r04h_call.sh).  The halo of the next (source, chunk) is requested during
+        // the LAST BUT ONE tap of the current chunk and stored at the end of the last one -- its staging registers are allocated
+        // for the whole loop anyway.  The waits in front of the stage barrier are COUNTED (VMEM operations retire in order: the
+        // transfer of stage it + 2 and a halo requested in this stage may still be in flight, everything older has landed), the
+        // barrier is the raw s_barrier (__syncthreads' fence would drain the counter).  hipcc puts s_waitcnt vmcnt(0) in front of
+        // every LDS read that MAY alias a transfer in flight: the buffer being filled and the buffer being read are __restrict__
+        // parameters of an inlined function (scoped-noalias metadata, as in wgrad_row_bf16_kernel's DMA loop).
+        // current stage: (c_s, c_chunk) + tap (kh, kw); its A rows start at halo pixel aoff = kh * HWD + kw (+ wave row, + x)
+        int c_s = st.s, c_chunk = st.chunk, tap = st.tap, kw = st.kw, aoff = st.kh * HWD + st.kw;
+        auto next_chunk = [&](int& ns, int& nc) {      // the (source, chunk) after the current one
+            ns = c_s;
+            nc = c_chunk + 1;
+            if (nc == (c_s ? nch_s1 : nch_s0)) {
+                nc = 0;
+                ++ns;
+            }
+        };
+        load_halo(c_s, c_chunk);
+        dma_seek(c_s, c_chunk, tap);
+        dma_next(&Bs[0][0]);
+        if (it0 + 1 < it1) dma_next(&Bs[1][0]);
         store_halo();
-        store_b(0);
-        __syncthreads();
-        for (int it = it0; it < it1; ++it) {
-            const int buf = (it - it0) & 1;
-            const int arow = (wave + st.kh) * HWD + (lane & 31) + st.kw;
-            IterState nx = st;
-            if (it + 1 < it1) tap_advance(nx);
-            const bool new_halo = (it + 1 < it1) && nx.tap == 0;     // the next stage starts another (source, chunk)
-            mma_group(buf, 0, arow);
+        if (it0 + 1 < it1 && tap == K * K - 1) {      // (a K-split range that begins on the last tap of a chunk)
+            int ns, nc;
+            next_chunk(ns, nc);
+            load_halo(ns, nc);
+        }
+        __syncthreads();                               // (drains the transfers: vmcnt(0))
+        auto stage_sync = [&](int vm) {      // vm: VMEM operations of this wave that may stay in flight
+#ifdef LU_EMU
+            __syncthreads();
+#else
+            if (vm == 0) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(n) lgkmcnt(0), expcnt untouched
+            else if (vm == 1) __builtin_amdgcn_s_waitcnt(0x0071);
+            else __builtin_amdgcn_s_waitcnt(0x0070 | (HPASS + 1));
+            __builtin_amdgcn_s_barrier();
+#endif
+        };
+        auto stage = [&](float* __restrict__ Bd, const float* __restrict__ Br, int arow, bool dma, bool halo_ld, bool halo_st) {
+            // (LU_DBG: -DLU_ABLATION tool builds only -- 1 no global loads / transfers, 2 no halo stores, 4 no stage barrier, 32 no LDS reads)
+            if (!LU_DBG(a, 32)) stage_begin(Br, arow);
+            stage_group(Br, 0);
             LU_SCHED_FENCE();
-            load_bv(nx);
-            if (new_halo) load_halo(nx);
+            if (!LU_DBG(a, 1)) {
+                if (halo_ld) {
+                    int ns, nc;
+                    next_chunk(ns, nc);
+                    load_halo(ns, nc);
+                }
+                if (dma) dma_next(Bd);
+            }
             LU_SCHED_FENCE();
 #pragma unroll
-            for (int g = 1; g < 8; ++g) mma_group(buf, g, arow);
-            LU_SCHED_FENCE();
-            if (new_halo) {
-                __syncthreads();      // every wave is done with the old halo
+            for (int g = 1; g < 8; ++g) {
+                stage_group(Br, g);
+                LU_SCHED_FENCE();
+            }
+            if (halo_st && !LU_DBG(a, 2)) {
+                if (!LU_DBG(a, 4)) {
+#ifdef LU_EMU
+                    __syncthreads();
+#else
+                    __builtin_amdgcn_s_barrier();      // every wave is done with the old halo (its reads were waited for by its MFMAs)
+#endif
+                }
                 store_halo();
             }
-            store_b(buf ^ 1);
-            __syncthreads();
-            st = nx;
+            if (!LU_DBG(a, 4)) stage_sync(!dma ? 0 : halo_ld ? 2 : 1);
+        };
+#ifndef LU_EMU
+        // EXPERIMENT (a.dbg run-time bits 64 / 128 / 192): the two blocks resident on a CU at different issue priorities
+        if (a.dbg & 192) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+            const unsigned wid = hw & 15, tg = (hw >> 16) & 15;
+            const unsigned sel = (a.dbg & 192) == 64 ? (tg & 1) : (a.dbg & 192) == 128 ? ((wid >> 1) & 1) : (wid & 1);
+            if (sel) __builtin_amdgcn_s_setprio(2);
+        }
+#endif
+        int b0 = 0, b2 = 2;
+        const int arow0 = wave * HWD + (lane & 31);
+        for (int it = it0; it < it1; ++it) {
+            const bool dma = it + 2 < it1;
+            stage(&Bs[b2][0], &Bs[b0][0], arow0 + aoff, dma, dma && tap == K * K - 2, it + 1 < it1 && tap == K * K - 1);
+            ++aoff;
+            if (++kw == K) {
+                kw = 0;
+                aoff += HWD - K;
+            }
+            if (++tap == K * K) {
+                tap = 0;
+                aoff = 0;
+                next_chunk(c_s, c_chunk);
+            }
+            b0 = b0 == 2 ? 0 : b0 + 1;
+            b2 = b2 == 2 ? 0 : b2 + 1;
         }
     }
 

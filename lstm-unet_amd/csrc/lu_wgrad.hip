@@ -382,36 +382,64 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
-    float av[K];      // (SLIDE: carried from one k-pair of a stage to the next)
-    auto mma_pair = [&](int buf, int kk2) {
+    float av[K];
+    auto mma_pair = [&](int buf, int kk2) {      // !SLIDE: every k-pair reads its K x rows and its dy value right where it needs them
         const float bv = Ys[buf][(kk2 + khalf) * BNw + wn * 32 + l31];
-        if (!SLIDE || kk2 == 0) {
 #pragma unroll
-            for (int t = 0; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
-        } else {
-#pragma unroll
-            for (int t = 0; t + 2 < K; ++t) av[t] = av[t + 2];
-#pragma unroll
-            for (int t = K - 2; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
-        }
+        for (int t = 0; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
 #pragma unroll
         for (int t = 0; t < K; ++t) acc[t] = lu_mfma(av[t], bv, acc[t]);
     };
+    // SLIDE (the product form, round 4): the LDS reads run AHEAD of the MFMAs.  A lane reads x rows m = 0 .. KP + K - 3 (+ khalf) and
+    // KP / 2 dy values per stage; k-pair p multiplies rows 2p .. 2p + K - 1 by dy value p, i.e. it adds two new rows and one dy value
+    // to what pair p - 1 held.  Pair p + 1's three values are requested before pair p's MFMAs are issued, through ONE base register
+    // per operand and immediate offsets, so the waits the compiler places are counted and a wave never sits on an LDS round trip
+    // with an empty MFMA queue (rounds 1-3: read -> s_waitcnt lgkmcnt(0) -> 2-3 MFMAs, covered only by the other resident waves).
+    // Same values, same MFMA order per accumulator: bit-identical to the !SLIDE form.
+    constexpr int NP = KP / 2, NX = KP + K - 2;
+    const float* const xrd = &Xs[0][khalf * BMw + wm * 32 + l31];
+    const float* const yrd = &Ys[0][khalf * BNw + wn * 32 + l31];
+    float xv[NX], bvv[NP];
+    auto rd_pair = [&](int buf, int p) {
+        bvv[p] = yrd[buf * (KP * BNw) + 2 * p * BNw];
+#pragma unroll
+        for (int m = (p == 0 ? 0 : 2 * p + K - 2); m < 2 * p + K; ++m) xv[m] = xrd[buf * (XP * BMw) + m * BMw];
+    };
+    auto mma_p = [&](int p) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) acc[t] = lu_mfma(xv[2 * p + t], bvv[p], acc[t]);
+    };
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
-        mma_pair(buf, 0);
+        if (SLIDE) {
+            rd_pair(buf, 0);
+            rd_pair(buf, 1);
+            mma_p(0);
+        } else {
+            mma_pair(buf, 0);
+        }
         LU_SCHED_FENCE();
         if (it + 1 < n_it) advance();
         load_stage(it + 1 < n_it ? it + 1 : it);
         LU_SCHED_FENCE();
+        if (SLIDE) {
 #pragma unroll
-        for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
+            for (int p = 1; p < NP - 1; ++p) {
+                rd_pair(buf, p + 1);
+                mma_p(p);
+                LU_SCHED_FENCE();
+            }
+        } else {
+#pragma unroll
+            for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
+        }
         LU_SCHED_FENCE();
         store_stage(buf ^ 1);
         if (want_bias && it + 1 < n_it && bphase == bme) bias_acc();      // (the last iteration re-fetched its own run: not counted twice)
         bphase = bphase + 1 == brc ? 0 : bphase + 1;
         LU_SCHED_FENCE();
-        mma_pair(buf, KP - 2);
+        if (SLIDE) mma_p(NP - 1);
+        else mma_pair(buf, KP - 2);
         __syncthreads();
     }
 

@@ -8,6 +8,8 @@ from lu_native import ops
 if os.environ.get('KB_LIB'):           # e.g. lstm-unet_amd/csrc/liblstmunet_abl.so (python -m lu_native.build --ablation)
     ops.LIB_PATH = os.path.abspath(os.environ['KB_LIB'])
 
+if os.environ.get('KB_CONV_FLAGS'):    # LU_CONV_F_* bits OR-ed into every conv descriptor
+    ops.CONV_FLAGS = int(os.environ['KB_CONV_FLAGS'], 0)
 dev = torch.device('cuda', 0)
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
 which = os.environ.get('KB', 'fwd,dgrad,wgrad').split(',')
