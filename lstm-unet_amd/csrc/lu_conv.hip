@@ -745,9 +745,10 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
 
     const int khalf = 4 * (lane >> 5);
     // One stage = 8 groups g = (s, j) of four MFMAs: k = 8 s + {j, 4 + j}; the A fragment row is the halo pixel (wave + kh,
-    // x + kw).  The LDS reads run AHEAD of the MFMAs (round 4): both A fragments of the stage and a ring of three B value sets,
-    // group g + 2 requested before group g is issued, so the waits the compiler places are counted, never drains (rounds 1-3:
-    // ds_read2_b32 -> s_waitcnt lgkmcnt(0) -> two MFMAs).  Same values, same MFMA order as before: bit-identical results.
+    // x + kw).  The LDS reads run AHEAD of the MFMAs (round 4; rounds 1-3: ds_read2_b32 -> s_waitcnt lgkmcnt(0) -> two MFMAs):
+    // the B values of group g + 1 are requested before group g is issued (two register sets), the s = 1 A fragment during group
+    // 0, and -- the stage barrier sits in the MIDDLE of a stage, see the loop -- the next stage's first operands during groups 5
+    // and 7.  Same values, same MFMA order as before: bit-identical results.
     const int boff = khalf * BN + (lane & 31);
     struct B4 {
         float x, y, z, w;
@@ -764,22 +765,20 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         acc[3] = lu_mfma(av, b.w, acc[3]);
     };
     float4 fa0, fa1;
-    B4 fb[3];
-    if (LU_DBG(a, 32)) {      // (tool builds: operands from registers)
-        fa0 = fa1 = *reinterpret_cast<const float4*>(lu_z16);
-        fb[0] = fb[1] = fb[2] = B4{fa0.x, fa0.y, fa0.z, fa0.w};
-    }
-    auto stage_begin = [&](const float* Br, int arow) {      // requests of the stage's first reads (right behind the barrier)
-        fa0 = rd_a(arow, 0);
-        fb[0] = rd_b(Br, 0);
-        fb[1] = rd_b(Br, 1);
-        fa1 = rd_a(arow, 1);
-    };
-    auto stage_group = [&](const float* Br, int g) {
-        if (g + 2 < 8 && !LU_DBG(a, 32)) fb[(g + 2) % 3] = rd_b(Br, g + 2);
+    B4 fb[2];
+    auto fa_of = [&](int g) {
         const float4& fa = (g >> 2) ? fa1 : fa0;
         const int j = g & 3;
-        mma4(j == 0 ? fa.x : j == 1 ? fa.y : j == 2 ? fa.z : fa.w, fb[g % 3]);
+        return j == 0 ? fa.x : j == 1 ? fa.y : j == 2 ? fa.z : fa.w;
+    };
+    auto simple_stage = [&](const float* Br, int arow) {      // (thin-source prologue: a few synchronous stages)
+        fa0 = rd_a(arow, 0);
+        fa1 = rd_a(arow, 1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            fb[0] = rd_b(Br, g);
+            mma4(fa_of(g), fb[0]);
+        }
     };
 
     // ---- thin sources (e.g. the 1-channel image): per-tap gather into the buffer used as a [256][20] tile ----
@@ -813,9 +812,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
                     *reinterpret_cast<float4*>(&Ah[((tid >> 2) + 128 * i) * A_LD + 4 * q]) = rt[i];
                 store_b(0);
                 __syncthreads();
-                stage_begin(&Bs[0][0], wave * 32 + (lane & 31));
-#pragma unroll
-                for (int g = 0; g < 8; ++g) stage_group(&Bs[0][0], g);
+                simple_stage(&Bs[0][0], wave * 32 + (lane & 31));
                 __syncthreads();
             }
         }
@@ -872,73 +869,95 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             load_halo(ns, nc);
         }
         __syncthreads();                               // (drains the transfers: vmcnt(0))
-        auto stage_sync = [&](int vm) {      // vm: VMEM operations of this wave that may stay in flight
+        // vm: VMEM operations of this wave that may stay in flight; lds: also wait for this wave's LDS operations (halo stores)
+        auto stage_sync = [&](int vm, bool lds) {
 #ifdef LU_EMU
             __syncthreads();
 #else
-            if (vm == 0) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(n) lgkmcnt(0), expcnt untouched
-            else if (vm == 1) __builtin_amdgcn_s_waitcnt(0x0071);
-            else __builtin_amdgcn_s_waitcnt(0x0070 | (HPASS + 1));
+            if (lds) {
+                if (vm == 0) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(n) lgkmcnt(0), expcnt untouched
+                else __builtin_amdgcn_s_waitcnt(0x0071);
+            } else {
+                if (vm == 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(n) only: the operand reads in flight stay in flight
+                else __builtin_amdgcn_s_waitcnt(0x0F70 | HPASS);
+            }
             __builtin_amdgcn_s_barrier();
 #endif
         };
-        auto stage = [&](float* __restrict__ Bd, const float* __restrict__ Br, int arow, bool dma, bool halo_ld, bool halo_st) {
-            // (LU_DBG: -DLU_ABLATION tool builds only -- 1 no global loads / transfers, 2 no halo stores, 4 no stage barrier, 32 no LDS reads)
-            if (!LU_DBG(a, 32)) stage_begin(Br, arow);
-            stage_group(Br, 0);
+        // One stage.  On entry fa0 (A fragment s = 0) and fb[0] (B values of group 0) of THIS stage are already requested.
+        //   Bd: the buffer the transfer of stage it + 2 fills, Br: this stage's tile, Bn: the next stage's tile.
+        // The stage barrier sits between groups 3 and 4 (all but the last tap of a chunk): what it orders -- the tile of stage
+        // it + 1 landed for every wave before anyone reads it, every wave done with stage it - 1 before its buffer is refilled --
+        // does not need the END of a stage, and in the middle a wave arrives with its next operands already requested and leaves
+        // with nothing to wait for: no LDS round trip behind the barrier, none at the stage boundary (groups 5 and 7 request the
+        // next stage's first operands).  Last tap of a chunk: two barriers at the end as before (halo exchange).
+        auto stage = [&](float* __restrict__ Bd, const float* __restrict__ Br, const float* __restrict__ Bn, int arow, int arow_n,
+                         bool dma, bool halo_ld, bool halo_st, bool more) {
+            fb[1] = rd_b(Br, 1);
+            fa1 = rd_a(arow, 1);
+            mma4(fa0.x, fb[0]);
             LU_SCHED_FENCE();
-            if (!LU_DBG(a, 1)) {
-                if (halo_ld) {
-                    int ns, nc;
-                    next_chunk(ns, nc);
-                    load_halo(ns, nc);
-                }
+            if (halo_ld) {
+                int ns, nc;
+                next_chunk(ns, nc);
+                load_halo(ns, nc);
+            }
+            LU_SCHED_FENCE();
+#pragma unroll
+            for (int g = 1; g < 4; ++g) {
+                fb[(g + 1) & 1] = rd_b(Br, g + 1);
+                mma4(fa_of(g), fb[g & 1]);
+                LU_SCHED_FENCE();
+            }
+            if (!halo_st) {
+                stage_sync(halo_ld ? 1 : 0, false);
                 if (dma) dma_next(Bd);
             }
             LU_SCHED_FENCE();
 #pragma unroll
-            for (int g = 1; g < 8; ++g) {
-                stage_group(Br, g);
+            for (int g = 4; g < 8; ++g) {
+                if (g < 7) fb[(g + 1) & 1] = rd_b(Br, g + 1);
+                else if (more && !halo_st) fb[0] = rd_b(Bn, 0);
+                if (g == 5 && more && !halo_st) fa0 = rd_a(arow_n, 0);
+                mma4(fa_of(g), fb[g & 1]);
                 LU_SCHED_FENCE();
             }
-            if (halo_st && !LU_DBG(a, 2)) {
-                if (!LU_DBG(a, 4)) {
+            if (halo_st) {
 #ifdef LU_EMU
-                    __syncthreads();
+                __syncthreads();
 #else
-                    __builtin_amdgcn_s_barrier();      // every wave is done with the old halo (its reads were waited for by its MFMAs)
+                __builtin_amdgcn_s_barrier();      // every wave is done with the old halo (its reads were waited for by its MFMAs)
 #endif
+                store_halo();                      // (the compiler's wait for the staged halo is vmcnt(0): the transfer goes behind it)
+                if (dma) dma_next(Bd);
+                stage_sync(dma ? 1 : 0, true);
+                if (more) {
+                    fa0 = rd_a(arow_n, 0);
+                    fb[0] = rd_b(Bn, 0);
                 }
-                store_halo();
             }
-            if (!LU_DBG(a, 4)) stage_sync(!dma ? 0 : halo_ld ? 2 : 1);
         };
-#ifndef LU_EMU
-        // EXPERIMENT (a.dbg run-time bits 64 / 128 / 192): the two blocks resident on a CU at different issue priorities
-        if (a.dbg & 192) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-            const unsigned wid = hw & 15, tg = (hw >> 16) & 15;
-            const unsigned sel = (a.dbg & 192) == 64 ? (tg & 1) : (a.dbg & 192) == 128 ? ((wid >> 1) & 1) : (wid & 1);
-            if (sel) __builtin_amdgcn_s_setprio(2);
-        }
-#endif
-        int b0 = 0, b2 = 2;
+        int b0 = 0, b1 = 1, b2 = 2;
         const int arow0 = wave * HWD + (lane & 31);
+        fa0 = rd_a(arow0 + aoff, 0);
+        fb[0] = rd_b(&Bs[0][0], 0);
         for (int it = it0; it < it1; ++it) {
-            const bool dma = it + 2 < it1;
-            stage(&Bs[b2][0], &Bs[b0][0], arow0 + aoff, dma, dma && tap == K * K - 2, it + 1 < it1 && tap == K * K - 1);
-            ++aoff;
-            if (++kw == K) {
-                kw = 0;
-                aoff += HWD - K;
-            }
+            const bool dma = it + 2 < it1, last_tap = tap == K * K - 1;
+            int aoff_n = aoff + 1;
+            if (kw + 1 == K) aoff_n += HWD - K;
+            if (last_tap) aoff_n = 0;
+            stage(&Bs[b2][0], &Bs[b0][0], &Bs[b1][0], arow0 + aoff, arow0 + aoff_n, dma, dma && tap == K * K - 2,
+                  it + 1 < it1 && last_tap, it + 1 < it1);
+            aoff = aoff_n;
+            if (++kw == K) kw = 0;
             if (++tap == K * K) {
                 tap = 0;
-                aoff = 0;
                 next_chunk(c_s, c_chunk);
             }
-            b0 = b0 == 2 ? 0 : b0 + 1;
-            b2 = b2 == 2 ? 0 : b2 + 1;
+            const int t = b0;
+            b0 = b1;
+            b1 = b2;
+            b2 = t;
         }
     }
 

@@ -331,7 +331,46 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         }
         *bslot = t;
     };
+    // Lean stage loads (round 4, aligned widths; the bf16 kernel's treatment): a run never straddles two image rows and Wout == Win,
+    // so consecutive runs are consecutive in memory -- ONE running pointer per operand piece, advanced by a constant (a frame wrap adds
+    // the frame gap); what is tested per stage is wave-uniform (the input row under the run, first / last run of an image row, pixels
+    // left in the slab) against per-thread constants.  The (frame, row, column) -> address arithmetic redone every stage (64-bit
+    // multiplies, four bounds per piece) was ~80 instructions per wave between the MFMAs.
+    const float* xptr[XPASS];
+    const float* yptr[YPASS];
+    bool xleft[XPASS], xright[XPASS], xin[XPASS];
+    const bool ycol = n0 + 4 * yq < a.N;
+    int64_t p_cur = p_begin;      // first pixel of the run the NEXT load_stage fetches
+    if (!RG) {
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int xr = xrow + 32 * i;
+            xin[i] = xr < XP && c0 + 4 * xq < a.C;
+            xleft[i] = xr < a.pad_l;                  // outside the image in the FIRST run of a row
+            xright[i] = xr >= KP + a.pad_l;           // ... in the LAST run of a row
+            xptr[i] = a.x + pf * a.x_fs + ((int64_t)(oy + kh - a.pad_t) * a.Win + ox0 - a.pad_l + xr) * a.x_ps + c0 + 4 * xq;
+        }
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i)
+            yptr[i] = a.dy + pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0 + yrow + 16 * i) * a.dy_ps + n0 + 4 * yq;
+    }
     auto load_stage = [&](int it) {
+        if (!RG) {
+            const int iy = oy + kh - a.pad_t;
+            const bool rowok = iy >= 0 && iy < a.Hin, first = ox0 == 0, last = ox0 + KP == a.Wout;
+            const int left = (int)(p_end - p_cur < KP ? p_end - p_cur : KP);      // pixels of this run inside the slab
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const bool okx = xin[i] && rowok && !(first && xleft[i]) && !(last && xright[i]);
+                rx[i] = *reinterpret_cast<const float4*>(okx ? xptr[i] : zp);
+            }
+#pragma unroll
+            for (int i = 0; i < YPASS; ++i) {
+                const bool oky = ycol && yrow + 16 * i < left;
+                ry[i] = *reinterpret_cast<const float4*>(oky ? yptr[i] : zp);
+            }
+            return;
+        }
         const int iy = oy + kh - a.pad_t;
         const int c = c0 + 4 * xq;
 #pragma unroll
@@ -358,14 +397,25 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < YPASS; ++i) *reinterpret_cast<float4*>(&Ys[buf][(yrow + 16 * i) * BNw + 4 * yq]) = ry[i];
     };
+    const int64_t xstep = (int64_t)KP * a.x_ps, ystep = (int64_t)KP * a.dy_ps;
+    const int64_t xwrap = a.x_fs - (int64_t)a.HWo * a.x_ps, ywrap = a.dy_fs - (int64_t)a.HWo * a.dy_ps;      // frame gap (0: dense)
     auto advance = [&]() {
         ox0 += KP;
+        bool wrapped = false;
         if (ox0 >= a.Wout) {          // (W % 16 == 0, or ragged rows with a masked last run): a run never straddles two rows
             ox0 = 0;
             if (++oy == a.Hout) {
                 oy = 0;
                 ++pf;
+                wrapped = true;
             }
+        }
+        if (!RG) {
+            p_cur += KP;
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) xptr[i] += xstep + (wrapped ? xwrap : 0);
+#pragma unroll
+            for (int i = 0; i < YPASS; ++i) yptr[i] += ystep + (wrapped ? ywrap : 0);
         }
     };
 
