@@ -447,32 +447,43 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
 
     const int arow = wave * (32 * MF) + (lane & 31);
     const int khalf = 4 * (lane >> 5);
-    // one stage = 8 groups of 2*NF MFMAs; group g uses k = 8*(g/4) + {g%4, 4 + g%4}
-    float af[MF][4];
+    // one stage = 8 groups of MF*NF MFMAs; group g uses k = 8*(g/4) + {g%4, 4 + g%4}.  The LDS reads run ahead of the MFMAs
+    // (round 4, as in conv_halo_kernel): both A fragments of the stage up front, the B values of group g + 1 requested before
+    // group g is issued (two register sets) -- counted waits instead of read -> s_waitcnt lgkmcnt(0) -> NF MFMAs.
+    float4 afr[MF][2];
+    float bvr[2][NF];
+    auto rd_af = [&](int buf, int s) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int row = arow + 32 * mf;
+            const int grp = 2 * s + (khalf >> 2);     // 16-byte channel group wanted by this half-wave
+            const int slot = DMA ? (grp ^ ((row >> 2) & 3)) : grp;
+            afr[mf][s] = *reinterpret_cast<const float4*>(&As[buf][row * ALD + 4 * slot]);
+        }
+    };
+    auto rd_bv = [&](int buf, int g) {
+        const int s = g >> 2, j = g & 3;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bvr[g & 1][nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
+    };
+    auto stage_begin = [&](int buf) {
+        rd_af(buf, 0);
+        rd_bv(buf, 0);
+        rd_af(buf, 1);
+    };
     auto mma_group = [&](int buf, int g) {
         const int s = g >> 2, j = g & 3;
-        if (j == 0) {
+        if (g + 1 < 8) rd_bv(buf, g + 1);
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                const int row = arow + 32 * mf;
-                const int grp = 2 * s + (khalf >> 2);     // 16-byte channel group wanted by this half-wave
-                const int slot = DMA ? (grp ^ ((row >> 2) & 3)) : grp;
-                float4 t = *reinterpret_cast<const float4*>(&As[buf][row * ALD + 4 * slot]);
-                af[mf][0] = t.x;
-                af[mf][1] = t.y;
-                af[mf][2] = t.z;
-                af[mf][3] = t.w;
-            }
+        for (int mf = 0; mf < MF; ++mf) {
+            const float4& fa = afr[mf][s];
+            const float av = j == 0 ? fa.x : j == 1 ? fa.y : j == 2 ? fa.z : fa.w;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(av, bvr[g & 1][nf], acc[mf][nf]);
         }
-        float bv[NF];
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(8 * s + khalf + j) * BN + 32 * nf + (lane & 31)];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(af[mf][j], bv[nf], acc[mf][nf]);
     };
     auto mma_stage = [&](int buf) {
+        stage_begin(buf);
 #pragma unroll
         for (int g = 0; g < 8; ++g) mma_group(buf, g);
     };
@@ -524,6 +535,7 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
             // The wave issues in order, but a 64-cycle MFMA leaves ~15 issue slots free behind it: the address
             // arithmetic + global loads of the next stage go after the FIRST MFMA group and its LDS stores before
             // the LAST one, so their issue time hides under MFMA execution instead of idling the matrix pipe.
+            stage_begin(buf);
             mma_group(buf, 0);
             LU_SCHED_FENCE();
             if (it + 1 < it1) iter_advance(st, a);
@@ -533,13 +545,18 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
                 if (!LU_DBG(a, 1)) dma_stage(st, buf ^ 1);
                 LU_SCHED_FENCE();
 #pragma unroll
-                for (int g = 1; g < 8; ++g) mma_group(buf, g);
+                for (int g = 1; g < 8; ++g) {
+                    mma_group(buf, g);
+                    LU_SCHED_FENCE();
+                }
             } else {
                 if (!LU_DBG(a, 1)) load_stage(st);
                 LU_SCHED_FENCE();
 #pragma unroll
-                for (int g = 1; g < 7; ++g) mma_group(buf, g);
-                LU_SCHED_FENCE();
+                for (int g = 1; g < 7; ++g) {
+                    mma_group(buf, g);
+                    LU_SCHED_FENCE();
+                }
                 if (!LU_DBG(a, 2)) store_stage(buf ^ 1);        // buf^1 was last read before the previous barrier
                 LU_SCHED_FENCE();
                 mma_group(buf, 7);

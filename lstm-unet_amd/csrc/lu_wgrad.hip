@@ -189,32 +189,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
-    auto mma_pair = [&](int buf, int kk2) {     // one k-pair (2 pixels): MF*NF MFMAs
-        float av[MF], bv[NF];
+    // one k-pair (2 pixels) = MF*NF MFMAs; its MF + NF operand values are requested one pair AHEAD (two register sets, round 4):
+    // counted waits instead of read -> s_waitcnt lgkmcnt(0) -> MFMAs.  Same values, same MFMA order.
+    float avr[2][MF], bvr[2][NF];
+    auto rd_pair = [&](int buf, int kk2) {
+        const int set = (kk2 >> 1) & 1;
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) av[mf] = As[buf][(kk2 + khalf) * BMw + wm * 32 * MF + mf * 32 + l31];
+        for (int mf = 0; mf < MF; ++mf) avr[set][mf] = As[buf][(kk2 + khalf) * BMw + wm * 32 * MF + mf * 32 + l31];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bv[nf] = Bs[buf][(kk2 + khalf) * BNw + wn * 32 * NF + nf * 32 + l31];
+        for (int nf = 0; nf < NF; ++nf) bvr[set][nf] = Bs[buf][(kk2 + khalf) * BNw + wn * 32 * NF + nf * 32 + l31];
+    };
+    auto mma_pair = [&](int kk2) {
+        const int set = (kk2 >> 1) & 1;
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(av[mf], bv[nf], acc[mf][nf]);
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = lu_mfma(avr[set][mf], bvr[set][nf], acc[mf][nf]);
     };
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
         // prefetch of the next stage is issued behind the first MFMA group, its LDS stores before the last one
         // (see lu_conv.hip); unguarded: the last iteration re-fetches its own stage
-        mma_pair(buf, 0);
+        rd_pair(buf, 0);
+        rd_pair(buf, 2);
+        mma_pair(0);
         LU_SCHED_FENCE();
         if (it + 1 < n_it) advance_stage();
         load_stage();
         LU_SCHED_FENCE();
 #pragma unroll
-        for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
-        LU_SCHED_FENCE();
+        for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) {
+            rd_pair(buf, kk2 + 2);
+            mma_pair(kk2);
+            LU_SCHED_FENCE();
+        }
         store_stage(buf ^ 1);
         LU_SCHED_FENCE();
-        mma_pair(buf, KP - 2);
+        mma_pair(KP - 2);
         __syncthreads();
     }
 
@@ -447,6 +458,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     // with an empty MFMA queue (rounds 1-3: read -> s_waitcnt lgkmcnt(0) -> 2-3 MFMAs, covered only by the other resident waves).
     // Same values, same MFMA order per accumulator: bit-identical to the !SLIDE form.
     constexpr int NP = KP / 2, NX = KP + K - 2;
+    constexpr int PD = 2;      // pairs of look-ahead
     const float* const xrd = &Xs[0][khalf * BMw + wm * 32 + l31];
     const float* const yrd = &Ys[0][khalf * BNw + wn * 32 + l31];
     float xv[NX], bvv[NP];
@@ -464,6 +476,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         if (SLIDE) {
             rd_pair(buf, 0);
             rd_pair(buf, 1);
+            if (PD > 1) rd_pair(buf, 2);
             mma_p(0);
         } else {
             mma_pair(buf, 0);
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
         if (SLIDE) {
 #pragma unroll
             for (int p = 1; p < NP - 1; ++p) {
-                rd_pair(buf, p + 1);
+                if (p + PD < NP) rd_pair(buf, p + PD);
                 mma_p(p);
                 LU_SCHED_FENCE();
             }
