@@ -1723,26 +1723,50 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
 
     // this lane's A-fragment address for (row 0 of its row group, tap (0, 0)); a tap adds a compile-time constant
     const int abase = (RW * wm * HWD + (lane & 31)) * PITCH + 16 * (lane >> 5);
-    auto mma_stage = [&](int hb, int tapoff, const float4& b0, const float4& b1) {
+    // One tap = RW MFMAs on the first 16 channels of the chunk (A fragments a0), RW on the second (a1).  The fragment reads run a
+    // whole MFMA group ahead: a1[i] is requested behind the MFMA on a0[i], and -- round 4 -- the NEXT tap's a0[i] behind the MFMA
+    // on a1[i] (same halo image, offset known at compile time), so a tap no longer opens with RW reads and an LDS round trip in
+    // front of its first MFMA (16 MFMAs of 32 cycles per tap: ~150 of ~660 cycles; only the first tap behind a chunk barrier still
+    // does -- the next halo image is complete only there).  No extra registers: a0 is dead while a1 is consumed.
+    // NAH of the RW fragments travel ahead: all of them where the registers allow (K = 3: a three-deep weight ring), half at K = 5
+    // with 8-row waves (a five-deep ring = 40 registers: with all eight ahead the fragments stay live across the bookkeeping
+    // between two taps and the kernel spills) -- the first NAH MFMAs of a tap then cover the reads of the others.
+    constexpr int NAH = (K == 5 && RW == 8) ? (B16 ? 4 : 0) : RW;      // (fp32 sources at K = 5: 247-252 registers already, none)
+    lu_bf16x8 a0[RW];
+    auto mma_stage = [&](int hb, int tapoff, const float4& b0, const float4& b1, bool first, bool ahead, int tapoff_next) {
         const unsigned char* ab = &Ah[hb * AH_BYTES + abase + tapoff];
+        const unsigned char* an = &Ah[hb * AH_BYTES + abase + tapoff_next];
         const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
-        lu_bf16x8 a0[RW], a1[RW];
+        lu_bf16x8 a1[RW];
 #pragma unroll
-        for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
+        for (int i = first ? 0 : NAH; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             acc[i] = lu_mfma_bf16(a0[i], bv0, acc[i]);
             a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH + 32);
         }
 #pragma unroll
-        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
-        LU_SCHED_GROUP(0x100, RW);
+        for (int i = 0; i < RW; ++i) {
+            acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
+            if (ahead && i < NAH) a0[i] = *reinterpret_cast<const lu_bf16x8*>(an + i * HWD * PITCH);
+        }
+        if (first) LU_SCHED_GROUP(0x100, RW);
+        else if (NAH < RW) LU_SCHED_GROUP(0x100, RW - NAH);
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             LU_SCHED_GROUP(0x008, 1);
             LU_SCHED_GROUP(0x100, 1);
         }
-        LU_SCHED_GROUP(0x008, RW);
+        if (ahead) {
+#pragma unroll
+            for (int i = 0; i < NAH; ++i) {
+                LU_SCHED_GROUP(0x008, 1);
+                LU_SCHED_GROUP(0x100, 1);
+            }
+            if (NAH < RW) LU_SCHED_GROUP(0x008, RW - NAH);
+        } else {
+            LU_SCHED_GROUP(0x008, RW);
+        }
     };
 
     const bool have_center = ctr1 && ce == n_full;           // this slice ends with the centre-tap stage
@@ -1768,7 +1792,9 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
                 constexpr int tap = decltype(tc)::value;
                 constexpr int sl = tap % D;
                 LU_SCHED_FENCE();
-                mma_stage(hb, ((tap / K) * HWD + (tap % K)) * PITCH, rb0[sl], rb1[sl]);
+                constexpr int tn = tap + 1 < KK ? tap + 1 : tap;
+                mma_stage(hb, ((tap / K) * HWD + (tap % K)) * PITCH, rb0[sl], rb1[sl], tap == 0, tap + 1 < KK,
+                          ((tn / K) * HWD + (tn % K)) * PITCH);
                 LU_SCHED_FENCE();
                 // the piece requested two taps ago is older than the fragments the MFMAs above waited for: it has landed
                 if (tap >= 2 && tap - 2 < HPASS) piece_store(tap - 2, hb ^ 1, ((tap - 2) & 1) ? rp1 : rp0);
@@ -1782,7 +1808,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
         }
         if (have_center) {                       // one more stage: the centre tap of the im2col chunk (ring slot 0 holds its fragments)
             LU_SCHED_FENCE();
-            mma_stage(hb, (PAD * HWD + PAD) * PITCH, rb0[0], rb1[0]);
+            mma_stage(hb, (PAD * HWD + PAD) * PITCH, rb0[0], rb1[0], true, false, 0);
             LU_SCHED_FENCE();
         }
     }
