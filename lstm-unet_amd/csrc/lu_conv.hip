@@ -770,7 +770,17 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     struct B4 {
         float x, y, z, w;
     };
+    // Column fragments.  Gate epilogue: fragment nf = gate nf, lane l = channel l (tile column 32 nf + l: four dwords 128 bytes
+    // apart).  Bias epilogue (round 4): INTERLEAVED fragments -- fragment nf covers tile columns 4 l + nf, so a lane's four B values
+    // are 16 contiguous bytes of the [16][128] tile (ONE ds_read_b128 per k-pair instead of two ds_read2_b32) and its four
+    // accumulators hold four CONSECUTIVE output columns of every pixel it owns: the epilogue stores 16 bytes per pixel straight
+    // from the registers, coalesced across the lanes (512 bytes per pixel), without the exchange through LDS.  Which columns a
+    // fragment covers does not touch any element's accumulation order: bit-identical results.
     auto rd_b = [&](const float* Br, int g) {
+        if (EPI == LU_EPI_BIAS) {
+            const float4 v = *reinterpret_cast<const float4*>(Br + khalf * BN + 4 * (lane & 31) + (8 * (g >> 2) + (g & 3)) * BN);
+            return B4{v.x, v.y, v.z, v.w};
+        }
         const float* p = Br + boff + (8 * (g >> 2) + (g & 3)) * BN;
         return B4{p[0], p[32], p[64], p[96]};
     };
@@ -985,35 +995,44 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     // tiles, 10 % of a fused step at the 256^2 level, and the two resident blocks of a CU reach it at the same time.  Each wave
     // turns its fragments round in a PRIVATE slice of the (dead: the loop ended on a barrier) halo LDS, no block barrier: a
     // lane then owns (pixel, four consecutive columns / channels).
-    if (EPI == LU_EPI_BIAS && a.out_vec4 && a.ksplit <= 1 && NF == 4) {
-        float* const Exw = Ah + wave * (16 * 36);          // [16 pixels][32 columns + 4]
-        const int cq = lane & 7;
-        float4 bq[NF];
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            const int col = n0 + 32 * nf + 4 * cq;
-            bq[nf] = (a.bias && col < a.N) ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == LU_EPI_BIAS) {
+        // interleaved fragments: acc[0..3][r] are columns n0 + 4 l .. + 3 of pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the row
+        const int col = n0 + 4 * (lane & 31);
+        const bool slab = a.ksplit > 1;
+        const bool vec = (a.N & 3) == 0 && (slab ? (reinterpret_cast<uintptr_t>(a.ws) & 15) == 0 : a.out_vec4 != 0);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!slab && a.bias) {
+            if (col + 3 < a.N) {
+                b4 = make_float4(a.bias[col], a.bias[col + 1], a.bias[col + 2], a.bias[col + 3]);
+            } else {
+                if (col < a.N) b4.x = a.bias[col];
+                if (col + 1 < a.N) b4.y = a.bias[col + 1];
+                if (col + 2 < a.N) b4.z = a.bias[col + 2];
+            }
         }
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr)          // pixel 16 half + (rr & 3) + 8 (rr >> 2) + 4 (lane >> 5) of the row
-                    Exw[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[nf][8 * half + rr];
-                LU_WAVE_SYNC();
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int lp = (lane >> 3) + 8 * q;
-                    const int ox = x0 + 16 * half + lp, col = n0 + 32 * nf + 4 * cq;
-                    float4 v = *reinterpret_cast<const float4*>(&Exw[lp * 36 + 4 * cq]);
-                    v.x += bq[nf].x; v.y += bq[nf].y; v.z += bq[nf].z; v.w += bq[nf].w;
-                    if (oy < a.Hin && ox < a.Win && col < a.N)
-                        *reinterpret_cast<float4*>(a.out + (int64_t)f * a.out_frame_stride +
-                                                   ((int64_t)oy * a.Win + ox) * a.out_pix_stride + col) = v;
-                }
-                LU_WAVE_SYNC();
+        for (int r = 0; r < 16; ++r) {
+            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (oy >= a.Hin || ox >= a.Win || col >= a.N) continue;
+            const int64_t pix = (int64_t)oy * a.Win + ox;
+            float* op;
+            if (slab) {
+                op = a.ws + ((int64_t)ks * a.M + (int64_t)f * a.HWo + pix) * a.N + col;
+            } else if (a.out_row_stride) {      // strided output rows
+                op = a.out + (int64_t)f * a.out_frame_stride + (int64_t)oy * a.out_row_stride + (int64_t)ox * a.out_pix_stride + col;
+            } else {
+                op = a.out + (int64_t)f * a.out_frame_stride + pix * a.out_pix_stride + col;
             }
+            const float4 v = make_float4(acc[0][r] + b4.x, acc[1][r] + b4.y, acc[2][r] + b4.z, acc[3][r] + b4.w);
+            if (vec) {
+                *reinterpret_cast<float4*>(op) = v;
+            } else {
+                op[0] = v.x;
+                if (col + 1 < a.N) op[1] = v.y;
+                if (col + 2 < a.N) op[2] = v.z;
+                if (col + 3 < a.N) op[3] = v.w;
+            }
+        }
         return;
     }
     if (EPI == LU_EPI_LSTM && a.lstm_vec4 && NF == 4 && HP * A_LD >= 8 * (8 * 132)) {
