@@ -237,7 +237,8 @@ enum {
     LU_WGRAD_F_PRB32 = 32,       /* bf16 kernel-row variant: 32-pixel stages where 64-pixel ones would be taken (A/B, tests) */
     LU_WGRAD_F_NO_RAGGED = 64,   /* fp32 kernel-row variant: only for W % 16 == 0 (other widths: the one-tap-per-block kernel) -- A/B */
     LU_WGRAD_F_NO_SLIDE = 512,   /* fp32 kernel-row variant: every k-pair re-reads its K x rows from LDS (the instance of rounds 1-2; A/B) */
-    LU_WGRAD_F_KP32 = 256,       /* fp32 kernel-row variant, 5x5, W % 32 == 0: 32-pixel stages (A/B: measured slower than 16) */
+    LU_WGRAD_F_KP32 = 256,       /* fp32 kernel-row variant, W % 32 == 0: 32-pixel stages -- the library's own choice since ABI v9 (the
+                                    bit is accepted and changes nothing) */
     LU_WGRAD_F_NO_NARROW_BF16 = 128, /* precision 1: keep the narrow layers (C < 64) on the fp32 all-taps / general kernels -- A/B */
     LU_WGRAD_F_TAPS9 = 1024,     /* precision 1, stride-1 3x3, C >= 64 (the all-taps form: one block = nine taps of a 64-channel x
                                   * 128-column tile, the library's own choice on 8 waves): 4 fat waves instead, one per SIMD,
@@ -246,7 +247,8 @@ enum {
     LU_WGRAD_F_DMA = 4096,       /* precision 1, bf16 operands, stride 1: tiles by global_load_lds straight into swizzled LDS rows (three stage
                                   * buffers, counted vmcnt waits) instead of staging registers + ds_write -- bit-identical; the library's own
                                   * choice for the all-taps 3x3 form (+3.5 %), opt-in for the 5x5 kernel-row form (measured -3 %) */
-    LU_WGRAD_F_NO_DMA = 8192     /* ... never (A/B, tests) */
+    LU_WGRAD_F_NO_DMA = 8192,    /* ... never (A/B, tests) */
+    LU_WGRAD_F_KP16 = 16384      /* fp32 kernel-row variant: 16-pixel stages where 32-pixel ones would be taken (A/B, tests) */
 };
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

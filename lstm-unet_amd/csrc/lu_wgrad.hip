@@ -1619,12 +1619,15 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         }
         a.xfold = (nxt == 1 || nxt == 2 || nxt == 4) ? 8 / nxt : 1;
         dim3 grid((unsigned)(nxt * a.xfold), (unsigned)(d->k * a.c_tiles), (unsigned)((splits + a.xfold - 1) / a.xfold));
-        const bool kp32 = !a.ragged && d->Wout % 32 == 0 && (d->flags & LU_WGRAD_F_KP32);      // 32-pixel stages: opt-in (measured slower)
+        // 32-pixel stages wherever a run of 32 stays inside an image row (half the block-wide barriers per MFMA; with the lean stage
+        // loads of round 4 faster than 16: 5x5 0.899 -> 0.914, 3x3 0.716 -> 0.732 of peak; rounds 1-3 had measured them slower)
+        const bool kp32 = !a.ragged && d->Wout % 32 == 0 && !(d->flags & (LU_WGRAD_F_KP16 | LU_WGRAD_F_NO_SLIDE));
         if (d->k == 5 && a.ragged) LU_LAUNCH((wgrad_row_kernel<5, true>), grid, dim3(512), stream, a);
         else if (d->k == 5 && kp32) LU_LAUNCH((wgrad_row_kernel<5, false, 32>), grid, dim3(512), stream, a);
         else if (d->k == 5 && (d->flags & LU_WGRAD_F_NO_SLIDE)) LU_LAUNCH((wgrad_row_kernel<5, false, 16, false>), grid, dim3(512), stream, a);
         else if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5, false>), grid, dim3(512), stream, a);
         else if (a.ragged) LU_LAUNCH((wgrad_row_kernel<3, true>), grid, dim3(512), stream, a);
+        else if (kp32) LU_LAUNCH((wgrad_row_kernel<3, false, 32>), grid, dim3(512), stream, a);
         else if (d->flags & LU_WGRAD_F_NO_SLIDE) LU_LAUNCH((wgrad_row_kernel<3, false, 16, false>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_row_kernel<3, false>), grid, dim3(512), stream, a);
     } else if (!xvec) {

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 8          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 9          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -19,6 +19,7 @@ LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_W
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128
 LU_WGRAD_F_KP32 = 256
+LU_WGRAD_F_KP16 = 16384
 LU_WGRAD_F_NO_SLIDE = 512
 LU_WGRAD_F_TAPS9 = 1024
 LU_WGRAD_F_NO_TAPS9 = 2048
