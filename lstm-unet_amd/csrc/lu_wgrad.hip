@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     // with an empty MFMA queue (rounds 1-3: read -> s_waitcnt lgkmcnt(0) -> 2-3 MFMAs, covered only by the other resident waves).
     // Same values, same MFMA order per accumulator: bit-identical to the !SLIDE form.
     constexpr int NP = KP / 2, NX = KP + K - 2;
-    constexpr int PD = 2;      // pairs of look-ahead
+    constexpr int PD = 2;      // pairs of look-ahead (5x5 with 32-pixel stages: two loop-invariant registers spill for it and it is still 0.9 % faster than one)
     const float* const xrd = &Xs[0][khalf * BMw + wm * 32 + l31];
     const float* const yrd = &Ys[0][khalf * BNw + wn * 32 + l31];
     float xv[NX], bvv[NP];
