@@ -384,6 +384,11 @@ def main():
         _die('--gpus %d but the launcher started WORLD_SIZE=%s ranks' % (args.gpus, os.environ.get('WORLD_SIZE')))
     if not torch.cuda.is_available():
         _die('no GPU visible: the training path has no CPU fallback')
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (gloo: "[Gloo] Rank 0 is connected to 1 peer
+    # ranks" on some builds; RCCL with NCCL_DEBUG set) -- file descriptor 1 points at stderr until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     backend_wanted = os.environ.get('LU_DP_BACKEND') or 'nccl'
     if args.gpus > 1 and backend_wanted == 'nccl' and torch.cuda.device_count() < args.gpus:
         _die('--gpus %d on RCCL needs one device per rank, %d visible' % (args.gpus, torch.cuda.device_count()))
@@ -695,6 +700,8 @@ def main():
             'variants': variants,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
     if dp.world_size > 1:
         torch.distributed.destroy_process_group()
