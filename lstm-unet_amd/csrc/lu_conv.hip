@@ -729,7 +729,8 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     // 16 bytes of row brow, columns 4 bq .. 4 bq + 3 = float tid * 4 of the [16][128] image, i.e. a wave's 64 lanes fill 1 KB.
     // The stream of weight tiles is walked by a RUNNING per-thread pointer (round 4): one 64-bit add per stage, a handful of scalar
     // instructions at a chunk change -- the (tap, chunk, source) -> address arithmetic redone every stage (64-bit multiplies,
-    // selects between the two sources' fields) was most of the ~0.3 us per stage that the loads cost the loop besides their data.
+    // selects between the two sources' fields: ~60 scalar + ~20 vector instructions per wave) was what "the loads" cost the loop:
+    // 5x5 input gradients 0.853 -> 0.877 of peak with nothing else changed.
     int d_s = 0, d_chunk = 0, d_tap = 0;      // (source, chunk, tap) of the NEXT tile to request
     const float* wq = nullptr;                 // ... its 16 bytes for this thread
     bool wok = false;                          // ... inside the kernel (row c < C, column < N)
@@ -865,15 +866,15 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             st.kh = st.tap / K;
             st.kw = st.tap - st.kh * K;
         }
-        // Pipeline (round 4).  The weight tile of stage it + 2 is requested by LDS-DMA during stage it into the third buffer -- a
-        // tile has two stages (~7 us) to land, where the register-staged form (load after the first group of stage it, s_waitcnt
-        // vmcnt(0) + ds_write at its end) left the fetch less than one and measurably waited for it: compiled out, the loads alone
-        // were 7.8 % of the 5x5 input gradients (tools/gpu/r04h_call.sh).  The halo of the next (source, chunk) is requested during
-        // the LAST BUT ONE tap of the current chunk and stored at the end of the last one -- its staging registers are allocated
-        // for the whole loop anyway.  The waits in front of the stage barrier are COUNTED (VMEM operations retire in order: the
-        // transfer of stage it + 2 and a halo requested in this stage may still be in flight, everything older has landed), the
+        // Pipeline (round 4; DESIGN 3.1b has the measurements).  The weight tile of stage it + 2 is requested by LDS-DMA during stage
+        // it into the third buffer: no staging registers, no ds_write, and -- what matters -- three buffers, so that the stage barrier
+        // can sit in the MIDDLE of a stage (see `stage` below).  (The two stages of lead are not what it is for: the register-staged
+        // form did not wait for memory either -- with L2-resident weights, tools/w_resident.py, it ran exactly as fast.)  The halo of
+        // the next (source, chunk) is requested during the LAST BUT ONE tap of the current chunk and stored at the end of the last one --
+        // its staging registers are allocated for the whole loop anyway.  The waits in front of the barriers are COUNTED (VMEM
+        // operations retire in order: a halo requested in this stage may still be in flight, everything older has landed), the
         // barrier is the raw s_barrier (__syncthreads' fence would drain the counter).  hipcc puts s_waitcnt vmcnt(0) in front of
-        // every LDS read that MAY alias a transfer in flight: the buffer being filled and the buffer being read are __restrict__
+        // every LDS read that MAY alias a transfer in flight: the buffer being filled and the buffers being read are __restrict__
         // parameters of an inlined function (scoped-noalias metadata, as in wgrad_row_bf16_kernel's DMA loop).
         // current stage: (c_s, c_chunk) + tap (kh, kw); its A rows start at halo pixel aoff = kh * HWD + kw (+ wave row, + x)
         int c_s = st.s, c_chunk = st.chunk, tap = st.tap, kw = st.kw, aoff = st.kh * HWD + st.kw;

@@ -1,3 +1,5 @@
+# Negative result: the two blocks resident on a CU at different issue priorities.  The run-time knob (ConvArgs.dbg bits
+# 64 / 128 / 192 -> s_setprio by HW_REG_HW_ID's workgroup-slot / wave-slot bits) lived in conv_halo_kernel for this measurement only.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for i in 1 2; do
 for fl in 0 0x400000 0x800000 0xC00000; do
