@@ -1,6 +1,6 @@
 """Clip-stream providers honouring the reference's batch contract (DataHandeling.py:454-493):
 
-    get_batch() -> (image, seg, full_seg, keep)
+    get_batch() -> (image, seg, full_seg, keep)      [+ dist [B,T,2,H,W] with return_dist=True, :371-377,490-491]
       image, seg : float32 [B,T,1,H,W] ('NCHW') or [B,T,H,W,1];  image per-frame z-scored (:103)
       seg        : values {-1 unlabeled, 0 background, 1 cell, 2 edge}
       full_seg   : [B,T]
@@ -233,10 +233,10 @@ class CTCRAMReaderSequence2D(object):
     def __init__(self, sequence_folder_list, image_crop_size=(128, 128), unroll_len=7, deal_with_end=0, batch_size=4,
                  queue_capacity=32, num_threads=3, data_format='NCHW', randomize=True, return_dist=False, keep_sample=1,
                  elastic_augmentation=True, seed=1, rank=0):
-        if return_dist:
-            raise NotImplementedError('return_dist (distance-map targets) is not used by the LSTM-UNet training path')
+        self.return_dist = bool(return_dist)      # distance-map targets beside the class map (DataHandeling.py:371-377,479-491)
         self.sequence_folder_list = list(sequence_folder_list)
         self.sub_seq_size = tuple(image_crop_size)
+        self.dist_sub_seq_size = (2,) + self.sub_seq_size
         self.unroll_len = unroll_len
         self.deal_with_end = deal_with_end
         self.batch_size = batch_size
@@ -289,6 +289,28 @@ class CTCRAMReaderSequence2D(object):
             self.sequence_data[tuple(entry) if isinstance(entry, list) else entry] = {
                 'images': images, 'segs': segs, 'full_seg': full, 'metadata': meta, 'max': float(images.max())}
 
+    @staticmethod
+    def _gt2dist_(gt_image):
+        """Distance of every pixel to the nearest and to the second-nearest cell EDGE (reference `DataHandeling.py:213-236`):
+        cells = 8-connected components of `gt == 1` (`cv2.connectedComponents`), a cell's edge = its pixels that a 3 x 3 erosion
+        removes (`cv2.erode`, whose default border does not erode from outside the image), distances by scipy's exact Euclidean
+        transform; pixels far from two cells keep the start values H + W + 2 and H + W + 3.  Returns `(stack, (dist_1, dist_2))`
+        like the reference.  Restated on scipy.ndimage (no OpenCV here); the result does not depend on the label order."""
+        gt_image = np.asarray(gt_image)
+        labeled, n = ndimage.label(gt_image == 1, structure=np.ones((3, 3)))
+        dist_1 = np.ones_like(gt_image, dtype=np.float64) * (gt_image.shape[0] + gt_image.shape[1]) + 2.
+        dist_2 = dist_1 + 1.
+        for lab in range(1, n + 1):
+            bw = labeled == lab
+            edge = bw & ~ndimage.binary_erosion(bw, structure=np.ones((3, 3)), border_value=1)
+            dist = ndimage.distance_transform_edt(~edge)
+            first = dist < dist_1
+            dist_2[first] = dist_1[first]
+            second = (dist < dist_2) & ~first
+            dist_1[first] = dist[first]
+            dist_2[second] = dist[second]
+        return np.stack((dist_1, dist_2), 0), (dist_1, dist_2)
+
     # ---- per-slot clip streams -----------------------------------------------------------------------------
     def _clip_stream(self, slot):
         """Endless frames of slot `slot`: (image, seg, full_seg, keep) with keep = 0 on the last frame of a clip."""
@@ -322,7 +344,12 @@ class CTCRAMReaderSequence2D(object):
                 img, seg = aug.frame(data['images'][t], data['segs'][t], data['max'])
                 if not (np.isfinite(img).all() and np.isfinite(seg).all()):
                     raise ValueError('non-finite values in frame {} after augmentation'.format(t))
-                yield img, seg, max(0.0, float(data['full_seg'][t])), 1.0 if j + 1 < len(idx) else 0.0
+                item = (img, seg, max(0.0, float(data['full_seg'][t])), 1.0 if j + 1 < len(idx) else 0.0)
+                if self.return_dist:      # (frames without labels carry zeros, DataHandeling.py:372-375)
+                    dist = np.zeros(self.dist_sub_seq_size, np.float32) if data['full_seg'][t] == -1 else \
+                        self._gt2dist_(seg)[0].astype(np.float32)
+                    item = item + (dist,)
+                yield item
 
     def start_queues(self, coord=None, debug=False):
         import queue
@@ -390,12 +417,18 @@ class CTCRAMReaderSequence2D(object):
         seg = np.empty((B, T, h, w), np.float32)
         full = np.empty((B, T), np.float32)
         keep = np.ones(B, np.float32)
+        dist = np.empty((B, T) + self.dist_sub_seq_size, np.float32) if self.return_dist else None
         for b in range(B):
             for t in range(T):
                 if self._error is not None:              # a producer thread died: surface its error here
                     raise self._error
-                image[b, t], seg[b, t], full[b, t], keep[b] = self._next_item(b)   # keep: the flag of the window's last frame
+                item = self._next_item(b)
+                image[b, t], seg[b, t], full[b, t], keep[b] = item[:4]      # keep: the flag of the window's last frame
+                if self.return_dist:
+                    dist[b, t] = item[4]
         axis = 2 if self.data_format[1] == 'C' else 4
+        if self.return_dist:      # (image, seg, full_seg, is_last, dist [B, T, 2, H, W]) as DataHandeling.py:490-491
+            return np.expand_dims(image, axis), np.expand_dims(seg, axis), full, keep, dist
         return np.expand_dims(image, axis), np.expand_dims(seg, axis), full, keep
 
 

@@ -187,3 +187,41 @@ def test_augmentation_helpers_match_the_reference_goldens():
         assert calls[0].tolist() == [shape[1], shape[0], 4, 0, 1] and calls[1].tolist() == [shape[1], shape[0], 0, -1, 0]
     assert np.array_equal(D.adjust_contrast(g['pc_in'], float(g['pc_factor'])), g['pc_contrast'])
     assert np.array_equal(D.adjust_brightness(D.adjust_contrast(g['pc_in'], float(g['pc_factor'])), float(g['pc_delta'])), g['pc_both'])
+
+
+def test_return_dist_distance_map_targets(tmp_path):
+    """`return_dist=True` (reference DataHandeling.py:213-236,371-377,479-491): a fifth batch element [B, T, 2, H, W] with each
+    pixel's distance to the nearest / second-nearest cell edge.  `_gt2dist_` against a brute-force restatement (8-connected
+    cells of gt == 1, edge = cell pixels with a non-cell 8-neighbour inside the image, plain Euclidean distances)."""
+    rng = np.random.default_rng(5)
+    gt = np.zeros((14, 17), np.float32)
+    gt[1:5, 1:6] = 1
+    gt[7:13, 9:16] = 1
+    gt[8, 10] = 2          # an edge-class pixel inside: a hole of the cell mask
+    gt[0, 12:15] = 1       # touches the image border: the border itself erodes nothing
+    gt[5, 6] = 1           # joined to the first cell through a corner (8-connectivity)
+    gt[rng.integers(0, 14, 5), rng.integers(0, 17, 5)] = -1
+    out, (d1, d2) = D.CTCRAMReaderSequence2D._gt2dist_(gt)
+    fg = gt == 1
+    lab, n = D.ndimage.label(fg, structure=np.ones((3, 3)))
+    assert n == 3 and out.shape == (2, 14, 17) and np.array_equal(out[0], d1) and np.array_equal(out[1], d2)
+    H, W = gt.shape
+    per_label = []
+    for k in range(1, n + 1):
+        edge = [(y, x) for y in range(H) for x in range(W) if lab[y, x] == k and any(
+            0 <= y + dy < H and 0 <= x + dx < W and lab[y + dy, x + dx] != k for dy in (-1, 0, 1) for dx in (-1, 0, 1))]
+        ey, ex = np.array(edge).T
+        yy, xx = np.mgrid[0:H, 0:W]
+        per_label.append(np.sqrt((yy[..., None] - ey) ** 2 + (xx[..., None] - ex) ** 2).min(-1))
+    two = np.sort(np.stack(per_label + [np.full((H, W), H + W + 2.), np.full((H, W), H + W + 3.)], 0), 0)[:2]
+    assert np.allclose(out, two, atol=1e-9)
+    # ... through the reader: shapes, zeros on frames whose label file could not be read, the map of the frame's own class map
+    root = str(tmp_path)
+    _make_ctc(root)
+    r = _reader(root, return_dist=True, randomize=False, elastic_augmentation=False)
+    img, seg, full, keep, dist = r.get_batch()
+    assert dist.shape == (2, 3, 2, 32, 32) and dist.dtype == np.float32 and img.shape == (2, 3, 1, 32, 32)
+    for b in range(2):
+        for t in range(3):
+            assert np.allclose(dist[b, t], D.CTCRAMReaderSequence2D._gt2dist_(seg[b, t, 0])[0], atol=1e-5)
+    assert len(_reader(root).get_batch()) == 4
