@@ -987,6 +987,10 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             b1 = b2;
             b2 = t;
         }
+        // The gate epilogue turns fragments round in the halo image.  A wave that gets there has passed the last mid-stage barrier,
+        // i.e. every wave has ISSUED its last reads of the image -- in practice thousands of cycles before the first exchange store;
+        // formally they have only completed once their owners have waited for them: one more barrier per tile.
+        if (EPI == LU_EPI_LSTM) __syncthreads();
     }
 
     // ---- epilogue: wave = patch row, accumulator row = x ----
