@@ -498,7 +498,10 @@ def test_wgrad_kernel_row_32_pixel_stages(be):
     per MFMA -- the library's own choice since round 4, LU_WGRAD_F_KP16 restores 16-pixel stages).  The MFMA k order over the
     pixels is unchanged, so dw is bit-identical to the 16-pixel instance; the bias sums fold two rows into one slot
     (summation order only)."""
-    for (fr, H, W, Cc, N, sp) in [(2, 5, 32, 72, 136, 3), (1, 4, 64, 64, 128, 2), (1, 3, 96, 132, 72, 1), (3, 2, 32, 64, 520, 4)]:
+    cases = [(2, 5, 32, 72, 136, 3), (1, 4, 64, 64, 128, 2), (1, 3, 96, 132, 72, 1), (3, 2, 32, 64, 520, 4)]
+    if be.name == 'emu':          # (the host emulator runs a subset: the CPU suite has to stay within minutes)
+        cases = cases[:1] + cases[2:3]
+    for (fr, H, W, Cc, N, sp) in cases:
         x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
         _, ref = _torch_conv_grads(x, rnd(5, 5, Cc, N), dy, 1)
         db0 = rnd(N)
