@@ -71,6 +71,19 @@ def test_conv_ksplit_and_many_mtiles(be):
     close(KH.conv2d(be, [xi, xh], [wi, wh], None, 5, 1, splits=4), ref, 5e-5)
 
 
+def test_conv_halo_ksplit_ranges_start_anywhere_in_a_chunk(be):
+    """conv_halo_kernel (N > 64) with a K split: the stage range of a slice may begin on ANY tap of a chunk -- in particular on the
+    last one (the next halo image is then requested in the prologue) and on the last but one (requested in the first stage) --
+    and may cross from the first source into the second; the weight tiles travel by LDS-DMA two stages ahead of their stage."""
+    for k, splits in ((5, (2, 3, 6, 7)), (3, (2, 4, 5, 7))):
+        xa, xb = rnd(2, 9, 35, 16), rnd(2, 9, 35, 32)            # 9 x 35: ragged patches (8 x 32 tiles hang over)
+        wa, wb, b = rnd(k, k, 16, 128, scale=0.1), rnd(k, k, 32, 128, scale=0.1), rnd(128)
+        ref = npo.conv2d_same(xa, wa, b, 1) + npo.conv2d_same(xb, wb, None, 1)
+        for sp in splits:                                          # 5x5: 75 stages -> slices of 38 / 25 / 13 / 11; 3x3: 27 -> 14 / 7 / 6 / 4
+            close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp), ref, 5e-5)
+        close(KH.conv2d(be, [xb], [wb], None, k, 1, splits=7 if k == 5 else 3), npo.conv2d_same(xb, wb, None, 1), 5e-5)
+
+
 def test_conv_block_numbering_variants_are_bitwise_equal(be):
     """Few-tile launches number their blocks in equal runs of (tile, split) work items per XCD (weights-major or
     activations-major order, lu_block_tile); LU_CONV_F_NO_BALANCE keeps the m-tile-per-XCD numbering.  The numbering moves
