@@ -154,6 +154,17 @@ __device__ __forceinline__ void iter_advance(IterState& st, const ConvArgs& a) {
 
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 
+// compile-time loop: fn(std::integral_constant<int, 0>{}), ..., fn(std::integral_constant<int, N - 1>{})
+template <class Fn, int... T>
+__device__ __forceinline__ void lu_static_for_impl(Fn&& fn, std::integer_sequence<int, T...>) {
+    (fn(std::integral_constant<int, T>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void lu_static_for(Fn&& fn) {
+    lu_static_for_impl(fn, std::make_integer_sequence<int, N>{});
+}
+
+
 // Epilogue for ONE accumulator row (pixel `pix` of frame `f`, linear row index m) of a lane: v[nf] are the lane's
 // values in the NF column fragments (column = 32*nf + (lane & 31)).
 template <int NF, int EPI>
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
 // weight tile is fetched.  Activation traffic per block drops ~15x (k = 5) versus the per-tap gather above, which
 // an ablation showed costs ~10 % of the MFMA rate.  Same MFMA/LDS fragment scheme, same epilogues.
 // ---------------------------------------------------------------------------------------------------------
-template <int K, int EPI>
+template <int K, int EPI, bool ST = false>      // ST: the taps of a chunk as a compile-time sequence (launches without a K split)
 __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
     constexpr int NF = 4, BN = 128, NT = 512, TH = 8, TW = 32;
@@ -732,6 +743,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     // selects between the two sources' fields: ~60 scalar + ~20 vector instructions per wave) was what "the loads" cost the loop:
     // 5x5 input gradients 0.853 -> 0.877 of peak with nothing else changed.
     int d_s = 0, d_chunk = 0, d_tap = 0;      // (source, chunk, tap) of the NEXT tile to request
+    int64_t d_wts = 0;                          // ... elements between two taps of its source
     const float* wq = nullptr;                 // ... its 16 bytes for this thread
     bool wok = false;                          // ... inside the kernel (row c < C, column < N)
     const bool colok = (EPI == LU_EPI_LSTM) || bcol < a.N;
@@ -742,6 +754,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         const int c = chunk * CK + brow;
         wq = (src ? w_s1 : w_s0) + (int64_t)tap * (src ? wts_s1 : wts_s0) + (int64_t)c * (src ? wrs_s1 : wrs_s0) + bcol;
         wok = c < (src ? C_s1 : C_s0) && colok;
+        d_wts = src ? wts_s1 : wts_s0;
     };
     auto dma_next = [&](float* Bd) {           // request the tile, step to the one after it
         lu_glds16(wok ? wq : zp, Bd + wave * 256);
@@ -752,6 +765,17 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         } else {
             dma_seek(d_s + 1, 0, 0);           // (past the last source: never requested -- the callers count stages)
         }
+    };
+    // mode 0: dma_next (run-time tap counter); 1: the next tile is the next tap of the same chunk; 2: ... tap 0 of the next chunk
+    auto dma_issue = [&](float* Bd, int mode) {
+        if (mode == 0) {
+            dma_next(Bd);
+            return;
+        }
+        lu_glds16(wok ? wq : zp, Bd + wave * 256);
+        if (mode == 1) wq += d_wts;
+        else if (d_chunk + 1 < (d_s ? nch_s1 : nch_s0)) dma_seek(d_s, d_chunk + 1, 0);
+        else dma_seek(d_s + 1, 0, 0);
     };
     auto store_b = [&](int buf) { *reinterpret_cast<float4*>(&Bs[buf][brow * BN + 4 * bq]) = rb; };      // (thin-source prologue)
 
@@ -920,7 +944,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         // with nothing to wait for: no LDS round trip behind the barrier, none at the stage boundary (groups 5 and 7 request the
         // next stage's first operands).  Last tap of a chunk: two barriers at the end as before (halo exchange).
         auto stage = [&](float* __restrict__ Bd, const float* __restrict__ Br, const float* __restrict__ Bn, int arow, int arow_n,
-                         bool dma, bool halo_ld, bool halo_st, bool more) {
+                         bool dma, int dmode, bool halo_ld, bool halo_st, bool more) {
             fb[1] = rd_b(Br, 1);
             fa1 = rd_a(arow, 1);
             mma4(fa0.x, fb[0]);
@@ -939,7 +963,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             }
             if (!halo_st) {
                 stage_sync(halo_ld ? 1 : 0, false);
-                if (dma) dma_next(Bd);
+                if (dma) dma_issue(Bd, dmode);
             }
             LU_SCHED_FENCE();
 #pragma unroll
@@ -957,7 +981,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
                 __builtin_amdgcn_s_barrier();      // every wave is done with the old halo (its reads were waited for by its MFMAs)
 #endif
                 store_halo();                      // (the compiler's wait for the staged halo is vmcnt(0): the transfer goes behind it)
-                if (dma) dma_next(Bd);
+                if (dma) dma_issue(Bd, dmode);
                 stage_sync(dma ? 1 : 0, true);
                 if (more) {
                     fa0 = rd_a(arow_n, 0);
@@ -969,12 +993,48 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
         const int arow0 = wave * HWD + (lane & 31);
         fa0 = rd_a(arow0 + aoff, 0);
         fb[0] = rd_b(&Bs[0][0], 0);
+        if constexpr (ST) {
+            // Launches without a K split (the bulk of a training step) walk whole chunks: the kernel rows 0 .. K - 2 of a chunk in a
+            // run-time loop whose body is the K taps of a row as a compile-time sequence -- no halo exchange can fall into them, the
+            // next tile is always the next tap of the same chunk, the A rows are the row's first halo pixel plus a constant -- and
+            // the last row apart, with the halo request (tap K*K - 2), the halo exchange (K*K - 1) and the step of the tile stream
+            // into the next chunk (behind tap K*K - 3) at fixed places.  The common path has no conditional branch and a third of
+            // the scalar instructions of the counted loop below (rocprofv3 SQ_INSTS_SALU / SQ_INSTS_BRANCH per MFMA: 2.2 / 0.45
+            // there against 0.85 / 0.06 in wgrad_row_kernel, profiles/r04_pmc_sq.json).
+            const int n_chunks = (it1 - it0) / (K * K);
+            auto rotate = [&]() {
+                const int t = b0;
+                b0 = b1;
+                b1 = b2;
+                b2 = t;
+            };
+            for (int ci = 0; ci < n_chunks; ++ci) {
+                const bool has_next = ci + 1 < n_chunks;
+                int rowb = arow0;      // halo pixel under (kernel row, kw = 0) of this wave's patch row
+                for (int kh = 0; kh < K - 1; ++kh) {
+                    lu_static_for<K>([&](auto kc) {
+                        constexpr int kw_ = decltype(kc)::value;
+                        stage(&Bs[b2][0], &Bs[b0][0], &Bs[b1][0], rowb + kw_, kw_ + 1 < K ? rowb + kw_ + 1 : rowb + HWD, true, 1, false,
+                              false, true);
+                        rotate();
+                    });
+                    rowb += HWD;
+                }
+                lu_static_for<K>([&](auto kc) {
+                    constexpr int kw_ = decltype(kc)::value;
+                    stage(&Bs[b2][0], &Bs[b0][0], &Bs[b1][0], rowb + kw_, kw_ + 1 < K ? rowb + kw_ + 1 : arow0, has_next || kw_ + 2 < K,
+                          kw_ == K - 3 ? 2 : 1, kw_ == K - 2 && has_next, kw_ == K - 1 && has_next, has_next || kw_ + 1 < K);
+                    rotate();
+                });
+                next_chunk(c_s, c_chunk);
+            }
+        } else {
         for (int it = it0; it < it1; ++it) {
             const bool dma = it + 2 < it1, last_tap = tap == K * K - 1;
             int aoff_n = aoff + 1;
             if (kw + 1 == K) aoff_n += HWD - K;
             if (last_tap) aoff_n = 0;
-            stage(&Bs[b2][0], &Bs[b0][0], &Bs[b1][0], arow0 + aoff, arow0 + aoff_n, dma, dma && tap == K * K - 2,
+            stage(&Bs[b2][0], &Bs[b0][0], &Bs[b1][0], arow0 + aoff, arow0 + aoff_n, dma, 0, dma && tap == K * K - 2,
                   it + 1 < it1 && last_tap, it + 1 < it1);
             aoff = aoff_n;
             if (++kw == K) kw = 0;
@@ -986,6 +1046,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
             b0 = b1;
             b1 = b2;
             b2 = t;
+        }
         }
         // The gate epilogue turns fragments round in the halo image.  A wave that gets there has passed the last mid-stage barrier,
         // i.e. every wave has ISSUED its last reads of the image -- in practice thousands of cycles before the first exchange store;
@@ -1626,15 +1687,6 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
 // (source pointer, weight base) is run-time state, updated once per K*K stages.  The weight-fragment ring is K deep so
 // that slot = tap % K stays static across chunks (K*K % K == 0).
 // ---------------------------------------------------------------------------------------------------------
-template <class Fn, int... T>
-__device__ __forceinline__ void lu_static_for_impl(Fn&& fn, std::integer_sequence<int, T...>) {
-    (fn(std::integral_constant<int, T>{}), ...);
-}
-template <int N, class Fn>
-__device__ __forceinline__ void lu_static_for(Fn&& fn) {
-    lu_static_for_impl(fn, std::make_integer_sequence<int, N>{});
-}
-
 struct ChunkDesc {
     const unsigned char* x;      // source activations of this block's frame (byte pointer)
     const unsigned char* w;      // this lane's fragment bytes of (tap 0, chunk)
@@ -2692,8 +2744,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         else if (d->precision == 2 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, true, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->precision == 2 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, true, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (d->precision == 2) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, true, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
-        else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM>), grid, dim3(512), stream, a);
-        else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM>), grid, dim3(512), stream, a);
+        else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM, true>), grid, dim3(512), stream, a);      // (the gate epilogue takes no K split)
+        else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM, true>), grid, dim3(512), stream, a);
         else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
         else if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, false>), grid, dim3(512), stream, a);
         else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 2, false>), grid, block, stream, a);
@@ -2790,7 +2842,9 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     const bool gen = d->dil != 1 || (d->flags & LU_CONV_F_GENERAL) != 0;   // A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
+        if (halo && NF_ == 4 && d->k == 5 && a.ksplit <= 1) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS, true>), grid, dim3(512), stream, a); \
+        else if (halo && NF_ == 4 && a.ksplit <= 1) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS, true>), grid, dim3(512), stream, a);   \
+        else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \
         else if (NF_ == 4 && BV_ && mf1 && dma)                                                                 \
