@@ -520,8 +520,8 @@ def main():
                 return r'wgrad_row_bf16_kernel<%s, ' % m.group(2)
             if name.startswith('wgrad_row_kernel<') and m:           # rocprof: wgrad_row_kernel<5> (older tables) or <5, false>
                 return r'wgrad_row_kernel<%s[,>]' % m.group(2)
-            if m and m.group(3):                                     # conv_halo_kernel<5,LU_EPI_LSTM> -> <5, 1>
-                return re.escape('%s<%s, %d>' % (m.group(1), m.group(2), 1 if m.group(3) == 'LSTM' else 0))
+            if m and m.group(3):                                     # conv_halo_kernel<5,LU_EPI_LSTM> -> <5, 1> (older tables), <5, 1, true / false>
+                return re.escape('%s<%s, %d' % (m.group(1), m.group(2), 1 if m.group(3) == 'LSTM' else 0)) + '[,>]'
             return re.escape(name) + (r'[<(]' if '<' not in name else '')
 
         def traffic_of(kind):
