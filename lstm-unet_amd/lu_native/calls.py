@@ -33,6 +33,7 @@ def conv_src(x, frame_stride, pix_stride, Cin, w, w_tap_stride, w_row_stride, dt
 
 
 SPLIT_CAP, SPLIT_MIN_IT = 32, 12      # most K splits / fewest k-steps per block conv_splits considers
+FORCE_SPLITS = None   # A/B tools (tools/step_sweep.py): an integer forces that K split on every launch the plan would consider
 IT_US = 1.89     # one k-step (16 channels of one tap) of a 256 x 128 fp32 tile, per block of a resident PAIR, microseconds
                  # (measured: 2048-block fused step, 620 k-steps, 9.39 ms = 8 block-times; a lone block needs 2.28)
 
@@ -57,50 +58,81 @@ def conv_tiles(frames, Hout, Wout, N, k, halo=True):
     return -(-(frames * Hout * Wout) // 256) * -(-N // 128)
 
 
-def conv_cost_us(frames, Hout, Wout, N, k, channels, splits, halo=True):
+def _knobs():
+    """The tunables the launch plans depend on, as a cache key: tools (tools/step_sweep.py) and tests change the module
+    globals between runs, and a memoised plan must not outlive the knobs it was made with."""
+    return (SPLIT_CAP, SPLIT_MIN_IT, IT_US, FORCE_SPLITS)
+
+
+def clear_plan_cache():
+    """For code that monkey-patches conv_splits / conv_cost_us themselves (the knob values are part of the cache key already)."""
+    _conv_splits.cache_clear()
+    _conv_plan.cache_clear()
+    _fused_step_cost_us.cache_clear()
+
+
+def conv_cost_us(frames, Hout, Wout, N, k, channels, splits, halo=True, it_us=None):
     """Modelled duration of the fp32 conv kernels with a K split (+ the slab reduce), microseconds."""
     M = frames * Hout * Wout
     n_it = k * k * -(-channels // 16)
-    t = launch_rounds(conv_tiles(frames, Hout, Wout, N, k, halo) * splits) * (n_it / float(splits) + 12) * IT_US
+    t = launch_rounds(conv_tiles(frames, Hout, Wout, N, k, halo) * splits) * (n_it / float(splits) + 12) * (IT_US if it_us is None else it_us)
     if splits > 1:
         t += (2 * splits + 1) * M * N * 4 / 4e6 + 5        # slabs written + read, result written, at ~4 TB/s
     return t
 
 
-@functools.lru_cache(maxsize=4096)      # pure functions of the launch shape: the streaming frame asks ~200 times per frame
+# The plans are pure functions of the launch shape AND the knobs above; the streaming frame asks ~200 times per frame, so they are
+# memoised -- on a key that carries the knob values (the public wrappers read the module globals at call time).
+@functools.lru_cache(maxsize=4096)
+def _conv_splits(frames, Hout, Wout, N, k, channels, halo, knobs):
+    cap, min_it, it_us, force = knobs
+    n_it = k * k * -(-channels // 16)
+    if force is not None:
+        return max(1, min(int(force), n_it))
+    if conv_tiles(frames, Hout, Wout, N, k, halo) > 2048 or n_it < 64:
+        return 1
+    cands = [s for s in range(1, cap + 1) if n_it // s >= min_it] or [1]
+    return min(cands, key=lambda s: (conv_cost_us(frames, Hout, Wout, N, k, channels, s, halo, it_us), s))
+
+
 def conv_splits(frames, Hout, Wout, N, k, channels, halo=True):
     """K-axis split for launches with too few 256x128 output tiles to fill 256 CUs: the split count with the smallest
     modelled duration (whole rounds of resident blocks matter more than the count itself: 152 tiles x 3 = 456 blocks is one
     round, x 4 = 608 is two)."""
-    n_it = k * k * -(-channels // 16)
-    if conv_tiles(frames, Hout, Wout, N, k, halo) > 2048 or n_it < 64:
-        return 1
-    cands = [s for s in range(1, SPLIT_CAP + 1) if n_it // s >= SPLIT_MIN_IT] or [1]
-    return min(cands, key=lambda s: (conv_cost_us(frames, Hout, Wout, N, k, channels, s, halo), s))
+    return _conv_splits(frames, Hout, Wout, N, k, channels, bool(halo), _knobs())
 
 
-@functools.lru_cache(maxsize=4096)      # pure functions of the launch shape: the streaming frame asks ~200 times per frame
-def conv_plan(frames, Hout, Wout, N, k, channels, halo_ok=True):
-    """(splits, use_halo, modelled microseconds) of an fp32 LU_EPI_BIAS launch.  Where the halo kernel applies, its 8 x 32
-    patches may hang over the image (136-pixel rows: 15 %); the general kernel tiles flattened pixel rows without waste
-    and wins such launches when they are K-split anyway (B = 1 L1 step: 3.20 -> 2.93 ms measured).  The halo kernel is the
-    faster one per k-step (134 vs 128 TFLOP/s in training), hence the 5 % margin."""
-    s_g = conv_splits(frames, Hout, Wout, N, k, channels, False)
-    c_g = conv_cost_us(frames, Hout, Wout, N, k, channels, s_g, False)
+@functools.lru_cache(maxsize=4096)
+def _conv_plan(frames, Hout, Wout, N, k, channels, halo_ok, knobs):
+    it_us = knobs[2]
+    s_g = _conv_splits(frames, Hout, Wout, N, k, channels, False, knobs)
+    c_g = conv_cost_us(frames, Hout, Wout, N, k, channels, s_g, False, it_us)
     if not halo_ok or conv_tiles(frames, Hout, Wout, N, k, True) == conv_tiles(frames, Hout, Wout, N, k, False):
         return s_g, halo_ok, c_g
-    s_h = conv_splits(frames, Hout, Wout, N, k, channels, True)
-    c_h = conv_cost_us(frames, Hout, Wout, N, k, channels, s_h, True)
+    s_h = _conv_splits(frames, Hout, Wout, N, k, channels, True, knobs)
+    c_h = conv_cost_us(frames, Hout, Wout, N, k, channels, s_h, True, it_us)
     if c_g < 0.95 * c_h:
         return s_g, False, c_g
     return s_h, True, c_h
 
 
-@functools.lru_cache(maxsize=4096)      # pure functions of the launch shape: the streaming frame asks ~200 times per frame
+def conv_plan(frames, Hout, Wout, N, k, channels, halo_ok=True):
+    """(splits, use_halo, modelled microseconds) of an fp32 LU_EPI_BIAS launch.  Where the halo kernel applies, its 8 x 32
+    patches may hang over the image (136-pixel rows: 15 %); the general kernel tiles flattened pixel rows without waste
+    and wins such launches when they are K-split anyway (B = 1 L1 step: 3.20 -> 2.93 ms measured).  The halo kernel is the
+    faster one per k-step (134 vs 128 TFLOP/s in training), hence the 5 % margin."""
+    return _conv_plan(frames, Hout, Wout, N, k, channels, bool(halo_ok), _knobs())
+
+
+@functools.lru_cache(maxsize=4096)
+def _fused_step_cost_us(frames, H, W, F, k, channels, knobs):
+    blocks = conv_tiles(frames, H, W, 4 * F, k)
+    return launch_rounds(blocks) * (k * k * -(-channels // 16) + 20) * knobs[2]
+
+
 def fused_step_cost_us(frames, H, W, F, k, channels):
     """Modelled duration of the fused fp32 ConvLSTM step (8 x 32-pixel patches x 32 hidden channels x 4 gates per block)."""
-    blocks = conv_tiles(frames, H, W, 4 * F, k)
-    return launch_rounds(blocks) * (k * k * -(-channels // 16) + 20) * IT_US
+    return _fused_step_cost_us(frames, H, W, F, k, channels, _knobs())
 
 
 def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_t, pad_l, N, bias, out,

@@ -723,7 +723,7 @@ class Engine:
         resizes) and fill the tails of the dgrad launches.  Same kernels on the same data: results are unchanged.
         `tensors`: main-stream tensors the side-stream launches read.  They are HELD (a reference each) until an event
         recorded behind those launches has completed -- tensor.record_stream() would do the same inside the caching
-        allocator, but its deferred frees made config-4 (832x992, 194 GB resident) 50 % slower: measured, tools/c4_try.py."""
+        allocator, but its deferred frees made config-4 (832x992, 194 GB resident) 50 % slower: measured in round 2 (profiles/HISTORY.md)."""
         dev = self.flat_params.device
         if not self.overlap_wgrad or dev.type != 'cuda' or ops.EVENT_LOG is not None:
             return contextlib.nullcontext()

@@ -54,12 +54,12 @@ def main(prec):
                 res.append('%s FAILED %s' % (label, str(e)[:60]))
         s = calls.conv_splits(fr, H, W, 4 * F, 5, cpad + F)
         if name.startswith('inf') and not bf:      # split-count sweep of the K-split route
-            ops.FUSED_MIN_TILES, orig, sw = 10 ** 9, calls.conv_splits, []
+            ops.FUSED_MIN_TILES, sw = 10 ** 9, []
             ops.CONV_FLAGS = 0
             for s2 in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
-                calls.conv_splits = lambda *a, s2=s2: s2
+                calls.FORCE_SPLITS = s2      # (part of the plan cache's key: calls._knobs)
                 sw.append('%d:%.0f' % (s2, timeit(lambda: ops.convlstm_step(x, h, c, wk, wr, b, ho, co, None))))
-            calls.conv_splits = orig
+            calls.FORCE_SPLITS = None
             print('   splits sweep (us):', ' '.join(sw), flush=True)
         print('%s %-7s s=%d model fused %5.0f split %5.0f | %s' % (prec, name, s, calls.fused_step_cost_us(fr, H, W, F, 5, cpad + F),
               calls.conv_cost_us(fr, H, W, 4 * F, 5, cpad + F, s), ' | '.join(res)), flush=True)
