@@ -455,6 +455,7 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     launched0 = dp.launched
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
@@ -464,6 +465,12 @@ def main():
     if dp.world_size > 1:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    ms1 = torch.cuda.memory_stats(dev)
+    # what the caching allocator did INSIDE the timed region: a retry = hipFree of every cached block + hipMalloc again, each a
+    # device synchronisation (config-4 at 192 GB resident is where this matters: round-4 verdict, "find the 0.8 s")
+    allocator = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_alloc_retries', 'num_ooms', 'num_device_alloc', 'num_device_free')}
+    allocator['reserved_gb'] = round(ms1.get('reserved_bytes.all.current', 0) / 2 ** 30, 2)
+    allocator['per'] = '%d timed steps' % args.steps
     dp_info = dp_report(dp, dev_index, trainer.engine, args.steps, dp.launched - launched0, args.sync_bn)
     if dp.world_size > 1:
         # proof of overlap: two more steps with per-bucket time stamps (outside the timed region: the stamps are device events,
@@ -695,6 +702,7 @@ def main():
             'step_tflop_per_gpu': round(total_flops / 1e12, 2),
             'step_tflops_achieved_per_gpu': round(total_flops / 1e12 / (ms_per_step * 1e-3), 2),
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'allocator': allocator,
             'inference': infer,
             'bf16_mode': mixed,
             'variants': variants,
