@@ -52,7 +52,9 @@ class PostPipeline(object):
 
     def __init__(self, edge_dist=2, min_cell_size=10, max_cell_size=100, fov=0, fov_fix=False, graph=False, depth=2):
         self.args = (edge_dist, min_cell_size, max_cell_size, fov, fov_fix)
-        self.depth = int(depth)      # frames in flight behind the forward (>= 2: see the class comment)
+        self.depth = int(depth)      # frames in flight behind the forward (>= 2 for overlap: see the class comment; 1 serialises)
+        if self.depth < 1:
+            raise ValueError('PostPipeline depth must be >= 1 (2 or more for overlap), got %r' % (depth,))
         self.stream = None
         self.pending = []
         self._procs = None

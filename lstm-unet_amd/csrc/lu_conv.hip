@@ -2490,19 +2490,12 @@ __global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __re
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// device address of this translation unit's lu_zero16 (looked up once; null on failure: the kernels then take the symbol itself)
+// device address of this translation unit's lu_zero16 on the current device (looked up once per device; null on failure: the kernels then take the symbol itself)
 const void* conv_zero16_address() {
 #ifdef LU_EMU
     return lu_zero16;
 #else
-    static const void* addr = nullptr;
-    static bool tried = false;
-    if (!tried) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lu_zero16)) == hipSuccess) addr = p;
-        tried = true;
-    }
-    return addr;
+    return LU_SYMBOL_ADDRESS(lu_zero16);      // per device (a process-wide cache handed device 0's address to device 1)
 #endif
 }
 

@@ -29,17 +29,45 @@ static inline void lu_glds16(const float* gptr, float* lds_wave_base) {
 #define LU_WAVE_SYNC() lu_emu::wave_barrier()      // lanes of a wave exchange data through LDS without a block barrier
 #else
 #include <hip/hip_runtime.h>
+#include <atomic>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Per-DEVICE host-side caches (function attributes, device-symbol addresses): one process may drive several devices (a test
+// that selects a second GPU, a multi-device host), and both a kernel's attributes and the address of a __device__ symbol belong
+// to the device they were looked up on.  Slots are indexed by hipGetDevice(); racing first calls compute the same value.
+#define LU_MAX_DEVICES 64
+static inline int lu_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= LU_MAX_DEVICES) return -1;
+    return d;
+}
+// address of a __device__ symbol on the current device, cached per device; null on failure (callers fall back to the symbol)
+#define LU_SYMBOL_ADDRESS(sym)                                                                                       \
+    ([]() -> const void* {                                                                                           \
+        static std::atomic<const void*> lu_addr_[LU_MAX_DEVICES];                                                    \
+        const int lu_d_ = lu_current_device();                                                                       \
+        if (lu_d_ < 0) return nullptr;                                                                               \
+        const void* lu_p_ = lu_addr_[lu_d_].load(std::memory_order_acquire);                                         \
+        if (!lu_p_) {                                                                                                \
+            void* lu_q_ = nullptr;                                                                                   \
+            if (hipGetSymbolAddress(&lu_q_, HIP_SYMBOL(sym)) == hipSuccess && lu_q_) {                               \
+                lu_addr_[lu_d_].store(lu_q_, std::memory_order_release);                                             \
+                lu_p_ = lu_q_;                                                                                       \
+            }                                                                                                        \
+        }                                                                                                            \
+        return lu_p_;                                                                                                \
+    }())
 #define LU_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
 // launch with `lds_bytes` of dynamic LDS (extern __shared__); beyond the 64 KB static limit the kernel has to opt in once
 #define LU_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...)                                                  \
     do {                                                                                                            \
-        static bool lu_dyn_ready_ = false;                                                                          \
-        if (!lu_dyn_ready_) {                                                                                       \
+        static std::atomic<unsigned long long> lu_dyn_ready_{0ull};      /* one bit per device */                    \
+        const int lu_dev_ = lu_current_device();                                                                    \
+        const unsigned long long lu_bit_ = lu_dev_ < 0 ? 0ull : (1ull << lu_dev_);                                  \
+        if (!(lu_dyn_ready_.load(std::memory_order_acquire) & lu_bit_) || !lu_bit_) {                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
-            lu_dyn_ready_ = true;                                                                                   \
+            lu_dyn_ready_.fetch_or(lu_bit_, std::memory_order_release);                                             \
         }                                                                                                           \
         hipLaunchKernelGGL(kernel, (grid), (block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__);               \
     } while (0)

@@ -62,10 +62,15 @@ class WeightedCELoss(object):
 
 def seg_measure(channel_axis, three_d=False, foreground_class_index=1):
     """SEG: mean over ground-truth objects of IoU with the predicted object covering >50 % of it
-    (4-connected components per frame).  Returns callable(gt_sequence, output_sequence) -> float."""
+    (4-connected components per frame).  Returns callable(gt_sequence, output_sequence) -> float.
+    three_d (losses.py:33-36): sequences of VOLUMES [B, T, D, H, W] (+ the channel axis), components 6-connected inside each
+    (b, t) volume -- the 3 x 3 x 3 element the reference stores at strel[1][1].  (The reference embeds it in a 5-D array and hands
+    that to ndimage.label together with the 3-D volumes of its (b, t) loop, which scipy rejects -- "structure and input must
+    have equal rank": its branch cannot run as written and no shipped model is 3-D; this is the evident intent.)"""
     if three_d:
-        raise NotImplementedError('no 3-D network exists in the reference (SURVEY §2)')
-    strel = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        strel = ndimage.generate_binary_structure(3, 1)       # == the reference's strel[1][1]
+    else:
+        strel = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
 
     def components(stack):
         lab = np.zeros(stack.shape, dtype=np.uint16)

@@ -246,6 +246,18 @@ class Engine:
         the halo kernel; oracle/torch_oracle.py restates the same rule)."""
         return self.precision == 'bf16' and (n_out >= 64 or (self.narrow_bf16 and n_out == 32 and stride == 1 and k in (3, 5)))
 
+    def _lstm_route(self, k, F, cin, B, H, W):
+        """(bf, tape16, x_center, src16) of a ConvLSTM layer's step -- THE routing predicate, shared by _lstm_forward and by
+        _down_consumers_bf16 (which decides whether the producer of the layer's input may store it as bf16):
+        bf = the gate convolution runs on bf16 MFMA operands; tape16 = fused bf16 step with the bf16 BPTT tape; x_center = the thin
+        image enters as an im2col chunk with one tap; src16 = both operands of the step are bf16 TENSORS (x is read as bf16 when
+        src16 and not x_center)."""
+        bf = self._bf16_conv(k, 1, 4 * F)
+        tape16 = bf and ops.fused_step_applies(B, H, W, F, True)
+        x_center = tape16 and cin % 4 != 0 and k * k * cin <= 32
+        src16 = tape16 and (x_center or cin % 8 == 0)
+        return bf, tape16, x_center, src16
+
     def _down_consumers_bf16(self, plan, bi, ci, B, H, W):
         """True when every consumer of conv unit `ci` of down block `bi` ([.., H, W, cout]) reads it as a bf16 MFMA operand, i.e. when
         storing it as bf16 changes no value anywhere: the block's next convolution; after the last one the next block's first
@@ -260,8 +272,9 @@ class Engine:
             return self._bf16_unit(nxt['k'], nxt['stride'], nxt['cout'])
         cout = blk['conv'][ci]['cout']
         if bi + 1 < len(down):
-            l = down[bi + 1]['lstm'][0]      # next block's first ConvLSTM: the conditions of _lstm_forward's bf16-tensor route
-            if not (self._bf16_conv(l['k'], 1, 4 * l['f']) and ops.fused_step_applies(B, H, W, l['f'], True) and cout % 8 == 0):
+            l = down[bi + 1]['lstm'][0]      # next block's first ConvLSTM: does its step read its input as a bf16 tensor?
+            _, _, x_center, src16 = self._lstm_route(l['k'], l['f'], cout, B, H, W)
+            if not (src16 and not x_center):
                 return False
             c0 = up[len(down) - 2 - bi]['conv'][0]      # skips = [image, D0, D1, D2] reversed: D_bi feeds up block n - 2 - bi
             return self._bf16_unit(c0['k'], c0['stride'], c0['cout'])
@@ -492,12 +505,13 @@ class Engine:
         dev = x_seq.device
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
-        bf = self._bf16_conv(k, 1, 4 * F)
-        tape16 = bf and ops.fused_step_applies(B, H, W, F, True)
-        x_center = tape16 and Cin % 4 != 0 and k * k * Cin <= 32      # thin image: im2col chunk, one tap
-        src16 = tape16 and (x_center or Cin % 8 == 0)                 # both operands of the step as bf16 tensors
+        bf, tape16, x_center, src16 = self._lstm_route(k, F, Cin, B, H, W)      # (thin image: im2col chunk, one tap)
         if x_seq.dtype == torch.bfloat16 and not (src16 and not x_center):
-            x_seq = ops.to_f32(x_seq)      # (this layer's step reads fp32: the producer stored bf16 for its other consumers)
+            # _down_consumers_bf16 asks the same predicate before a producer stores bf16, so this cannot happen for a down-block
+            # activation; a bf16 tensor from anywhere else would be a silently rounded fp32 operand -- refuse in training
+            if tape is not None:
+                raise RuntimeError('ConvLSTM %s reads fp32 but was handed a bf16 activation (routing predicates drifted)' % pre)
+            x_seq = ops.to_f32(x_seq)
         x5 = x_seq.view(T, B, H, W, -1)
         x16 = None
         if bf:

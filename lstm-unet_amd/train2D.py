@@ -27,6 +27,17 @@ from lu_native.engine import Adam
 from utils import log_print, select_gpu
 
 
+class AgreedFailure(Exception):
+    """A failure every data-parallel rank raises at the same loop position (train(): agree_on_failure).  `handled`: the error
+    that started it is of a type the reference saves and closes on (ValueError from a reader, the spot-instance notice,
+    train2D.py:222-227) -- every rank checkpoints and returns normally; otherwise every rank checkpoints and RE-RAISES, so a
+    launcher sees one outcome for one failure.  The rank that failed carries its own exception as __cause__."""
+
+    def __init__(self, message, handled):
+        super(AgreedFailure, self).__init__(message)
+        self.handled = bool(handled)
+
+
 class AWSError(Exception):
     pass
 
@@ -270,16 +281,23 @@ def train(params):
     in_step_with_peers = False
 
     def agree_on_failure(local_err):
-        """One scalar all-reduce: a rank that fails (data error, spot-instance notice) takes the others with it at the same
-        loop position instead of leaving them in a gradient all-reduce."""
+        """One two-word all-reduce: a rank that fails (data error, spot-instance notice) takes the others with it at the same
+        loop position instead of leaving them in a gradient all-reduce.  The words count the failing ranks by KIND -- an error
+        type the reference handles (save, close, return) or any other (save, re-raise) -- so that all ranks end the same way."""
+        if local_err is None and dp.world_size == 1:
+            return
+        mine_handled = isinstance(local_err, (ValueError, AWSError))
+        n_handled, n_other = (1.0 if (local_err is not None and mine_handled) else 0.0,
+                              1.0 if (local_err is not None and not mine_handled) else 0.0)
         if dp.world_size > 1:
-            flag = torch.tensor([1.0 if local_err is not None else 0.0], device=Nets._device())
+            flag = torch.tensor([n_handled, n_other], device=Nets._device())
             dp.all_reduce_(flag)
-            if float(flag.item()) > 0 and local_err is None:
-                local_err = ValueError('another data-parallel rank reported an error')
-        if local_err is not None:
-            local_err._lu_agreed = True      # every rank raises here, at the same loop position
-            raise local_err
+            n_handled, n_other = (float(v) for v in flag.cpu())
+        if n_handled + n_other == 0:
+            return
+        what = 'this rank: %s: %s' % (type(local_err).__name__, local_err) if local_err is not None else \
+            'another data-parallel rank reported an error'
+        raise AgreedFailure(what, handled=(n_other == 0)) from local_err      # every rank raises here, at the same loop position
 
     try:
         for _ in range(trainer.step, params.num_iterations + 1):
@@ -355,8 +373,8 @@ def train(params):
     except BaseException as err:
         # the reference saves and closes on these three (train2D.py:222-227); a reader failure of any other type that
         # agree_on_failure has spread to all ranks is checkpointed the same way and then re-raised
-        handled = isinstance(err, (KeyboardInterrupt, ValueError, AWSError))
-        agreed = bool(getattr(err, '_lu_agreed', False))
+        agreed = isinstance(err, AgreedFailure)
+        handled = err.handled if agreed else isinstance(err, (KeyboardInterrupt, ValueError, AWSError))
         if not handled and not agreed:
             raise
         # agree_on_failure raised on every rank at once; anything else (SIGINT to one pid, an error inside a step) may be

@@ -127,9 +127,11 @@ with engine_backend('emu'):
     train2D.Trainer = lambda *a, **k: (made.append(real_trainer(*a, **k)), made[-1])[1]
     try:
         train2D.train(params)
-        assert os.environ['LU_TEST_ERR'] == 'ValueError' or rank == 0      # (the peers leave with the agreed ValueError)
-    except RuntimeError as exc:       # not one of the reference's three: checkpointed like them, then re-raised on the failing rank
-        assert os.environ['LU_TEST_ERR'] == 'RuntimeError' and getattr(exc, '_lu_agreed', False), exc
+        assert os.environ['LU_TEST_ERR'] == 'ValueError'      # a type the reference handles: EVERY rank saves and returns
+        print('returned normally', flush=True)
+    except train2D.AgreedFailure as exc:       # not one of the reference's three: checkpointed like them, then re-raised on EVERY rank
+        assert os.environ['LU_TEST_ERR'] == 'RuntimeError' and not exc.handled, exc
+        assert (rank == 1) == isinstance(exc.__cause__, RuntimeError)      # the failing rank carries its own error as the cause
         print('re-raised:', exc, flush=True)
     trainer = made[0]
     n_bn = len(trainer.engine.S)
@@ -163,6 +165,9 @@ def test_dp_loop_failure_on_one_rank_stops_all_ranks_without_hanging(tmp_path, e
     a, b = np.load(tmp_path / 'done_0.npy'), np.load(tmp_path / 'done_1.npy')
     assert a[0] == b[0] == 4 and a[1] == b[1]              # four completed steps on both ranks, same number of collectives
     assert 'another data-parallel rank reported an error' in outs[0] and 'non-finite' in outs[1]
+    # one outcome for one agreed failure: both ranks return, or both ranks re-raise
+    marker = 'returned normally' if err_kind == 'ValueError' else 're-raised:'
+    assert all(marker in o for o in outs), outs
     ck = os.listdir(os.path.join(str(tmp_path), 'LSTMUNet', 't'))
     assert len(ck) == 1                                     # one run directory for the job (rank 0's time stamp)
     run_dir = os.path.join(str(tmp_path), 'LSTMUNet', 't', ck[0])

@@ -158,11 +158,23 @@ def test_train_step_parity(dev):
         e = make_engine(net, p, cin, dev, False)
         opt = Adam(e, lr=1e-3)
         tm = tho.TorchULSTM(net, cin, p, dtype=torch.float64)
+        # calibration (round 5): the torch oracle in fp32 on the same inputs, weights and carried state -- an independent fp32
+        # implementation whose own distance from the fp64 gradients is printed next to the product's
+        t32 = tho.TorchULSTM(net, cin, p, dtype=torch.float32) if name in GRAD_TOL else None
         cwt = torch.tensor(cw, dtype=torch.float32, device=dev)
         for step in range(2):
             x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
             gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
             loss_ref, logits_ref, grads_ref = tm.train_step(x, gt, cw, lr=1e-3)
+            if t32 is not None:
+                _, _, g32 = t32.train_step(x, gt, cw, lr=1e-3, apply=False)
+                fl32 = grad_floor({k: v.numpy() for k, v in grads_ref.items()})
+                w32 = max((rel_err(g32[k].numpy(), grads_ref[k].numpy(), fl32), k) for k in grads_ref)
+                l32 = max((float(np.linalg.norm(g32[k].numpy().astype(np.float64) - grads_ref[k].numpy()) /
+                                 max(np.linalg.norm(grads_ref[k].numpy()), fl32 * (3.0 if '.conv.' in k and k.endswith('.bias') else 1.0))),
+                           k) for k in grads_ref)
+                print('train_step_parity %s step %d: torch-fp32 oracle vs fp64: worst max-rel %.3e (%s), worst L2-rel %.3e (%s)' %
+                      (name, step, w32[0], w32[1], l32[0], l32[1]))
             lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
             g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
             sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
@@ -195,6 +207,10 @@ def test_train_step_parity(dev):
             # keep the two trajectories glued: continue the oracle from the product's weights
             for k in grads_ref:
                 tm.P[k] = torch.tensor(e.P[k].cpu().numpy(), dtype=torch.float64)
+                if t32 is not None:
+                    t32.P[k] = torch.tensor(e.P[k].cpu().numpy(), dtype=torch.float32)
+            if t32 is not None:
+                t32.reset_states_per_batch(keep)
 
 
 def test_head_depth_other_than_three(dev):

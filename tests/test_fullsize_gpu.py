@@ -599,14 +599,20 @@ def test_config4_frame_vs_fp64_oracle(full_engine):
 # fused / K-split ConvLSTM routes forced; (b) the torch oracle ALSO runs in fp32 on the same inputs (an independent fp32
 # implementation: torch-CPU / oneDNN kernels, different summation orders) and its own distance from the fp64 gradients is the
 # yardstick: the loss surface has kinks (hard-sigmoid, LeakyReLU, BatchNorm over few samples), so ANY fp32
-# evaluation lands ~1e-2 of a tensor's maximum away on its worst tensor -- measured at 64x64, T=4, B=2: torch-fp32 1.09e-2
-# (down.1.conv.1.kernel), HIP 1.74e-2 (up.0.bn.0.beta); L2-relative 2.8e-3 / 3.6e-3.  Stated tolerance, fp32:
-#     worst tensor  (max-abs / tensor-max, L2-relative):  HIP <= GRAD_WORST_X  * torch-fp32's worst tensor  (floors 2e-3 / 5e-4)
-#     median tensor (both metrics):                        HIP <= GRAD_MEDIAN_X * torch-fp32's median tensor (floor 2e-4)
+# evaluation lands ~1e-2 of a tensor's maximum away on its worst tensor.  MEASURED on the MI355X box (profiles/r05_grad_tables/,
+# 16 host threads), worst tensor of torch-fp32 | HIP, max-abs / tensor-max and L2-relative:
+#     64x64 T=4 B=2            4.8e-3  3.4e-3 | 1.74e-2 3.6e-3        256x256 T=2 B=1          1.56e-2 2.1e-3 | 1.57e-2 1.8e-3
+#     256x256 T=1 B=4 carried  2.48e-2 3.0e-3 | 2.46e-2 3.7e-3        208x248 T=2 B=1 ragged   1.22e-2 2.9e-3 | 1.73e-2 1.9e-3
+# (the same 64x64 case on 8 host threads: torch-fp32 1.09e-2 -- the flips move with the summation order).  The worst tensor is a
+# different one in the two implementations except where both hit the same flip (the carried case: down.3.conv.0.kernel in both,
+# 2.46e-2 / 2.48e-2); a flip is ONE element spiking, so max-abs is heavy-tailed while L2-relative is not.  Stated tolerance, fp32:
+#     worst tensor, L2-relative:            HIP <= GRAD_L2_X     * torch-fp32's worst tensor of the SAME case
+#     worst tensor, max-abs / tensor-max:   HIP <= GRAD_MAXABS_X * torch-fp32's worst tensor POOLED over all four cases
+#     median tensor (both metrics):         HIP <= GRAD_MEDIAN_X * torch-fp32's median tensor of the same case
 # bf16 mode has no independent implementation to calibrate against: it is compared with the rounded-forward / exact-backward
 # oracle at the mode's own contract (the engine's backward rounds dy and the saved gates to bf16 as well).
-GRAD_WORST_X, GRAD_MEDIAN_X = 4.0, 3.0
-GRAD_FLOORS = {'worst_mr': 2e-3, 'worst_l2': 5e-4, 'median': 2e-4}
+GRAD_L2_X, GRAD_MAXABS_X, GRAD_MEDIAN_X = 2.0, 2.0, 3.0
+GRAD_FLOORS = {'worst_l2': 5e-4, 'median': 2e-4}
 BF16_GRAD_TOL = (0.4, 0.2)      # (max-abs / tensor-max, L2-relative) against the rounding oracle
 
 GRAD_CASES = {
@@ -706,17 +712,32 @@ def _summ(rows):
     return {'worst_mr': mr[-1], 'worst_l2': l2[-1], 'median_mr': mr[len(mr) // 2], 'median_l2': l2[len(l2) // 2]}
 
 
+_POOLED = {}
+
+
+def _pooled_torch_fp32_worst(oracle_farm):
+    """Largest worst-tensor max-abs / tensor-max error of the torch-fp32 oracle over ALL gradient cases of this run."""
+    if 'v' not in _POOLED:
+        worst = 0.0
+        for name in GRAD_CASES:
+            rows, _ = _grad_rows(oracle_farm.result(name + '.f32')['grads'], oracle_farm.result(name + '.f64')['grads'])
+            worst = max(worst, max(r[0] for r in rows))
+        _POOLED['v'] = worst
+    return _POOLED['v']
+
+
 def _check_fp32_case(full_engine, oracle_farm, case, routes=(None,)):
     ref = oracle_farm.result(case + '.f64')
     t32 = oracle_farm.result(case + '.f32')
     rows_t, gmax = _grad_rows(t32['grads'], ref['grads'])
     st = _summ(rows_t)
+    pooled = _pooled_torch_fp32_worst(oracle_farm)
     print('%s: fp64 oracle loss %.7f (%.0f s), torch-fp32 loss %.7f (%.0f s), largest gradient %.3e' %
           (case, ref['loss'], ref['seconds'], t32['loss'], t32['seconds'], gmax))
-    print('   torch-fp32 vs fp64 : worst max-rel %.3e  worst L2-rel %.3e  median %.3e / %.3e' %
-          (st['worst_mr'], st['worst_l2'], st['median_mr'], st['median_l2']))
+    print('   torch-fp32 vs fp64 : worst max-rel %.3e  worst L2-rel %.3e  median %.3e / %.3e   (worst max-rel pooled over the %d cases: %.3e)' %
+          (st['worst_mr'], st['worst_l2'], st['median_mr'], st['median_l2'], len(GRAD_CASES), pooled))
     table = {'case': case, 'spec': {k: v for k, v in GRAD_CASES[case].items() if k != 'arith'}, 'loss_fp64': ref['loss'],
-             'loss_torch_fp32': t32['loss'], 'torch_fp32': st, 'routes': {},
+             'loss_torch_fp32': t32['loss'], 'torch_fp32': st, 'torch_fp32_pooled_worst_max_rel': pooled, 'routes': {},
              'rows_torch_fp32': {k: (mr, l2) for mr, l2, k, _ in rows_t}}
     fails = []
     for route in routes:
@@ -733,8 +754,8 @@ def _check_fp32_case(full_engine, oracle_farm, case, routes=(None,)):
         table['routes'][tag] = {'loss': loss, 'summary': sh, 'rows': {k: (mr, l2, gm) for mr, l2, k, gm in rows}}
         if abs(loss - ref['loss']) > 1e-4 * max(1.0, abs(ref['loss'])):
             fails.append('%s: loss %.7f vs %.7f' % (tag, loss, ref['loss']))
-        lim = {'worst_mr': max(GRAD_WORST_X * st['worst_mr'], GRAD_FLOORS['worst_mr']),
-               'worst_l2': max(GRAD_WORST_X * st['worst_l2'], GRAD_FLOORS['worst_l2']),
+        lim = {'worst_mr': GRAD_MAXABS_X * pooled,
+               'worst_l2': max(GRAD_L2_X * st['worst_l2'], GRAD_FLOORS['worst_l2']),
                'median_mr': max(GRAD_MEDIAN_X * st['median_mr'], GRAD_FLOORS['median']),
                'median_l2': max(GRAD_MEDIAN_X * st['median_l2'], GRAD_FLOORS['median'])}
         for key in lim:

@@ -121,6 +121,61 @@ def test_seg_measure_goldens(golden_dir):
                0.59999996) < 1e-6
 
 
+def test_seg_measure_three_d_volumes():
+    """losses.py:33-36: volumes [B, T, D, H, W], 6-connected components per (b, t) volume.  Two cells that touch only through the
+    depth axis are ONE object; a depth-stacked prediction equal to the ground truth scores 1; a 2-D frame handled as a one-slice
+    volume gives the 2-D metric."""
+    import losses
+    calc3 = losses.seg_measure(channel_axis=5, three_d=True)
+    gt = np.zeros((1, 1, 3, 8, 8, 1), np.float32)
+    gt[0, 0, 0, 1:4, 1:4, 0] = 1                      # slice 0
+    gt[0, 0, 1, 1:4, 1:4, 0] = 1                      # same cell, next slice: connected through depth
+    gt[0, 0, 2, 5:7, 5:7, 0] = 1                      # a second cell
+    logits = np.zeros(gt.shape[:-1] + (3,), np.float32)
+    logits[..., 1] = gt[..., 0] * 4 - 2
+    assert abs(float(calc3(gt, logits)) - 1.0) < 1e-6
+    half = logits.copy()
+    half[0, 0, 1, ..., 1] = -2                        # the prediction misses slice 1 of the first cell: 9 of 18 voxels, not > 50 %
+    assert abs(float(calc3(gt, half)) - 0.5) < 1e-6   # first cell scores 0, second 1
+    rng = np.random.default_rng(3)
+    g2 = (rng.random((2, 3, 16, 16, 1)) > 0.6).astype(np.float32)
+    l2 = rng.standard_normal((2, 3, 16, 16, 3)).astype(np.float32)
+    a = float(losses.seg_measure(channel_axis=4)(g2, l2))
+    b = float(calc3(g2[:, :, None], l2[:, :, None]))
+    assert abs(a - b) < 1e-6
+
+
+def test_post_pipeline_depth_is_validated():
+    import Inference2D
+    with pytest.raises(ValueError):
+        Inference2D.PostPipeline(depth=0)
+    assert Inference2D.PostPipeline(depth=1).depth == 1
+
+
+def test_launch_plan_cache_follows_its_knobs():
+    """conv_splits / conv_plan / fused_step_cost_us are memoised -- on a key that carries SPLIT_CAP, SPLIT_MIN_IT,
+    IT_US and FORCE_SPLITS, so an A/B tool that changes a knob between runs measures what it thinks it measures."""
+    from lu_native import calls
+    shape = (1, 34, 34, 2048, 5, 768)
+    base = calls.conv_splits(*shape)
+    assert base > 1 and calls.conv_plan(*shape)[0] >= 1
+    old = (calls.SPLIT_CAP, calls.IT_US, calls.FORCE_SPLITS)
+    try:
+        calls.SPLIT_CAP = 2
+        assert calls.conv_splits(*shape) <= 2 and calls.conv_plan(*shape)[0] <= 2
+        calls.SPLIT_CAP = old[0]
+        assert calls.conv_splits(*shape) == base
+        calls.FORCE_SPLITS = 7
+        assert calls.conv_splits(*shape) == 7 and calls.conv_plan(*shape)[0] == 7
+        calls.FORCE_SPLITS = None
+        c0 = calls.fused_step_cost_us(1, 34, 34, 512, 5, 768)
+        calls.IT_US = 2 * old[1]
+        assert abs(calls.fused_step_cost_us(1, 34, 34, 512, 5, 768) - 2 * c0) < 1e-6 * c0
+    finally:
+        calls.SPLIT_CAP, calls.IT_US, calls.FORCE_SPLITS = old
+    assert calls.conv_splits(*shape) == base
+
+
 def test_edge_rule_bbox_and_data_contract(golden_dir):
     import DataHandeling
     import utils
