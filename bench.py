@@ -254,6 +254,83 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
 
 
+def dry_run_plan(args):
+    """`--gpus N --dry-run`: everything a multi-GPU launch depends on, checked and printed WITHOUT touching RCCL or building a model
+    -- visible devices against N and the backend, the launcher environment (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_* when one
+    is set), the dmabuf-IPC switch RCCL needs on this driver, a free rendezvous port, the exact command the self-launch would
+    run, the per-rank plan (device, clip slots, frames per step) and the gradient buckets the engine will hand to the collective
+    layer (ranges of the flat gradient buffer in backward-completion order, merged by DataParallel.bucket_ready exactly as in a
+    step).  ONE JSON line on stdout; exit code 0 when a real launch would start, 2 (and `problems`) when it would be refused."""
+    import socket
+    import Params
+    from lu_native.dp import DataParallel
+    from lu_native.plan import make_plan, param_specs
+    n = args.gpus
+    backend = os.environ.get('LU_DP_BACKEND') or 'nccl'
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    problems = []
+    if n_dev < 1:
+        problems.append('no GPU visible: the training path has no CPU fallback')
+    elif backend == 'nccl' and n_dev < n:
+        problems.append('--gpus %d on RCCL needs one device per rank, %d visible (LU_DP_BACKEND=gloo shares devices: control flow only)' % (n, n_dev))
+    env = {k: os.environ.get(k) for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LU_DP_BACKEND',
+                                          'HSA_ENABLE_IPC_MODE_LEGACY', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'NCCL_DEBUG')}
+    if env['WORLD_SIZE'] is not None and int(env['WORLD_SIZE']) != n:
+        problems.append('--gpus %d but the launcher environment says WORLD_SIZE=%s' % (n, env['WORLD_SIZE']))
+    if env['WORLD_SIZE'] is not None and n > 1:
+        for k in ('RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            if env[k] is None:
+                problems.append('launcher environment lacks %s' % k)
+    if env['HSA_ENABLE_IPC_MODE_LEGACY'] not in (None, '0') and backend == 'nccl' and n > 1:
+        problems.append('HSA_ENABLE_IPC_MODE_LEGACY=%s: this host driver only supports dmabuf IPC; RCCL fails with '
+                        'hipIpcGetMemHandle: invalid argument unless it is 0 (the self-launch sets 0 when it is unset)' % env['HSA_ENABLE_IPC_MODE_LEGACY'])
+    port = None
+    try:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', int(env['MASTER_PORT']) if (env['WORLD_SIZE'] is not None and env['MASTER_PORT']) else 0))
+            port = sk.getsockname()[1]
+    except OSError as exc:
+        problems.append('rendezvous port on 127.0.0.1 not available: %s' % exc)
+    passthrough = [a for a in sys.argv[1:] if a != '--dry-run']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + passthrough
+    H, W = (args.hw if args.hw else (args.size, args.size))
+    B, T = args.batch, args.unroll
+    ranks = [{'rank': r, 'local_rank': r, 'device': 'cuda:%d' % (r % max(n_dev, 1)), 'global_slots': list(range(r * B, (r + 1) * B)),
+              'frames_per_step': B * T} for r in range(n)]
+    # gradient buckets: the engine's segments (one per block, decoder first) through the collective layer's own merging rule
+    plan = make_plan(net_by_name(args.net), 1)
+    total, members = 0, {}
+    for name, shape, _ in param_specs(plan):
+        cnt = int(np.prod(shape))
+        blk = '.'.join(name.split('.')[:2])
+        lo, hi = members.get(blk, (total, total))
+        members[blk] = (min(lo, total), total + (cnt + 3) // 4 * 4)
+        total += (cnt + 3) // 4 * 4
+    order = ['up.%d' % i for i in reversed(range(len(plan['up'])))] + ['down.%d' % i for i in reversed(range(len(plan['down'])))]
+    launched = []
+    sim = DataParallel.solo()
+    sim.world_size = max(n, 2)      # (the merging rule only runs for N > 1; nothing here issues a collective)
+    sim._launch = lambda s_, e_: launched.append((s_, e_))
+    for blk in order:
+        sim.bucket_ready(*members[blk])
+    if sim._carry is not None:
+        launched.append(sim._carry)
+    line = {'dry_run': True, 'ok': not problems, 'problems': problems, 'n_gpus': n, 'backend': backend, 'visible_devices': n_dev,
+            'device_names': [torch.cuda.get_device_name(i) for i in range(n_dev)], 'environment': env,
+            'rendezvous': {'addr': '127.0.0.1', 'port_probed_free': port}, 'self_launch_command': ' '.join(cmd),
+            'self_launch_sets': {'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')},
+            'config': {'workload': '%dx%d, seq_len=%d, batch=%d per GPU, %s, %s' % (H, W, T, B, NET_WORDS[args.net], args.precision),
+                       'global_batch': n * B, 'scaling': 'weak'},
+            'ranks': ranks, 'parameters': total,
+            'gradient_buckets': [{'start': s_, 'end': e_, 'mbytes': round(4 * (e_ - s_) / 1e6, 1)} for s_, e_ in launched],
+            'collectives_per_step': {'gradient_all_reduce': len(launched), 'loss_sums_all_reduce': 1,
+                                     'sync_bn_all_reduce': (2 * sum(len(b['conv']) for b in plan['down'] + plan['up']) - 2) if args.sync_bn else 0},
+            'next': 'python bench.py --gpus %d --check   (self-check, timing, overlap trace)' % n}
+    print(json.dumps(line), flush=True)
+    sys.exit(0 if not problems else 2)
+
+
 def dp_self_check(dp, dev):
     """`--check` (N > 1): before anything is timed, one data-parallel training step with SyncBN on N ranks x 1 slot must equal the
     single-process step on the N-slot batch -- loss to 1e-5, the all-reduced PRE-ADAM gradients to 2e-6 of the largest gradient
@@ -375,9 +452,14 @@ def main():
                     help='skip the `variants` block (lstm3 / default5 in fp32 and bf16, N = 1, headline net only)')
     ap.add_argument('--lib', default=None, metavar='SO',
                     help='A/B: another build of the kernel library (same ABI), e.g. the previous commit\'s for a same-box comparison')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='validate devices / environment / rendezvous port for --gpus N and print the rank plan and gradient buckets as '
+                         'one JSON line, without touching RCCL or building a model (exit code 2 if a real launch would be refused)')
     args = ap.parse_args()
     if args.gpus < 1:
         _die('--gpus must be >= 1')
+    if args.dry_run:
+        dry_run_plan(args)                   # does not return
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args.gpus)               # does not return
     if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:

@@ -78,8 +78,12 @@ enum {
                                   * bias NOT added, `out` unused; the consumer sums them (lu_lstm_gates_fwd_slabs) */
     LU_CONV_F_NO_NARROW = 4096,  /* precision 1, stride-1 3x3 / 5x5 with N = 32 / 64: take the gather kernel instead of the narrow
                                   * blocks of the halo kernel (A/B runs and tests: the two must agree) */
-    LU_CONV_F_HALF_BLOCK = 8192  /* precision 1 halo kernel, N > 64 (5x5; 3x3 on bf16 sources): 4-wave blocks on 8 x 32 patches, two
+    LU_CONV_F_HALF_BLOCK = 8192, /* precision 1 halo kernel, N > 64 (5x5; 3x3 on bf16 sources): 4-wave blocks on 8 x 32 patches, two
                                   * independent blocks per CU, instead of one 8-wave block on a 16 x 32 patch (bit-identical) */
+    LU_CONV_F_SPLIT_TAPS = 16384 /* precision 0 halo kernel with splits > 1: slices of ceil(k*k*chunks / splits) pipeline stages that may
+                                  * begin on any tap of a chunk (the run-time counted loop of ABI <= v9) instead of whole 16-channel
+                                  * chunks per slice on the compile-time tap sequence (the default since ABI v10 whenever every slice
+                                  * gets a chunk; another summation split: results differ by fp32 re-association) -- A/B, tests */
 };
 
 typedef struct lu_conv_desc {

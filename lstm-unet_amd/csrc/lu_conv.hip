@@ -75,6 +75,8 @@ struct ConvArgs {
                            // loop costs s_getpc + s_load + s_waitcnt lgkmcnt(0), and that wait also drains the LDS reads in flight
     int32_t dbg;           // ablation bits, honoured only in -DLU_ABLATION tool builds: 1 skip prefetch, 2 skip LDS stores, 4 skip barrier
     int32_t ksplit;        // > 1: K (tap x channel-chunk) range split over blockIdx.y, partial tiles -> ws
+    int32_t split_chunks;  // fp32 halo kernel, ksplit > 1: slices are WHOLE 16-channel chunks (k*k stages each) -- the compile-time tap
+                           // sequence then serves K-split launches too (round 5); 0: ceil(n_it / ksplit) stages from any tap on
     float* ws;             // [ksplit][M][N] partial sums (LU_EPI_BIAS only)
     int32_t out_pix_stride;
     const float* bias;
@@ -514,8 +516,9 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     // ---- vector sources: two-stage software pipeline, one (tap, 16-channel chunk) per stage ----
     int it0 = 0, it1 = a.n_it;
     if (a.ksplit > 1) {
-        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
-        it0 = ks * per;
+        // ST (whole chunks per slice, round 5): ceil(chunks / ksplit) chunks of K*K stages each; the counted loop: any stage range
+        const int per = ST ? ((a.n_it / (K * K) + a.ksplit - 1) / a.ksplit) * (K * K) : (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per < a.n_it ? ks * per : a.n_it;
         it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
     }
     if (it1 > it0) {
@@ -873,8 +876,9 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs a) {
     // ---- vector sources ----
     int it0 = 0, it1 = a.n_it;
     if (a.ksplit > 1) {
-        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
-        it0 = ks * per;
+        // ST (whole chunks per slice, round 5): ceil(chunks / ksplit) chunks of K*K stages each; the counted loop: any stage range
+        const int per = ST ? ((a.n_it / (K * K) + a.ksplit - 1) / a.ksplit) * (K * K) : (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per < a.n_it ? ks * per : a.n_it;
         it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
     }
     if (it1 > it0) {
@@ -2490,6 +2494,13 @@ __global__ void s2_dgrad_weights_kernel(const float* __restrict__ w, float* __re
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// non-empty slices when `chunks` chunks are dealt out ceil(chunks / splits) at a time
+int lu_conv_chunk_splits(int chunks, int splits) {
+    if (chunks <= 0 || splits <= 0) return 0;
+    const int per = (chunks + splits - 1) / splits;
+    return (chunks + per - 1) / per;
+}
+
 // device address of this translation unit's lu_zero16 on the current device (looked up once per device; null on failure: the kernels then take the symbol itself)
 const void* conv_zero16_address() {
 #ifdef LU_EMU
@@ -2831,12 +2842,16 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
                   a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride, a.post_scale, a.post_shift, a.post_alpha);
         return LU_CHECK_LAUNCH();
     }
+    // fp32 halo kernel with a K split: whole chunks per slice (the compile-time tap sequence, round 5) whenever every slice gets
+    // at least one chunk; LU_CONV_F_SPLIT_TAPS keeps the counted loop (slices of ceil(n_it / splits) stages from any tap on)
+    a.split_chunks = (halo && nf == 4 && a.ksplit > 1 && !(d->flags & LU_CONV_F_SPLIT_TAPS) &&
+                      lu_conv_chunk_splits(a.n_it / a.kk, a.ksplit) == a.ksplit) ? 1 : 0;
     const dim3 grid = tile_grid();
     const bool gen = d->dil != 1 || (d->flags & LU_CONV_F_GENERAL) != 0;   // A/B knob for tools/kbench.py
 #define LU_CONV_CASE(NF_, BV_)                                                                  \
     if (nf == NF_ && bvec == BV_) {                                                             \
-        if (halo && NF_ == 4 && d->k == 5 && a.ksplit <= 1) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS, true>), grid, dim3(512), stream, a); \
-        else if (halo && NF_ == 4 && a.ksplit <= 1) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS, true>), grid, dim3(512), stream, a);   \
+        if (halo && NF_ == 4 && d->k == 5 && (a.ksplit <= 1 || a.split_chunks)) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS, true>), grid, dim3(512), stream, a); \
+        else if (halo && NF_ == 4 && (a.ksplit <= 1 || a.split_chunks)) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS, true>), grid, dim3(512), stream, a);   \
         else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \

@@ -90,3 +90,39 @@ def test_bench_self_launches_n_ranks(backend):
     # whole-job rate = all ranks' frames over the max-over-ranks time
     assert abs(line['value'] - 2 * 1 * 2 / (line['ms_per_step'] * 1e-3)) <= 0.01 * line['value']
     print('bench --gpus 2 over %s: %s' % (backend, {k: dp[k] for k in dp if k != 'devices'}))
+
+
+def test_bench_dry_run_prints_the_rank_plan_without_a_gpu():
+    """`bench.py --gpus 8 --dry-run`: validates devices / environment / port and prints the exact
+    rank plan and gradient buckets without touching RCCL.  Here (no GPU): exit code 2 with the reason, and still the plan."""
+    rc, line, err = _run_bench(['--gpus', '8', '--dry-run', '--sync-bn'], {})
+    assert line is not None and line['dry_run'] and line['n_gpus'] == 8 and len(line['ranks']) == 8
+    import torch
+    if not torch.cuda.is_available():
+        assert rc == 2 and not line['ok'] and any('no GPU visible' in p for p in line['problems'])
+    assert [r['global_slots'] for r in line['ranks']][:2] == [[0, 1, 2, 3], [4, 5, 6, 7]] and line['config']['global_batch'] == 32
+    assert [b['mbytes'] for b in line['gradient_buckets']] == [189.4, 101.2, 7.8]          # DESIGN §5: three buckets per step
+    assert line['gradient_buckets'][0]['start'] == 0 and line['gradient_buckets'][-1]['end'] == line['parameters'] == 74606532
+    assert line['collectives_per_step'] == {'gradient_all_reduce': 3, 'loss_sums_all_reduce': 1, 'sync_bn_all_reduce': 32}
+    cmd = line['self_launch_command']
+    assert '--nproc-per-node 8' in cmd and '--master-addr 127.0.0.1' in cmd and '--dry-run' not in cmd and '--gpus 8' in cmd
+    assert line['self_launch_sets'] == {'HSA_ENABLE_IPC_MODE_LEGACY': '0'} or os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
+    # a launcher environment that disagrees with --gpus is named as a problem, like the real launch refuses it
+    rc, line, err = _run_bench(['--gpus', '8', '--dry-run'], {'WORLD_SIZE': '4', 'RANK': '0'})
+    assert rc == 2 and any('WORLD_SIZE=4' in p for p in line['problems']) and any('MASTER_PORT' in p for p in line['problems'])
+
+
+@pytest.mark.gpu
+def test_bench_dry_run_on_the_gpu_box():
+    """On a box with fewer than 8 devices the RCCL plan is refused with the reason (exit code 2); the gloo plan (ranks sharing
+    devices: control flow only) is accepted."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    rc, line, err = _run_bench(['--gpus', '8', '--dry-run'], {'LU_DP_BACKEND': 'gloo'})
+    assert rc == 0 and line['ok'] and line['visible_devices'] == n_dev and line['backend'] == 'gloo', (line, err)
+    assert [r['device'] for r in line['ranks']] == ['cuda:%d' % (r % n_dev) for r in range(8)]
+    rc, line, err = _run_bench(['--gpus', '8', '--dry-run'], {'LU_DP_BACKEND': 'nccl'})
+    if n_dev < 8:
+        assert rc == 2 and any('one device per rank' in p for p in line['problems'])
+    else:
+        assert rc == 0 and line['ok']

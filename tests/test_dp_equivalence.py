@@ -94,8 +94,9 @@ import numpy as np, torch
 from conftest import tiny_net
 import train2D, Networks
 from lu_native.dp import DataParallel
-dp = DataParallel()                     # LU_DP_BACKEND=gloo: both ranks on the ONE GPU of the box, HIP kernels underneath
-assert dp.world_size == 2 and torch.cuda.is_available()
+dp = DataParallel(bucket_bytes=int(os.environ.get('LU_TEST_BUCKET_BYTES', 64 << 20)))      # LU_DP_BACKEND=gloo: all ranks on the ONE GPU of the box, HIP kernels underneath
+assert dp.world_size == int(os.environ['WORLD_SIZE']) and torch.cuda.is_available()
+assert list(dp.shard_slots(dp.world_size)) == [dp.rank] and list(dp.shard_slots(2 * dp.world_size)) == [2 * dp.rank, 2 * dp.rank + 1]
 d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
 net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
 tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3,
@@ -110,7 +111,8 @@ _, _, loss2 = tr.train_step(d['x'][sl, ::-1].copy(), d['gt'][sl, ::-1].copy())
 torch.cuda.synchronize()
 if dp.rank == 0:
     np.savez(os.path.join(%(tmp)r, 'dp_gpu_out.npz'), params=tr.engine.flat_params.cpu().numpy(),
-             loss=np.array([float(loss), float(loss2)]), grads1=grads1)
+             loss=np.array([float(loss), float(loss2)]), grads1=grads1, launched=np.array([dp.launched]),
+             ranges=np.array(dp.last_ranges))
 dp.barrier()
 '''
 
@@ -164,6 +166,46 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     # sharp check -- 8.7e-5 of the largest gradient)
     frac = 2e-3 if precision == 'fp32' else 5e-2
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= frac, (diff.max(), (diff > 1e-4).mean())
+
+
+@pytest.mark.gpu
+def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp_path):
+    """EIGHT ranks x 1 slot on the real kernels (gloo, all on the one GPU of the test box): shard_slots
+    with W = 8, SyncBN with 8 contributors, the gradient all-reduce in THREE OR MORE buckets (a small bucket size: the tiny
+    net's 0.1 MB of gradients would otherwise leave as one), loss sums over 8 ranks -- loss and pre-Adam gradients must equal
+    the single-process step on the 8-slot batch.  What an 8-GPU box adds to this is RCCL itself and one device per rank."""
+    import train2D
+    import Networks
+    W = 8
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((W, 3, 1, 24, 32)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(W, 3, 1, 24, 32)).astype(np.float32)
+    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
+    script = tmp_path / 'worker_gpu.py'
+    script.write_text(GPU_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    port = 29600 + (os.getpid() + 333) % 1500
+    procs = [subprocess.Popen([sys.executable, str(script), 'fp32'],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(W), LOCAL_RANK='0', LU_DP_BACKEND='gloo',
+                                       LU_TEST_BUCKET_BYTES='65536', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(W)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+    tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, seed=3)
+    _, _, l1 = tr.train_step(x, gt)
+    ref_grads1 = tr.engine.flat_grads.cpu().numpy()
+    tr.model.reset_states_per_batch(np.ones(W, np.float32))
+    _, _, l2 = tr.train_step(x[:, ::-1].copy(), gt[:, ::-1].copy())
+    got = np.load(tmp_path / 'dp_gpu_out.npz')
+    g_err = np.abs(got['grads1'] - ref_grads1).max() / np.abs(ref_grads1).max()
+    ranges = got['ranges']
+    print('dp8 over gloo on one GPU vs single: loss err %.3e, step-1 gradient err / max|g| %.3e, %d buckets %s' %
+          (np.abs(got['loss'] - np.array([float(l1), float(l2)])).max(), g_err, len(ranges), ranges.tolist()))
+    assert np.abs(got['loss'] - np.array([float(l1), float(l2)])).max() <= 1e-5 and g_err <= 2e-6
+    # buckets: at least three, contiguous, covering the flat gradient buffer front to back (backward-completion order)
+    assert len(ranges) >= 3 and ranges[0][0] == 0 and ranges[-1][1] == tr.engine.n_flat
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1))
 
 
 RCCL_WORKER = r'''

@@ -103,7 +103,8 @@ from conftest import tiny_net
 import Params, train2D
 from lu_native.dp import DataParallel
 rank = int(os.environ['RANK'])
-with engine_backend('emu'):
+world = int(os.environ['WORLD_SIZE'])
+with engine_backend(os.environ.get('LU_TEST_BACKEND', 'emu')):
     Params.CTCParams.net_kernel_params = tiny_net(3)
     params = Params.CTCParams(dict(experiment_name='t', crop_size=(16, 16), batch_size=1, unroll_len=2, num_iterations=8,
                                    validation_interval=100, print_to_console_interval=1, save_checkpoint_iteration=1,
@@ -113,7 +114,7 @@ with engine_backend('emu'):
     real, calls = prov.get_batch, [0]
     def flaky():
         calls[0] += 1
-        if rank == 1 and calls[0] == 5:
+        if rank == world - 1 and calls[0] == 5:
             if os.environ['LU_TEST_ERR'] == 'ValueError':
                 raise ValueError('non-finite values in frame 3 after augmentation')
             raise RuntimeError('non-finite: the reader workers stopped')      # DataHandeling._next_item's type
@@ -131,7 +132,7 @@ with engine_backend('emu'):
         print('returned normally', flush=True)
     except train2D.AgreedFailure as exc:       # not one of the reference's three: checkpointed like them, then re-raised on EVERY rank
         assert os.environ['LU_TEST_ERR'] == 'RuntimeError' and not exc.handled, exc
-        assert (rank == 1) == isinstance(exc.__cause__, RuntimeError)      # the failing rank carries its own error as the cause
+        assert (rank == world - 1) == isinstance(exc.__cause__, RuntimeError)      # the failing rank carries its own error as the cause
         print('re-raised:', exc, flush=True)
     trainer = made[0]
     n_bn = len(trainer.engine.S)
@@ -176,3 +177,34 @@ def test_dp_loop_failure_on_one_rank_stops_all_ranks_without_hanging(tmp_path, e
         mine = [f for f in files if f.endswith('.rank%d.pt' % r)]
         assert len(mine) == 2, files                        # rotated like ckpt-*.pt (max_to_keep = 2)
     assert os.path.exists(os.path.join(run_dir, 'model.ckpt.index'))
+
+
+@pytest.mark.gpu
+def test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files(tmp_path):
+    """EIGHT ranks over gloo on the one GPU of the test box, HIP kernels underneath (make the first
+    8-GPU box boring): the training loop of train2D with 8 contributors -- slot sharding, the per-step failure flag, a reader
+    error on the LAST rank at iteration 5 that every rank must leave the loop with at the same step, the collective error-path
+    checkpoint (BatchNorm statistics averaged over 8 ranks), one run directory, eight rotating per-rank state files."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text(DP_LOOP_WORKER % {'root': root, 'tmp': str(tmp_path)})
+    port = 29700 + (os.getpid() + 77) % 1200
+    W = 8
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(W), LOCAL_RANK='0', LU_DP_BACKEND='gloo',
+                                       LU_TEST_BACKEND='hip', LU_TEST_ERR='ValueError', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(W)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    done = [np.load(tmp_path / ('done_%d.npy' % r)) for r in range(W)]
+    assert all(d[0] == 4 for d in done) and len(set(int(d[1]) for d in done)) == 1      # same step, same number of collectives
+    assert all('returned normally' in o for o in outs)
+    assert all('another data-parallel rank reported an error' in o for o in outs[:-1]) and 'non-finite' in outs[-1]
+    ck = os.listdir(os.path.join(str(tmp_path), 'LSTMUNet', 't'))
+    assert len(ck) == 1
+    files = sorted(os.listdir(os.path.join(str(tmp_path), 'LSTMUNet', 't', ck[0], 'tf_ckpts')))
+    for r in range(W):
+        assert len([f for f in files if f.endswith('.rank%d.pt' % r)]) == 2, files

@@ -6,7 +6,8 @@ as few as 1024 pixels), so its gradient is ill-conditioned: perturbing the WEIGH
 relative 1e-6 / 1e-5 moves its own gradients by up to 8e-3 / 4e-2 of a tensor's max at config-1 size
 (measured with tests/diag/, notes in DESIGN.md §9).  fp32 arithmetic therefore cannot agree with fp64 better than
 that on the big case (and the second step starts from fp32-drifted weights/state); the small cases (few kink
-crossings) are held to 2e-3, config-1 to 2x its measured error (0.055 max-relative / 0.013 L2-relative per tensor), and
+crossings) are held to 2e-3, config-1 to a stated multiple of the torch-fp32 oracle's own error on the same inputs (round 5,
+see GRAD_TOL below: 5x / 3x, floors 5e-3 / 2e-3 -- measured 2.6e-3 / 1.1e-3 against torch-fp32's 1.1e-3 / 7e-4), and
 `test_layerwise_backward_consistency` checks every backward kernel of the big case against an fp64
 evaluation FROM THE SAME DEVICE INPUTS to 1e-6 (no chaos in that comparison).  'hip' = real gfx950 library (`-m gpu`); 'emu' = same
 host code on the host-emulated kernels (CPU, small shapes) to validate tape/backward plumbing.
@@ -84,16 +85,18 @@ GPU_CASES = [
     ('c1', c1_net(), 1, 1, 4, 128, 128, False),
     ('k5-odd', tiny_net(5, (32, 64, 32, 64), (32, 16, 16, 8)), 3, 2, 3, 35, 35, True),
 ]
-# config-1 end-to-end against the fp64 oracle, MEASURED on the MI355X (gpurun_out/r02h_gpu_tests.log): worst max-abs /
-# tensor-max 2.71e-2 (down.2.conv.1.kernel, step 0; 1.2e-3 at step 1), worst L2-relative 6.3e-3 (down.2.lstm.0.recurrent_kernel;
-# 1.2e-3 at step 1).  Tolerances = 2x the measured values; the kink-flip conditioning that puts them above the small-net
-# 2e-3 is quantified in DESIGN.md §9, and every backward kernel of this case is held to 1e-5 from the same device inputs
-# (test_layerwise_backward_consistency, test_lstm_bptt_backward_consistency).
-GRAD_TOL = {'c1': 0.055}     # max-abs / tensor-max
-# Round 3: the BatchNorm column sums changed their (still fixed) summation order; the same comparison then measured 1.36e-2 on a
-# 32-element BatchNorm beta gradient at step 1 (gpurun_out/r03k_tests.log) -- one kink flip at these weights, §9 -- while the
-# per-kernel fp64 re-evaluation from the same device inputs stayed at 1e-9: stated 2e-2.
-GRAD_L2_TOL = {'c1': 0.02}   # ||g - g_ref||_2 / ||g_ref||_2 per tensor
+# config-1 end-to-end against the fp64 oracle.  Rounds 2-3 stated "2x what the HIP path measured" (0.055 / 0.02, from 2.7e-2 / 6.3e-3 on
+# the kernels of that time).  Round 5: the tolerance is a stated multiple of what an INDEPENDENT fp32 implementation -- the torch
+# oracle run in fp32 on the same inputs, weights and carried state, inline in the test -- is away from the same fp64 gradients:
+#     worst tensor, max-abs / tensor-max:  HIP <= C1_MAXABS_X * torch-fp32's worst   (floor 5e-3)
+#     worst tensor, L2-relative:           HIP <= C1_L2_X     * torch-fp32's worst   (floor 2e-3)
+# MEASURED on the MI355X (profiles/r05_c1_three_way.log, tests/diag/diag3_gpu.py): step 0 torch-fp32 1.10e-3 / 7.1e-4, HIP 2.58e-3 /
+# 1.14e-3 (medians 2.3e-4 / 2.1e-4 vs 2.9e-4 / 3.1e-4); step 1 torch-fp32 1.76e-3 / 7.9e-4, HIP 1.10e-3 / 5.4e-4.  The product's
+# forward noise at level 0 is 3x torch's (h: 1.8e-7 vs 6.3e-8 max, the 15-instruction tanh of DESIGN 1.2: 1.5e-7 absolute), 1.2-1.4x
+# below; every backward kernel of this case is held to 1e-5 from the same device inputs (test_layerwise_backward_consistency,
+# test_lstm_bptt_backward_consistency).
+GRAD_TOL = {'c1': None}      # name -> None: calibrated in the test (GPU_CASES with an inline torch-fp32 pass)
+C1_MAXABS_X, C1_L2_X, C1_MAXABS_FLOOR, C1_L2_FLOOR = 5.0, 3.0, 5e-3, 2e-3
 
 
 def _all_cases(request_dev):
@@ -184,13 +187,15 @@ def test_train_step_parity(dev):
             assert abs(loss - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref))), (name, step)
             fl = grad_floor({k: v.numpy() for k, v in grads_ref.items()})
             worst = max((rel_err(e.G[k].cpu().numpy(), grads_ref[k].numpy(), fl), k) for k in grads_ref)
-            assert worst[0] <= GRAD_TOL.get(name, 2e-3), (name, step, worst)
+            tol_max = 2e-3 if t32 is None else max(C1_MAXABS_X * w32[0], C1_MAXABS_FLOOR)
+            tol_l2 = 2e-3 if t32 is None else max(C1_L2_X * l32[0], C1_L2_FLOOR)
+            assert worst[0] <= tol_max, (name, step, worst, tol_max)
             # (a conv bias in front of BatchNorm has an exactly-zero true gradient -- the mean subtraction cancels it -- so the
             # product's value there is pure fp32 rounding noise: its floor is wider)
             l2 = max((float(np.linalg.norm(e.G[k].cpu().numpy().astype(np.float64) - grads_ref[k].numpy()) /
                             max(np.linalg.norm(grads_ref[k].numpy()), fl * (3.0 if '.conv.' in k and k.endswith('.bias') else 1.0))),
                       k) for k in grads_ref)
-            assert l2[0] <= GRAD_L2_TOL.get(name, 2e-3), (name, step, l2)
+            assert l2[0] <= tol_l2, (name, step, l2, tol_l2)
             print('train_step_parity %s step %d: worst max-rel %.3e (%s), worst L2-rel %.3e (%s)' %
                   (name, step, worst[0], worst[1], l2[0], l2[1]))
             opt.apply_gradients()

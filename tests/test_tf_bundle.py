@@ -252,3 +252,40 @@ def test_string_tensor_checksum_uses_uint32_lengths(tmp_path):
         tb.read_scalar_string(prefix + '.old', tb.OBJECT_GRAPH_KEY)
     with pytest.warns(UserWarning, match='object graph unreadable'):
         assert tb.resolve_through_object_graph(prefix + '.old', ['v']) == {}
+
+
+def test_ckpt_probe_tool_reports_found_missing_and_misshaped(tmp_path, capsys):
+    """tools/ckpt_probe.py: the key list of any model.ckpt diffed against the names and shapes
+    tf_bundle expects -- device-free (the static plan), exit code 0 only when every model variable is there."""
+    import os
+    import pickle
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    try:
+        import ckpt_probe
+    finally:
+        sys.path.pop(0)
+    import tf_bundle as tb
+    from conftest import tiny_net
+    net = tiny_net(3)
+    want, _ = ckpt_probe.expected_variables(net, 1)
+    rng = np.random.default_rng(0)
+    tensors = {p + tb.SUFFIX: rng.standard_normal(s).astype(np.float32) for p, s in want.items()}
+    tensors['optimizer/iter' + tb.SUFFIX] = np.array(3, dtype=np.int64)
+    good = str(tmp_path / 'model.ckpt')
+    tb.write_bundle(good, tensors, strings={tb.OBJECT_GRAPH_KEY: tb._object_graph(want.keys())})
+    pk = str(tmp_path / 'model_params.pickle')
+    with open(pk, 'wb') as fh:
+        pickle.dump({'name': 'ULSTMnet2D', 'params': (net,)}, fh)
+    assert ckpt_probe.main([good + '.index', '--params', pk, '--json', str(tmp_path / 'r.json')]) == 0
+    out = capsys.readouterr().out
+    assert 'found %d' % len(want) in out and 'missing 0' in out
+    bad = dict(tensors)
+    keys = sorted(want)
+    del bad[keys[0] + tb.SUFFIX]
+    bad[keys[5] + tb.SUFFIX] = np.zeros((2, 2), np.float32)
+    tb.write_bundle(str(tmp_path / 'bad.ckpt'), bad)
+    assert ckpt_probe.main([str(tmp_path / 'bad.ckpt'), '--params', pk]) == 1
+    out = capsys.readouterr().out
+    assert 'missing: ' + keys[0] in out and 'shape:   ' + keys[5] in out
