@@ -80,6 +80,9 @@ enum {
                                   * blocks of the halo kernel (A/B runs and tests: the two must agree) */
     LU_CONV_F_HALF_BLOCK = 8192, /* precision 1 halo kernel, N > 64 (5x5; 3x3 on bf16 sources): 4-wave blocks on 8 x 32 patches, two
                                   * independent blocks per CU, instead of one 8-wave block on a 16 x 32 patch (bit-identical) */
+    LU_CONV_F_LOOP_GEN2 = 32768, /* bf16 halo kernel: the second loop generation (taps of a chunk kernel row by kernel row, one LDS fragment
+                                  * read per MFMA) where the third (ABI v10: kernel column by kernel column, a halo row's fragment feeds up
+                                  * to k MFMAs; another fp32 summation order, results agree to rounding) would be taken -- A/B, tests */
     LU_CONV_F_SPLIT_TAPS = 16384 /* precision 0 halo kernel with splits > 1: slices of ceil(k*k*chunks / splits) pipeline stages that may
                                   * begin on any tap of a chunk (the run-time counted loop of ABI <= v9) instead of whole 16-channel
                                   * chunks per slice on the compile-time tap sequence (the default since ABI v10 whenever every slice

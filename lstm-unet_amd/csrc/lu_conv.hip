@@ -516,9 +516,8 @@ __global__ __launch_bounds__(64 * (8 / MF), 2 * (2 / MF)) void conv_fwd_kernel(C
     // ---- vector sources: two-stage software pipeline, one (tap, 16-channel chunk) per stage ----
     int it0 = 0, it1 = a.n_it;
     if (a.ksplit > 1) {
-        // ST (whole chunks per slice, round 5): ceil(chunks / ksplit) chunks of K*K stages each; the counted loop: any stage range
-        const int per = ST ? ((a.n_it / (K * K) + a.ksplit - 1) / a.ksplit) * (K * K) : (a.n_it + a.ksplit - 1) / a.ksplit;
-        it0 = ks * per < a.n_it ? ks * per : a.n_it;
+        const int per = (a.n_it + a.ksplit - 1) / a.ksplit;
+        it0 = ks * per;
         it1 = it0 + per < a.n_it ? it0 + per : a.n_it;
     }
     if (it1 > it0) {
@@ -1896,6 +1895,215 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Third loop generation of the bf16 fragment kernel (round 5): same tile, same LDS images, same weight-fragment stream, same
+// epilogue as conv_halo_frag2_kernel -- another ORDER of the K*K taps of a chunk, chosen for the bytes it moves per MFMA.
+// Generations 1-2 walk the taps kernel row by kernel row and read, per tap, one A fragment (ds_read_b128, 1 KB per wave) per
+// patch row and channel half: ONE LDS read per MFMA -- at the bf16 rate that is half of the LDS pipe's 256 B/clk at full MFMA
+// speed, and on these power-limited kernels (1.6-1.9 GHz under load) LDS bytes are watts.  But tap (kh, kw) on
+// patch row i and tap (kh + 1, kw) on patch row i - 1 read the SAME halo pixels: walking a kernel COLUMN kw, halo row j of a
+// wave's RW + K - 1 rows feeds the up-to-K products (row i = j - kh, tap (kh, kw)) from one read:
+//     per (kernel column, channel half):  RW + K - 1 reads for RW * K MFMAs      (K = 5, RW = 8: 12 for 40, 0.3 per MFMA; K = 3: 10 for 24)
+// The fragment of a halo row is live for its own step only (a ring of LA + 1 fragments runs LA steps ahead); the weight ring
+// holds one kernel column (slot = kh, both channel halves; a slot is refilled, one half at a time, right behind its last use --
+// RW + K - 1 + K steps of lead); the next chunk's halo pieces are requested / stored at sub-stage boundaries (a sub-stage = one
+// kernel column x one channel half).  Everything is a compile-time sequence as in generation 2; only the chunk is run-time state.
+// Each accumulator sums its taps column-major instead of row-major: another fp32 summation order -- results agree with
+// generations 1-2 to rounding (tests compare with the oracle and with generation 2 at 5e-5), not bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int EPI, int RW, bool B16, int WM = 2>
+__global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag3_kernel(ConvArgs a) {
+    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
+    constexpr int BN = 128, NT = 256 * WM, TH = WM * RW, TW = 32, KK = K * K;
+    constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
+    constexpr int CKS = CKB;
+    constexpr int PC = B16 ? 8 : 4;
+    constexpr int G = CKS / PC;
+    constexpr int ESZ = B16 ? 2 : 4;
+    constexpr int HPASS = (HP * G + NT - 1) / NT;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int EX_LD = BN + 4;
+    constexpr int PITCH = 80;
+    constexpr int AH_BYTES = HP * PITCH;
+    constexpr int NJ = RW + K - 1;                     // halo rows under a wave's RW patch rows = fragment steps per sub-stage
+    constexpr int NSUB = 2 * K;                        // sub-stages per chunk: (kernel column, channel half)
+    constexpr int NS = NSUB * NJ;                      // fragment steps per chunk
+    constexpr int LA = 3, NR = LA + 1;                 // A-fragment look-ahead (steps) / ring size
+    constexpr int PPS = (HPASS + NSUB - 3) / (NSUB - 2);      // halo pieces requested per sub-stage (stored two sub-stages later)
+    static_assert(PPS * (NSUB - 2) >= HPASS, "every halo piece has a sub-stage to be requested in and one to be stored in");
+    static_assert(WM == 1 || WM == 2, "one or two row groups of waves");
+    static_assert(EPI != LU_EPI_LSTM || WM * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
+    static_assert(4 * WM * 16 * 36 * 4 <= 2 * AH_BYTES, "bias-epilogue exchange (a 16 x 36 slice per wave) aliases the two halo images");
+    LU_DYN_LDS(unsigned char, Ah);                      // [2][AH_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = LU_UNIFORM(tid >> 6);              // wave-uniform: everything derived from it lives in scalar registers
+    const int wm = wave >> 2, wn = wave & 3;
+    int tile, nt, ks;
+    if (!lu_block_tile(a, tile, nt, ks)) return;
+    const int f = tile / a.tiles_pf;
+    const int t2 = tile - f * a.tiles_pf;
+    const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
+    const int n0 = nt * BN;
+    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_z16);
+    const int q = tid % G;
+    const int nfr = (a.N + 31) >> 5;
+    // This wave's column fragment.  A fragment beyond N (a partial last column tile) is CLAMPED to the last real one instead of
+    // being fed zeros: its accumulators are never stored (every epilogue path tests col < N), and the weight loads below stay
+    // free of selects -- `frag_ok ? pointer : zeros` per load became an exec-masked branch per load in the instruction stream.
+    const int frag_raw = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
+    const int frag = frag_raw < nfr ? frag_raw : nfr - 1;
+    const unsigned voff = (unsigned)lane * 16u;         // this lane's 16 bytes inside a 1 KB k-step of a fragment
+
+    const int nch0 = a.src[0].nchunk, nch1 = a.n_src > 1 ? a.src[1].nchunk : 0;
+    const bool ctr1 = a.src1_center != 0;
+    const int n_full = nch0 + (ctr1 ? 0 : nch1);
+    auto describe = [&](int ci) {
+        ChunkDesc d;
+        const int s_ = (ci >= nch0) ? 1 : 0;
+        const int ch = ci - (s_ ? nch0 : 0);
+        const int nch = s_ ? a.src[1].nchunk : nch0;
+        d.x = reinterpret_cast<const unsigned char*>(a.src[s_].x) + (int64_t)f * a.src[s_].frame_stride * ESZ;
+        // UNIFORM base of (tap 0, this chunk, this wave's fragment); the lane part travels as a 32-bit offset (saddr + voffset loads)
+        d.w = reinterpret_cast<const unsigned char*>(a.src[s_].w) + ((int64_t)ch * nfr + frag) * 2048;
+        d.wts = (s_ && ctr1) ? 0 : (int64_t)nch * nfr * 2048;      // (the centre-tap image holds ONE tap)
+        d.ps = a.src[s_].pix_stride;
+        d.C = a.src[s_].C;
+        d.c0 = ch * CKS;
+        d.single = (s_ && ctr1) ? 1 : 0;
+        return d;
+    };
+    int cb = 0, ce = n_full;
+    if (a.ksplit > 1) {
+        const int per = (n_full + a.ksplit - 1) / a.ksplit;
+        cb = ks * per < n_full ? ks * per : n_full;
+        ce = cb + per < n_full ? cb + per : n_full;
+    }
+
+    auto piece_load = [&](int p, const ChunkDesc& d, lu_u4& r, bool want) {
+        const int hp = (tid + NT * p) / G;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
+        const bool ok = want && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int c = d.c0 + PC * q;
+        const int64_t off = ((int64_t)(iy * a.Win + ix) * d.ps + c) * ESZ;
+        r = *((ok && c < d.C) ? reinterpret_cast<const lu_u4*>(d.x + off) : zp);
+    };
+    auto piece_store = [&](int p, int hb, const lu_u4& r) {
+        const int hp = (tid + NT * p) / G;
+        if (hp < HP) {
+            if (B16) {
+                *reinterpret_cast<lu_u4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
+            } else {
+                lu_u2 v;
+                v.x = lu_pack2bf(lu_bits2f(r.x), lu_bits2f(r.y));
+                v.y = lu_pack2bf(lu_bits2f(r.z), lu_bits2f(r.w));
+                *reinterpret_cast<lu_u2*>(&Ah[hb * AH_BYTES + hp * PITCH + 8 * q]) = v;
+            }
+        }
+    };
+    // one channel half (k-step) of a weight fragment: 16 bytes per lane
+    auto load_bh = [&](const ChunkDesc& d, int tap, int half, float4& b) {
+        const unsigned char* wp = d.w + tap * d.wts + 1024 * half;      // scalar arithmetic
+        b = *reinterpret_cast<const float4*>(wp + voff);
+    };
+
+    f32x16 acc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // this lane's A-fragment address for (halo row 0 of its row group, kernel column 0, channel half 0)
+    const int abase = (RW * wm * HWD + (lane & 31)) * PITCH + 16 * (lane >> 5);
+
+    const bool have_center = ctr1 && ce == n_full;
+    if (ce > cb || have_center) {
+        ChunkDesc cur = describe(cb < ce ? cb : n_full);
+        float4 rb0[K], rb1[K];                // the weight ring: slot kh = tap (kh, current kernel column), both channel halves
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            load_bh(cur, kh * K, 0, rb0[kh]);
+            load_bh(cur, kh * K, 1, rb1[kh]);
+        }
+        {
+            lu_u4 rh[HPASS];
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_load(p, cur, rh[p], true);
+#pragma unroll
+            for (int p = 0; p < HPASS; ++p) piece_store(p, 0, rh[p]);
+        }
+        __syncthreads();
+        int hb = 0;
+        lu_u4 rp[2 * PPS];
+#pragma unroll
+        for (int i = 0; i < 2 * PPS; ++i) rp[i] = lu_u4{0u, 0u, 0u, 0u};
+        lu_bf16x8 fr[NR];
+        for (int ci = cb; ci < ce; ++ci) {
+            const bool has_next = ci + 1 < ce || have_center;
+            const ChunkDesc nxt = describe(has_next ? ci + 1 : ci);
+            const unsigned char* const ab = &Ah[hb * AH_BYTES + abase];
+            lu_static_for<NS>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                constexpr int u = s_ / NJ, j = s_ % NJ, kw = u / 2, half = u % 2;
+                if (j == 0) {                 // sub-stage boundary: the next chunk's halo, PPS pieces at a time
+#pragma unroll
+                    for (int i = 0; i < PPS; ++i) {
+                        const int ps_ = (u - 2) * PPS + i;      // requested two sub-stages ago: older than anything the MFMAs since waited for
+                        if (u >= 2 && ps_ < HPASS) piece_store(ps_, hb ^ 1, rp[i + PPS * (u & 1)]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < PPS; ++i) {
+                        const int pl_ = u * PPS + i;
+                        if (u < NSUB - 2 && pl_ < HPASS) piece_load(pl_, nxt, rp[i + PPS * (u & 1)], has_next);
+                    }
+                }
+                // A fragments run LA steps ahead of their MFMAs (cold only behind the chunk barrier: the image is complete there)
+                if (s_ == 0) {
+#pragma unroll
+                    for (int t = 0; t < LA; ++t)
+                        fr[t % NR] = *reinterpret_cast<const lu_bf16x8*>(ab + ((t % NJ) * HWD + 0) * PITCH);
+                }
+                if (s_ + LA < NS) {
+                    constexpr int sn = s_ + LA < NS ? s_ + LA : 0;
+                    constexpr int un = sn / NJ, jn = sn % NJ;
+                    fr[sn % NR] = *reinterpret_cast<const lu_bf16x8*>(ab + (jn * HWD + un / 2) * PITCH + 32 * (un % 2));
+                }
+                // halo row j of this kernel column feeds patch row j - kh through tap (kh, kw)
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    if (j - kh >= 0 && j - kh < RW) {
+                        const lu_bf16x8 bv = __builtin_bit_cast(lu_bf16x8, half ? rb1[kh] : rb0[kh]);
+                        acc[j - kh] = lu_mfma_bf16(fr[s_ % NR], bv, acc[j - kh]);
+                    }
+                }
+                // slot kh = j - (RW - 1) has seen its last product of this sub-stage: refill this half with the next kernel column's
+                if (j >= RW - 1) {
+                    constexpr int kh = j - (RW - 1) < K ? j - (RW - 1) : 0;
+                    if (kw + 1 < K) load_bh(cur, kh * K + kw + 1, half, half ? rb1[kh] : rb0[kh]);
+                    else load_bh(nxt, kh * K, half, half ? rb1[kh] : rb0[kh]);
+                }
+                LU_SCHED_FENCE();
+            });
+            __syncthreads();                     // the next halo is complete and every wave is done with the old one
+            hb ^= 1;
+            cur = nxt;
+        }
+        if (have_center) {                       // one more stage: the centre tap of the im2col chunk (ring slot 0 holds its fragments)
+            const unsigned char* const ab = &Ah[hb * AH_BYTES + abase + (PAD * HWD + PAD) * PITCH];
+            const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, rb0[0]), bv1 = __builtin_bit_cast(lu_bf16x8, rb1[0]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const lu_bf16x8 a0 = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
+                const lu_bf16x8 a1 = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH + 32);
+                acc[i] = lu_mfma_bf16(a0, bv0, acc[i]);
+                acc[i] = lu_mfma_bf16(a1, bv1, acc[i]);
+            }
+        }
+    }
+    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Input gradient of a stride-2 3x3 convolution (first layer of a down block; TF-SAME on even extents: pad 0 before, 1
 // after), bf16 MFMA operands, ALL FOUR output parity classes in one pass over dy.
 //   dx[2a+py, 2b+px, c] = sum over the taps (kh, kw) with kh = py (mod 2), kw = px (mod 2) of dy[a - (kh - py)/2, b - (kw - px)/2, n] w[kh, kw, c, n]
@@ -2663,6 +2871,13 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
     }
     const bool want_xcd_n = (d->flags & LU_CONV_F_XCD_BY_N) != 0;
     const bool gen1 = (d->flags & LU_CONV_F_LOOP_GEN1) != 0;      // A/B: the first loop generation of the bf16 fragment kernel
+    const bool gen2 = (d->flags & LU_CONV_F_LOOP_GEN2) != 0;      // A/B: the second (row-major taps) where the third (column-major, round 5) is taken
+#define LU_ARGS(...) __VA_ARGS__
+#define LU_LAUNCH_FRAG23(targs, grid_, blk_, lds_)                                                          \
+    do {                                                                                                     \
+        if (gen2) LU_LAUNCH_DYN((conv_halo_frag2_kernel<targs>), grid_, blk_, lds_, stream, a);              \
+        else LU_LAUNCH_DYN((conv_halo_frag3_kernel<targs>), grid_, blk_, lds_, stream, a);                   \
+    } while (0)
     bool src16 = false;      // all sources bf16 tensors (a property of the launch: mixed element types are rejected)
     for (int s2 = 0; s2 < a.n_src; ++s2) {
         LU_REQUIRE(!a.src[s2].bf16 || (halo && d->precision == 1),
@@ -2732,13 +2947,13 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         const dim3 grid = tile_grid();
         LU_REQUIRE(d->dil == 1 && d->stride == 1 && k_h == d->k, "lu_conv2d_fwd: LSTM epilogue needs stride 1, dil 1, a square kernel");
         // (3x3: the first loop generation -- its 8-row-patch instance fits 4 waves per SIMD, the unrolled one does not: measured)
-        if (half_blk && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true, 1>), grid, dim3(256), halo_bf16_lds(5, 4), stream, a);
-        else if (half_blk && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, false, 1>), grid, dim3(256), halo_bf16_lds(5, 4), stream, a);
-        else if (half_blk) LU_LAUNCH_DYN((conv_halo_frag2_kernel<3, LU_EPI_LSTM, 8, true, 1>), grid, dim3(256), halo_bf16_lds(3, 4), stream, a);
-        else if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 1 && !gen1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 1 && !gen1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 8, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 1 && !gen1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
+        if (half_blk && src16 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, true, 1), grid, dim3(256), halo_bf16_lds(5, 4));
+        else if (half_blk && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, false, 1), grid, dim3(256), halo_bf16_lds(5, 4));
+        else if (half_blk) LU_LAUNCH_FRAG23(LU_ARGS(3, LU_EPI_LSTM, 8, true, 1), grid, dim3(256), halo_bf16_lds(3, 4));
+        else if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, true), grid, dim3(512), halo_bf16_lds(5, 8));
+        else if (d->precision == 1 && !gen1 && src16 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 4, true), grid, dim3(512), halo_bf16_lds(5, 4));
+        else if (d->precision == 1 && !gen1 && d->k == 5 && th == 16) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, false), grid, dim3(512), halo_bf16_lds(5, 8));
+        else if (d->precision == 1 && !gen1 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 4, false), grid, dim3(512), halo_bf16_lds(5, 4));
         else if (d->precision == 1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (d->precision == 1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (d->precision == 1 && src16) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
@@ -2804,25 +3019,25 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         else if (narrow)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, false, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && half_blk && src16 && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true, 1>), gridb, dim3(256), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, true, 1), gridb, dim3(256), halo_bf16_lds(5, 4));
         else if (halo && half_blk && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, false, 1>), gridb, dim3(256), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, false, 1), gridb, dim3(256), halo_bf16_lds(5, 4));
         else if (halo && half_blk)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<3, LU_EPI_BIAS, 8, true, 1>), gridb, dim3(256), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(3, LU_EPI_BIAS, 8, true, 1), gridb, dim3(256), halo_bf16_lds(3, 4));
         else if (halo && !gen1 && src16 && d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, true), gridb, dim3(512), halo_bf16_lds(5, 8));
         else if (halo && !gen1 && src16 && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 4, true), gridb, dim3(512), halo_bf16_lds(5, 4));
         else if (halo && !gen1 && d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 8, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, false), gridb, dim3(512), halo_bf16_lds(5, 8));
         else if (halo && !gen1 && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<5, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 4, false), gridb, dim3(512), halo_bf16_lds(5, 4));
         else if (halo && src16 && d->k == 5 && th == 16)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
         else if (halo && src16 && d->k == 5)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (halo && !gen1 && src16 && d->k == 3 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag2_kernel<3, LU_EPI_BIAS, 8, true>), gridb, dim3(512), halo_bf16_lds(3, 8), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(3, LU_EPI_BIAS, 8, true), gridb, dim3(512), halo_bf16_lds(3, 8));
         else if (halo && src16)
             LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && d->k == 5 && th == 16)

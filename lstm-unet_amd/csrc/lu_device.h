@@ -27,6 +27,7 @@ static inline void lu_glds16(const float* gptr, float* lds_wave_base) {
 #define LU_SCHED_FENCE() ((void)0)
 #define LU_SCHED_GROUP(mask, n) ((void)0)
 #define LU_WAVE_SYNC() lu_emu::wave_barrier()      // lanes of a wave exchange data through LDS without a block barrier
+#define LU_UNIFORM(x) (x)                          // (device: v_readfirstlane -- tells the compiler a value is wave-uniform)
 #else
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -119,6 +120,9 @@ __device__ __forceinline__ void lu_glds16(const float* gptr, float* lds_wave_bas
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 int lu_check_launch();
+// a value that is the same in every lane of the wave (derived from the wave index, say), moved to a scalar register: address
+// arithmetic and selects on it become SALU instructions, and a branch / select on it needs no exec masking
+#define LU_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 // 16 bytes of zeros in device memory: masked-out lanes of the tile loaders read THIS instead of branching

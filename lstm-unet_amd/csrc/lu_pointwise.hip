@@ -21,7 +21,7 @@ void lu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
-extern "C" int lu_abi_version(void) { return 9; }
+extern "C" int lu_abi_version(void) { return 10; }
 
 // ---------------------------------------------------------------------------------------------
 // CRC-32C (Castagnoli), slicing-by-8, HOST code: the checksum of TensorFlow tensor bundles (tf_bundle.py reads / writes

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 9          # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 10         # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -15,6 +15,8 @@ LU_CONV_F_LOOP_GEN1, LU_CONV_F_GATES_BF16, LU_CONV_F_SRC1_CENTER, LU_CONV_F_NO_B
 LU_CONV_F_SLABS_ONLY = 2048
 LU_CONV_F_NO_NARROW = 4096
 LU_CONV_F_HALF_BLOCK = 8192
+LU_CONV_F_SPLIT_TAPS = 16384
+LU_CONV_F_LOOP_GEN2 = 32768
 LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE, LU_WGRAD_F_PRB32 = 1, 2, 4, 8, 16, 32
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128

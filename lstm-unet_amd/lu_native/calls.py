@@ -71,11 +71,23 @@ def clear_plan_cache():
     _fused_step_cost_us.cache_clear()
 
 
+def chunk_splits(chunks, splits):
+    """Non-empty slices when `chunks` chunks are dealt out ceil(chunks / splits) at a time (mirrors lu_conv_chunk_splits: the fp32
+    halo kernel takes its compile-time tap sequence for a K split only if every slice gets a chunk)."""
+    if chunks <= 0 or splits <= 0:
+        return 0
+    per = -(-chunks // splits)
+    return -(-chunks // per)
+
+
 def conv_cost_us(frames, Hout, Wout, N, k, channels, splits, halo=True, it_us=None):
     """Modelled duration of the fp32 conv kernels with a K split (+ the slab reduce), microseconds."""
     M = frames * Hout * Wout
     n_it = k * k * -(-channels // 16)
-    t = launch_rounds(conv_tiles(frames, Hout, Wout, N, k, halo) * splits) * (n_it / float(splits) + 12) * (IT_US if it_us is None else it_us)
+    per = n_it / float(splits)
+    if halo and splits > 1 and chunk_splits(-(-channels // 16), splits) == splits:
+        per = -(-(-(-channels // 16)) // splits) * k * k      # fp32 halo kernel: whole 16-channel chunks per slice (the longest one)
+    t = launch_rounds(conv_tiles(frames, Hout, Wout, N, k, halo) * splits) * (per + 12) * (IT_US if it_us is None else it_us)
     if splits > 1:
         t += (2 * splits + 1) * M * N * 4 / 4e6 + 5        # slabs written + read, result written, at ~4 TB/s
     return t
@@ -92,6 +104,9 @@ def _conv_splits(frames, Hout, Wout, N, k, channels, halo, knobs):
     if conv_tiles(frames, Hout, Wout, N, k, halo) > 2048 or n_it < 64:
         return 1
     cands = [s for s in range(1, cap + 1) if n_it // s >= min_it] or [1]
+    if halo:      # whole chunks per slice (round 5): only split counts that leave no slice empty
+        nch = -(-channels // 16)
+        cands = [s for s in cands if s == 1 or chunk_splits(nch, s) == s] or [1]
     return min(cands, key=lambda s: (conv_cost_us(frames, Hout, Wout, N, k, channels, s, halo, it_us), s))
 
 

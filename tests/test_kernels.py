@@ -79,9 +79,31 @@ def test_conv_halo_ksplit_ranges_start_anywhere_in_a_chunk(be):
         xa, xb = rnd(2, 9, 35, 16), rnd(2, 9, 35, 32)            # 9 x 35: ragged patches (8 x 32 tiles hang over)
         wa, wb, b = rnd(k, k, 16, 128, scale=0.1), rnd(k, k, 32, 128, scale=0.1), rnd(128)
         ref = npo.conv2d_same(xa, wa, b, 1) + npo.conv2d_same(xb, wb, None, 1)
+        ST = cabi.LU_CONV_F_SPLIT_TAPS      # (the default since ABI v10 deals out whole chunks where every slice gets one: next test)
         for sp in splits:                                          # 5x5: 75 stages -> slices of 38 / 25 / 13 / 11; 3x3: 27 -> 14 / 7 / 6 / 4
+            close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp, flags=ST), ref, 5e-5)
+            close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp), ref, 5e-5)      # 3 chunks: sp = 2, 3 chunk-aligned, the others counted
+        close(KH.conv2d(be, [xb], [wb], None, k, 1, splits=7 if k == 5 else 3, flags=ST), npo.conv2d_same(xb, wb, None, 1), 5e-5)
+
+
+def test_conv_halo_ksplit_whole_chunks_on_the_compile_time_tap_sequence(be):
+    """Round 5 (ABI v10): a K split of the fp32 halo kernel deals out WHOLE 16-channel chunks -- ceil(chunks / splits) per slice --
+    so that K-split launches run the compile-time tap sequence of the unsplit ones (conv_halo_kernel<K, BIAS, ST = true>).  Chunk
+    counts that do not divide (7 chunks over 2 / 3 / 4 / 7 slices: 4+3, 3+3+1, 2+2+2+1, 1 x 7), slices that cross from the first
+    source into the second, ragged patches, a ragged last chunk (C = 40: 16 + 16 + 8) -- against the oracle; 5 slices of 7 chunks would
+    leave one empty, so the library keeps the counted loop there (same result as LU_CONV_F_SPLIT_TAPS, bit for bit)."""
+    ST = cabi.LU_CONV_F_SPLIT_TAPS
+    for k in (5, 3):
+        xa, xb = rnd(2, 9, 35, 40), rnd(2, 9, 35, 64)
+        wa, wb, b = rnd(k, k, 40, 128, scale=0.1), rnd(k, k, 64, 128, scale=0.1), rnd(128)
+        ref = npo.conv2d_same(xa, wa, b, 1) + npo.conv2d_same(xb, wb, None, 1)      # 3 + 4 = 7 chunks
+        for sp in (2, 3, 4, 7):
             close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp), ref, 5e-5)
-        close(KH.conv2d(be, [xb], [wb], None, k, 1, splits=7 if k == 5 else 3), npo.conv2d_same(xb, wb, None, 1), 5e-5)
+        a5 = KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=5)
+        close(a5, ref, 5e-5)
+        assert np.array_equal(a5, KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=5, flags=ST))
+    # the slab form (LU_CONV_F_SLABS_ONLY + lu_lstm_gates_fwd_slabs) rides on the same launch: covered by
+    # test_conv_post_affine_lrelu_and_slab_gates, whose K-split launches take whole chunks as well
 
 
 def test_conv_block_numbering_variants_are_bitwise_equal(be):
@@ -171,11 +193,15 @@ def test_conv_halo_variant(be):
     close(gates[..., F:2 * F], npo.hard_sigmoid(z[..., F:2 * F]), 2e-5)
 
 
-@pytest.mark.parametrize('patch', ['8', '16', 'half'])
+@pytest.mark.parametrize('patch', ['8', '16', 'half', '8-gen2', '16-gen2', 'half-gen2'])
 def test_conv_bf16_mfma_variant(be, patch):
     # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks) forced through lu_conv_desc.flags; 'half': 4-wave blocks
-    # on 8 x 32 patches (conv_halo_frag2_kernel<..., WM = 1>, two independent blocks per CU)
-    _conv_bf16_cases(be, {'16': cabi.LU_CONV_F_PATCH16, '8': cabi.LU_CONV_F_PATCH8, 'half': cabi.LU_CONV_F_HALF_BLOCK}[patch])
+    # on 8 x 32 patches (WM = 1, two independent blocks per CU).  Default = the third loop generation (round 5, ABI v10:
+    # conv_halo_frag3_kernel, kernel-column-major taps) wherever the second would run; '-gen2' = LU_CONV_F_LOOP_GEN2
+    if be.name == 'emu' and patch in ('16-gen2', 'half-gen2'):
+        pytest.skip('host emulator: one second-generation variant keeps the CPU suite within minutes')
+    base = {'16': cabi.LU_CONV_F_PATCH16, '8': cabi.LU_CONV_F_PATCH8, 'half': cabi.LU_CONV_F_HALF_BLOCK}[patch.split('-')[0]]
+    _conv_bf16_cases(be, base | (cabi.LU_CONV_F_LOOP_GEN2 if patch.endswith('gen2') else 0))
 
 
 def test_conv_bf16_half_blocks_are_bitwise_equal_to_the_full_blocks(be):
@@ -183,33 +209,53 @@ def test_conv_bf16_half_blocks_are_bitwise_equal_to_the_full_blocks(be):
     per output -- bias layers (3x3 / 5x5 on bf16 sources, two sources, ragged extents, a partial column tile, a K split) and the
     fused ConvLSTM step on the bf16 tape (5x5, and 3x3 -- which half blocks move from the first loop generation to the second)
     must give the same bits as the library's default kernels."""
-    HB = cabi.LU_CONV_F_HALF_BLOCK
     emu = be.name == 'emu'          # (the host emulator runs a subset: the CPU suite has to stay within minutes)
+    # Third generation (the default): every block shape of the 5x5 kernel and the two 3x3 shapes that run it sum in the same order
+    x5, w5, b5 = KH.bf16_round(rnd(2 - emu, 19, 33, 72)), rnd(5, 5, 72, 160, scale=0.1), rnd(160)
+    o5 = [KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=f_, bf16_src=(0,))
+          for f_ in (cabi.LU_CONV_F_HALF_BLOCK, cabi.LU_CONV_F_PATCH16, cabi.LU_CONV_F_PATCH8)[:3 if not emu else 2]]
+    assert all(np.array_equal(o5[0], o) for o in o5[1:])
+    close(o5[0], npo.conv2d_same(x5, KH.bf16_round(w5), b5, 1), 5e-5)
+    if not emu:
+        x3, w3, b3 = KH.bf16_round(rnd(2, 20, 40, 40)), rnd(3, 3, 40, 136, scale=0.1), rnd(136)
+        o3 = [KH.conv2d(be, [x3], [w3], b3, 3, precision=1, flags=f_, bf16_src=(0,))
+              for f_ in (cabi.LU_CONV_F_HALF_BLOCK, cabi.LU_CONV_F_PATCH16, cabi.LU_CONV_F_PATCH8)]
+        assert np.array_equal(o3[0], o3[1])                       # half blocks / 16-row patches: the third generation
+        close(o3[0], o3[2], 5e-5)                                 # 8-row patches: the first generation's kernel (row-major taps)
+        close(o3[0], npo.conv2d_same(x3, KH.bf16_round(w3), b3, 1), 5e-5)
+    # Second generation (LU_CONV_F_LOOP_GEN2) and first: the statement of round 4, bit for bit
+    HB = cabi.LU_CONV_F_HALF_BLOCK | cabi.LU_CONV_F_LOOP_GEN2
+    G2 = cabi.LU_CONV_F_LOOP_GEN2
     for (fr, H, W, Cc, N, k, sp) in [(2, 20, 40, 40, 136, 3, 1), (1, 16, 32, 64, 128, 3, 1), (2, 19, 33, 72, 160, 5, 1),
                                      (1, 9, 33, 96, 72, 5, 2)][:4 if not emu else 1] + ([(1, 9, 33, 40, 72, 5, 2)] if emu else []):
         x = KH.bf16_round(rnd(fr, H, W, Cc))
         w, b = rnd(k, k, Cc, N, scale=0.1), rnd(N)
-        for f0 in (cabi.LU_CONV_F_PATCH8, cabi.LU_CONV_F_PATCH16)[:2 if not emu else 1]:
+        for f0 in (cabi.LU_CONV_F_PATCH8 | G2, cabi.LU_CONV_F_PATCH16 | G2)[:2 if not emu else 1]:
             want = KH.conv2d(be, [x], [w], b, k, splits=sp, precision=1, flags=f0, bf16_src=(0,))
             assert np.array_equal(KH.conv2d(be, [x], [w], b, k, splits=sp, precision=1, flags=HB, bf16_src=(0,)), want)
     xa, xb = KH.bf16_round(rnd(1, 17, 32, 40)), KH.bf16_round(rnd(1, 17, 32, 24))
     wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
     assert np.array_equal(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=HB, bf16_src=(0, 1)),
-                          KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, bf16_src=(0, 1)))
+                          KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=G2, bf16_src=(0, 1)))
     x5 = rnd(1, 16, 34, 36)                                      # fp32 sources: 5x5 only (the 3x3 halo needs bf16 pieces)
     w5, b5 = rnd(5, 5, 36, 128, scale=0.1), rnd(128)
-    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=HB), KH.conv2d(be, [x5], [w5], b5, 5, precision=1))
+    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=HB), KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=G2))
+    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=cabi.LU_CONV_F_HALF_BLOCK),      # ... and the third, fp32 sources
+                          KH.conv2d(be, [x5], [w5], b5, 5, precision=1))
     F = 32
     for (k, cin, center) in [(5, 8, False), (3, 8, False), (3, 1, True), (5, 1, True)][:4 if not emu else 3]:
         x, h, c = rnd(2 - emu, 18, 40, cin), rnd(2 - emu, 18, 40, F, scale=0.5), rnd(2 - emu, 18, 40, F)
         ker, rec, b = rnd(k, k, cin, 4 * F, scale=0.3), rnd(k, k, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
-        want = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center)
+        want = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=G2)
         got = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=HB)
         for a_, b_ in zip(got, want):
             assert np.array_equal(a_, b_), (k, cin, center)
     x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)      # fp32 sources, fp32 gates out
     ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
     for a_, b_ in zip(KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=HB),
+                      KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=G2)):
+        assert np.array_equal(a_, b_)
+    for a_, b_ in zip(KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=cabi.LU_CONV_F_HALF_BLOCK),      # third generation
                       KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1)):
         assert np.array_equal(a_, b_)
 
@@ -219,13 +265,17 @@ def _conv_bf16_cases(be, flags=0):
     on the SAME bf16-rounded operands only the summation order differs (tolerance as for the fp32 kernels); against
     the unrounded oracle the error is the bf16 operand rounding (2^-9 relative per operand)."""
     R = KH.bf16_round
+    gen2 = bool(flags & cabi.LU_CONV_F_LOOP_GEN2)
     for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
                                      (1, 8, 33, 100, 96, 3, 2)]:
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
         got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags)
         close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
-        # the two loop generations of the kernel walk the same (chunk, tap) order: bit-identical
-        assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_CONV_F_LOOP_GEN1))
+        g1 = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_CONV_F_LOOP_GEN1)
+        if gen2:      # the first two loop generations walk the same (chunk, tap) order: bit-identical
+            assert np.array_equal(got, g1)
+        else:         # the third sums a chunk's taps kernel column by kernel column: the same products, another fp32 order
+            close(got, g1, 5e-5)
         full = npo.conv2d_same(x, w, b, 1)
         assert np.abs(got - full).max() <= 2.0 ** -7 * np.abs(full).max()
     xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources (UpBlock concat)
@@ -252,7 +302,7 @@ def _conv_bf16_cases(be, flags=0):
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
         got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags, bf16_src=(0,))
         close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
-        if sp == 1:
+        if sp == 1 and (gen2 or k == 5):      # (3x3, third generation: fp32 sources stay on the first generation's kernel, another order)
             assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1, precision=1, flags=flags))
     close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=flags, bf16_src=(0, 1)),
           npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb)), 5e-5)
@@ -265,7 +315,11 @@ def _conv_bf16_cases(be, flags=0):
     hg, cg, g16, h16 = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags)
     assert np.array_equal(hg, h0) and np.array_equal(cg, c0)
     hg1, cg1, g161, _ = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags | cabi.LU_CONV_F_LOOP_GEN1)
-    assert np.array_equal(hg1, hg) and np.array_equal(cg1, cg) and np.array_equal(g161, g16)
+    if gen2:
+        assert np.array_equal(hg1, hg) and np.array_equal(cg1, cg) and np.array_equal(g161, g16)
+    else:
+        close(hg1, hg, 3e-5)
+        close(cg1, cg, 3e-5)
     assert np.array_equal(g16, R(g0)) and np.array_equal(h16, R(h0))
     for (k, cin) in [(5, 1), (3, 3)]:
         x, h, c = rnd(2, 16, 32, cin), rnd(2, 16, 32, F, scale=0.5), rnd(2, 16, 32, F)
@@ -1041,8 +1095,11 @@ def test_conv3_bf16_sources_tall_patch_equals_the_8_row_kernel(be):
     for (H, W, Cc, N) in [(20, 40, 40, 136), (16, 32, 64, 128)]:
         x = KH.bf16_round(rnd(2, H, W, Cc))
         w, b = rnd(3, 3, Cc, N, scale=0.1), rnd(N)
-        o8 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH8, bf16_src=(0,))
-        o16 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16, bf16_src=(0,))
+        G2 = cabi.LU_CONV_F_LOOP_GEN2      # (the tall patch of the third generation sums column-major: to rounding, below)
+        o8 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH8 | G2, bf16_src=(0,))
+        o16 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16 | G2, bf16_src=(0,))
         assert np.array_equal(o8, o16)
         ref = npo.conv2d_same(x.astype(np.float64), KH.bf16_round(w).astype(np.float64), b.astype(np.float64), 1)
         close(o16, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))
+        o16g3 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16, bf16_src=(0,))
+        close(o16g3, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))
