@@ -586,7 +586,7 @@ def main():
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only): a STATIC table
             if (H, W, T, B) == (256, 256, 8, 4):      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
                 sfx = '' if args.precision == 'fp32' else '_bf16'
-                name = next(n for n in ('r04_pmc_traffic%s.json' % sfx, 'r03_pmc_traffic%s.json' % sfx, 'r02_pmc_traffic%s.json' % sfx, 'r01_pmc_traffic%s.json' % sfx)
+                name = next(n for n in ('r05_pmc_traffic%s.json' % sfx, 'r04_pmc_traffic%s.json' % sfx, 'r03_pmc_traffic%s.json' % sfx, 'r02_pmc_traffic%s.json' % sfx, 'r01_pmc_traffic%s.json' % sfx)
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     blob = json.load(fh)
@@ -626,7 +626,7 @@ def main():
         util_db, util_src, util_build = {}, None, None
         try:
             if (H, W, T, B, args.net) == (256, 256, 8, 4, 'params'):
-                name = next(n for n in ('r04_pmc_mfma_util.json', 'r03_pmc_mfma_util.json', 'r02_pmc_mfma_util.json')
+                name = next(n for n in ('r05_pmc_mfma_util.json', 'r04_pmc_mfma_util.json', 'r03_pmc_mfma_util.json', 'r02_pmc_mfma_util.json')
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     blob = json.load(fh)
