@@ -583,10 +583,16 @@ def main():
         ev, ops.EVENT_LOG = ops.EVENT_LOG, None
         traffic_db, traffic_src, traffic_build = {}, None, None
         build_id = lu_build.build_id()
-        try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes (config-2 only): a STATIC table
-            if (H, W, T, B) == (256, 256, 8, 4):      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
-                sfx = '' if args.precision == 'fp32' else '_bf16'
-                name = next(n for n in ('r05_pmc_traffic%s.json' % sfx, 'r04_pmc_traffic%s.json' % sfx, 'r03_pmc_traffic%s.json' % sfx, 'r02_pmc_traffic%s.json' % sfx, 'r01_pmc_traffic%s.json' % sfx)
+        # which workload's counter tables: config-2 (no suffix), config-4 (_c4), the config-5 per-GPU shape (_c5shape); the net
+        # variants carry their name (round 5: the round-4 tables covered config-2 / params only)
+        wl_sfx = {(256, 256, 8, 4): '', (832, 992, 16, 2): '_c4', (512, 512, 8, 2): '_c5shape'}.get((H, W, T, B))
+        if wl_sfx is not None and args.net != 'params':
+            wl_sfx = '_' + args.net + wl_sfx
+        try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes: a STATIC table
+            if wl_sfx is not None:      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
+                sfx = ('' if args.precision == 'fp32' else '_bf16') + wl_sfx
+                rounds = ('r05', 'r04', 'r03', 'r02', 'r01') if wl_sfx == '' else ('r05',)
+                name = next(n for n in ['%s_pmc_traffic%s.json' % (r_, sfx) for r_ in rounds]
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     blob = json.load(fh)
@@ -604,7 +610,7 @@ def main():
             name = kind.split(' ')[0]
             m = re.match(r'(\w+)<(\d)(?:,LU_EPI_(LSTM|BIAS))?', name)
             if name.startswith('conv_halo_frag_kernel<') and m:
-                return r'conv_halo_frag2?_kernel<%s, %d, ' % (m.group(2), 1 if m.group(3) == 'LSTM' else 0)
+                return r'conv_halo_frag[23]?_kernel<%s, %d, ' % (m.group(2), 1 if m.group(3) == 'LSTM' else 0)
             if name.startswith('wgrad_row_bf16_kernel<') and m:      # rocprof: wgrad_row_bf16_kernel<5, 128, true, true, 1, 64>
                 return r'wgrad_row_bf16_kernel<%s, ' % m.group(2)
             if name.startswith('wgrad_row_kernel<') and m:           # rocprof: wgrad_row_kernel<5> (older tables) or <5, false>
@@ -625,8 +631,9 @@ def main():
         # itself: frac_of_clocked_peak = achieved / (peak x clock / 2400 MHz)
         util_db, util_src, util_build = {}, None, None
         try:
-            if (H, W, T, B, args.net) == (256, 256, 8, 4, 'params'):
-                name = next(n for n in ('r05_pmc_mfma_util.json', 'r04_pmc_mfma_util.json', 'r03_pmc_mfma_util.json', 'r02_pmc_mfma_util.json')
+            if wl_sfx is not None:
+                rounds = ('r05', 'r04', 'r03', 'r02') if wl_sfx == '' else ('r05',)
+                name = next(n for n in ['%s_pmc_mfma_util%s.json' % (r_, wl_sfx) for r_ in rounds]
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
                     blob = json.load(fh)

@@ -255,7 +255,12 @@ enum {
                                   * buffers, counted vmcnt waits) instead of staging registers + ds_write -- bit-identical; the library's own
                                   * choice for the all-taps 3x3 form (+3.5 %), opt-in for the 5x5 kernel-row form (measured -3 %) */
     LU_WGRAD_F_NO_DMA = 8192,    /* ... never (A/B, tests) */
-    LU_WGRAD_F_KP16 = 16384      /* fp32 kernel-row variant: 16-pixel stages where 32-pixel ones would be taken (A/B, tests) */
+    LU_WGRAD_F_KP16 = 16384,     /* fp32 kernel-row variant: 16-pixel stages where 32-pixel ones would be taken (A/B, tests) */
+    LU_WGRAD_F_HALF_BLOCK = 65536, /* precision 1, bf16 operands, stride-1 5x5: 4-wave blocks of 64 channels x 128 columns (two independent blocks
+                                  * per CU) instead of 8-wave blocks of 128 channels -- round 5 A/B; bit-identical */
+    LU_WGRAD_F_XREALIGN = 32768  /* precision 1, bf16 operands, stride-1 5x5, 128-channel tiles: every tap fetches its own re-aligned x rows
+                                  * with transposing LDS reads instead of cutting them out of one fetch with funnel shifts / register
+                                  * moves (round 5 A/B; bit-identical) */
 };
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

@@ -1927,7 +1927,10 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag3_kernel(ConvArgs a
     constexpr int NJ = RW + K - 1;                     // halo rows under a wave's RW patch rows = fragment steps per sub-stage
     constexpr int NSUB = 2 * K;                        // sub-stages per chunk: (kernel column, channel half)
     constexpr int NS = NSUB * NJ;                      // fragment steps per chunk
-    constexpr int LA = 3, NR = LA + 1;                 // A-fragment look-ahead (steps) / ring size
+#ifndef LU_G3_LA
+#define LU_G3_LA 3      // (tools/build_variant.py: A/B builds only)
+#endif
+    constexpr int LA = LU_G3_LA, NR = LA + 1;          // A-fragment look-ahead (steps) / ring size
     constexpr int PPS = (HPASS + NSUB - 3) / (NSUB - 2);      // halo pieces requested per sub-stage (stored two sub-stages later)
     static_assert(PPS * (NSUB - 2) >= HPASS, "every halo piece has a sub-stage to be requested in and one to be stored in");
     static_assert(WM == 1 || WM == 2, "one or two row groups of waves");

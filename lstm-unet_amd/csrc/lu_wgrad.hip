@@ -596,8 +596,14 @@ constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 //   (the 1 KB of an instruction is contiguous), so bank conflicts of the transposing fragment reads are avoided by a swizzle
 //   applied to the SOURCE address instead: the 64-byte column segment s of row r is stored at segment s ^ (r & 3) (256-byte
 //   rows: four rows of a fragment read land on four different bank quarters) resp. s ^ ((r >> 1) & 1) (128-byte rows).
-template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8, bool DMA = false>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
-__global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
+//   XRD (round 5): how a tap's x fragment is formed.  0: the 8 + K - 1 rows of a k-step are fetched once and the K fragments cut out of
+//   the registers -- a 16-bit funnel shift per register for odd taps, and (what the instruction stream showed) four v_mov per tap
+//   whose first register is odd: an MFMA operand is an EVEN-aligned register tuple, so "pure renaming" only works for taps 0 and 4.
+//   1.4-1.8 VALU instructions per MFMA in the loop body (profiles/r04_pmc_sq.json: 2.5 over the whole kernel).  2: every tap reads its
+//   own rows t .. t + 7 with two transposing reads (row offsets keep the 8-byte alignment): 2 K + 2 NFW reads per k-step instead of
+//   NR + 2 NFW (K = 5: 14 instead of 7; the LDS pipe is ~35 % busy with that), no VALU instruction left in the loop body.
+template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8, bool DMA = false, int XRD = 0>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+__global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
     constexpr int PRB = PRBT;      // (shadows the file-level default inside this kernel)
     constexpr int BMw = CT, BNw = 128, XP = S * (PRB - 1) + K, NT = 64 * NWV;
     constexpr int WMC = CT / 32, WNN = NWV / WMC, NFW = BNw / (32 * WNN);
@@ -853,7 +859,17 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 1 : 2)) void wgrad_row_bf16_k
         lu_bf16x8 bv[NFW];
 #pragma unroll
         for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf * (PRB * YLD) + yoff + 16 * j * YLD + 32 * nf + yseg[nf]], YLD);
-        if constexpr (S == 1) {
+        if constexpr (S == 1 && XRD == 2) {
+#pragma unroll
+            for (int kr = 0; kr < R; ++kr) {
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const lu_bf16x8 av = frag(&Xs[buf * (XPA * XLD) + xoff + xseg[kr] + (kr * XP + 16 * j + t) * XLD], XLD);
+#pragma unroll
+                    for (int nf = 0; nf < NFW; ++nf) acc[kr * K + t][nf] = lu_mfma_bf16(av, bv[nf], acc[kr * K + t][nf]);
+                }
+            }
+        } else if constexpr (S == 1) {
 #pragma unroll
             for (int kr = 0; kr < R; ++kr) {      // the R input rows of the tile (all-taps form) -- one for the kernel-row form
                 short xw[4 * NR];
@@ -1506,7 +1522,11 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
     // bf16 kernel-row variant: channel tile, and the bias rows per split that go with it (also needed by a phase-2 call)
-    const int ct_bf16 = (d->k == 1 || (d->stride == 2 && d->k == 5)) ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
+    // LU_WGRAD_F_HALF_BLOCK (round 5 A/B): 4-wave blocks of 64 channels x 128 columns -- the same 32c x 64n x K wave tile as the 128-channel /
+    // 8-wave block, TWO independent blocks per CU (66 KB of LDS each) so that one block's stage barrier / staging phase runs under the
+    // other's MFMAs, at 1.5x the staged bytes per MFMA (the dy tile is fetched by twice as many blocks)
+    const bool half_wg = (d->flags & LU_WGRAD_F_HALF_BLOCK) && d->k == 5 && d->stride == 1 && d->x_dtype == LU_BF16 && d->dy_dtype == LU_BF16;
+    const int ct_bf16 = (d->k == 1 || (d->stride == 2 && d->k == 5) || half_wg) ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
                                                                                           : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
     // all-taps form of the 3x3 layers (one block = all nine taps of a 64-channel x 128-column tile): 4 fat waves, or 8 thin ones
     // Measured (round 4, same-box A/B, config-2 shapes): 8 waves 0.196 -> 0.215 of peak on the Params-net 3x3 layers, 0.295 -> 0.345 on
@@ -1592,6 +1612,14 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         else if (d->stride == 2 && ct == 128) LU_WGB2(3, 128);
         else if (d->stride == 2) LU_WGB2(3, 64);
         else if (d->k == 1) LU_WGB(1, 64);
+        else if (half_wg && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32))
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 64, true, true, 1, 64, 1, 4>), grid, dim3(256), wgrad_row_bf16_lds(5, 64, 1, 64, true, 1, 256), stream, a);
+        else if (half_wg)
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 64, true, true, 1, 32, 1, 4>), grid, dim3(256), wgrad_row_bf16_lds(5, 64, 1, 32, true, 1, 256), stream, a);
+        else if (xb && yb && d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32) && (d->flags & LU_WGRAD_F_XREALIGN))
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 64, 1, 8, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 64, true), stream, a);
+        else if (xb && yb && d->k == 5 && ct == 128 && (d->flags & LU_WGRAD_F_XREALIGN))
+            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 32, 1, 8, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 32, true), stream, a);
         else if (d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32)) LU_WGB64(5);
         else if (d->k == 5 && ct == 128) LU_WGB(5, 128);
         else if (d->k == 5) LU_WGB(5, 64);

@@ -27,6 +27,8 @@ LU_WGRAD_F_TAPS9 = 1024
 LU_WGRAD_F_NO_TAPS9 = 2048
 LU_WGRAD_F_DMA = 4096
 LU_WGRAD_F_NO_DMA = 8192
+LU_WGRAD_F_XREALIGN = 32768
+LU_WGRAD_F_HALF_BLOCK = 65536
 
 
 class ConvSrc(C.Structure):

@@ -354,7 +354,8 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     if bf16_row and stride == 2:
         row_variant = True           # (the bias gradient rides on this launch as well)
     if bf16_row:
-        ct = 64 if (k == 1 or (stride == 2 and k == 5) or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
+        half_wg = bool(WGRAD_FLAGS & cabi.LU_WGRAD_F_HALF_BLOCK) and k == 5 and stride == 1 and xb and yb      # (mirrors lu_conv2d_wgrad)
+        ct = 64 if (k == 1 or (stride == 2 and k == 5) or half_wg or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
             (128 if (Cin % 128 == 0 or Cin > 256) else 64)
         all_taps = (k == 3 and stride == 1 and Cin >= 64 and      # mirrors lu_conv2d_wgrad: the all-taps form of the 3x3 layers
                     not (WGRAD_FLAGS & (cabi.LU_WGRAD_F_NO_TAPS9 | cabi.LU_WGRAD_F_CT64 | cabi.LU_WGRAD_F_CT128)))

@@ -705,6 +705,28 @@ def test_wgrad_bf16_lds_dma_equals_register_staging(be):
         close(got, gw, 2e-4)
 
 
+def test_wgrad_bf16_realigned_x_reads_equal_the_funnel_shift_form(be):
+    """LU_WGRAD_F_XREALIGN (round 5): every tap of the 5x5 kernel-row form fetches its own re-aligned x rows (two transposing LDS
+    reads per tap) instead of cutting the K fragments out of one fetch with funnel shifts and register moves: the same fragments in
+    the same MFMA order -- bit-identical weight and bias gradients.  128-channel tiles, 64- and 32-pixel stages, image borders,
+    a masked channel tail (C = 200), odd slab counts."""
+    cases = [(1, 5, 64, 128, 136, 2), (2, 4, 32, 128, 128, 3), (3, 3, 96, 200, 136, 2), (1, 6, 128, 256, 128, 1)]
+    if be.name == 'emu':
+        cases = [(1, 3, 64, 128, 136, 2), (1, 4, 32, 128, 128, 1)]
+    for (fr, H, W, Cc, N, sp) in cases:
+        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
+        want, db0 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32))
+        got, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
+                                  flags=cabi.LU_WGRAD_F_XREALIGN)
+        assert np.array_equal(got, want) and np.array_equal(db, db0), (Cc, N, sp)
+        # LU_WGRAD_F_HALF_BLOCK: 4-wave blocks of 64 channels (two independent blocks per CU), the same wave tile and pixel order
+        got, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
+                                  flags=cabi.LU_WGRAD_F_HALF_BLOCK)
+        assert np.array_equal(got, want) and np.array_equal(db, db0), ('half', Cc, N, sp)
+        _, gw = _torch_conv_grads(KH.bf16_round(x), rnd(5, 5, Cc, N), KH.bf16_round(dy), 1)
+        close(got, gw, 2e-4)
+
+
 @pytest.mark.parametrize('form', ['fat4', 'w8'])
 def test_wgrad_bf16_all_taps_form_equals_the_kernel_row_form(be, form):
     """The all-taps form of the 3x3 layers (round 4; LU_WGRAD_F_TAPS9: its fat-wave instance): one block accumulates all nine taps of a 64-channel x 128-column tile (x tile = three

@@ -7,16 +7,19 @@
 tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 bash tools/gpu/pmc_traffic.sh $tag | tail -14
+# ... and (round 5) for the other workloads the bench lines below report: config-4, the config-5 per-GPU shape, the two net variants
+PMC_EXTRA="--hw 832 992 --batch 2 --unroll 16" PMC_SFX=_c4 PMC_MODES=fp32 bash tools/gpu/pmc_traffic.sh $tag | tail -4
+PMC_EXTRA="--size 512 --batch 2" PMC_SFX=_c5shape PMC_MODES=bf16 bash tools/gpu/pmc_traffic.sh $tag | tail -4
+for net in lstm3 default5; do PMC_EXTRA="--net $net" PMC_SFX=_$net bash tools/gpu/pmc_traffic.sh $tag | tail -6; done
 python - <<PY
-import json
-for sfx in ('', '_bf16'):
-    p = 'gpurun_out/${tag}_pmc_traffic%s.json' % sfx
+import json, glob, os
+for p in sorted(glob.glob('gpurun_out/${tag}_pmc_traffic*.json')):
     d = json.load(open(p))
     d['collected'] = 'round 5 final binary %s, $tag' % d.get('build_id')
     json.dump(d, open(p, 'w'), indent=1)
-    json.dump(d, open('profiles/r05_pmc_traffic%s.json' % sfx, 'w'), indent=1)      # (the box's copy: read by bench.py below)
-d = json.load(open('gpurun_out/${tag}_pmc_mfma_util.json'))
-json.dump(d, open('profiles/r05_pmc_mfma_util.json', 'w'), indent=1)
+    json.dump(d, open('profiles/r05_' + os.path.basename(p)[len('${tag}_'):], 'w'), indent=1)      # (the box's copy: read by bench.py below)
+for p in sorted(glob.glob('gpurun_out/${tag}_pmc_mfma_util*.json')):
+    json.dump(json.load(open(p)), open('profiles/r05_' + os.path.basename(p)[len('${tag}_'):], 'w'), indent=1)
 PY
 python bench.py > gpurun_out/${tag}_f32_bench_line.json 2> gpurun_out/${tag}_f32_bench.err; tail -2 gpurun_out/${tag}_f32_bench.err
 python bench.py --steps 8 --warmup 3 --no-variants --no-cpu-baseline --by-shape gpurun_out/${tag}_f32_by_shape.json > gpurun_out/${tag}_f32_long_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err

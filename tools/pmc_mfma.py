@@ -17,8 +17,10 @@ def _build_id():
 
 
 def summarize(path):
-    db = sorted(glob.glob(path + '/**/*.db', recursive=True))[0]
-    cur = sqlite3.connect(db).cursor()
+    dbs = sorted(glob.glob(path + '/**/*.db', recursive=True))
+    if not dbs:          # (PMC_MODES of tools/gpu/pmc_traffic.sh: a pass that was not run)
+        return {}
+    cur = sqlite3.connect(dbs[0]).cursor()
     agg = {}
     for k, c, n, v, d in cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(end-start) from "
                                      "counters_collection group by kernel_name, counter_name"):
