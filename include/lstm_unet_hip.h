@@ -257,7 +257,7 @@ enum {
     LU_WGRAD_F_NO_DMA = 8192,    /* ... never (A/B, tests) */
     LU_WGRAD_F_KP16 = 16384,     /* fp32 kernel-row variant: 16-pixel stages where 32-pixel ones would be taken (A/B, tests) */
     LU_WGRAD_F_HALF_BLOCK = 65536, /* precision 1, bf16 operands, stride-1 5x5: 4-wave blocks of 64 channels x 128 columns (two independent blocks
-                                  * per CU) instead of 8-wave blocks of 128 channels -- round 5 A/B; bit-identical */
+                                  * per CU) instead of 8-wave blocks of 128 channels -- round 5 A/B; bit-identical dw, dbias to fp32 re-association */
     LU_WGRAD_F_XREALIGN = 32768  /* precision 1, bf16 operands, stride-1 5x5, 128-channel tiles: every tap fetches its own re-aligned x rows
                                   * with transposing LDS reads instead of cutting them out of one fetch with funnel shifts / register
                                   * moves (round 5 A/B; bit-identical) */

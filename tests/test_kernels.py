@@ -719,10 +719,13 @@ def test_wgrad_bf16_realigned_x_reads_equal_the_funnel_shift_form(be):
         got, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
                                   flags=cabi.LU_WGRAD_F_XREALIGN)
         assert np.array_equal(got, want) and np.array_equal(db, db0), (Cc, N, sp)
-        # LU_WGRAD_F_HALF_BLOCK: 4-wave blocks of 64 channels (two independent blocks per CU), the same wave tile and pixel order
+        # LU_WGRAD_F_HALF_BLOCK: 4-wave blocks of 64 channels (two independent blocks per CU), the same wave tile and pixel order: the
+        # weight gradient is bit-identical; the bias gradient's stages are shared out over twice as many blocks (K * c_tiles), i.e.
+        # its fp32 partial sums associate differently
         got, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
                                   flags=cabi.LU_WGRAD_F_HALF_BLOCK)
-        assert np.array_equal(got, want) and np.array_equal(db, db0), ('half', Cc, N, sp)
+        assert np.array_equal(got, want), ('half', Cc, N, sp)
+        close(db, db0, 1e-5 * max(1.0, float(np.abs(db0).max())))
         _, gw = _torch_conv_grads(KH.bf16_round(x), rnd(5, 5, Cc, N), KH.bf16_round(dy), 1)
         close(got, gw, 2e-4)
 
