@@ -68,14 +68,34 @@ def state_shapes(net, B, H, W):
 
 
 def run_job(spec, params):
-    """One oracle train_step (no Adam): loss + every gradient tensor.  spec: H, W, T, B, seed, dtype ('float64' | 'float32'),
-    bf16_operands, carried, threads."""
+    """kind 'grad' (default): one oracle train_step (no Adam) -> loss + every gradient tensor.
+    kind 'forward': one forward pass (training or inference mode, no moving-statistics update) -> logits, loss (labels: True),
+    carried h / c of every ConvLSTM layer.
+    spec: H, W, T, B, seed, dtype ('float64' | 'float32'), bf16_operands, carried, threads, [kind, training, labels]."""
     import torch
     sys.path[:0] = [p for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd')) if p not in sys.path]
     from oracle import torch_oracle as tho
     import Params
     torch.set_num_threads(max(1, min(int(spec.get('threads', 16)), os.cpu_count() or 1)))
     net = Params.CTCParams.net_kernel_params
+    if spec.get('kind') == 'forward':
+        B, T, H, W = spec['B'], spec['T'], spec['H'], spec['W']
+        rng = np.random.default_rng(spec['seed'])
+        x = rng.standard_normal((B, T, H, W, 1)).astype(np.float32)
+        gt = labels(rng, B, T, H, W) if spec.get('labels') else None
+        dt = getattr(torch, spec['dtype'])
+        tm = tho.TorchULSTM(net, 1, params, dtype=dt, bf16_operands=bool(spec.get('bf16_operands')))
+        t0 = time.time()
+        with torch.no_grad():
+            ref = tm.forward(torch.tensor(x, dtype=dt), training=bool(spec['training']), update_moving=False)
+            loss = float(tho.weighted_ce(torch.tensor(gt, dtype=dt), ref, [0.15, 0.25, 0.6])) if gt is not None else float('nan')
+        out = {'logits': ref.numpy().astype(np.float64), 'loss': np.float64(loss), 'seconds': np.float64(time.time() - t0),
+               'max_logit': np.float64(float(ref.abs().max()))}
+        for bi, blk in enumerate(tm.states):
+            for li, (h, c) in enumerate(blk):
+                out['h:%d:%d' % (bi, li)] = h.numpy().astype(np.float64)
+                out['c:%d:%d' % (bi, li)] = c.numpy().astype(np.float64)
+        return out
     x, gt, states, keep = make_inputs(spec, state_shapes(net, spec['B'], spec['H'], spec['W']))
     dt = getattr(torch, spec['dtype'])
     tm = tho.TorchULSTM(net, 1, params, dtype=dt, bf16_operands=bool(spec.get('bf16_operands')))
@@ -122,8 +142,14 @@ class Farm(object):
         if rc != 0:
             raise RuntimeError('oracle job %s failed (rc %d):\n%s' % (key, rc, open(log.name).read()[-2000:]))
         d = np.load(out)
-        return {'loss': float(d['loss']), 'seconds': float(d['seconds']), 'max_logit': float(d['max_logit']),
-                'grads': {k[2:]: d[k] for k in d.files if k.startswith('g:')}}
+        res = {'loss': float(d['loss']), 'seconds': float(d['seconds']), 'max_logit': float(d['max_logit']),
+               'grads': {k[2:]: d[k] for k in d.files if k.startswith('g:')}}
+        if 'logits' in d.files:
+            res['logits'] = d['logits']
+            n_blk = 1 + max(int(k.split(':')[1]) for k in d.files if k.startswith('h:'))
+            res['states'] = [[(d['h:%d:%d' % (bi, li)], d['c:%d:%d' % (bi, li)])
+                              for li in range(sum(1 for k in d.files if k.startswith('h:%d:' % bi)))] for bi in range(n_blk)]
+        return res
 
     def close(self):
         for p, _, log, _ in self.jobs.values():

@@ -398,7 +398,7 @@ def test_bf16_inference_state_copy_survives_no_in_place_state_edit():
         assert torch.equal(g(f)[1], w)
 
 
-def _t8_compare(full_engine, precision, B, training, seed):
+def _t8_compare(full_engine, precision, B, training, seed, farm=None):
     """Params.py-width net, 64x64, T = 8 (the reference's unroll window, Params.py:38-40; SURVEY §8c states its tolerance
     'after T=8 steps'): HIP engine vs the fp64 torch oracle (bf16 mode: the oracle on bf16-rounded operands).
     -> dict of measured errors."""
@@ -411,17 +411,16 @@ def _t8_compare(full_engine, precision, B, training, seed):
     e = _clone_engine(full_engine, precision=precision)
     lg = e.forward(torch.from_numpy(_to_tb(x)).to(dev), T, B, training)
     got = np.swapaxes(lg.cpu().numpy().reshape(T, B, H, W, 3), 0, 1).astype(np.float64)
-    tm = tho.TorchULSTM(net, 1, p, dtype=torch.float64, bf16_operands=(precision == 'bf16'))
-    with torch.no_grad():
-        ref = tm.forward(torch.tensor(x, dtype=torch.float64), training=training, update_moving=False).numpy()
+    o = farm.result(_fwd_key(precision, B, T, H, W, training, seed))      # the fp64 oracle pass (its own host process)
+    ref, o_states = o['logits'], o['states']
     m = max(1.0, float(np.abs(ref).max()))
     out = {'max_logit': m, 'logit_err': float(np.abs(got - ref).max()),
            'logit_err_last_frame': float(np.abs(got[:, -1] - ref[:, -1]).max())}
     h_err = c_err = 0.0
-    for blk_e, blk_o in zip(e.states, tm.states):
+    for blk_e, blk_o in zip(e.states, o_states):
         for (h_e, c_e), (h_o, c_o) in zip(blk_e, blk_o):
-            h_err = max(h_err, float(np.abs(h_e.cpu().numpy() - h_o.numpy()).max()))
-            c_err = max(c_err, float(np.abs(c_e.cpu().numpy() - c_o.numpy()).max()))
+            h_err = max(h_err, float(np.abs(h_e.cpu().numpy() - h_o).max()))
+            c_err = max(c_err, float(np.abs(c_e.cpu().numpy() - c_o).max()))
     out['h_err'], out['c_err'] = h_err, c_err
     top2 = np.sort(ref, -1)
     gap = top2[..., -1] - top2[..., -2]
@@ -430,12 +429,12 @@ def _t8_compare(full_engine, precision, B, training, seed):
 
 
 @pytest.mark.parametrize('case', ['train-B1', 'infer-B1', 'train-B4'])
-def test_full_width_t8_vs_fp64_oracle(full_engine, case):
+def test_full_width_t8_vs_fp64_oracle(full_engine, oracle_farm, case):
     """fp32, eight recurrent steps at K up to 12 800 against the fp64 oracle -- the tolerance SURVEY §8c states is FOR this
     length: logits <= 1e-3 * max(1, |ref|), argmax equal outside the 2e-3 top-2 band, carried h / c <= 1e-3, SEG <= 1e-3.
     B = 4 so that the frame-batched launches (4 slots per step, the config-2 shape of the launch grid) are compared too."""
     training, B = case.startswith('train'), int(case[-1])
-    r = _t8_compare(full_engine, 'fp32', B, training, seed=21 + B)
+    r = _t8_compare(full_engine, 'fp32', B, training, seed=21 + B, farm=oracle_farm)
     band = r['gap'] < 2e-3
     mism = (r['got'].argmax(-1) != r['ref'].argmax(-1))
     print('T=8 fp32 %s: max|logit| %.3f, logit err %.3e (last frame %.3e), carried h err %.3e, c err %.3e, tie-band pixels %d, '
@@ -450,12 +449,12 @@ def test_full_width_t8_vs_fp64_oracle(full_engine, case):
 
 
 @pytest.mark.parametrize('case', ['train-B1', 'infer-B1', 'train-B4'])
-def test_full_width_t8_bf16_vs_rounding_oracle(full_engine, case):
+def test_full_width_t8_bf16_vs_rounding_oracle(full_engine, oracle_farm, case):
     """bf16 mode over the same eight steps against the fp64 oracle evaluated on bf16-ROUNDED operands: the contract of the
     mode is 1.5e-2 * max|logit| on logits, labels equal outside a 2e-2 * max|logit| tie band; the carried state
     is compared at 2e-2 (h, c are O(1))."""
     training, B = case.startswith('train'), int(case[-1])
-    r = _t8_compare(full_engine, 'bf16', B, training, seed=31 + B)
+    r = _t8_compare(full_engine, 'bf16', B, training, seed=31 + B, farm=oracle_farm)
     m = r['max_logit']
     band = r['gap'] < 2e-2 * m
     mism = (r['got'].argmax(-1) != r['ref'].argmax(-1))
@@ -500,7 +499,7 @@ def _labels(rng, B, T, H, W):
     return gt
 
 
-def _full_frame_compare(full_engine, precision, B, T, H, W, training, seed):
+def _full_frame_compare(full_engine, precision, B, T, H, W, training, seed, farm=None):
     from lu_native import ops
     dev = full_engine.device
     net = _params_net()
@@ -516,17 +515,14 @@ def _full_frame_compare(full_engine, precision, B, T, H, W, training, seed):
     sums, _ = ops.wce_forward(lg.view(-1, 3), g, torch.tensor(cw, device=dev), False)
     loss = float(ops.wce_loss(sums).cpu()[0])
     got = np.swapaxes(lg.cpu().numpy().reshape(T, B, H, W, 3), 0, 1).astype(np.float64)
-    tm = tho.TorchULSTM(net, 1, p, dtype=torch.float64, bf16_operands=(precision == 'bf16'))
-    with _oracle_threads(), torch.no_grad():
-        ref_t = tm.forward(torch.tensor(x, dtype=torch.float64), training=training, update_moving=False)
-        loss_ref = float(tho.weighted_ce(torch.tensor(gt, dtype=torch.float64), ref_t, cw))
-    ref = ref_t.numpy()
+    o = farm.result(_fwd_key(precision, B, T, H, W, training, seed))      # the fp64 oracle pass (its own host process)
+    ref, loss_ref = o['logits'], o['loss']
     m = max(1.0, float(np.abs(ref).max()))
     h_err = c_err = 0.0
-    for blk_e, blk_o in zip(e.states, tm.states):
+    for blk_e, blk_o in zip(e.states, o['states']):
         for (h_e, c_e), (h_o, c_o) in zip(blk_e, blk_o):
-            h_err = max(h_err, float(np.abs(h_e.cpu().numpy() - h_o.numpy()).max()))
-            c_err = max(c_err, float(np.abs(c_e.cpu().numpy() - c_o.numpy()).max()))
+            h_err = max(h_err, float(np.abs(h_e.cpu().numpy() - h_o).max()))
+            c_err = max(c_err, float(np.abs(c_e.cpu().numpy() - c_o).max()))
     top2 = np.sort(ref, -1)
     del e
     torch.cuda.empty_cache()
@@ -546,13 +542,13 @@ def _report(tag, r, band):
 
 
 @pytest.mark.parametrize('case', ['T8-B1', 'T2-B4'])
-def test_config2_frame_size_vs_fp64_oracle(full_engine, case):
+def test_config2_frame_size_vs_fp64_oracle(full_engine, oracle_farm, case):
     """BASELINE config-2's frames -- 256x256, Params.py widths, training mode (BatchNorm batch statistics over B*T frames,
     Networks.py:67-71), the launch geometry of the headline bench (16x32 / 8x32 patches, no tile-starved routes) -- against the
     fp64 oracle at SURVEY §8c's tolerance: logits <= 1e-3 * max(1, |ref|), loss <= 1e-4 relative, carried h / c <= 1e-3, argmax
     equal outside the 2e-3 top-2 band, SEG within 1e-3.  T = 8, B = 1 is the full unroll window; T = 2, B = 4 the full batch."""
     T, B = int(case[1]), int(case[-1])
-    r = _full_frame_compare(full_engine, 'fp32', B, T, 256, 256, True, seed=41 + B)
+    r = _full_frame_compare(full_engine, 'fp32', B, T, 256, 256, True, seed=41 + B, farm=oracle_farm)
     band = r['gap'] < 2e-3
     mism, a, b = _report('config-2 frame size fp32 %s' % case, r, band)
     assert r['logit_err'] <= 1e-3 * r['max_logit']
@@ -563,11 +559,11 @@ def test_config2_frame_size_vs_fp64_oracle(full_engine, case):
 
 
 @pytest.mark.parametrize('case', ['T8-B1', 'T2-B4'])
-def test_config2_frame_size_bf16_vs_rounding_oracle(full_engine, case):
+def test_config2_frame_size_bf16_vs_rounding_oracle(full_engine, oracle_farm, case):
     """The same frames in bf16 mode against the fp64 oracle on bf16-ROUNDED operands; the mode's contract:
     logits 1.5e-2 * max|logit|, loss 2e-2 relative, carried h / c 2e-2, labels equal outside a 2e-2 * max|logit| tie band."""
     T, B = int(case[1]), int(case[-1])
-    r = _full_frame_compare(full_engine, 'bf16', B, T, 256, 256, True, seed=41 + B)
+    r = _full_frame_compare(full_engine, 'bf16', B, T, 256, 256, True, seed=41 + B, farm=oracle_farm)
     m = r['max_logit']
     band = r['gap'] < 2e-2 * m
     mism, a, b = _report('config-2 frame size bf16 %s' % case, r, band)
@@ -577,11 +573,11 @@ def test_config2_frame_size_bf16_vs_rounding_oracle(full_engine, case):
     assert not (mism & ~band).any()
 
 
-def test_config4_frame_vs_fp64_oracle(full_engine):
+def test_config4_frame_vs_fp64_oracle(full_engine, oracle_farm):
     """One 832x992 frame (Fluo-C2DL-MSC/01, BASELINE config-4) through the Params-width net in training mode against the fp64
     oracle: the ragged tile geometry of that shape (104 x 31 patches at level 0, 124- / 62-pixel rows below: masked patch
     columns, the RG weight-gradient rows are covered by the gradient test) at the fp32 tolerance."""
-    r = _full_frame_compare(full_engine, 'fp32', 1, 1, 832, 992, True, seed=47)
+    r = _full_frame_compare(full_engine, 'fp32', 1, 1, 832, 992, True, seed=47, farm=oracle_farm)
     band = r['gap'] < 2e-3
     mism, a, b = _report('config-4 frame 832x992 fp32', r, band)
     assert r['logit_err'] <= 1e-3 * r['max_logit']
@@ -626,11 +622,26 @@ _ARITH = {'f64': dict(dtype='float64', bf16_operands=False), 'f32': dict(dtype='
           'r64': dict(dtype='float64', bf16_operands=True)}
 
 
+def _fwd_key(precision, B, T, H, W, training, seed):
+    return 'fwd.%s.B%d.T%d.%dx%d.%s.s%d' % (precision, B, T, H, W, 'train' if training else 'infer', seed)
+
+
+# every forward-oracle pass of this module (round 5: they run in the farm too -- a dozen 30-second fp64 passes in a row were 6 of
+# the suite's minutes): (precision, B, T, H, W, training, seed, labels)
+FWD_CASES = [(p_, B, 8, 64, 64, tr, s0 + B, False) for p_, s0 in (('fp32', 21), ('bf16', 31)) for B, tr in ((1, True), (1, False), (4, True))] + \
+            [(p_, B, T, 256, 256, True, 41 + B, True) for p_ in ('fp32', 'bf16') for B, T in ((1, 8), (4, 2))] + \
+            [('fp32', 1, 1, 832, 992, True, 47, True)]
+
+
 @pytest.fixture(scope='module')
 def oracle_farm(full_engine):
     """Every oracle pass of the gradient cases as its own host process, started at first use (tests/oracle_farm.py)."""
     import oracle_farm as of
     farm = of.Farm({k: v for k, v in full_engine.export_params().items()})
+    for (p_, B, T, H, W, tr, seed, lab) in sorted(FWD_CASES, key=lambda c: -c[1] * c[2] * c[3] * c[4]):
+        farm.submit(_fwd_key(p_, B, T, H, W, tr, seed),
+                    dict(kind='forward', H=H, W=W, T=T, B=B, seed=seed, training=tr, labels=lab, dtype='float64',
+                         bf16_operands=(p_ == 'bf16'), threads=12))
     # longest jobs first
     order = sorted(GRAD_CASES.items(), key=lambda kv: -kv[1]['H'] * kv[1]['W'] * kv[1]['T'] * kv[1]['B'])
     for ar in ('f64', 'r64', 'f32'):
