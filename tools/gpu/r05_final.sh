@@ -57,5 +57,10 @@ for mode in fp32 bf16; do
 done
 cd $R && bash tools/gpu/r02_inf_prof.sh ${tag}_inf 2>&1 | grep "launches/frame"
 python tools/post_ab.py bf16 gpurun_out/${tag}_post_832x992.json 2>&1 | grep -v amdgpu | tail -9
+# instruction / wait counters per kernel (SQ_INSTS_* per MFMA, wave-cycle shares): profiles/r05_pmc_sq.json
+bash tools/gpu/pmc_sq.sh $tag 2>&1 | tail -12
+# config-4: kernel trace of one step (per-kernel table) -- the allocator-pool finding of this round is in profiles/r05_c4_trace_per_step_and_gaps.txt
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_c4 -- python $R/bench.py --hw 832 992 --batch 2 --unroll 16 --steps 1 --warmup 2 --no-bf16 --no-infer --no-cpu-baseline --no-variants > /dev/null 2>&1)
+python tools/prof_summary.py gpurun_out/${tag}_prof_c4 gpurun_out/${tag}_c4_kernel_stats 60 | head -4; python tools/trace_gaps.py gpurun_out/${tag}_prof_c4 --step-marker adam_kernel | head -6; rm -rf gpurun_out/${tag}_prof_c4
 # bf16 vs fp32 training on the same stream (the bf16 accuracy contract: loss curves, held-out IoU, argmax agreement)
 python tools/train_compare.py 300 > gpurun_out/${tag}_bf16_vs_fp32_training.json 2> gpurun_out/${tag}_train_compare.err; tail -c 400 gpurun_out/${tag}_bf16_vs_fp32_training.json
