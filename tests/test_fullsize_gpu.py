@@ -4,7 +4,6 @@ oracle parity of the FULL-WIDTH network on small crops (logits tolerance, argmax
 the streaming-inference contract -- and, since round 4, the fp64 oracle AT FULL FRAME SIZE: config-2's 256x256 frames over
 T = 8 (logits, loss, carried h / c; fp32 and bf16), one 832x992 frame of config-4's ragged tile geometry, and every gradient
 tensor of a Params-width training step against the oracle's autograd (train2D.py:87-95, Networks.py:208-254)."""
-import contextlib
 import os
 import numpy as np
 import pytest
@@ -472,31 +471,10 @@ def test_full_width_t8_bf16_vs_rounding_oracle(full_engine, oracle_farm, case):
 
 
 # ---- round 4: the fp64 oracle at full frame size, and full-width gradients ------------------------------------------------
-@contextlib.contextmanager
-def _oracle_threads(n=16):
-    """torch's CPU convolutions collapse when oversubscribed on the 256-core GPU host (bench.py's walk-up probe): bound the
-    oracle's thread count for the big frames."""
-    old = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(n, os.cpu_count() or 1)))
-    try:
-        yield
-    finally:
-        torch.set_num_threads(old)
-
-
 def _labels(rng, B, T, H, W):
-    """{-1, 0, 1, 2} maps with structure: blobs of cells with edges, ~10 % of the pixels unlabeled."""
-    gt = np.zeros((B, T, H, W), np.float32)
-    yy, xx = np.mgrid[0:H, 0:W]
-    for b in range(B):
-        for t in range(T):
-            for _ in range(max(4, H * W // 6000)):
-                cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(5, 16)
-                d = np.hypot(yy - cy, xx - cx)
-                gt[b, t][d < r] = 1
-                gt[b, t][(d >= r) & (d < r + 2)] = 2
-    gt[rng.random(gt.shape) < 0.1] = -1
-    return gt
+    """{-1, 0, 1, 2} maps with structure (tests/oracle_farm.py: the oracle processes draw the same maps from the same seed)."""
+    import oracle_farm as of
+    return of.labels(rng, B, T, H, W)
 
 
 def _full_frame_compare(full_engine, precision, B, T, H, W, training, seed, farm=None):
