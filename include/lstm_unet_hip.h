@@ -301,6 +301,17 @@ int lu_lstm_gates_bwd_bf16(void* gates_dz, const float* c_prev, const float* c_c
 int lu_convert_f32_bf16(const float* x, void* y, int64_t n, lu_stream_t stream);
 int lu_convert_bf16_f32(const void* x, float* y, int64_t n, lu_stream_t stream);
 
+/* Three-way bf16 split along a reduction axis (precision 'bf16x3': fp32 convolutions on the bf16 MFMA at fp32 accuracy).
+ * x [rows][L] fp32 (row stride x_row_stride) -> y [rows][6][Lp] (row stride y_row_stride >= 6 Lp, zero for l in [L, Lp)), where
+ * x = hi + mid + lo exactly (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)) and block j holds piece
+ * order 0 (activations): lo, mid, hi, mid, hi, hi      order 1 (weights): hi, mid, lo, hi, mid, hi
+ * so that a bf16 GEMM over the 6 Lp-long axis of an order-0 operand and an order-1 operand sums the six products
+ * lo hi + mid mid + hi lo + mid hi + hi mid + hi hi = x w (1 + O(2^-26)), small terms first.  out_dtype LU_BF16: y is bf16;
+ * LU_F32: the same values as fp32 (a weight image on its way into lu_pack_weights_bf16, which rounds them without change).
+ * New in this build; no counterpart in the reference (its arithmetic is TensorFlow's fp32 convolution, Networks.py:48-50). */
+int lu_split6(const float* x, int64_t rows, int32_t L, int64_t x_row_stride, void* y, int64_t y_row_stride, int32_t Lp,
+              int32_t order, int32_t out_dtype, lu_stream_t stream);
+
 /* im2col image of a thin input for LU_CONV_F_SRC1_CENTER: y[f, oy, ox, (kh*k + kw)*C + c] = bf16(x[f, oy+kh-p, ox+kw-p, c])
  * (zero outside the frame, zero for channels >= k*k*C); y is [frames, H, W, 32] bf16, k*k*C <= 32, p = (k-1)/2. */
 int lu_im2col_bf16(const float* x, void* y, int32_t frames, int32_t H, int32_t W, int32_t C, int32_t k,

@@ -21,7 +21,7 @@ void lu_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lu_last_error(void) { return g_lu_err; }
-extern "C" int lu_abi_version(void) { return 10; }
+extern "C" int lu_abi_version(void) { return 11; }
 
 // ---------------------------------------------------------------------------------------------
 // CRC-32C (Castagnoli), slicing-by-8, HOST code: the checksum of TensorFlow tensor bundles (tf_bundle.py reads / writes
@@ -233,6 +233,79 @@ __global__ void convert_f32_bf16_kernel(const float* __restrict__ x, unsigned sh
 __global__ void convert_bf16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
         y[i] = lu_bits2f((unsigned)x[i] << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Three-way bf16 split of fp32 values (precision = 'bf16x3'): x = hi + mid + lo EXACTLY, hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid) (both residuals are exact in fp32; the last one has at most 8 significant bits left).  A product
+// of two fp32 numbers is then the sum of nine bf16 x bf16 products (each exact in fp32); the six of relative size >= 2^-18
+// -- hi hi, hi mid, mid hi, hi lo, mid mid, lo hi -- carry it to 2^-26, below fp32's own rounding unit.  The bf16 MFMA
+// kernels form those six products by themselves when the REDUCTION axis of the GEMM is laid out six times: an activation
+// row [L] becomes [6][Lp] in block order A = (lo, mid, hi, mid, hi, hi), a weight row in block order B = (hi, mid, lo, hi,
+// mid, hi) -- block j of one times block j of the other runs through the six products, small terms first (they are summed
+// before the accumulator is large).  16x the fp32 MFMA rate / 6 products = 2.7x the fp32 MFMA roofline at fp32 accuracy.
+//   x [rows][L] (row stride xs) -> y [rows][6][Lp] (row stride ys), zero for l in [L, Lp); OUT32: the pieces as fp32 values
+//   (weights on their way into the fragment packers, which round exactly-representable values without changing them).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float x, float& hi, float& mid, float& lo) {
+    hi = lu_bits2f((unsigned)lu_f2bf(x) << 16);
+    const float r1 = x - hi;
+    mid = lu_bits2f((unsigned)lu_f2bf(r1) << 16);
+    lo = lu_bits2f((unsigned)lu_f2bf(r1 - mid) << 16);
+}
+__device__ __forceinline__ float split_pick(int piece, float hi, float mid, float lo) { return piece == 0 ? hi : (piece == 1 ? mid : lo); }
+// piece (0 hi, 1 mid, 2 lo) held by block j: order A = 2 1 0 1 0 0, order B = 0 1 2 0 1 0 (two bits per block, block 0 lowest)
+constexpr unsigned SPLIT_ORDER_A = 2u | (1u << 2) | (0u << 4) | (1u << 6) | (0u << 8) | (0u << 10);
+constexpr unsigned SPLIT_ORDER_B = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (1u << 8) | (0u << 10);
+
+template <bool OUT32>
+__global__ void split6_vec4_kernel(const float* __restrict__ x, int64_t xs, void* __restrict__ yv, int64_t ys, int64_t rows, int L4,
+                                   int Lp, unsigned order) {
+    // one thread per (row, four consecutive l): a 16-byte read, six 8-byte (bf16) or 16-byte (fp32) writes
+    const int64_t total = rows * L4;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t r = i / L4;
+        const int q = (int)(i - r * L4);
+        const float4 v = *reinterpret_cast<const float4*>(x + r * xs + 4 * q);
+        float h[4], m[4], l[4];
+        split3(v.x, h[0], m[0], l[0]);
+        split3(v.y, h[1], m[1], l[1]);
+        split3(v.z, h[2], m[2], l[2]);
+        split3(v.w, h[3], m[3], l[3]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int pc = (int)((order >> (2 * j)) & 3u);
+            const float a = split_pick(pc, h[0], m[0], l[0]), b = split_pick(pc, h[1], m[1], l[1]);
+            const float c = split_pick(pc, h[2], m[2], l[2]), d = split_pick(pc, h[3], m[3], l[3]);
+            if (OUT32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + r * ys + (int64_t)j * Lp + 4 * q) = make_float4(a, b, c, d);
+            } else {
+                lu_u2 o;
+                o.x = lu_pack2bf(a, b);
+                o.y = lu_pack2bf(c, d);
+                *reinterpret_cast<lu_u2*>(reinterpret_cast<unsigned short*>(yv) + r * ys + (int64_t)j * Lp + 4 * q) = o;
+            }
+        }
+    }
+}
+
+template <bool OUT32>
+__global__ void split6_kernel(const float* __restrict__ x, int64_t xs, void* __restrict__ yv, int64_t ys, int64_t rows, int L, int Lp,
+                              unsigned order) {
+    // any L / Lp (thin inputs: the one-channel image padded to 4 channels per block): one thread per (row, l < Lp)
+    const int64_t total = rows * Lp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t r = i / Lp;
+        const int l = (int)(i - r * Lp);
+        float h = 0.f, m = 0.f, lo = 0.f;
+        if (l < L) split3(x[r * xs + l], h, m, lo);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float v = split_pick((int)((order >> (2 * j)) & 3u), h, m, lo);
+            if (OUT32) reinterpret_cast<float*>(yv)[r * ys + (int64_t)j * Lp + l] = v;
+            else reinterpret_cast<unsigned short*>(yv)[r * ys + (int64_t)j * Lp + l] = lu_f2bf(v);
+        }
+    }
 }
 
 // y[f, oy, ox, (kh*k + kw)*C + c] = bf16(x[f, oy+kh-p, ox+kw-p, c]); 32 bf16 per pixel (zero beyond k*k*C); one thread per
@@ -1013,6 +1086,33 @@ extern "C" int lu_convert_f32_bf16(const float* x, void* y, int64_t n, lu_stream
 extern "C" int lu_convert_bf16_f32(const void* x, float* y, int64_t n, lu_stream_t stream) {
     LU_REQUIRE(x && y && n > 0, "lu_convert_bf16_f32: bad arguments");
     LU_LAUNCH(convert_bf16_f32_kernel, dim3(grid_for(n, 4)), dim3(NT), stream, (const unsigned short*)x, y, n);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_split6(const float* x, int64_t rows, int32_t L, int64_t x_row_stride, void* y, int64_t y_row_stride,
+                        int32_t Lp, int32_t order, int32_t out_dtype, lu_stream_t stream) {
+    LU_REQUIRE(x && y && rows > 0 && L > 0 && Lp >= L && x_row_stride >= L && y_row_stride >= 6 * (int64_t)Lp,
+               "lu_split6: bad arguments");
+    LU_REQUIRE((order == 0 || order == 1) && (out_dtype == LU_F32 || out_dtype == LU_BF16), "lu_split6: order is 0 (A) or 1 (B), out_dtype LU_F32 / LU_BF16");
+    const unsigned ord = order == 0 ? SPLIT_ORDER_A : SPLIT_ORDER_B;
+    const bool o32 = out_dtype == LU_F32;
+    const bool vec = L == Lp && (L & 3) == 0 && (x_row_stride & 3) == 0 && (y_row_stride & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (vec) {
+        const int64_t total = rows * (L / 4);
+        if (o32) {
+            LU_LAUNCH(split6_vec4_kernel<true>, dim3(grid_for(total, 2)), dim3(NT), stream, x, x_row_stride, y, y_row_stride, rows, (int)(L / 4), (int)Lp, ord);
+        } else {
+            LU_LAUNCH(split6_vec4_kernel<false>, dim3(grid_for(total, 2)), dim3(NT), stream, x, x_row_stride, y, y_row_stride, rows, (int)(L / 4), (int)Lp, ord);
+        }
+    } else {
+        const int64_t total = rows * Lp;
+        if (o32) {
+            LU_LAUNCH(split6_kernel<true>, dim3(grid_for(total, 2)), dim3(NT), stream, x, x_row_stride, y, y_row_stride, rows, (int)L, (int)Lp, ord);
+        } else {
+            LU_LAUNCH(split6_kernel<false>, dim3(grid_for(total, 2)), dim3(NT), stream, x, x_row_stride, y, y_row_stride, rows, (int)L, (int)Lp, ord);
+        }
+    }
     return LU_CHECK_LAUNCH();
 }
 

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 10         # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 11         # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -85,6 +85,7 @@ PROTOTYPES = {
     'lu_lstm_gates_bwd': (C.c_int, [P, P, P, P, i64, P, P, P, P, i32, i64, i32, S]),
     'lu_lstm_gates_bwd_bf16': (C.c_int, [P, P, P, P, i64, P, P, P, i32, i64, i32, S]),
     'lu_convert_f32_bf16': (C.c_int, [P, P, i64, S]),
+    'lu_split6': (C.c_int, [P, i64, i32, i64, P, i64, i32, i32, i32, S]),
     'lu_convert_bf16_f32': (C.c_int, [P, P, i64, S]),
     'lu_im2col_bf16': (C.c_int, [P, P, i32, i32, i32, i32, i32, S]),
     'lu_colreduce_workspace_bytes': (C.c_size_t, [i64, i32]),

@@ -64,9 +64,13 @@ class Engine:
         """precision: 'fp32' (default; v_mfma_f32_32x32x2_f32 everywhere -- the parity configuration) or 'bf16'
         (BASELINE config 5: stride-1 3x3 / 5x5 convolutions with more than 64 output channels -- ConvLSTM steps, their
         recurrent / input gradients, the wide encoder / decoder convs -- feed bf16-rounded operands to
-        v_mfma_f32_32x32x16_bf16; fp32 master weights, activations, accumulators, statistics, loss and optimiser)."""
-        if precision not in ('fp32', 'bf16'):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        v_mfma_f32_32x32x16_bf16; fp32 master weights, activations, accumulators, statistics, loss and optimiser)
+        or 'bf16x3' (fp32 ARITHMETIC on the bf16 MFMA: the ConvLSTM convolutions -- 93 % of the FLOPs -- run the bf16 kernels on
+        the exact three-way bf16 split of their fp32 operands, six bf16 products per fp32 product, fp32 accumulation: every
+        product to 2^-26, below fp32's rounding unit (_lstm_forward_x3); everything else is the fp32 path, nothing is
+        stored rounded)."""
+        if precision not in ('fp32', 'bf16', 'bf16x3'):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
         self.precision = precision
         # bilinear source-coordinate convention of UpBlock2D (Networks.py:143): 'tf2.0' = the legacy v1 op that
         # keras.backend.resize_images calls in the TensorFlow release the reference pins; 'half_pixel' = tf.image.resize v2
@@ -503,6 +507,8 @@ class Engine:
         F = spec['f']
         k = spec['k']
         dev = x_seq.device
+        if self._x3_route(k, F, Cin, B, H, W):
+            return self._lstm_forward_x3(bi, li, spec, x_seq, T, B, tape)
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
         bf, tape16, x_center, src16 = self._lstm_route(k, F, Cin, B, H, W)      # (thin image: im2col chunk, one tap)
@@ -587,6 +593,8 @@ class Engine:
 
     def _lstm_backward(self, rec, dh_seq, need_dx):
         """BPTT inside the window; gradients do not flow into the carried state."""
+        if rec.get('x3'):
+            return self._lstm_backward_x3(rec, dh_seq, need_dx)
         bi, li, spec, T, B = rec['bi'], rec['li'], rec['spec'], rec['T'], rec['B']
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel']
@@ -662,6 +670,133 @@ class Engine:
             dx = ops.conv2d_dgrad(dz_seq if (dx_bf or not tape16) else dz_f32(), kernel, (H, W), 1, bf16=dx_bf,
                                   bank=self.bank if self.prep_batch else None)
         rec['h_all'] = rec['c_all'] = rec['x'] = rec['h16_all'] = rec['x25'] = rec['x16'] = None
+        return dx
+
+    # ------------------------------------------------------------------ ConvLSTM layer, precision 'bf16x3'
+    def _x3_route(self, k, F, cin, B, H, W):
+        """precision 'bf16x3': does this ConvLSTM layer run on the split operands?  The domain of the fused bf16 step and of the
+        bf16 kernel-row weight gradient (W % 32 == 0, F % 32 == 0, F >= 64); other layers take the fp32 kernels."""
+        return (self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and W % 32 == 0 and
+                ops.fused_step_applies(B, H, W, F, True))
+
+    def _x3_weight(self, name, role, make, cp=None):
+        """bf16 fragment image of the three-way split of a kernel (block order B), once per weight change."""
+        return self._pack(name, role, lambda: ops.split6_weights(make(), cp))
+
+    def _lstm_forward_x3(self, bi, li, spec, x_seq, T, B, tape):
+        """The ConvLSTM layer of precision 'bf16x3' (reference Networks.py:48-50,62-63; the fp32 form: _lstm_forward).  x_t and
+        h_{t-1} enter the fused bf16 step as split6 tensors (six channel blocks of the exact three-way bf16 split), the
+        kernels in the matching block order, so the step's MFMAs sum x w and h r to 2^-26 per product in fp32 accumulators;
+        gates, c and h come out of the epilogue in fp32 exactly as in fp32 mode and NOTHING is stored rounded: the tape is
+        the fp32 tape plus the split copy of the hidden sequence (the recurrent operand of the next step and the x operand
+        of the hoisted recurrent weight gradient)."""
+        _, H, W, Cin = x_seq.shape
+        F, k = spec['f'], spec['k']
+        dev = x_seq.device
+        pre = f'down.{bi}.lstm.{li}'
+        kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
+        cp = -(-Cin // 4) * 4      # channels per block: the bf16 kernels read 16-byte groups (6 cp % 8 == 0)
+        k6 = self._x3_weight(pre + '.kernel', 'x3', lambda: kernel, cp)
+        r6 = self._x3_weight(pre + '.recurrent_kernel', 'x3', lambda: rec_k)
+        x6 = ops.split6(x_seq, cp).view(T, B, H, W, 6 * cp)      # one pass per window; also the x operand of the kernel gradient
+        st = self._states[bi][li]
+        if st is not None and tuple(st[0].shape) != (B, H, W, F):
+            raise ValueError('stateful ConvLSTM: batch/shape changed from %s to %s' % (tuple(st[0].shape), (B, H, W, F)))
+        if tape is None:
+            h_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.float32)
+            c_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.float32)
+            if st is None:
+                h_prev, c_prev = h_seq.new_zeros((B, H, W, F)), h_seq.new_zeros((B, H, W, F))
+            else:
+                h_prev, c_prev = st
+            hit = self._state16.get((bi, li))
+            h6 = hit[1] if (hit is not None and hit[0] is h_prev) else ops.split6(h_prev)
+            for t in range(T):
+                ops.convlstm_step(x6[t], h6, c_prev, k6, r6, bias, h_seq[t], c_seq[t], None)
+                h_prev, c_prev = h_seq[t], c_seq[t]
+                h6 = ops.split6(h_prev)
+            if self.persistent_states and st is not None:
+                st[0].copy_(h_prev)
+                st[1].copy_(c_prev)
+                self._state16.pop((bi, li), None)
+            elif self.persistent_states:
+                self._states[bi][li] = [h_prev.clone(), c_prev.clone()]
+                self._state16.pop((bi, li), None)
+            else:
+                self._states[bi][li] = [h_prev, c_prev]
+                self._state16[(bi, li)] = (h_prev, h6)
+            self._h16_seq = None
+            return h_seq.view(T * B, H, W, F)
+        h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
+        c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
+        h6_all = torch.empty((T + 1, B, H, W, 6 * F), device=dev, dtype=torch.bfloat16)
+        ops.state_begin(h_all[0], None if st is None else st[0], self._keep)
+        ops.state_begin(c_all[0], None if st is None else st[1], self._keep)
+        ops.split6(h_all[0], out=h6_all[0])
+        gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32)
+        for t in range(T):
+            ops.convlstm_step(x6[t], h6_all[t], c_all[t], k6, r6, bias, h_all[t + 1], c_all[t + 1], gates[t])
+            if t + 1 < T:
+                ops.split6(h_all[t + 1], out=h6_all[t + 1])
+        self._states[bi][li] = [h_all[T], c_all[T]]
+        self._alias.add((bi, li))
+        self._state16.pop((bi, li), None)
+        tape.append({'kind': 'lstm', 'x3': True, 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'x6': x6, 'h_all': h_all,
+                     'c_all': c_all, 'gates': gates, 'T': T, 'B': B, 'h6_all': h6_all})
+        self._h16_seq = None
+        return h_all[1:].view(T * B, H, W, F)
+
+    def _x3_wgrad(self, x6, dy6, dw):
+        """dw = x (*) dy on the split operands: the six products of ops.SPLIT_TERMS as six launches of the bf16 kernel-row weight
+        gradient on channel-slice views of the two split6 tensors, smallest term first, accumulated in fp32 (beta = 1)."""
+        for i, (px, py) in enumerate(ops.SPLIT_TERMS):
+            ops.conv2d_wgrad(ops.split_piece(x6, px), ops.split_piece(dy6, py), dw, 1, beta=0.0 if i == 0 else 1.0, bf16=True)
+
+    def _lstm_backward_x3(self, rec, dh_seq, need_dx):
+        """BPTT of a 'bf16x3' ConvLSTM layer: the fp32 gate backward, then every convolution of the fp32 path -- the recurrent
+        gradient per step, the hoisted weight gradients, the input gradient -- on split6 operands."""
+        bi, li, spec, T, B = rec['bi'], rec['li'], rec['spec'], rec['T'], rec['B']
+        pre = f'down.{bi}.lstm.{li}'
+        kernel, rec_k = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel']
+        h_all, c_all, gates, x_seq, x6, h6_all = rec['h_all'], rec['c_all'], rec['gates'], rec['x'], rec['x6'], rec['h6_all']
+        _, _, H, W, F = h_all.shape
+        k = spec['k']
+        Cin = x_seq.shape[3]
+        dev = h_all.device
+        p = (k - 1) // 2
+        dz = gates      # in place, as in fp32 mode
+        dz6 = torch.empty((T, B, H, W, 24 * F), device=dev, dtype=torch.bfloat16)
+        dh5 = dh_seq.view(T, B, H, W, F)
+        dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
+        dh_rec = None
+        self._sync_weight_images()
+        rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k)) if T > 1 else None
+        for t in reversed(range(T)):
+            dc_in = dc[(t + 1) & 1] if t < T - 1 else None
+            ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
+            ops.split6(dz[t], out=dz6[t])
+            if t > 0:
+                if dh_rec is None:
+                    dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
+                ops.conv_raw([(dz6[t], rt6)], B, H, W, H, W, k, 1, 1, p, p, F, None, dh_rec)
+        rec['gates'] = None
+        dz_seq = dz.view(T * B, H, W, 4 * F)
+        dz6_seq = dz6.view(T * B, H, W, 24 * F)
+        hp6 = h6_all[:T].view(T * B, H, W, 6 * F)
+        x6s = x6.view(T * B, H, W, -1)
+        with self._wgrad_side(dz_seq, dz6_seq, hp6, x6s, x_seq):
+            ops.bias_grad(dz_seq, self.G[pre + '.bias'])       # exact fp32 column sums
+            self._x3_wgrad(hp6, dz6_seq, self.G[pre + '.recurrent_kernel'])
+            if 6 * Cin == x6s.shape[3] and ops.bf16_row_wgrad_ok(ops.split_piece(x6s, 'hi'), ops.split_piece(dz6_seq, 'hi'), k, 1):
+                self._x3_wgrad(x6s, dz6_seq, self.G[pre + '.kernel'])
+            else:      # thin image (or an odd channel count): the fp32 weight gradient, as in fp32 mode
+                ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
+        dx = None
+        if need_dx:
+            kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel))
+            dx = torch.empty((T * B, H, W, Cin), device=dev, dtype=torch.float32)
+            ops.conv_raw([(dz6_seq, kt6)], T * B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx)
+        rec['h_all'] = rec['c_all'] = rec['x'] = rec['x6'] = rec['h6_all'] = None
         return dx
 
     # ------------------------------------------------------------------ forward / backward

@@ -399,7 +399,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
     _chk(x_t, h_prev, c_prev, kernel.data if packed else kernel, rec.data if packed else rec, bias, h_out, c_out, gates_out,
          h16_out)
     frames, H, W, _ = x_t.shape
-    F = rec.shape[2]
+    F = rec.shape[3] // 4      # (not rec.shape[2]: precision 'bf16x3' lays the recurrent kernel's rows out six times)
     k = rec.shape[0]
     p = (k - 1) // 2
     # The fused epilogue cannot take a K split, so tile-starved steps (streaming inference: B = 1) run the conv with
@@ -416,7 +416,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
             srcs = [_src(x_t, kernel), _src(h_prev, rec)]
         with _timed(('conv_halo_frag_kernel<%d,LU_EPI_LSTM,*,bf16> (fused bf16-MFMA ConvLSTM step)' % k) if bf16 else
                     'conv_halo_kernel<%d,LU_EPI_LSTM> (fused ConvLSTM step: two-source implicit GEMM + gate epilogue)' % k,
-                    2.0 * k * k * (cin_flops + F) * 4 * F * frames * H * W):
+                    2.0 * k * k * (cin_flops + rec.shape[2]) * 4 * F * frames * H * W):
             calls.conv2d(lib(), _stream(), srcs, frames, H, W, H, W, k, 1, 1, p, p,
                          4 * F, _p(bias), None, 0, 0,
                          lstm=(c_prev.data_ptr(), c_prev.stride(0), c_out.data_ptr(), c_out.stride(0), h_out.data_ptr(),
@@ -473,6 +473,50 @@ def to_f32(x, out=None):
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     calls.check(lib(), lib().lu_convert_bf16_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'lu_convert_bf16_f32')
+    return out
+
+
+def split6(x, lp=None, out=None):
+    """fp32 activations [frames,H,W,C] -> the bf16 tensor [frames,H,W,6*lp] of precision 'bf16x3' (lu_split6, order A: blocks lo, mid,
+    hi, mid, hi, hi of the exact three-way bf16 split x = hi + mid + lo; channels [C, lp) of a block are zero).  Against weights
+    laid out by split6_weights a bf16 convolution over the 6*lp channels IS the fp32 convolution to 2^-26 per product."""
+    _chk(x, out)
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2) and \
+        x.stride(0) == x.shape[1] * x.stride(1), 'split6: dense pixel rows'
+    frames, H, W, Cc = x.shape
+    lp = Cc if lp is None else lp
+    if out is None:
+        out = torch.empty((frames, H, W, 6 * lp), device=x.device, dtype=torch.bfloat16)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape == (frames, H, W, 6 * lp)
+    calls.check(lib(), lib().lu_split6(x.data_ptr(), frames * H * W, Cc, x.stride(2), out.data_ptr(), 6 * lp, lp, 0, cabi.LU_BF16,
+                                       _stream()), 'lu_split6')
+    return out
+
+
+SPLIT_A = {'lo': 0, 'mid': 1, 'hi': 2}      # first block of an order-A tensor that holds each piece
+# the six products of precision 'bf16x3' as (piece of x, piece of dy), smallest first -- the order the channel blocks of a
+# split6 / split6_weights pair run through them
+SPLIT_TERMS = (('lo', 'hi'), ('mid', 'mid'), ('hi', 'lo'), ('mid', 'hi'), ('hi', 'mid'), ('hi', 'hi'))
+
+
+def split_piece(x6, piece):
+    """Channel-slice VIEW [frames,H,W,lp] of one piece ('hi', 'mid', 'lo') of a split6 tensor."""
+    lp = x6.shape[3] // 6
+    b = SPLIT_A[piece]
+    return x6[..., b * lp:(b + 1) * lp]
+
+
+def split6_weights(w, cp=None):
+    """fp32 kernel [k,k,C,N] (contiguous) -> fp32 [k,k,6*cp,N] holding the pieces of its three-way bf16 split in block order B
+    (hi, mid, lo, hi, mid, hi; rows [C, cp) of a block zero): every value is exactly representable in bf16, so
+    pack_bf16 of the result is the weight image that goes with split6 activations."""
+    _chk(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
+    k0, k1, Cc, N = w.shape
+    cp = Cc if cp is None else cp
+    out = torch.empty((k0, k1, 6 * cp, N), device=w.device, dtype=torch.float32)
+    calls.check(lib(), lib().lu_split6(w.data_ptr(), k0 * k1, Cc * N, Cc * N, out.data_ptr(), 6 * cp * N, cp * N, 1, cabi.LU_F32,
+                                       _stream()), 'lu_split6')
     return out
 
 

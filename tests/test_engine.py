@@ -689,3 +689,74 @@ def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precisi
         outs.append(got)
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+# precision 'bf16x3': two stacked ConvLSTMs at W = 32 -- the first reads the thin image (fp32 kernel gradient, zero-padded
+# split blocks), the second a 64-channel input (split kernel gradient, split input gradient); level 1 (F = 8) stays fp32
+X3_NET = {'down_conv_kernels': [[(3, 16)], [(3, 8)]], 'lstm_kernels': [[(3, 64), (5, 64)], [(3, 8)]],
+          'up_conv_kernels': [[(3, 16)], [(3, 16), (1, 3)]]}
+
+
+def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch):
+    """Engine(precision='bf16x3'): the ConvLSTM convolutions run the bf16-MFMA kernels on the exact three-way bf16 split of
+    their fp32 operands (six bf16 products per fp32 product, fp32 accumulation: 2^-26 per product).  The claim is fp32
+    ARITHMETIC, so the test is the fp32 engine's own: logits and every gradient tensor are compared with the fp64 oracle and
+    must sit where the fp32 engine sits (<= 2x its error + 1e-6), and the two engines agree to 2e-5 / 2e-4 -- two hundred
+    times closer than the bf16 mode's contract."""
+    from lu_native import calls, ops
+    from lu_native.engine import Engine
+    seen = []
+    real = calls.conv2d
+    monkeypatch.setattr(calls, 'conv2d', lambda *a, **k: (seen.append(k.get('precision', 0)), real(*a, **k))[1])
+    net, cin, B, T, H, W = X3_NET, 1, 1, 3, 8, 32
+    rng = np.random.default_rng(33)
+    p = perturbed_params(net, cin, 6)
+    x = rng.standard_normal((B, T, H, W, cin)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
+    cwt = torch.tensor([0.15, 0.25, 0.6], dtype=torch.float32, device=dev)
+    res = {}
+    for prec in ('fp32', 'bf16x3'):
+        del seen[:]
+        e = Engine(net, pad_image=False, precision=prec)
+        e.build(cin, dev)
+        e.load_params(p)
+        outs = []
+        for win in range(2):      # second window: carried state through state_begin + its split copy
+            lg = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, True)
+            g = torch.from_numpy(to_tb(gt[..., None])).to(dev).view(-1)
+            sums, _ = ops.wce_forward(lg.view(-1, 3), g, cwt, False)
+            e.backward(ops.wce_backward(lg.view(-1, 3), g, cwt, sums, 1.0).view(lg.shape))
+            outs.append((lg.cpu().numpy().astype(np.float64), {k: v.cpu().numpy().astype(np.float64) for k, v in e.G.items()}))
+            e.reset_states_per_batch(np.ones(B, np.float32))
+        inf = e.forward(torch.from_numpy(to_tb(x)).to(dev), T, B, False).cpu().numpy().astype(np.float64)      # inference route
+        res[prec] = (outs, inf)
+        n_bf16 = sum(seen)
+        # fused steps 2 layers x T x 2 windows (+ T inference) + recurrent gradients 2 x (T - 1) x 2 + one input gradient x 2
+        assert (n_bf16 == 0) if prec == 'fp32' else (n_bf16 >= 2 * T * 3 + 4 * (T - 1) + 2), (prec, n_bf16)
+    for win in range(2):
+        (l32, g32), (l3, g3) = res['fp32'][0][win], res['bf16x3'][0][win]
+        assert np.abs(l3 - l32).max() <= 2e-5 * np.abs(l32).max(), (win, np.abs(l3 - l32).max() / np.abs(l32).max())
+        fl = grad_floor(g32)
+        # (a conv bias in front of a BatchNorm has an exactly-zero true gradient: what either engine holds there is its own
+        # rounding noise -- 2e-6 of the largest gradient here -- and is left to the oracle comparison below, which has a floor)
+        def noise_only(k):
+            return '.conv.' in k and k.endswith('.bias') and k.replace('.conv.', '.bn.').replace('.bias', '.gamma') in g32
+        worst = max((float(np.linalg.norm(g3[k] - g32[k]) / max(np.linalg.norm(g32[k]), fl)), k) for k in g32 if not noise_only(k))
+        assert worst[0] <= 2e-4, (win, worst)
+    assert np.abs(res['bf16x3'][1] - res['fp32'][1]).max() <= 2e-5 * np.abs(res['fp32'][1]).max()
+    # against the fp64 oracle (first window: zero state): both engines at fp32 rounding distance
+    o = npo.model_forward(net, p, x, training=True, pad_image=False)['logits']
+    e32 = np.abs(from_tb(res['fp32'][0][0][0], B, T) - o).max()
+    e3 = np.abs(from_tb(res['bf16x3'][0][0][0], B, T) - o).max()
+    assert e3 <= 2.0 * e32 + 1e-6 * np.abs(o).max(), (e3, e32)
+    # ... and every gradient tensor of the first window against fp64 autograd (oracle/torch_oracle.py): the split engine's worst
+    # tensor within 2x the fp32 engine's worst (+ 1e-5 of the tensor scale)
+    tm = tho.TorchULSTM(net, cin, p, dtype=torch.float64)
+    _, _, gref = tm.train_step(x, gt, [0.15, 0.25, 0.6], lr=1e-3, apply=False)
+    gref = {k: v.numpy() for k, v in gref.items()}
+    fl = grad_floor(gref)
+    w32 = max(rel_err(res['fp32'][0][0][1][k], gref[k], fl) for k in gref)
+    w3 = max((rel_err(res['bf16x3'][0][0][1][k], gref[k], fl), k) for k in gref)
+    print('bf16x3 vs fp64 oracle: logits %.3e (fp32 engine %.3e), worst gradient tensor %.3e %s (fp32 engine %.3e)' %
+          (e3 / np.abs(o).max(), e32 / np.abs(o).max(), w3[0], w3[1], w32))
+    assert w3[0] <= 2.0 * w32 + 1e-5, (w3, w32)

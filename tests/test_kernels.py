@@ -1128,3 +1128,66 @@ def test_conv3_bf16_sources_tall_patch_equals_the_8_row_kernel(be):
         close(o16, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))
         o16g3 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16, bf16_src=(0,))
         close(o16g3, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+def np_split3(x):
+    """numpy restatement of the three-way bf16 split (lu_split6): x == hi + mid + lo exactly."""
+    x = f32(x)
+    hi = KH.bf16_round(x)
+    r1 = (x - hi).astype(np.float32)
+    mid = KH.bf16_round(r1)
+    lo = KH.bf16_round((r1 - mid).astype(np.float32))
+    return hi, mid, lo
+
+
+SPLIT_ORDER = {0: (2, 1, 0, 1, 0, 0), 1: (0, 1, 2, 0, 1, 0)}      # piece (0 hi, 1 mid, 2 lo) in block j of order A / B
+
+
+def split6_ref(x2d, lp, order):
+    rows, L = x2d.shape
+    pc = np_split3(x2d)
+    out = np.zeros((rows, 6, lp), np.float32)
+    for j, p in enumerate(SPLIT_ORDER[order]):
+        out[:, j, :L] = pc[p]
+    return out
+
+
+def test_split6_pieces_are_exact_and_in_block_order(be):
+    """lu_split6 (precision 'bf16x3'): the three bf16 pieces sum to the fp32 value EXACTLY, each block holds the piece its order
+    names, pad columns are zero; 16-byte and scalar forms, bf16 and fp32 outputs, strided rows."""
+    mags = np.exp(RNG.uniform(np.log(1e-12), np.log(1e12), size=(37, 16))) * RNG.choice([-1.0, 1.0], size=(37, 16))
+    xs = f32(mags)
+    xs[0, :4] = [0.0, -0.0, 1.0, np.float32(1.0) + np.float32(2.0 ** -23)]
+    xs[1, :4] = [3.0e38, -3.0e38, 1.17549435e-38 * 4096, 65504.0]
+    for (L, lp, xstride, ypad) in [(16, 16, 16, 0), (12, 12, 16, 8), (5, 8, 16, 0), (1, 4, 16, 4)]:
+        x2d = np.ascontiguousarray(xs[:, :L])
+        hi, mid, lo = np_split3(x2d)
+        assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x2d.astype(np.float64))
+        xd = be.dev(xs)      # rows of 16 floats; the kernel reads the first L of each
+        for order in (0, 1):
+            ref = split6_ref(x2d, lp, order)
+            ys = 6 * lp + ypad
+            yb = be.empty((37, ys), np.int16)
+            ck(be, be.lib.lu_split6(be.ptr(xd), 37, L, xstride, be.ptr(yb), ys, lp, order, cabi.LU_BF16, be.stream), 'split6 bf16')
+            got = KH.bf16_values(be.host(yb))[:, :6 * lp].reshape(37, 6, lp)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (L, lp, order)
+            yf = be.empty((37, ys))
+            ck(be, be.lib.lu_split6(be.ptr(xd), 37, L, xstride, be.ptr(yf), ys, lp, order, cabi.LU_F32, be.stream), 'split6 f32')
+            assert np.array_equal(be.host(yf)[:, :6 * lp].reshape(37, 6, lp).view(np.uint32), ref.view(np.uint32)), (L, lp, order)
+
+
+@pytest.mark.parametrize('k', [3, 5])
+def test_split6_convolution_on_the_bf16_kernels_is_fp32_arithmetic(be, k):
+    """A bf16-MFMA convolution over the six channel blocks of a split6 activation (order A) and a split6 kernel (order B) IS the
+    fp32 convolution: against the fp64 oracle it sits where the exact-fp32 MFMA kernel sits (<= 2x its error; 2^-26 per
+    product, fp32 accumulation), a hundred times below the plain bf16 kernel's rounding."""
+    fr, H, W, Cc, N = 1, 8, 32, 16, 128
+    x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
+    ref = npo.conv2d_same(x, w, b, 1)
+    e32 = np.abs(KH.conv2d(be, [x], [w], b, k, 1) - ref).max()
+    x6 = split6_ref(x.reshape(-1, Cc), Cc, 0).reshape(fr, H, W, 6 * Cc)
+    w6 = split6_ref(w.reshape(k * k, Cc * N), Cc * N, 1).reshape(k, k, 6 * Cc, N)
+    e6 = np.abs(KH.conv2d(be, [x6], [w6], b, k, 1, precision=1, bf16_src=(0,)) - ref).max()
+    e16 = np.abs(KH.conv2d(be, [x], [w], b, k, 1, precision=1) - ref).max()
+    print('split6 conv k=%d: |err| vs fp64  fp32 MFMA %.3e   bf16x3 %.3e   bf16 %.3e' % (k, e32, e6, e16))
+    assert e6 <= 2.0 * e32 + 1e-6 and e16 >= 100.0 * e6
