@@ -127,7 +127,7 @@ def measure_variant(net, precision, batches, B, T, H, W, dp, steps, warmup):
     ev, ops.EVENT_LOG = ops.EVENT_LOG, None
     rows, _ = summarize_events(ev)
     flops, fwd = step_flops(net, H, W, B, T)
-    peak = PEAK_FP32_MFMA_TFLOPS if precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == 'bf16' else PEAK_FP32_MFMA_TFLOPS
     del tr
     torch.cuda.empty_cache()
     return {'ms_per_step': round(1e3 * sec, 3), 'frames_per_s': round(B * T / sec, 3),
@@ -441,8 +441,13 @@ def main():
                     help='A/B: derived weight images one launch at a time per step, recurrent state copied / masked eagerly (before round 3)')
     ap.add_argument('--ab-old-tail', action='store_true',
                     help='A/B: bf16 mode with the decoder tail on the kernels of round 2 (gather / fp32 tiles, fp32 all-taps weight gradients)')
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
-                    help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else)")
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
+                    help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else); bf16x3: fp32 arithmetic "
+                         "on the bf16 MFMA (ConvLSTM convolutions on the exact three-way bf16 split of their fp32 operands)")
+    ap.add_argument('--no-x3', action='store_true', help='skip the secondary bf16x3-mode measurement of the same step')
+    ap.add_argument('--ab-x3-split-pass', action='store_true', help='A/B, bf16x3: a split6 pass over h per step instead of the gate epilogue writing it')
+    ap.add_argument('--ab-x3-wgrad6', action='store_true', help='A/B, bf16x3: one weight-gradient launch per product (six) instead of two launches with the terms as frames')
+    ap.add_argument('--wgrad-overlap', action='store_true', help='A/B: weight gradients on the side stream (the default in bf16 mode only)')
     ap.add_argument('--net', choices=list(NETS), default='params',
                     help='kernel-size variant (SURVEY D1): params = train2D.py default = the headline; default5 = 5x5 everywhere; '
                          'lstm3 = 3x3 ConvLSTM (north_star wording)')
@@ -501,6 +506,12 @@ def main():
     batches = synthetic_batches(4, B, T, H, W, dp.rank, dev)
     if args.no_wgrad_overlap:
         trainer.engine.overlap_wgrad = False
+    if args.wgrad_overlap:
+        trainer.engine.overlap_wgrad = True
+    if args.ab_x3_split_pass:
+        trainer.engine.x3_fused_split = False
+    if args.ab_x3_wgrad6:
+        trainer.engine.x3_wgrad_launches = 6
     if args.ab_f32_act:
         trainer.engine.act_bf16 = False
         trainer.engine.grad_bf16 = False
@@ -754,6 +765,24 @@ def main():
                  'what': 'same workload with --precision bf16: bf16 MFMA operands (v_mfma_f32_32x32x16_bf16) on the '
                          'convolutions and weight gradients, fp32 accumulate / master weights / state / optimiser'}
         del tr16
+    # ---- secondary: the same step with precision 'bf16x3' -- fp32 ARITHMETIC on the bf16 MFMA (exact three-way bf16 split of the
+    # ---- ConvLSTM operands, six bf16 products per fp32 product, fp32 accumulation; lu_native/engine.py), N = 1 only ----
+    split3 = None
+    if args.precision == 'fp32' and dp.world_size == 1 and not args.no_x3:
+        try:
+            del trainer
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        split3 = measure_variant(net, 'bf16x3', batches, B, T, H, W, dp, args.steps, args.warmup)
+        split3['what'] = ("same workload with --precision bf16x3: every ConvLSTM convolution (93 % of the FLOPs) on v_mfma_f32_32x32x16_bf16 "
+                          "over the exact three-way bf16 split of its fp32 operands -- x = hi + mid + lo, six bf16 products per fp32 product, "
+                          "each exact in the fp32 accumulator, the dropped ones below 2^-26 -- everything else on the fp32 kernels; nothing "
+                          "is stored rounded.  'step_tflops_achieved' / 'frac_of_fp32_mfma_peak' count the ALGORITHMIC fp32 FLOPs of the step "
+                          "(the MFMA pipe executes 6x that on the split layers: see mfma_kernels, priced against the bf16 peak)")
+        split3['frac_of_fp32_mfma_peak'] = round(split3['step_tflops_achieved'] / PEAK_FP32_MFMA_TFLOPS, 4)
+        split3.pop('frac_of_peak', None)
+        split3.pop('peak', None)
     # ---- the kernel-size variants SURVEY D1 asks to report beside the headline net (N = 1, default headline run only) ----
     variants = None
     if dp.world_size == 1 and args.net == 'params' and not args.no_variants:
@@ -778,11 +807,13 @@ def main():
             'metric': 'training frames/sec (seq_len*batch) at %dx%d' % (H, W),
             'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 as 3 x bf16 (exact split, 6 MFMA products, fp32 accumulate)'}[args.precision],
+            'data': 'synthetic',
             'config': {'workload': ('BASELINE config-2 per GPU: ' if (H, W, T, B, args.net) == (256, 256, 8, 4, 'params') else
                                     ('BASELINE config-4: ' if (H, W, T, B) == (832, 992, 16, 2) else '')) +
                                    '%dx%d, seq_len=%d, batch=%d slots/GPU, ConvLSTM-UNet %s, %s, random-init' %
                                    (H, W, T, B, NET_WORDS[args.net], 'fp32' if args.precision == 'fp32' else
+                                    'fp32 arithmetic, ConvLSTM convolutions as six bf16-MFMA products of the exact three-way bf16 split' if args.precision == 'bf16x3' else
                                     'bf16 MFMA operands on the wide stride-1 convs (fp32 master weights / accumulate / wgrad)'),
                        'net': args.net, 'global_batch': B * dp.world_size, 'seq_len': T,
                        'parallelism': 'dp%d' % dp.world_size, 'sync_bn': bool(args.sync_bn)},
@@ -794,6 +825,7 @@ def main():
             'allocator': allocator,
             'inference': infer,
             'bf16_mode': mixed,
+            'bf16x3_mode': split3,
             'variants': variants,
             'roofline': roofline, 'cpu_baseline': cpu,
         }

@@ -83,6 +83,9 @@ enum {
     LU_CONV_F_LOOP_GEN2 = 32768, /* bf16 halo kernel: the second loop generation (taps of a chunk kernel row by kernel row, one LDS fragment
                                   * read per MFMA) where the third (ABI v10: kernel column by kernel column, a halo row's fragment feeds up
                                   * to k MFMAs; another fp32 summation order, results agree to rounding) would be taken -- A/B, tests */
+    LU_CONV_F_H16_SPLIT = 65536, /* LU_EPI_LSTM, precision 1 (ABI v11): h16_out receives the lu_split6 image of h -- [pixel][6][F] bf16, channel blocks
+                                  * lo, mid, hi, mid, hi, hi of the exact three-way bf16 split -- instead of its rounded bf16 copy: the recurrent
+                                  * operand of the next step of precision 'bf16x3' (fp32 arithmetic on the bf16 MFMA) */
     LU_CONV_F_SPLIT_TAPS = 16384 /* precision 0 halo kernel with splits > 1: slices of ceil(k*k*chunks / splits) pipeline stages that may
                                   * begin on any tap of a chunk (the run-time counted loop of ABI <= v9) instead of whole 16-channel
                                   * chunks per slice on the compile-time tap sequence (the default since ABI v10 whenever every slice
@@ -233,6 +236,13 @@ typedef struct lu_wgrad_desc {
     int32_t x_dtype, dy_dtype;/* LU_F32 / LU_BF16: x / dy are bf16 tensors (precision 1, kernel-row bf16 variant only:
                                * stride-1 3x3 / 5x5, C >= 64, C % 8 == 0, N % 8 == 0, W % 32 == 0); strides in elements */
     int32_t flags;            /* LU_WGRAD_F_* */
+    int32_t terms;            /* 0 / 1: plain.  > 1 (ABI v11, precision 'bf16x3'; bf16 kernel-row variant, stride 1, bf16 operands only, no
+                               * dbias unless every piece of dy occurs exactly once): the sum runs over `terms` x `frames` frames -- frame f of
+                               * term t reads x at x + t * x_term_stride + f * x_frame_stride and dy at dy + t * dy_term_stride + f *
+                               * dy_frame_stride (strides in elements).  With the channel blocks of two lu_split6 tensors as the terms (x in
+                               * order 0, dy in order 1, term stride = one block) ONE launch sums the six bf16 products of the exact three-way
+                               * split: the fp32 weight gradient on the bf16 MFMA, accumulated inside the blocks instead of across launches. */
+    int64_t x_term_stride, dy_term_stride;
 } lu_wgrad_desc;
 
 enum {

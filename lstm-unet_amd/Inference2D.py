@@ -217,7 +217,7 @@ FLAGS = [
     (('--save_intermediate_path',), dict(dest='save_intermediate_path', type=str,
                                          help='Path to save intermediate files, used only with --save_intermediate')),
     (('--dry_run',), dict(dest='dry_run', action='store_const', const=True, help='Do not write any outputs')),
-    (('--precision',), dict(dest='precision', choices=['fp32', 'bf16'],
+    (('--precision',), dict(dest='precision', choices=['fp32', 'bf16', 'bf16x3'],
                             help='[MI355X] fp32 (default) or bf16 MFMA operands for the wide convolutions')),
     (('--resize',), dict(dest='resize', choices=['tf2.0', 'half_pixel'],
                          help='[MI355X] bilinear convention of the up blocks; default: what model_params.pickle recorded')),

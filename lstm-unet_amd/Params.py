@@ -66,7 +66,7 @@ _INFER_DEFAULTS = dict(
     data_reader=DataHandeling.CTCInferenceReader, data_format='NCHW',
     FOV=0, min_cell_size=10, max_cell_size=100, edge_dist=2, pre_sequence_frames=4,
     dry_run=False, save_intermediate=True, save_intermediate_path='./tmp/output/PhC-C2DL-PSC/01',
-    precision='fp32',      # MI355X option: 'bf16' = bf16 MFMA operands
+    precision='fp32',      # MI355X option: 'bf16' = bf16 MFMA operands; 'bf16x3' = fp32 arithmetic on the bf16 MFMA (exact 3-way split)
     resize=None,           # bilinear convention: None = what model_params.pickle recorded (else 'tf2.0'); 'tf2.0' / 'half_pixel' override
     fov_fix=False,         # MI355X option: True masks columns [0, FOV) instead of the reference's single column (Inference2D.py:97)
     graph=False,           # MI355X option: True replays the per-frame launch sequence from a captured hipGraph

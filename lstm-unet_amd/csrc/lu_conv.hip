@@ -68,6 +68,7 @@ struct ConvArgs {
     int32_t gates_bf16;    // LSTM epilogue of the fragment kernel: gates_out is bf16
     unsigned short* h16_out;   // ... optional bf16 copy of h
     int64_t h16_fs;
+    int32_t h16_split;     // ... (LU_CONV_F_H16_SPLIT) h16_out is the split6 image of h: [pixel][6][F], blocks lo, mid, hi, mid, hi, hi
     int32_t lstm_vec4;     // conv_halo_kernel, LSTM epilogue: every state / gate tensor 16-byte aligned -> float4 loads / stores through LDS
     int32_t out_vec4s;     // general kernel: as out_vec4, strided output rows (parity planes) allowed
     int32_t out_vec4;      // tile kernels, bias epilogue: dense 16-byte aligned output rows, N % 4 == 0 -> float4 stores through LDS
@@ -1312,7 +1313,26 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 #undef LU_GATE
             *reinterpret_cast<float4*>(a.c_out + (int64_t)f * a.c_out_fs + pix * F + ch) = cn;
             *reinterpret_cast<float4*>(a.h_out + (int64_t)f * a.h_fs + pix * F + ch) = hn;
-            if (a.h16_out) {
+            if (a.h16_out && a.h16_split) {
+                // precision 'bf16x3': the next step's recurrent operand = the exact three-way bf16 split of h, six channel blocks
+                // in order A (lu_split6) -- written here, where h is in registers, instead of by a pass over h per step
+                float4 hh, hm, hl;
+                lu_split3(hn.x, hh.x, hm.x, hl.x);
+                lu_split3(hn.y, hh.y, hm.y, hl.y);
+                lu_split3(hn.z, hh.z, hm.z, hl.z);
+                lu_split3(hn.w, hh.w, hm.w, hl.w);
+                lu_u2 vh, vm, vl;
+                vh.x = lu_pack2bf(hh.x, hh.y); vh.y = lu_pack2bf(hh.z, hh.w);
+                vm.x = lu_pack2bf(hm.x, hm.y); vm.y = lu_pack2bf(hm.z, hm.w);
+                vl.x = lu_pack2bf(hl.x, hl.y); vl.y = lu_pack2bf(hl.z, hl.w);
+                unsigned short* hp = a.h16_out + (int64_t)f * a.h16_fs + pix * (6 * F) + ch;
+                *reinterpret_cast<lu_u2*>(hp) = vl;
+                *reinterpret_cast<lu_u2*>(hp + F) = vm;
+                *reinterpret_cast<lu_u2*>(hp + 2 * F) = vh;
+                *reinterpret_cast<lu_u2*>(hp + 3 * F) = vm;
+                *reinterpret_cast<lu_u2*>(hp + 4 * F) = vh;
+                *reinterpret_cast<lu_u2*>(hp + 5 * F) = vh;
+            } else if (a.h16_out) {
                 lu_u2 hv;
                 hv.x = lu_pack2bf(hn.x, hn.y);
                 hv.y = lu_pack2bf(hn.z, hn.w);
@@ -2938,6 +2958,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
                        d->h_frame_stride % 4 == 0 && d->gates_frame_stride % 4 == 0) ? 1 : 0;
         a.h16_out = (unsigned short*)d->h16_out;
         a.h16_fs = d->h16_frame_stride;
+        a.h16_split = (d->flags & LU_CONV_F_H16_SPLIT) ? 1 : 0;
+        LU_REQUIRE(!a.h16_split || a.h16_out, "lu_conv2d_fwd: LU_CONV_F_H16_SPLIT needs h16_out");
         LU_REQUIRE((!a.gates_bf16 && !a.h16_out) || (d->precision == 1 && halo),
                    "lu_conv2d_fwd: the bf16 tape outputs (h16_out, LU_CONV_F_GATES_BF16) belong to the bf16 halo kernel");
         if (d->precision != 0 && halo)

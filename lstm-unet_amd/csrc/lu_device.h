@@ -207,3 +207,14 @@ __device__ __host__ static inline unsigned short lu_f2bf(float f) {
 #ifdef LU_EMU
 static inline unsigned lu_pack2bf(float lo, float hi) { return (unsigned)lu_f2bf(lo) | ((unsigned)lu_f2bf(hi) << 16); }
 #endif
+
+// Exact three-way bf16 split of an fp32 value (precision 'bf16x3', lu_split6): x == hi + mid + lo; both residuals are exact in fp32.
+__device__ __host__ static inline void lu_split3(float x, float& hi, float& mid, float& lo) {
+    unsigned u = (unsigned)lu_f2bf(x) << 16;
+    memcpy(&hi, &u, 4);
+    const float r1 = x - hi;
+    u = (unsigned)lu_f2bf(r1) << 16;
+    memcpy(&mid, &u, 4);
+    u = (unsigned)lu_f2bf(r1 - mid) << 16;
+    memcpy(&lo, &u, 4);
+}

@@ -247,12 +247,7 @@ __global__ void convert_bf16_f32_kernel(const unsigned short* __restrict__ x, fl
 //   x [rows][L] (row stride xs) -> y [rows][6][Lp] (row stride ys), zero for l in [L, Lp); OUT32: the pieces as fp32 values
 //   (weights on their way into the fragment packers, which round exactly-representable values without changing them).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split3(float x, float& hi, float& mid, float& lo) {
-    hi = lu_bits2f((unsigned)lu_f2bf(x) << 16);
-    const float r1 = x - hi;
-    mid = lu_bits2f((unsigned)lu_f2bf(r1) << 16);
-    lo = lu_bits2f((unsigned)lu_f2bf(r1 - mid) << 16);
-}
+__device__ __forceinline__ void split3(float x, float& hi, float& mid, float& lo) { lu_split3(x, hi, mid, lo); }
 __device__ __forceinline__ float split_pick(int piece, float hi, float mid, float lo) { return piece == 0 ? hi : (piece == 1 ? mid : lo); }
 // piece (0 hi, 1 mid, 2 lo) held by block j: order A = 2 1 0 1 0 0, order B = 0 1 2 0 1 0 (two bits per block, block 0 lowest)
 constexpr unsigned SPLIT_ORDER_A = 2u | (1u << 2) | (0u << 4) | (1u << 6) | (0u << 8) | (0u << 10);

@@ -36,6 +36,8 @@ struct WgradArgs {
     int32_t ragged, wst, rows_per;      // fp32 kernel-row variant, W % 16 != 0: slabs of whole rows, ceil(W / 16) runs per row
     const void* zero16; // device address of lu_zero16 (bf16 kernel-row variant: a kernel ARGUMENT lives in SGPRs; taken through the
                         // symbol it costs s_getpc + s_load + s_waitcnt lgkmcnt(0) -- which also drains the LDS reads -- per use)
+    int32_t tf;         // bf16 kernel-row variant, lu_wgrad_desc.terms > 1: frames per term (0: one term); M counts terms * tf frames
+    int64_t x_tj, y_tj; // ... what a term change adds to the element cursors on top of a frame step: term stride - tf * frame stride
 };
 
 template <int MF, int NF, int WM, int WN, bool THIN, bool YVEC>
@@ -655,6 +657,16 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
         oy = r / a.Wout;
         ox0 = r - oy * a.Wout;
     }
+    // terms (precision 'bf16x3'): frame pf of the launch is frame pf % tf of term pf / tf; a term change is a frame step plus a
+    // constant (x_tj / y_tj), counted down at the frame wraps -- nothing per stage
+    int tleft = 0x7fffffff;
+    int64_t xterm0 = 0, yterm0 = 0;
+    if (a.tf > 0) {
+        const int term = (int)(pf / a.tf);
+        tleft = a.tf - (int)(pf - (int64_t)term * a.tf);
+        xterm0 = term * a.x_tj;
+        yterm0 = term * a.y_tj;
+    }
     // The bias gradient (column sums of the dy tile) is shared out over the K * c_tiles blocks that stream the SAME dy tile:
     // block `bslot` takes the stages s with s % brc == bslot.  (One block doing all of it runs a few percent behind its
     // siblings, the group stops sharing dy / x in L2 and the launch's fabric traffic doubles: 3.2 -> 5.3 GB measured.)
@@ -691,8 +703,8 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
             yvo[i] = yr * a.dy_ps + YE * q;
             ybits |= (n0 + YE * q < a.N ? 1u : 0u) << i;
         }
-        xcur = pf * a.x_fs + ((int64_t)(oy + kh - a.pad_t) * a.Win + (ox0 - a.pad_l)) * a.x_ps + c0;
-        ycur = pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n0;
+        xcur = pf * a.x_fs + xterm0 + ((int64_t)(oy + kh - a.pad_t) * a.Win + (ox0 - a.pad_l)) * a.x_ps + c0;
+        ycur = pf * a.dy_fs + yterm0 + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n0;
     }
     const int64_t x_gap = a.x_fs - (int64_t)a.HWo * a.x_ps, y_gap = a.dy_fs - (int64_t)a.HWo * a.dy_ps;      // (S == 1: Hin * Win == HWo)
     const lu_u4* const zpa = zp;
@@ -730,6 +742,11 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
                     ++pf;
                     xcur += x_gap;
                     ycur += y_gap;
+                    if (--tleft == 0) {      // (terms: the next frame belongs to the next term)
+                        tleft = a.tf;
+                        xcur += a.x_tj;
+                        ycur += a.y_tj;
+                    }
                 }
             }
             return;
@@ -961,6 +978,11 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
                 ++pf;
                 xcur += x_gap;
                 ycur += y_gap;
+                if (--tleft == 0) {
+                    tleft = a.tf;
+                    xcur += a.x_tj;
+                    ycur += a.y_tj;
+                }
             }
         }
     };
@@ -1466,7 +1488,13 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.dy_ps = d->dy_pix_stride;
     a.C = d->C;
     a.N = d->N;
-    a.M = (int64_t)d->frames * d->Hout * d->Wout;
+    const int terms = d->terms > 1 ? d->terms : 1;
+    a.M = (int64_t)d->frames * terms * d->Hout * d->Wout;
+    if (terms > 1) {
+        a.tf = d->frames;
+        a.x_tj = d->x_term_stride - (int64_t)d->frames * d->x_frame_stride;
+        a.y_tj = d->dy_term_stride - (int64_t)d->frames * d->dy_frame_stride;
+    }
     a.chunk = ((a.M + splits - 1) / splits + 63) / 64 * 64;     // multiple of every kernel's pixel run (16 / 32 / 64)
     a.HWo = d->Hout * d->Wout;
     a.Wout = d->Wout;
@@ -1518,6 +1546,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     LU_REQUIRE((!xb && !yb) || row_bf16,
                "lu_conv2d_wgrad: bf16 operands need the bf16 kernel-row variant (precision 1, stride-1 3x3 / 5x5 with C >= 64 or 1x1 with C >= 32, "
                "C %% 8 == 0, N %% 8 == 0, W %% 32 == 0, 16-byte aligned)");
+    LU_REQUIRE(terms == 1 || (row_bf16 && row_variant && xb && yb && d->x_term_stride % 8 == 0 && d->dy_term_stride % 8 == 0),
+               "lu_conv2d_wgrad: terms > 1 belongs to the bf16 kernel-row variant on bf16 operands (stride-1 3x3 / 5x5, C >= 64, W %% 32 == 0)");
     LU_REQUIRE(!d->dbias || row_variant || small3 || (row_s2 && row_bf16),
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");

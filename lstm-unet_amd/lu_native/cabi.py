@@ -17,6 +17,7 @@ LU_CONV_F_NO_NARROW = 4096
 LU_CONV_F_HALF_BLOCK = 8192
 LU_CONV_F_SPLIT_TAPS = 16384
 LU_CONV_F_LOOP_GEN2 = 32768
+LU_CONV_F_H16_SPLIT = 65536
 LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE, LU_WGRAD_F_PRB32 = 1, 2, 4, 8, 16, 32
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128
@@ -55,7 +56,8 @@ class WgradDesc(C.Structure):
                 ('k', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
                 ('dw', c_f32p), ('dw_tap_stride', i64), ('dw_row_stride', i32), ('splits', i32),
                 ('beta', f32), ('precision', i32), ('workspace', C.c_void_p),
-                ('dbias', c_f32p), ('dbias_beta', f32), ('phase', i32), ('x_dtype', i32), ('dy_dtype', i32), ('flags', i32)]
+                ('dbias', c_f32p), ('dbias_beta', f32), ('phase', i32), ('x_dtype', i32), ('dy_dtype', i32), ('flags', i32),
+                ('terms', i32), ('x_term_stride', i64), ('dy_term_stride', i64)]
 
 
 class PrepOp(C.Structure):      # lu_prep_op: one flip (kind 0) / bf16 pack (kind 1) of lu_weight_prep_batch's device table

@@ -178,8 +178,9 @@ def conv2d(lib, stream, srcs, frames, Hin, Win, Hout, Wout, k, stride, dil, pad_
 
 def wgrad_desc(x, x_fs, x_ps, Cin, dy, dy_fs, dy_ps, N, frames, Hin, Win, Hout, Wout, k, stride, pad_t, pad_l,
                dw, dw_tap_stride, dw_row_stride, splits, beta, precision=0, dbias=None, dbias_beta=0.0,
-               x_dtype=cabi.LU_F32, dy_dtype=cabi.LU_F32, flags=0):
+               x_dtype=cabi.LU_F32, dy_dtype=cabi.LU_F32, flags=0, terms=0, x_term_stride=0, dy_term_stride=0):
     d = cabi.WgradDesc()
+    d.terms, d.x_term_stride, d.dy_term_stride = terms, x_term_stride, dy_term_stride
     d.x, d.x_frame_stride, d.x_pix_stride, d.C = x, x_fs, x_ps, Cin
     d.dy, d.dy_frame_stride, d.dy_pix_stride, d.N = dy, dy_fs, dy_ps, N
     d.frames, d.Hin, d.Win, d.Hout, d.Wout = frames, Hin, Win, Hout, Wout

@@ -119,6 +119,8 @@ class Engine:
         self.s2_fwd_bf16 = True      # stride-2 forward convs behind a ConvLSTM read its bf16 copy (A/B: bench.py --conv-flags 4096 turns it off)
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
+        self.x3_wgrad_launches = 2   # precision 'bf16x3': the six products of a weight gradient in two launches with the terms as frames (A/B: 6)
+        self.x3_fused_split = True   # precision 'bf16x3': the gate epilogue writes the split image of h (A/B: False = a split6 pass per step)
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
                                          # tensors instead of adopting the step's output tensors as the state
 
@@ -679,9 +681,10 @@ class Engine:
         return (self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and W % 32 == 0 and
                 ops.fused_step_applies(B, H, W, F, True))
 
-    def _x3_weight(self, name, role, make, cp=None):
-        """bf16 fragment image of the three-way split of a kernel (block order B), once per weight change."""
-        return self._pack(name, role, lambda: ops.split6_weights(make(), cp))
+    def _x3_weight(self, name, role, make, cp=None, order=1):
+        """bf16 fragment image of the three-way split of a kernel (block order B; A for the kernels that meet dz, which is
+        split in order B), once per weight change."""
+        return self._pack(name, role, lambda: ops.split6_weights(make(), cp, order))
 
     def _lstm_forward_x3(self, bi, li, spec, x_seq, T, B, tape):
         """The ConvLSTM layer of precision 'bf16x3' (reference Networks.py:48-50,62-63; the fp32 form: _lstm_forward).  x_t and
@@ -712,9 +715,10 @@ class Engine:
             hit = self._state16.get((bi, li))
             h6 = hit[1] if (hit is not None and hit[0] is h_prev) else ops.split6(h_prev)
             for t in range(T):
-                ops.convlstm_step(x6[t], h6, c_prev, k6, r6, bias, h_seq[t], c_seq[t], None)
+                h6_next = torch.empty((B, H, W, 6 * F), device=dev, dtype=torch.bfloat16) if self.x3_fused_split else None
+                ops.convlstm_step(x6[t], h6, c_prev, k6, r6, bias, h_seq[t], c_seq[t], None, h6_out=h6_next)
                 h_prev, c_prev = h_seq[t], c_seq[t]
-                h6 = ops.split6(h_prev)
+                h6 = h6_next if h6_next is not None else ops.split6(h_prev)
             if self.persistent_states and st is not None:
                 st[0].copy_(h_prev)
                 st[1].copy_(c_prev)
@@ -735,8 +739,11 @@ class Engine:
         ops.split6(h_all[0], out=h6_all[0])
         gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32)
         for t in range(T):
-            ops.convlstm_step(x6[t], h6_all[t], c_all[t], k6, r6, bias, h_all[t + 1], c_all[t + 1], gates[t])
-            if t + 1 < T:
+            # (the gate epilogue writes the split image of h_t next to h_t: LU_CONV_F_H16_SPLIT; A/B: x3_fused_split = False)
+            fused = self.x3_fused_split and t + 1 < T
+            ops.convlstm_step(x6[t], h6_all[t], c_all[t], k6, r6, bias, h_all[t + 1], c_all[t + 1], gates[t],
+                              h6_out=h6_all[t + 1] if fused else None)
+            if t + 1 < T and not fused:
                 ops.split6(h_all[t + 1], out=h6_all[t + 1])
         self._states[bi][li] = [h_all[T], c_all[T]]
         self._alias.add((bi, li))
@@ -746,11 +753,20 @@ class Engine:
         self._h16_seq = None
         return h_all[1:].view(T * B, H, W, F)
 
-    def _x3_wgrad(self, x6, dy6, dw):
-        """dw = x (*) dy on the split operands: the six products of ops.SPLIT_TERMS as six launches of the bf16 kernel-row weight
-        gradient on channel-slice views of the two split6 tensors, smallest term first, accumulated in fp32 (beta = 1)."""
-        for i, (px, py) in enumerate(ops.SPLIT_TERMS):
-            ops.conv2d_wgrad(ops.split_piece(x6, px), ops.split_piece(dy6, py), dw, 1, beta=0.0 if i == 0 else 1.0, bf16=True)
+    def _x3_wgrad(self, x6, dy6, dw, dbias=None):
+        """dw = x (*) dy on the split operands (x6 in order A, dy6 in order B: block t against block t is term t of
+        ops.SPLIT_TERMS).  Two launches of the bf16 kernel-row weight gradient with the terms as extra frames
+        (lu_wgrad_desc.terms): the three small products -- whose dy blocks are hi, mid, lo, i.e. dy itself, so the bias gradient
+        rides on this launch as the column sums of the three pieces -- then the three large ones on top (beta = 1).
+        x3_wgrad_launches = 6: one launch per product on channel-slice views (the first form, A/B)."""
+        if self.x3_wgrad_launches == 6:
+            lp, ln = x6.shape[3] // 6, dy6.shape[3] // 6
+            for t in range(6):
+                ops.conv2d_wgrad(x6[..., t * lp:(t + 1) * lp], dy6[..., t * ln:(t + 1) * ln], dw, 1, beta=0.0 if t == 0 else 1.0,
+                                 bf16=True, dbias=dbias if t < 3 else None, dbias_beta=0.0 if t == 0 else 1.0)
+            return
+        ops.conv2d_wgrad(x6, dy6, dw, 1, beta=0.0, bf16=True, dbias=dbias, terms=(0, 3))
+        ops.conv2d_wgrad(x6, dy6, dw, 1, beta=1.0, bf16=True, terms=(3, 3))
 
     def _lstm_backward_x3(self, rec, dh_seq, need_dx):
         """BPTT of a 'bf16x3' ConvLSTM layer: the fp32 gate backward, then every convolution of the fp32 path -- the recurrent
@@ -770,11 +786,11 @@ class Engine:
         dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
         dh_rec = None
         self._sync_weight_images()
-        rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k)) if T > 1 else None
+        rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k), order=0) if T > 1 else None
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
             ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
-            ops.split6(dz[t], out=dz6[t])
+            ops.split6(dz[t], out=dz6[t], order=1)      # (order B: block t of dz6 meets block t of the order-A x6 / h6 in the weight gradients)
             if t > 0:
                 if dh_rec is None:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
@@ -785,15 +801,15 @@ class Engine:
         hp6 = h6_all[:T].view(T * B, H, W, 6 * F)
         x6s = x6.view(T * B, H, W, -1)
         with self._wgrad_side(dz_seq, dz6_seq, hp6, x6s, x_seq):
-            ops.bias_grad(dz_seq, self.G[pre + '.bias'])       # exact fp32 column sums
-            self._x3_wgrad(hp6, dz6_seq, self.G[pre + '.recurrent_kernel'])
+            # (+ the bias gradient: the column sums of the hi, mid and lo blocks of dz6 add up to those of dz)
+            self._x3_wgrad(hp6, dz6_seq, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'])
             if 6 * Cin == x6s.shape[3] and ops.bf16_row_wgrad_ok(ops.split_piece(x6s, 'hi'), ops.split_piece(dz6_seq, 'hi'), k, 1):
                 self._x3_wgrad(x6s, dz6_seq, self.G[pre + '.kernel'])
             else:      # thin image (or an odd channel count): the fp32 weight gradient, as in fp32 mode
                 ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
         dx = None
         if need_dx:
-            kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel))
+            kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0)
             dx = torch.empty((T * B, H, W, Cin), device=dev, dtype=torch.float32)
             ops.conv_raw([(dz6_seq, kt6)], T * B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx)
         rec['h_all'] = rec['c_all'] = rec['x'] = rec['x6'] = rec['h6_all'] = None

@@ -325,12 +325,21 @@ def bf16_row_wgrad_ok(x, dy, k, stride):
             Hout == Hin and Wout == Win and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
 
 
-def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta=0.0):
+def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta=0.0, terms=None):
     """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy.
     dbias (optional [N]): the layer's bias gradient = column sums of dy -- summed on the side by the kernel-row wgrad
     kernels where they apply, by a separate lu_colsum pass elsewhere.
-    x / dy may be bf16 tensors (the bf16 BPTT tape) when the bf16 kernel-row variant applies (bf16_row_wgrad_ok)."""
+    x / dy may be bf16 tensors (the bf16 BPTT tape) when the bf16 kernel-row variant applies (bf16_row_wgrad_ok).
+    terms = (first block, count) with x / dy split6 tensors (x in order A, dy in order B; precision 'bf16x3'): ONE launch sums
+    block t of x against block t of dy for the `count` blocks from `first` on -- lu_wgrad_desc.terms; dbias then is the column sum
+    of those dy blocks (the first three of order B are hi, mid, lo: exactly dy)."""
     _chk(x, dy, dw, dbias)
+    n_terms, xts, yts = 0, 0, 0
+    if terms is not None:
+        first, n_terms = terms
+        assert x.dtype == dy.dtype == torch.bfloat16 and x.shape[3] % 6 == 0 and dy.shape[3] % 6 == 0 and first + n_terms <= 6
+        xts, yts = x.shape[3] // 6, dy.shape[3] // 6
+        x, dy = x[..., first * xts:(first + 1) * xts], dy[..., first * yts:(first + 1) * yts]
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     k = dw.shape[0]
@@ -359,7 +368,7 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
             (128 if (Cin % 128 == 0 or Cin > 256) else 64)
         all_taps = (k == 3 and stride == 1 and Cin >= 64 and      # mirrors lu_conv2d_wgrad: the all-taps form of the 3x3 layers
                     not (WGRAD_FLAGS & (cabi.LU_WGRAD_F_NO_TAPS9 | cabi.LU_WGRAD_F_CT64 | cabi.LU_WGRAD_F_CT128)))
-        splits = calls.wgrad_splits_bf16_row(frames * Hout * Wout, k, Cin, N, ct, all_taps=all_taps)
+        splits = calls.wgrad_splits_bf16_row(frames * max(1, n_terms) * Hout * Wout, k, Cin, N, ct, all_taps=all_taps)
     else:
         splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
                                     target_blocks=3072)      # re-measured after the kernel-row variants: ~3000 blocks >= 6000
@@ -368,7 +377,9 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
                          splits, beta, precision=1 if bf16 else 0,
                          dbias=dbias.data_ptr() if (dbias is not None and (row_variant or small3)) else None,
                          dbias_beta=dbias_beta, x_dtype=cabi.LU_BF16 if xb else cabi.LU_F32,
-                         dy_dtype=cabi.LU_BF16 if yb else cabi.LU_F32, flags=WGRAD_FLAGS)
+                         dy_dtype=cabi.LU_BF16 if yb else cabi.LU_F32, flags=WGRAD_FLAGS, terms=n_terms, x_term_stride=xts,
+                         dy_term_stride=yts)
+    assert n_terms == 0 or (bf16_row and stride == 1 and k in (3, 5)), 'terms: the bf16 kernel-row weight gradient, stride 1'
     if dbias is not None and not (row_variant or small3):
         bias_grad(dy, dbias, dbias_beta)
     nbytes = lib().lu_conv2d_wgrad_workspace_bytes(C.byref(d))
@@ -381,23 +392,25 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
         kind = 'wgrad_row_bf16_kernel<%d> (bf16-MFMA weight gradients hoisted over T)' % k
     if EVENT_LOG is not None:      # bench.py's roofline pass: time the MFMA kernel alone, the slab reduce outside the bracket
         d.phase = 1
-        with _timed(kind, 2.0 * k * k * Cin * N * frames * Hout * Wout):
+        with _timed(kind, 2.0 * k * k * Cin * N * frames * max(1, n_terms) * Hout * Wout):
             calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
         d.phase = 2
     calls.check(lib(), lib().lu_conv2d_wgrad(C.byref(d), _stream()), 'lu_conv2d_wgrad')
     return dw
 
 
-def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out, h16_out=None, x_center=False):
+def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_out, h16_out=None, x_center=False, h6_out=None):
     """One ConvLSTM2D cell step (reference Networks.py:48-50,62-63).  Fused two-source conv + gate
     epilogue when F % 32 == 0, otherwise conv -> pre-activations -> gate kernel.
     bf16 mode extras (fused bf16 kernel only): h_prev may be the bf16 copy of the previous hidden state, h16_out receives
     the bf16 copy of the new one, gates_out may be a bf16 tensor (the bf16 BPTT tape), and with x_center=True x_t is the
-    im2col image of a thin input (ops.im2col_bf16) whose kernel was packed as ONE tap."""
+    im2col image of a thin input (ops.im2col_bf16) whose kernel was packed as ONE tap.
+    precision 'bf16x3' (fused bf16 kernel on split6 operands): h6_out receives the split6 image of the new hidden state
+    ([frames,H,W,6F] bf16, LU_CONV_F_H16_SPLIT) -- the next step's recurrent operand, written by the gate epilogue."""
     packed = isinstance(kernel, PackedW)
     bf16 = packed and kernel.precision == 1
     _chk(x_t, h_prev, c_prev, kernel.data if packed else kernel, rec.data if packed else rec, bias, h_out, c_out, gates_out,
-         h16_out)
+         h16_out, h6_out)
     frames, H, W, _ = x_t.shape
     F = rec.shape[3] // 4      # (not rec.shape[2]: precision 'bf16x3' lays the recurrent kernel's rows out six times)
     k = rec.shape[0]
@@ -408,6 +421,11 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
         flags = CONV_FLAGS
         if gates_out is not None and gates_out.dtype == torch.bfloat16:
             flags |= cabi.LU_CONV_F_GATES_BF16
+        if h6_out is not None:
+            assert bf16 and h16_out is None and h6_out.dtype == torch.bfloat16 and h6_out.is_contiguous() and \
+                h6_out.shape == (frames, H, W, 6 * F)
+            flags |= cabi.LU_CONV_F_H16_SPLIT
+            h16_out = h6_out
         cin_flops = kernel.shape[2] * (kernel.shape[0] * kernel.shape[1]) / float(k * k)
         if x_center:       # the hidden state goes first: the centre-tap image chunk is the last pipeline stage
             flags |= cabi.LU_CONV_F_SRC1_CENTER
@@ -424,7 +442,7 @@ def convlstm_step(x_t, h_prev, c_prev, kernel, rec, bias, h_out, c_out, gates_ou
                          precision=kernel.precision if packed else 0, flags=flags,
                          h16=None if h16_out is None else (h16_out.data_ptr(), h16_out.stride(0)))
     else:
-        assert h16_out is None and not x_center and h_prev.dtype == torch.float32 and \
+        assert h16_out is None and h6_out is None and not x_center and h_prev.dtype == torch.float32 and \
             (gates_out is None or gates_out.dtype == torch.float32), 'the bf16 tape belongs to the fused bf16 step'
         assert c_prev.is_contiguous() and c_out.is_contiguous()
         # K-split steps hand their partial slabs straight to the gate kernel (one pass over z less than reduce + gates)
@@ -476,10 +494,12 @@ def to_f32(x, out=None):
     return out
 
 
-def split6(x, lp=None, out=None):
-    """fp32 activations [frames,H,W,C] -> the bf16 tensor [frames,H,W,6*lp] of precision 'bf16x3' (lu_split6, order A: blocks lo, mid,
-    hi, mid, hi, hi of the exact three-way bf16 split x = hi + mid + lo; channels [C, lp) of a block are zero).  Against weights
-    laid out by split6_weights a bf16 convolution over the 6*lp channels IS the fp32 convolution to 2^-26 per product."""
+def split6(x, lp=None, out=None, order=0):
+    """fp32 activations [frames,H,W,C] -> the bf16 tensor [frames,H,W,6*lp] of precision 'bf16x3' (lu_split6; order 0 = A: blocks lo,
+    mid, hi, mid, hi, hi of the exact three-way bf16 split x = hi + mid + lo; order 1 = B: hi, mid, lo, hi, mid, hi; channels
+    [C, lp) of a block are zero).  Against weights laid out by split6_weights in the OTHER order a bf16 convolution over the
+    6*lp channels IS the fp32 convolution to 2^-26 per product; block t of an order-A tensor against block t of an order-B tensor
+    is term t of ops.SPLIT_TERMS (conv2d_wgrad(..., terms=...))."""
     _chk(x, out)
     assert x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1 and x.stride(1) == x.shape[2] * x.stride(2) and \
         x.stride(0) == x.shape[1] * x.stride(1), 'split6: dense pixel rows'
@@ -488,12 +508,14 @@ def split6(x, lp=None, out=None):
     if out is None:
         out = torch.empty((frames, H, W, 6 * lp), device=x.device, dtype=torch.bfloat16)
     assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape == (frames, H, W, 6 * lp)
-    calls.check(lib(), lib().lu_split6(x.data_ptr(), frames * H * W, Cc, x.stride(2), out.data_ptr(), 6 * lp, lp, 0, cabi.LU_BF16,
-                                       _stream()), 'lu_split6')
+    with _timed('hbm:split6_kernel (bf16x3: three-way bf16 split of an activation, 1 fp32 read + 6 bf16 writes)',
+                (4.0 * Cc + 12.0 * lp) * frames * H * W):
+        calls.check(lib(), lib().lu_split6(x.data_ptr(), frames * H * W, Cc, x.stride(2), out.data_ptr(), 6 * lp, lp, int(order),
+                                           cabi.LU_BF16, _stream()), 'lu_split6')
     return out
 
 
-SPLIT_A = {'lo': 0, 'mid': 1, 'hi': 2}      # first block of an order-A tensor that holds each piece
+SPLIT_A = {'lo': 0, 'mid': 1, 'hi': 2}      # first block of an order-A tensor that holds each piece (order B: hi 0, mid 1, lo 2)
 # the six products of precision 'bf16x3' as (piece of x, piece of dy), smallest first -- the order the channel blocks of a
 # split6 / split6_weights pair run through them
 SPLIT_TERMS = (('lo', 'hi'), ('mid', 'mid'), ('hi', 'lo'), ('mid', 'hi'), ('hi', 'mid'), ('hi', 'hi'))
@@ -506,16 +528,16 @@ def split_piece(x6, piece):
     return x6[..., b * lp:(b + 1) * lp]
 
 
-def split6_weights(w, cp=None):
+def split6_weights(w, cp=None, order=1):
     """fp32 kernel [k,k,C,N] (contiguous) -> fp32 [k,k,6*cp,N] holding the pieces of its three-way bf16 split in block order B
-    (hi, mid, lo, hi, mid, hi; rows [C, cp) of a block zero): every value is exactly representable in bf16, so
-    pack_bf16 of the result is the weight image that goes with split6 activations."""
+    (hi, mid, lo, hi, mid, hi; rows [C, cp) of a block zero; order=0: A, for activations split in order B): every value is exactly
+    representable in bf16, so pack_bf16 of the result is the weight image that goes with split6 activations."""
     _chk(w)
     assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
     k0, k1, Cc, N = w.shape
     cp = Cc if cp is None else cp
     out = torch.empty((k0, k1, 6 * cp, N), device=w.device, dtype=torch.float32)
-    calls.check(lib(), lib().lu_split6(w.data_ptr(), k0 * k1, Cc * N, Cc * N, out.data_ptr(), 6 * cp * N, cp * N, 1, cabi.LU_F32,
+    calls.check(lib(), lib().lu_split6(w.data_ptr(), k0 * k1, Cc * N, Cc * N, out.data_ptr(), 6 * cp * N, cp * N, int(order), cabi.LU_F32,
                                        _stream()), 'lu_split6')
     return out
 

@@ -490,7 +490,7 @@ def build_arg_parser():
     parser.add_argument('--data_provider', dest='data_provider', choices=['synthetic', 'ctc'],
                         help='[MI355X] synthetic clips (default) or the Cell-Tracking-Challenge RAM reader over '
                              '--root_data_dir / --train_sequence_list (needs the metadata_<seq>.pickle files)')
-    parser.add_argument('--precision', dest='precision', choices=['fp32', 'bf16'],
+    parser.add_argument('--precision', dest='precision', choices=['fp32', 'bf16', 'bf16x3'],
                         help='[MI355X] fp32 (default) or bf16-MFMA operands for the wide stride-1 convolutions')
     parser.add_argument('--resize', dest='resize', choices=['tf2.0', 'half_pixel'],
                         help="[MI355X] bilinear convention of the up blocks: 'tf2.0' (default; TensorFlow 2.0 / 2.1, the release the "

@@ -235,9 +235,29 @@ def conv2d_dgrad(be, dy, w, in_hw, stride):
 
 
 def conv2d_wgrad(be, x, dy, k, stride, splits=1, dw0=None, beta=0.0, precision=0, dbias0=None, dbias_beta=0.0, flags=0,
-                 x_bf16=False, dy_bf16=False):
+                 x_bf16=False, dy_bf16=False, terms=None):
     """-> dw, or (dw, dbias) when dbias0 (initial contents of the bias-gradient buffer) is given.
-    x_bf16 / dy_bf16: hand the operand over as a bf16 tensor (the bf16 BPTT tape)."""
+    x_bf16 / dy_bf16: hand the operand over as a bf16 tensor (the bf16 BPTT tape).
+    terms = (first, count): x / dy are split6 tensors [frames,H,W,6*C] / [.., 6*N] (bf16); the launch sums blocks first ..
+    first + count - 1 of x against the same blocks of dy (lu_wgrad_desc.terms)."""
+    if terms is not None:
+        first, cnt = terms
+        frames, Hin, Win, C6 = x.shape
+        _, Hout, Wout, N6 = dy.shape
+        Cin, N = C6 // 6, N6 // 6
+        _, pt, _ = calls.same_pad(Hin, k, stride)
+        _, pl, _ = calls.same_pad(Win, k, stride)
+        dw = be.empty((k, k, Cin, N)) if dw0 is None else be.dev(dw0)
+        xd, dyd = be.dev(bf16_bits(x), np.int16), be.dev(bf16_bits(dy), np.int16)
+        db = None if dbias0 is None else be.dev(dbias0)
+        d = calls.wgrad_desc(be.ptr(xd, first * Cin), Hin * Win * C6, C6, Cin, be.ptr(dyd, first * N), Hout * Wout * N6, N6, N, frames,
+                             Hin, Win, Hout, Wout, k, stride, pt, pl, be.ptr(dw), Cin * N, N, splits, beta, precision=1,
+                             dbias=be.ptr(db), dbias_beta=dbias_beta, x_dtype=cabi.LU_BF16, dy_dtype=cabi.LU_BF16, flags=flags,
+                             terms=cnt, x_term_stride=Cin, dy_term_stride=N)
+        ws = be.empty((be.lib.lu_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4 + 4,))
+        d.workspace = be.ptr(ws)
+        calls.check(be.lib, be.lib.lu_conv2d_wgrad(C.byref(d), be.stream), 'wgrad terms')
+        return be.host(dw) if db is None else (be.host(dw), be.host(db))
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
     _, pt, _ = calls.same_pad(Hin, k, stride)

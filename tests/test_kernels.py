@@ -1191,3 +1191,26 @@ def test_split6_convolution_on_the_bf16_kernels_is_fp32_arithmetic(be, k):
     e16 = np.abs(KH.conv2d(be, [x], [w], b, k, 1, precision=1) - ref).max()
     print('split6 conv k=%d: |err| vs fp64  fp32 MFMA %.3e   bf16x3 %.3e   bf16 %.3e' % (k, e32, e6, e16))
     assert e6 <= 2.0 * e32 + 1e-6 and e16 >= 100.0 * e6
+
+
+@pytest.mark.parametrize('case', [(5, 2, 4, 32, 64, 128, 3), (3, 3, 4, 64, 64, 128, 5), (5, 1, 8, 32, 128, 128, 1)])
+def test_split6_weight_gradient_with_the_terms_as_frames_is_fp32_arithmetic(be, case):
+    """lu_wgrad_desc.terms: ONE launch of the bf16 kernel-row weight gradient sums block t of a split6 x (order A) against block t
+    of a split6 dy (order B) over the terms -- pixel slabs that begin inside any term (splits > 1), the two-launch form of the
+    engine (terms 0-2 with the bias gradient = column sums of hi + mid + lo = dy, then terms 3-5 on top) -- and the result is the
+    fp32 weight gradient: against the fp64 oracle it sits where the exact-fp32 kernel sits, far below the bf16 kernel."""
+    k, fr, H, W, Cc, N, splits = case
+    x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N, scale=0.3)
+    _, ref = _torch_conv_grads(x, np.zeros((k, k, Cc, N), np.float32), dy, 1)
+    x6 = split6_ref(x.reshape(-1, Cc), Cc, 0).reshape(fr, H, W, 6 * Cc)
+    dy6 = split6_ref(dy.reshape(-1, N), N, 1).reshape(fr, H, W, 6 * N)
+    dw_a, db = KH.conv2d_wgrad(be, x6, dy6, k, 1, splits=splits, terms=(0, 3), dbias0=np.full(N, 7.0, np.float32))
+    dw = KH.conv2d_wgrad(be, x6, dy6, k, 1, splits=splits, terms=(3, 3), dw0=dw_a, beta=1.0)
+    one = KH.conv2d_wgrad(be, x6, dy6, k, 1, splits=max(1, splits - 1), terms=(0, 6))      # all six in one launch: the same sum
+    e32 = np.abs(KH.conv2d_wgrad(be, x, dy, k, 1, splits=splits) - ref).max()
+    e6 = np.abs(dw - ref).max()
+    e16 = np.abs(KH.conv2d_wgrad(be, x, dy, k, 1, splits=splits, precision=1) - ref).max()
+    print('split6 wgrad k=%d: |err| vs fp64  fp32 MFMA %.3e   bf16x3 %.3e   bf16 %.3e' % (k, e32, e6, e16))
+    assert e6 <= 2.0 * e32 + 2e-6 * np.abs(ref).max() and e16 >= 30.0 * e6
+    close(one, dw, 5e-5 * max(1.0, np.abs(ref).max()))
+    close(db, dy.reshape(-1, N).astype(np.float64).sum(0), 2e-4)
