@@ -794,7 +794,7 @@ def main():
         variants = {}
         for vname in ('lstm3', 'default5'):
             variants[vname] = {'net': NET_WORDS[vname]}
-            for prec in ('fp32', 'bf16'):
+            for prec in ('fp32', 'bf16', 'bf16x3'):
                 variants[vname][prec] = measure_variant(net_by_name(vname), prec, batches, B, T, H, W, dp, args.steps, args.warmup)
     cpu = None
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:

@@ -307,6 +307,13 @@ int lu_lstm_gates_bwd_bf16(void* gates_dz, const float* c_prev, const float* c_c
                            const float* dh_a, int64_t dh_a_frame_stride, const float* dh_b, const float* dc_in,
                            float* dc_prev_out, int32_t frames, int64_t pix_per_frame, int32_t F, lu_stream_t stream);
 
+/* The fp32 gate backward (lu_lstm_gates_bwd, dz in place of the saved gates) that also writes the lu_split6 image of dz --
+ * dz6 [frames * pix_per_frame][6][4F] bf16, channel blocks in order 1 (hi, mid, lo, hi, mid, hi) -- in the same pass: the operand of
+ * the recurrent / input gradients and the weight gradients of precision 'bf16x3' (ABI v11).  F % 4 == 0, 16-byte aligned tensors. */
+int lu_lstm_gates_bwd_split(float* gates_dz, const float* c_prev, const float* c_cur,
+                            const float* dh_a, int64_t dh_a_frame_stride, const float* dh_b, const float* dc_in,
+                            void* dz6, float* dc_prev_out, int32_t frames, int64_t pix_per_frame, int32_t F, lu_stream_t stream);
+
 /* element-wise conversions between fp32 and bf16 (round to nearest even) on n elements */
 int lu_convert_f32_bf16(const float* x, void* y, int64_t n, lu_stream_t stream);
 int lu_convert_bf16_f32(const void* x, float* y, int64_t n, lu_stream_t stream);

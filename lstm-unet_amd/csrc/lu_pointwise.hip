@@ -227,6 +227,70 @@ __global__ void lstm_gates_bwd_bf16_kernel(unsigned short* gates_dz, const float
     }
 }
 
+// The fp32 step with the split image of dz written in the same pass (precision 'bf16x3'): dz6 [row][6][4F] bf16, channel blocks in
+// order B (hi, mid, lo, hi, mid, hi of the exact three-way bf16 split) -- the operand of the recurrent / input gradient convolutions
+// and of the weight gradients -- next to the fp32 dz (in place of the gates: the bias gradient and thin-input layers read it).
+// Four channels per thread, 16-byte fp32 accesses, 8-byte bf16 stores; F % 4 == 0.
+__global__ void lstm_gates_bwd_split_kernel(float* gates_dz, const float* __restrict__ c_prev, const float* __restrict__ c_cur,
+                                            const float* __restrict__ dh_a, int64_t dha_fs, const float* __restrict__ dh_b,
+                                            const float* __restrict__ dc_in, unsigned short* __restrict__ dz6,
+                                            float* __restrict__ dc_prev_out, int64_t total4, int64_t ppf, int F) {
+    const int F4 = F >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total4; i += (int64_t)gridDim.x * NT) {
+        const int64_t row = i / F4;
+        const int ch = 4 * (int)(i - row * F4);
+        const int64_t f = row / ppf;
+        const int64_t e = row * F + ch;
+        float4 dh = *reinterpret_cast<const float4*>(dh_a + f * dha_fs + (row - f * ppf) * F + ch);
+        if (dh_b) {
+            const float4 b = *reinterpret_cast<const float4*>(dh_b + e);
+            dh.x += b.x; dh.y += b.y; dh.z += b.z; dh.w += b.w;
+        }
+        float* gp = gates_dz + row * 4 * F + ch;
+        const float4 ri = *reinterpret_cast<const float4*>(gp), rf = *reinterpret_cast<const float4*>(gp + F),
+                     rg = *reinterpret_cast<const float4*>(gp + 2 * F), ro = *reinterpret_cast<const float4*>(gp + 3 * F);
+        const float4 cc = *reinterpret_cast<const float4*>(c_cur + e), cp = *reinterpret_cast<const float4*>(c_prev + e);
+        float4 dcin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dc_in) dcin = *reinterpret_cast<const float4*>(dc_in + e);
+        float z[4][4], dcp[4];      // [gate][channel]
+        const float gi[4] = {ri.x, ri.y, ri.z, ri.w}, gf[4] = {rf.x, rf.y, rf.z, rf.w}, gg[4] = {rg.x, rg.y, rg.z, rg.w},
+                    go[4] = {ro.x, ro.y, ro.z, ro.w};
+        const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, ccv[4] = {cc.x, cc.y, cc.z, cc.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w},
+                    dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {      // (the formulas of lstm_gates_bwd_kernel, in its order of operations: bit-identical dz)
+            const float tc = lu_tanh_fast(ccv[j]);
+            float dc = dhv[j] * go[j] * (1.f - tc * tc);
+            if (dc_in) dc += dci[j];
+            z[0][j] = dc * gg[j] * hsig_grad_from_out(gi[j]);
+            z[1][j] = dc * cpv[j] * hsig_grad_from_out(gf[j]);
+            z[2][j] = dc * gi[j] * (1.f - gg[j] * gg[j]);
+            z[3][j] = dhv[j] * tc * hsig_grad_from_out(go[j]);
+            dcp[j] = dc * gf[j];
+        }
+        unsigned short* sp = dz6 + row * (24 * (int64_t)F) + ch;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(gp + g * F) = make_float4(z[g][0], z[g][1], z[g][2], z[g][3]);
+            float h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lu_split3(z[g][j], h[j], m[j], l[j]);
+            lu_u2 vh, vm, vl;
+            vh.x = lu_pack2bf(h[0], h[1]); vh.y = lu_pack2bf(h[2], h[3]);
+            vm.x = lu_pack2bf(m[0], m[1]); vm.y = lu_pack2bf(m[2], m[3]);
+            vl.x = lu_pack2bf(l[0], l[1]); vl.y = lu_pack2bf(l[2], l[3]);
+            unsigned short* q = sp + g * F;      // block j of the pixel at + j * 4F: hi, mid, lo, hi, mid, hi
+            *reinterpret_cast<lu_u2*>(q) = vh;
+            *reinterpret_cast<lu_u2*>(q + 4 * F) = vm;
+            *reinterpret_cast<lu_u2*>(q + 8 * F) = vl;
+            *reinterpret_cast<lu_u2*>(q + 12 * F) = vh;
+            *reinterpret_cast<lu_u2*>(q + 16 * F) = vm;
+            *reinterpret_cast<lu_u2*>(q + 20 * F) = vh;
+        }
+        *reinterpret_cast<float4*>(dc_prev_out + e) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+    }
+}
+
 __global__ void convert_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) y[i] = lu_f2bf(x[i]);
 }
@@ -1053,6 +1117,22 @@ extern "C" int lu_lstm_gates_bwd(const float* gates, const float* c_prev, const 
     const int64_t total = (int64_t)frames * ppf * F;
     LU_LAUNCH(lstm_gates_bwd_kernel, dim3(grid_for(total)), dim3(NT), stream, gates, c_prev, c_cur, dh_a, dh_a_fs,
               dh_b, dc_in, dz, dc_prev_out, total, ppf, (int)F);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_lstm_gates_bwd_split(float* gates_dz, const float* c_prev, const float* c_cur, const float* dh_a,
+                                       int64_t dh_a_fs, const float* dh_b, const float* dc_in, void* dz6, float* dc_prev_out,
+                                       int32_t frames, int64_t ppf, int32_t F, lu_stream_t stream) {
+    LU_REQUIRE(gates_dz && c_prev && c_cur && dh_a && dz6 && dc_prev_out && frames > 0 && ppf > 0 && F > 0 && F % 4 == 0 &&
+                   dh_a_fs % 4 == 0,
+               "lu_lstm_gates_bwd_split: bad arguments (F %% 4 == 0 required)");
+    LU_REQUIRE(((reinterpret_cast<uintptr_t>(gates_dz) | reinterpret_cast<uintptr_t>(c_prev) | reinterpret_cast<uintptr_t>(c_cur) |
+                 reinterpret_cast<uintptr_t>(dh_a) | reinterpret_cast<uintptr_t>(dh_b) | reinterpret_cast<uintptr_t>(dc_in) |
+                 reinterpret_cast<uintptr_t>(dc_prev_out)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz6) & 7) == 0,
+               "lu_lstm_gates_bwd_split: 16-byte aligned fp32 tensors, 8-byte aligned dz6");
+    const int64_t total4 = (int64_t)frames * ppf * (F / 4);
+    LU_LAUNCH(lstm_gates_bwd_split_kernel, dim3(grid_for(total4)), dim3(NT), stream, gates_dz, c_prev, c_cur, dh_a, dh_a_fs, dh_b,
+              dc_in, (unsigned short*)dz6, dc_prev_out, total4, ppf, (int)F);
     return LU_CHECK_LAUNCH();
 }
 

@@ -86,6 +86,7 @@ PROTOTYPES = {
     'lu_lstm_gates_fwd_slabs': (C.c_int, [P, i32, P, P, P, P, P, i32, i64, i32, i64, S]),
     'lu_lstm_gates_bwd': (C.c_int, [P, P, P, P, i64, P, P, P, P, i32, i64, i32, S]),
     'lu_lstm_gates_bwd_bf16': (C.c_int, [P, P, P, P, i64, P, P, P, i32, i64, i32, S]),
+    'lu_lstm_gates_bwd_split': (C.c_int, [P, P, P, P, i64, P, P, P, P, i32, i64, i32, S]),
     'lu_convert_f32_bf16': (C.c_int, [P, P, i64, S]),
     'lu_split6': (C.c_int, [P, i64, i32, i64, P, i64, i32, i32, i32, S]),
     'lu_convert_bf16_f32': (C.c_int, [P, P, i64, S]),

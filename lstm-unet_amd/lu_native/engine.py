@@ -789,8 +789,12 @@ class Engine:
         rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k), order=0) if T > 1 else None
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
-            ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
-            ops.split6(dz[t], out=dz6[t], order=1)      # (order B: block t of dz6 meets block t of the order-A x6 / h6 in the weight gradients)
+            # dz6 in order B: block t of dz6 meets block t of the order-A x6 / h6 in the weight gradients
+            if self.x3_fused_split and F % 4 == 0:
+                ops.lstm_gates_bwd_split(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz6[t], dc[t & 1])
+            else:
+                ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
+                ops.split6(dz[t], out=dz6[t], order=1)
             if t > 0:
                 if dh_rec is None:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)

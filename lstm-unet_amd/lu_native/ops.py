@@ -580,6 +580,23 @@ def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc_in, dz, dc_prev_out):
                     'lu_lstm_gates_bwd')
 
 
+def lstm_gates_bwd_split(gates_dz, c_prev, c_cur, dh_a, dh_b, dc_in, dz6, dc_prev_out):
+    """lstm_gates_bwd with dz written IN PLACE of the fp32 gates and, in the same pass, its split6 image (order B) into dz6
+    [frames,H,W,24F] bf16 -- precision 'bf16x3' (lu_lstm_gates_bwd_split)."""
+    _chk(gates_dz, c_prev, c_cur, dh_a, dh_b, dc_in, dz6, dc_prev_out)
+    frames, H, W, F = c_cur.shape
+    for t in (gates_dz, c_prev, c_cur, dz6, dc_prev_out):
+        assert t.is_contiguous()
+    assert dz6.dtype == torch.bfloat16 and dz6.shape == (frames, H, W, 24 * F) and gates_dz.dtype == torch.float32
+    n_in = 4 + 2 + 1 + (dh_b is not None) + (dc_in is not None)
+    with _timed('hbm:lstm_gates_bwd_split_kernel (bf16x3 gate backward: dz in place of the gates + its split image, dc)',
+                (4.0 * (n_in + 4 + 1) + 2.0 * 24) * F * frames * H * W):
+        calls.check(lib(), lib().lu_lstm_gates_bwd_split(gates_dz.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(), dh_a.data_ptr(),
+                                                         dh_a.stride(0), _p(dh_b), _p(dc_in), dz6.data_ptr(),
+                                                         dc_prev_out.data_ptr(), frames, H * W, F, _stream()),
+                    'lu_lstm_gates_bwd_split')
+
+
 def lstm_gates_bwd_bf16(gates_dz, c_prev, c_cur, dh_a, dh_b, dc_in, dc_prev_out):
     """BPTT gate backward on the bf16 tape: gates_dz holds the saved gates (bf16) and receives dz (bf16) in place."""
     _chk(gates_dz, c_prev, c_cur, dh_a, dh_b, dc_in, dc_prev_out)

@@ -397,6 +397,11 @@ def test_bf16_inference_state_copy_survives_no_in_place_state_edit():
         assert torch.equal(g(f)[1], w)
 
 
+def _oracle_of(precision):
+    """precision 'bf16x3' claims fp32 arithmetic: it is compared with the oracle passes of the fp32 tests, at their tolerances."""
+    return 'fp32' if precision == 'bf16x3' else precision
+
+
 def _t8_compare(full_engine, precision, B, training, seed, farm=None):
     """Params.py-width net, 64x64, T = 8 (the reference's unroll window, Params.py:38-40; SURVEY §8c states its tolerance
     'after T=8 steps'): HIP engine vs the fp64 torch oracle (bf16 mode: the oracle on bf16-rounded operands).
@@ -410,7 +415,7 @@ def _t8_compare(full_engine, precision, B, training, seed, farm=None):
     e = _clone_engine(full_engine, precision=precision)
     lg = e.forward(torch.from_numpy(_to_tb(x)).to(dev), T, B, training)
     got = np.swapaxes(lg.cpu().numpy().reshape(T, B, H, W, 3), 0, 1).astype(np.float64)
-    o = farm.result(_fwd_key(precision, B, T, H, W, training, seed))      # the fp64 oracle pass (its own host process)
+    o = farm.result(_fwd_key(_oracle_of(precision), B, T, H, W, training, seed))      # the fp64 oracle pass (its own host process)
     ref, o_states = o['logits'], o['states']
     m = max(1.0, float(np.abs(ref).max()))
     out = {'max_logit': m, 'logit_err': float(np.abs(got - ref).max()),
@@ -427,17 +432,18 @@ def _t8_compare(full_engine, precision, B, training, seed, farm=None):
     return out
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('case', ['train-B1', 'infer-B1', 'train-B4'])
-def test_full_width_t8_vs_fp64_oracle(full_engine, oracle_farm, case):
+def test_full_width_t8_vs_fp64_oracle(full_engine, oracle_farm, case, precision):
     """fp32, eight recurrent steps at K up to 12 800 against the fp64 oracle -- the tolerance SURVEY §8c states is FOR this
     length: logits <= 1e-3 * max(1, |ref|), argmax equal outside the 2e-3 top-2 band, carried h / c <= 1e-3, SEG <= 1e-3.
     B = 4 so that the frame-batched launches (4 slots per step, the config-2 shape of the launch grid) are compared too."""
     training, B = case.startswith('train'), int(case[-1])
-    r = _t8_compare(full_engine, 'fp32', B, training, seed=21 + B, farm=oracle_farm)
+    r = _t8_compare(full_engine, precision, B, training, seed=21 + B, farm=oracle_farm)
     band = r['gap'] < 2e-3
     mism = (r['got'].argmax(-1) != r['ref'].argmax(-1))
-    print('T=8 fp32 %s: max|logit| %.3f, logit err %.3e (last frame %.3e), carried h err %.3e, c err %.3e, tie-band pixels %d, '
-          'argmax mismatches outside the band %d' % (case, r['max_logit'], r['logit_err'], r['logit_err_last_frame'],
+    print('T=8 %s %s: max|logit| %.3f, logit err %.3e (last frame %.3e), carried h err %.3e, c err %.3e, tie-band pixels %d, '
+          'argmax mismatches outside the band %d' % (precision, case, r['max_logit'], r['logit_err'], r['logit_err_last_frame'],
                                                     r['h_err'], r['c_err'], int(band.sum()), int((mism & ~band).sum())))
     assert r['logit_err'] <= 1e-3 * r['max_logit']
     assert r['h_err'] <= 1e-3 and r['c_err'] <= 1e-3
@@ -493,7 +499,7 @@ def _full_frame_compare(full_engine, precision, B, T, H, W, training, seed, farm
     sums, _ = ops.wce_forward(lg.view(-1, 3), g, torch.tensor(cw, device=dev), False)
     loss = float(ops.wce_loss(sums).cpu()[0])
     got = np.swapaxes(lg.cpu().numpy().reshape(T, B, H, W, 3), 0, 1).astype(np.float64)
-    o = farm.result(_fwd_key(precision, B, T, H, W, training, seed))      # the fp64 oracle pass (its own host process)
+    o = farm.result(_fwd_key(_oracle_of(precision), B, T, H, W, training, seed))      # the fp64 oracle pass (its own host process)
     ref, loss_ref = o['logits'], o['loss']
     m = max(1.0, float(np.abs(ref).max()))
     h_err = c_err = 0.0
@@ -519,16 +525,17 @@ def _report(tag, r, band):
     return mism, a, b
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('case', ['T8-B1', 'T2-B4'])
-def test_config2_frame_size_vs_fp64_oracle(full_engine, oracle_farm, case):
+def test_config2_frame_size_vs_fp64_oracle(full_engine, oracle_farm, case, precision):
     """BASELINE config-2's frames -- 256x256, Params.py widths, training mode (BatchNorm batch statistics over B*T frames,
     Networks.py:67-71), the launch geometry of the headline bench (16x32 / 8x32 patches, no tile-starved routes) -- against the
     fp64 oracle at SURVEY §8c's tolerance: logits <= 1e-3 * max(1, |ref|), loss <= 1e-4 relative, carried h / c <= 1e-3, argmax
     equal outside the 2e-3 top-2 band, SEG within 1e-3.  T = 8, B = 1 is the full unroll window; T = 2, B = 4 the full batch."""
     T, B = int(case[1]), int(case[-1])
-    r = _full_frame_compare(full_engine, 'fp32', B, T, 256, 256, True, seed=41 + B, farm=oracle_farm)
+    r = _full_frame_compare(full_engine, precision, B, T, 256, 256, True, seed=41 + B, farm=oracle_farm)
     band = r['gap'] < 2e-3
-    mism, a, b = _report('config-2 frame size fp32 %s' % case, r, band)
+    mism, a, b = _report('config-2 frame size %s %s' % (precision, case), r, band)
     assert r['logit_err'] <= 1e-3 * r['max_logit']
     assert abs(r['loss'] - r['loss_ref']) <= 1e-4 * max(1.0, abs(r['loss_ref']))
     assert r['h_err'] <= 1e-3 and r['c_err'] <= 1e-3
@@ -715,7 +722,9 @@ def _pooled_torch_fp32_worst(oracle_farm):
     return _POOLED['v']
 
 
-def _check_fp32_case(full_engine, oracle_farm, case, routes=(None,)):
+def _check_fp32_case(full_engine, oracle_farm, case, routes=(None,), precision='fp32'):
+    """precision 'bf16x3' (fp32 arithmetic on the bf16 MFMA) is held to the SAME limits as the fp32 engine: stated multiples of the
+    torch-fp32 oracle's own distance from fp64."""
     ref = oracle_farm.result(case + '.f64')
     t32 = oracle_farm.result(case + '.f32')
     rows_t, gmax = _grad_rows(t32['grads'], ref['grads'])
@@ -730,13 +739,13 @@ def _check_fp32_case(full_engine, oracle_farm, case, routes=(None,)):
              'rows_torch_fp32': {k: (mr, l2) for mr, l2, k, _ in rows_t}}
     fails = []
     for route in routes:
-        loss, grads = _engine_grads(full_engine, 'fp32', case, route)
+        loss, grads = _engine_grads(full_engine, precision, case, route)
         assert set(grads) == set(ref['grads']) and len(grads) == 78
         rows, _ = _grad_rows(grads, ref['grads'])
         sh = _summ(rows)
         tag = route or 'library'
-        print('   HIP fp32 [%-7s]   : worst max-rel %.3e  worst L2-rel %.3e  median %.3e / %.3e   loss %.7f' %
-              (tag, sh['worst_mr'], sh['worst_l2'], sh['median_mr'], sh['median_l2'], loss))
+        print('   HIP %s [%-7s]   : worst max-rel %.3e  worst L2-rel %.3e  median %.3e / %.3e   loss %.7f' %
+              (precision, tag, sh['worst_mr'], sh['worst_l2'], sh['median_mr'], sh['median_l2'], loss))
         for mr, l2, k, gm in sorted(rows, reverse=True)[:6]:
             tr = table['rows_torch_fp32'][k]
             print('      %-38s max-rel %.3e  L2-rel %.3e  (torch-fp32: %.3e / %.3e; tensor max %.3e)' % (k, mr, l2, tr[0], tr[1], gm))
@@ -750,7 +759,7 @@ def _check_fp32_case(full_engine, oracle_farm, case, routes=(None,)):
         for key in lim:
             if sh[key] > lim[key]:
                 fails.append('%s: %s %.3e > %.3e' % (tag, key, sh[key], lim[key]))
-    _save_table(case + '.fp32', table)
+    _save_table(case + '.' + precision, table)
     assert not fails, fails
 
 
@@ -771,34 +780,37 @@ def _check_bf16_case(full_engine, oracle_farm, case):
     assert sh['worst_mr'] <= BF16_GRAD_TOL[0] and sh['worst_l2'] <= BF16_GRAD_TOL[1]
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_full_width_every_gradient_tensor_vs_oracle_autograd(full_engine, oracle_farm, precision):
     """Params.py widths (74.6 M parameters), 64x64, T = 4, B = 2: loss and EVERY gradient tensor of one train_step
     (train2D.py:87-95: forward(training) -> weighted CE -> BPTT inside the window) against torch autograd through the fp64 oracle,
     tolerance = a stated multiple of the torch-fp32 oracle's own error on the same inputs (fp32); bf16 mode: the oracle with
     bf16-rounded forward operands at the mode's contract.  A sign or indexing error in ANY tensor's gradient is an O(1) error."""
-    if precision == 'fp32':
-        _check_fp32_case(full_engine, oracle_farm, 'w64-T4-B2')
+    if precision in ('fp32', 'bf16x3'):
+        _check_fp32_case(full_engine, oracle_farm, 'w64-T4-B2', precision=precision)
     else:
         _check_bf16_case(full_engine, oracle_farm, 'w64-T4-B2')
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_config2_frame_size_every_gradient_vs_oracle(full_engine, oracle_farm, precision):
     """BASELINE config-2's frame size, Params widths, T = 2, B = 1 (recurrent input gradient, BPTT through two steps): all 78
     gradient tensors.  fp32 runs three times -- the library's own routing, every ConvLSTM step forced onto the fused kernel,
     every step forced onto (K-split) convolution + gate kernel -- against the same oracle pass (VERDICT round 4, next #1a / #1c)."""
     if precision == 'fp32':
         _check_fp32_case(full_engine, oracle_farm, 'c2-256-T2-B1', routes=(None, 'fused', 'split'))
+    elif precision == 'bf16x3':      # (its ConvLSTM steps always run the fused bf16 kernel: one route)
+        _check_fp32_case(full_engine, oracle_farm, 'c2-256-T2-B1', precision='bf16x3')
     else:
         _check_bf16_case(full_engine, oracle_farm, 'c2-256-T2-B1')
 
 
-def test_config2_batch4_carried_state_every_gradient_vs_oracle(full_engine, oracle_farm):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_config2_batch4_carried_state_every_gradient_vs_oracle(full_engine, oracle_farm, precision):
     """256x256, T = 1, B = 4 -- the four-frame launches of a config-2 ConvLSTM step -- starting from a random CARRIED state with
     one slot reset (set_states + reset_states_per_batch, Networks.py:77-98: the state a window inherits is a constant of the
     step, truncated BPTT), so that the recurrent kernel's gradient is exercised through lu_state_begin at full frame size."""
-    _check_fp32_case(full_engine, oracle_farm, 'c2-256-T1-B4-carried')
+    _check_fp32_case(full_engine, oracle_farm, 'c2-256-T1-B4-carried', precision=precision)
 
 
 def test_config4_ragged_gradients_vs_oracle(full_engine, oracle_farm):

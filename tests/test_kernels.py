@@ -1214,3 +1214,27 @@ def test_split6_weight_gradient_with_the_terms_as_frames_is_fp32_arithmetic(be, 
     assert e6 <= 2.0 * e32 + 2e-6 * np.abs(ref).max() and e16 >= 30.0 * e6
     close(one, dw, 5e-5 * max(1.0, np.abs(ref).max()))
     close(db, dy.reshape(-1, N).astype(np.float64).sum(0), 2e-4)
+
+
+def test_gate_backward_with_the_split_image_of_dz(be):
+    """lu_lstm_gates_bwd_split (precision 'bf16x3'): dz in place of the fp32 gates and dc bit for bit what lu_lstm_gates_bwd writes,
+    dz6 = the lu_split6 image (order B) of exactly that dz."""
+    fr, H, W, F = 2, 3, 5, 8
+    sh = (fr, H, W, F)
+    gates = f32(RNG.uniform(-0.2, 1.2, size=(fr, H, W, 4 * F)).clip(0.0, 1.0))
+    gates[..., 2 * F:3 * F] = np.tanh(rnd(*sh))
+    c_prev, c_cur, dh_a, dh_b, dc_in = [rnd(*sh) for _ in range(5)]
+    for (db, di) in [(dh_b, dc_in), (None, None)]:
+        gd, cp, cc, da = be.dev(gates), be.dev(c_prev), be.dev(c_cur), be.dev(dh_a)
+        dbd, did = (None if db is None else be.dev(db)), (None if di is None else be.dev(di))
+        dz, dcp = be.empty((fr, H, W, 4 * F)), be.empty(sh)
+        ck(be, be.lib.lu_lstm_gates_bwd(be.ptr(gd), be.ptr(cp), be.ptr(cc), be.ptr(da), H * W * F, be.ptr(dbd), be.ptr(did), be.ptr(dz),
+                                        be.ptr(dcp), fr, H * W, F, be.stream), 'gates bwd')
+        g2, dcp2, dz6 = be.dev(gates), be.empty(sh), be.empty((fr, H, W, 24 * F), np.int16)
+        ck(be, be.lib.lu_lstm_gates_bwd_split(be.ptr(g2), be.ptr(cp), be.ptr(cc), be.ptr(da), H * W * F, be.ptr(dbd), be.ptr(did),
+                                              be.ptr(dz6), be.ptr(dcp2), fr, H * W, F, be.stream), 'gates bwd split')
+        dz_ref = be.host(dz)
+        assert np.array_equal(be.host(g2).view(np.uint32), dz_ref.view(np.uint32))
+        assert np.array_equal(be.host(dcp2).view(np.uint32), be.host(dcp).view(np.uint32))
+        ref6 = split6_ref(dz_ref.reshape(-1, 4 * F), 4 * F, 1).reshape(fr, H, W, 24 * F)
+        assert np.array_equal(KH.bf16_values(be.host(dz6)).view(np.uint32), ref6.view(np.uint32))
