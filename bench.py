@@ -601,7 +601,7 @@ def main():
             wl_sfx = '_' + args.net + wl_sfx
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes: a STATIC table
             if wl_sfx is not None:      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
-                sfx = ('' if args.precision == 'fp32' else '_bf16') + wl_sfx
+                sfx = ('' if args.precision == 'fp32' else '_' + args.precision) + wl_sfx
                 rounds = ('r05', 'r04', 'r03', 'r02', 'r01') if wl_sfx == '' else ('r05',)
                 name = next(n for n in ['%s_pmc_traffic%s.json' % (r_, sfx) for r_ in rounds]
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))

@@ -258,7 +258,7 @@ __global__ void lstm_gates_bwd_split_kernel(float* gates_dz, const float* __rest
         const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, ccv[4] = {cc.x, cc.y, cc.z, cc.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w},
                     dci[4] = {dcin.x, dcin.y, dcin.z, dcin.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {      // (the formulas of lstm_gates_bwd_kernel, in its order of operations: bit-identical dz)
+        for (int j = 0; j < 4; ++j) {      // (the formulas of lstm_gates_bwd_kernel, in its order of operations)
             const float tc = lu_tanh_fast(ccv[j]);
             float dc = dhv[j] * go[j] * (1.f - tc * tc);
             if (dc_in) dc += dci[j];

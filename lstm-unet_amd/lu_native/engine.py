@@ -509,7 +509,7 @@ class Engine:
         F = spec['f']
         k = spec['k']
         dev = x_seq.device
-        if self._x3_route(k, F, Cin, B, H, W):
+        if self._x3_route(k, F, Cin, B, H, W, training=tape is not None):
             return self._lstm_forward_x3(bi, li, spec, x_seq, T, B, tape)
         pre = f'down.{bi}.lstm.{li}'
         kernel, rec_k, bias = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel'], self.P[pre + '.bias']
@@ -675,10 +675,11 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ ConvLSTM layer, precision 'bf16x3'
-    def _x3_route(self, k, F, cin, B, H, W):
-        """precision 'bf16x3': does this ConvLSTM layer run on the split operands?  The domain of the fused bf16 step and of the
-        bf16 kernel-row weight gradient (W % 32 == 0, F % 32 == 0, F >= 64); other layers take the fp32 kernels."""
-        return (self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and W % 32 == 0 and
+    def _x3_route(self, k, F, cin, B, H, W, training=True):
+        """precision 'bf16x3': does this ConvLSTM layer run on the split operands?  The domain of the fused bf16 step (F % 32 == 0,
+        F >= 64) and -- training -- of the bf16 kernel-row weight gradient (W % 32 == 0; inference frames, padded to any
+        width, have no weight gradient); other layers take the fp32 kernels."""
+        return (self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and (W % 32 == 0 or not training) and
                 ops.fused_step_applies(B, H, W, F, True))
 
     def _x3_weight(self, name, role, make, cp=None, order=1):

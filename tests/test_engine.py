@@ -760,3 +760,34 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch):
     print('bf16x3 vs fp64 oracle: logits %.3e (fp32 engine %.3e), worst gradient tensor %.3e %s (fp32 engine %.3e)' %
           (e3 / np.abs(o).max(), e32 / np.abs(o).max(), w3[0], w3[1], w32))
     assert w3[0] <= 2.0 * w32 + 1e-5, (w3, w32)
+
+
+def test_bf16x3_streaming_inference_on_ragged_frames(dev):
+    """precision 'bf16x3', the Inference2D.py:45-62 call pattern (B = 1, T = 1, pad_image: 13 x 21 frames reflect-padded to 32 x 40 inside --
+    no weight gradient, so any width takes the split route): three frames with carried state within 2e-5 * max|logit| of the fp32
+    engine, labels identical outside a 1e-4 tie band."""
+    from lu_native import calls
+    from lu_native.engine import Engine
+    net, cin = X3_NET, 1
+    rng = np.random.default_rng(9)
+    p = perturbed_params(net, cin, 5)
+    frames = [rng.standard_normal((1, 13, 21, cin)).astype(np.float32) for _ in range(3)]
+    outs, seen = {}, []
+    real = calls.conv2d
+    calls.conv2d = lambda *a, **k: (seen.append(k.get('precision', 0)), real(*a, **k))[1]
+    try:
+        for prec in ('fp32', 'bf16x3'):
+            del seen[:]
+            e = Engine(net, pad_image=True, precision=prec)
+            e.build(cin, dev)
+            e.load_params(p)
+            outs[prec] = [e.forward(torch.from_numpy(f).to(dev), 1, 1, False).cpu().numpy().astype(np.float64) for f in frames]
+            assert (sum(seen) == 0) if prec == 'fp32' else (sum(seen) == 2 * len(frames)), (prec, sum(seen))      # two split ConvLSTM layers per frame
+    finally:
+        calls.conv2d = real
+    for a, b in zip(outs['fp32'], outs['bf16x3']):
+        assert a.shape == (1, 13, 21, 3)
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), np.abs(a - b).max() / np.abs(a).max()
+        top2 = np.sort(a, -1)
+        band = (top2[..., -1] - top2[..., -2]) < 1e-4 * np.abs(a).max()
+        assert np.all((a.argmax(-1) == b.argmax(-1)) | band)

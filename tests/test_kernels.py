@@ -1217,8 +1217,9 @@ def test_split6_weight_gradient_with_the_terms_as_frames_is_fp32_arithmetic(be, 
 
 
 def test_gate_backward_with_the_split_image_of_dz(be):
-    """lu_lstm_gates_bwd_split (precision 'bf16x3'): dz in place of the fp32 gates and dc bit for bit what lu_lstm_gates_bwd writes,
-    dz6 = the lu_split6 image (order B) of exactly that dz."""
+    """lu_lstm_gates_bwd_split (precision 'bf16x3'): dz in place of the fp32 gates and dc = what lu_lstm_gates_bwd writes (the same
+    formulas; to fp32 rounding -- hipcc contracts the two kernels' multiply-adds differently), dz6 = the lu_split6 image (order B)
+    of EXACTLY the dz this kernel wrote."""
     fr, H, W, F = 2, 3, 5, 8
     sh = (fr, H, W, F)
     gates = f32(RNG.uniform(-0.2, 1.2, size=(fr, H, W, 4 * F)).clip(0.0, 1.0))
@@ -1233,8 +1234,8 @@ def test_gate_backward_with_the_split_image_of_dz(be):
         g2, dcp2, dz6 = be.dev(gates), be.empty(sh), be.empty((fr, H, W, 24 * F), np.int16)
         ck(be, be.lib.lu_lstm_gates_bwd_split(be.ptr(g2), be.ptr(cp), be.ptr(cc), be.ptr(da), H * W * F, be.ptr(dbd), be.ptr(did),
                                               be.ptr(dz6), be.ptr(dcp2), fr, H * W, F, be.stream), 'gates bwd split')
-        dz_ref = be.host(dz)
-        assert np.array_equal(be.host(g2).view(np.uint32), dz_ref.view(np.uint32))
-        assert np.array_equal(be.host(dcp2).view(np.uint32), be.host(dcp).view(np.uint32))
-        ref6 = split6_ref(dz_ref.reshape(-1, 4 * F), 4 * F, 1).reshape(fr, H, W, 24 * F)
+        dz_ref, dz_got = be.host(dz), be.host(g2)
+        close(dz_got, dz_ref, 2e-6 * max(1.0, float(np.abs(dz_ref).max())))
+        close(be.host(dcp2), be.host(dcp), 2e-6 * max(1.0, float(np.abs(be.host(dcp)).max())))
+        ref6 = split6_ref(dz_got.reshape(-1, 4 * F), 4 * F, 1).reshape(fr, H, W, 24 * F)
         assert np.array_equal(KH.bf16_values(be.host(dz6)).view(np.uint32), ref6.view(np.uint32))

@@ -12,7 +12,7 @@ for mode in fp32 bf16; do
              "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM" \
              "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_BRANCH"; do
     i=$((i+1)); d=$R/gpurun_out/pmcsq_${mode}_$i; rm -rf $d
-    rocprofv3 --kernel-trace --pmc $grp -d $d -- python $R/bench.py --precision $mode --steps 1 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 --no-variants > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $grp -d $d -- python $R/bench.py --precision $mode --steps 1 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 --no-x3 --no-variants > /dev/null 2>&1
     dirs="$dirs,$d"
   done
   args="$args $mode=${dirs#,}"

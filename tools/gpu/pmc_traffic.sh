@@ -6,17 +6,17 @@
 tag=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for mode in ${PMC_MODES:-fp32 bf16}; do
-  sfx=""; [ $mode = bf16 ] && sfx="_bf16"
+for mode in ${PMC_MODES:-fp32 bf16 bf16x3}; do
+  sfx=""; [ $mode != fp32 ] && sfx="_$mode"
   sfx="$sfx$PMC_SFX"
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $R/gpurun_out/pmc_${mode}_$ctr
-    rocprofv3 --kernel-trace --pmc $ctr -d $R/gpurun_out/pmc_${mode}_$ctr -- python $R/bench.py --precision $mode --steps 1 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 --no-variants $PMC_EXTRA > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $ctr -d $R/gpurun_out/pmc_${mode}_$ctr -- python $R/bench.py --precision $mode --steps 1 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 --no-x3 --no-variants $PMC_EXTRA > /dev/null 2>&1
   done
   python $R/tools/pmc_summary.py $R/gpurun_out/pmc_${mode}_FETCH_SIZE $R/gpurun_out/pmc_${mode}_WRITE_SIZE $R/gpurun_out/${tag}_pmc_traffic$sfx.json
   rm -rf $R/gpurun_out/pmc_${mode}_FETCH_SIZE $R/gpurun_out/pmc_${mode}_WRITE_SIZE
   rm -rf $R/gpurun_out/pmc_${mode}_mfma
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${mode}_mfma -- python $R/bench.py --precision $mode --steps 1 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 --no-variants $PMC_EXTRA > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${mode}_mfma -- python $R/bench.py --precision $mode --steps 1 --warmup 1 --no-cpu-baseline --no-infer --no-bf16 --no-x3 --no-variants $PMC_EXTRA > /dev/null 2>&1
 done
-cd $R && python tools/pmc_mfma.py gpurun_out/pmc_fp32_mfma gpurun_out/pmc_bf16_mfma gpurun_out/${tag}_pmc_mfma_util$PMC_SFX.json 2>&1 | tail -12
-rm -rf gpurun_out/pmc_fp32_mfma gpurun_out/pmc_bf16_mfma
+cd $R && python tools/pmc_mfma.py gpurun_out/pmc_fp32_mfma gpurun_out/pmc_bf16_mfma gpurun_out/pmc_bf16x3_mfma gpurun_out/${tag}_pmc_mfma_util$PMC_SFX.json 2>&1 | tail -18
+rm -rf gpurun_out/pmc_fp32_mfma gpurun_out/pmc_bf16_mfma gpurun_out/pmc_bf16x3_mfma

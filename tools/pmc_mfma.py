@@ -1,7 +1,7 @@
 """MFMA utilisation and shader clock per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass.
 GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs, so
     clock = GUI_ACTIVE / 8 / duration,   MFMA utilisation = BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs).
-usage: python tools/pmc_mfma.py gpurun_out/pmc_mfma_fp32 gpurun_out/pmc_mfma_bf16 profiles/r01_pmc_mfma_util.json"""
+usage: python tools/pmc_mfma.py gpurun_out/pmc_mfma_fp32 gpurun_out/pmc_mfma_bf16 [gpurun_out/pmc_mfma_bf16x3] profiles/r01_pmc_mfma_util.json"""
 import glob
 import json
 import os
@@ -40,9 +40,13 @@ if __name__ == '__main__':
     res = {'build_id': _build_id(), 'note': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of bench.py --steps 1 --warmup 1 '
                    '(config-2); utilisation = MFMA-busy cycles / SIMD cycles available at the measured clock',
            'fp32': summarize(sys.argv[1]), 'bf16': summarize(sys.argv[2])}
-    with open(sys.argv[3], 'w') as fh:
+    out = sys.argv[3]
+    if len(sys.argv) > 4:      # (round 5: a third pass, precision 'bf16x3':  <fp32 dir> <bf16 dir> <bf16x3 dir> <out>)
+        res['bf16x3'] = summarize(sys.argv[3])
+        out = sys.argv[4]
+    with open(out, 'w') as fh:
         json.dump(res, fh, indent=1)
-    for mode in ('fp32', 'bf16'):
+    for mode in [m_ for m_ in ('fp32', 'bf16', 'bf16x3') if m_ in res]:
         for k, v in list(res[mode].items())[:6]:
             print(mode, '%-78s util %5.1f %%  clock %.2f GHz  %8.1f us x %d' % (k[:78], 100 * v['mfma_utilisation'], v['shader_clock_ghz'],
                                                                                   v['avg_duration_us'], v['launches']))
