@@ -119,6 +119,8 @@ class Engine:
         self.s2_fwd_bf16 = True      # stride-2 forward convs behind a ConvLSTM read its bf16 copy (A/B: bench.py --conv-flags 4096 turns it off)
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
+        self.x3_lean_bytes = 24e9    # precision 'bf16x3': a layer whose split dz of the whole window would exceed this many bytes forms its
+                                     # weight / input gradients step by step from one step's split tensors instead (config-4: 162 GB at level 0)
         self.x3_wgrad_launches = 2   # precision 'bf16x3': the six products of a weight gradient in two launches with the terms as frames (A/B: 6)
         self.x3_fused_split = True   # precision 'bf16x3': the gate epilogue writes the split image of h (A/B: False = a split6 pass per step)
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
@@ -702,11 +704,11 @@ class Engine:
         cp = -(-Cin // 4) * 4      # channels per block: the bf16 kernels read 16-byte groups (6 cp % 8 == 0)
         k6 = self._x3_weight(pre + '.kernel', 'x3', lambda: kernel, cp)
         r6 = self._x3_weight(pre + '.recurrent_kernel', 'x3', lambda: rec_k)
-        x6 = ops.split6(x_seq, cp).view(T, B, H, W, 6 * cp)      # one pass per window; also the x operand of the kernel gradient
         st = self._states[bi][li]
         if st is not None and tuple(st[0].shape) != (B, H, W, F):
             raise ValueError('stateful ConvLSTM: batch/shape changed from %s to %s' % (tuple(st[0].shape), (B, H, W, F)))
         if tape is None:
+            x6 = ops.split6(x_seq, cp).view(T, B, H, W, 6 * cp)
             h_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.float32)
             c_seq = torch.empty((T, B, H, W, F), device=dev, dtype=torch.float32)
             if st is None:
@@ -734,7 +736,16 @@ class Engine:
             return h_seq.view(T * B, H, W, F)
         h_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
-        h6_all = torch.empty((T + 1, B, H, W, 6 * F), device=dev, dtype=torch.bfloat16)
+        # lean: the split images live for one step only (two rolling slots of h6 here; backward re-splits h_t, x_t and forms dz6_t
+        # per step) -- for layers whose window-long split dz would not fit beside the fp32 tape
+        lean = 2.0 * T * B * H * W * 24 * F > self.x3_lean_bytes
+        if not lean:
+            x6 = ops.split6(x_seq, cp).view(T, B, H, W, 6 * cp)      # one pass per window; also the x operand of the kernel gradient
+        else:         # (the window-long split of x is not kept either)
+            x6 = None
+            x6_t = torch.empty((B, H, W, 6 * cp), device=dev, dtype=torch.bfloat16)
+            x5f = x_seq.view(T, B, H, W, Cin)
+        h6_all = torch.empty((2 if lean else T + 1, B, H, W, 6 * F), device=dev, dtype=torch.bfloat16)
         ops.state_begin(h_all[0], None if st is None else st[0], self._keep)
         ops.state_begin(c_all[0], None if st is None else st[1], self._keep)
         ops.split6(h_all[0], out=h6_all[0])
@@ -742,19 +753,20 @@ class Engine:
         for t in range(T):
             # (the gate epilogue writes the split image of h_t next to h_t: LU_CONV_F_H16_SPLIT; A/B: x3_fused_split = False)
             fused = self.x3_fused_split and t + 1 < T
-            ops.convlstm_step(x6[t], h6_all[t], c_all[t], k6, r6, bias, h_all[t + 1], c_all[t + 1], gates[t],
-                              h6_out=h6_all[t + 1] if fused else None)
+            src, dst = (h6_all[t & 1], h6_all[(t + 1) & 1]) if lean else (h6_all[t], h6_all[t + 1])
+            ops.convlstm_step(ops.split6(x5f[t], cp, out=x6_t) if lean else x6[t], src, c_all[t], k6, r6, bias, h_all[t + 1],
+                              c_all[t + 1], gates[t], h6_out=dst if fused else None)
             if t + 1 < T and not fused:
-                ops.split6(h_all[t + 1], out=h6_all[t + 1])
+                ops.split6(h_all[t + 1], out=dst)
         self._states[bi][li] = [h_all[T], c_all[T]]
         self._alias.add((bi, li))
         self._state16.pop((bi, li), None)
-        tape.append({'kind': 'lstm', 'x3': True, 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'x6': x6, 'h_all': h_all,
-                     'c_all': c_all, 'gates': gates, 'T': T, 'B': B, 'h6_all': h6_all})
+        tape.append({'kind': 'lstm', 'x3': True, 'bi': bi, 'li': li, 'spec': spec, 'x': x_seq, 'x6': None if lean else x6, 'h_all': h_all,
+                     'c_all': c_all, 'gates': gates, 'T': T, 'B': B, 'h6_all': None if lean else h6_all, 'cp': cp})
         self._h16_seq = None
         return h_all[1:].view(T * B, H, W, F)
 
-    def _x3_wgrad(self, x6, dy6, dw, dbias=None):
+    def _x3_wgrad(self, x6, dy6, dw, dbias=None, beta0=0.0):
         """dw = x (*) dy on the split operands (x6 in order A, dy6 in order B: block t against block t is term t of
         ops.SPLIT_TERMS).  Two launches of the bf16 kernel-row weight gradient with the terms as extra frames
         (lu_wgrad_desc.terms): the three small products -- whose dy blocks are hi, mid, lo, i.e. dy itself, so the bias gradient
@@ -763,10 +775,10 @@ class Engine:
         if self.x3_wgrad_launches == 6:
             lp, ln = x6.shape[3] // 6, dy6.shape[3] // 6
             for t in range(6):
-                ops.conv2d_wgrad(x6[..., t * lp:(t + 1) * lp], dy6[..., t * ln:(t + 1) * ln], dw, 1, beta=0.0 if t == 0 else 1.0,
-                                 bf16=True, dbias=dbias if t < 3 else None, dbias_beta=0.0 if t == 0 else 1.0)
+                ops.conv2d_wgrad(x6[..., t * lp:(t + 1) * lp], dy6[..., t * ln:(t + 1) * ln], dw, 1, beta=beta0 if t == 0 else 1.0,
+                                 bf16=True, dbias=dbias if t < 3 else None, dbias_beta=beta0 if t == 0 else 1.0)
             return
-        ops.conv2d_wgrad(x6, dy6, dw, 1, beta=0.0, bf16=True, dbias=dbias, terms=(0, 3))
+        ops.conv2d_wgrad(x6, dy6, dw, 1, beta=beta0, bf16=True, dbias=dbias, dbias_beta=beta0, terms=(0, 3))
         ops.conv2d_wgrad(x6, dy6, dw, 1, beta=1.0, bf16=True, terms=(3, 3))
 
     def _lstm_backward_x3(self, rec, dh_seq, need_dx):
@@ -781,6 +793,8 @@ class Engine:
         Cin = x_seq.shape[3]
         dev = h_all.device
         p = (k - 1) // 2
+        if h6_all is None:
+            return self._lstm_backward_x3_lean(rec, dh_seq, need_dx)
         dz = gates      # in place, as in fp32 mode
         dz6 = torch.empty((T, B, H, W, 24 * F), device=dev, dtype=torch.bfloat16)
         dh5 = dh_seq.view(T, B, H, W, F)
@@ -819,6 +833,59 @@ class Engine:
             ops.conv_raw([(dz6_seq, kt6)], T * B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx)
         rec['h_all'] = rec['c_all'] = rec['x'] = rec['x6'] = rec['h6_all'] = None
         return dx
+
+    def _lstm_backward_x3_lean(self, rec, dh_seq, need_dx):
+        """_lstm_backward_x3 for layers whose window-long split tensors would not fit (config-4): per step t one split dz6_t, the
+        split images of h_{t-1} and x_t re-formed from the fp32 tape, and the step's share of every gradient -- recurrent gradient,
+        both weight gradients (accumulated over t with beta = 1: the fp32 sum the hoisted launch forms inside its slabs), input
+        gradient -- before the buffers are reused.  Same products, same accumulators; the sum over t happens in dw."""
+        bi, li, spec, T, B = rec['bi'], rec['li'], rec['spec'], rec['T'], rec['B']
+        pre = f'down.{bi}.lstm.{li}'
+        kernel, rec_k = self.P[pre + '.kernel'], self.P[pre + '.recurrent_kernel']
+        h_all, c_all, gates, x_seq, cp = rec['h_all'], rec['c_all'], rec['gates'], rec['x'], rec['cp']
+        _, _, H, W, F = h_all.shape
+        k = spec['k']
+        Cin = x_seq.shape[3]
+        dev = h_all.device
+        p = (k - 1) // 2
+        dz = gates
+        x5 = x_seq.view(T, B, H, W, Cin)
+        dh5 = dh_seq.view(T, B, H, W, F)
+        dz6 = torch.empty((B, H, W, 24 * F), device=dev, dtype=torch.bfloat16)
+        h6 = torch.empty((B, H, W, 6 * F), device=dev, dtype=torch.bfloat16)
+        x6 = torch.empty((B, H, W, 6 * cp), device=dev, dtype=torch.bfloat16)
+        dc = torch.empty((2, B, H, W, F), device=dev, dtype=torch.float32)
+        dh_rec = None
+        self._sync_weight_images()
+        rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k), order=0) if T > 1 else None
+        kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0) if need_dx else None
+        dx = torch.empty((T, B, H, W, Cin), device=dev, dtype=torch.float32) if need_dx else None
+        x_split = 6 * Cin == 6 * cp and ops.bf16_row_wgrad_ok(ops.split_piece(x6, 'hi'), ops.split_piece(dz6, 'hi'), k, 1)
+        first = True
+        for t in reversed(range(T)):
+            dc_in = dc[(t + 1) & 1] if t < T - 1 else None
+            if self.x3_fused_split and F % 4 == 0:
+                ops.lstm_gates_bwd_split(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz6, dc[t & 1])
+            else:
+                ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
+                ops.split6(dz[t], out=dz6, order=1)
+            if t > 0:
+                if dh_rec is None:
+                    dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
+                ops.conv_raw([(dz6, rt6)], B, H, W, H, W, k, 1, 1, p, p, F, None, dh_rec)
+            beta0 = 0.0 if first else 1.0
+            ops.split6(h_all[t], out=h6)
+            self._x3_wgrad(h6, dz6, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'], beta0=beta0)
+            if x_split:
+                ops.split6(x5[t], cp, out=x6)
+                self._x3_wgrad(x6, dz6, self.G[pre + '.kernel'], beta0=beta0)
+            else:
+                ops.conv2d_wgrad(x5[t], dz[t], self.G[pre + '.kernel'], 1, beta=beta0)
+            if need_dx:
+                ops.conv_raw([(dz6, kt6)], B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx[t])
+            first = False
+        rec['gates'] = rec['h_all'] = rec['c_all'] = rec['x'] = None
+        return None if dx is None else dx.view(T * B, H, W, Cin)
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, x_tb, T, B, training):

@@ -46,8 +46,8 @@ for n in ('f32_bench_line','f32_long_bench_line','x3_bench_line','bf16_bench_lin
         if n == 'f32_bench_line': print('   variants:', {k: {p: (v[p]['ms_per_step'], v[p]['frac_of_peak']) for p in ('fp32','bf16','bf16x3')} for k, v in d['variants'].items()}); print('   cpu:', d['cpu_baseline']['value'], d['cpu_baseline']['tensorflow_probe']); print('   bf16x3_mode:', {k: v for k, v in d['bf16x3_mode'].items() if k not in ('what','mfma_kernels')})
     except Exception as e: print(n, 'FAILED', e)
 PY
-# streaming repeatability: five processes per precision (the bench's own inference block)
-for prec in fp32 bf16 bf16x3; do for i in 1 2 3 4 5; do
+# streaming repeatability: three processes per precision (the bench's own inference block)
+for prec in fp32 bf16 bf16x3; do for i in 1 2 3; do
 python bench.py --precision $prec --steps 1 --warmup 1 --no-cpu-baseline --no-variants --no-bf16 --no-x3 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stream $prec run $i', d['inference']['frames_per_s'], d['inference']['frames_per_s_with_postprocess'], d['inference']['frames_per_s_with_postprocess_runs'])"
