@@ -209,7 +209,12 @@ static inline unsigned lu_pack2bf(float lo, float hi) { return (unsigned)lu_f2bf
 #endif
 
 // Exact three-way bf16 split of an fp32 value (precision 'bf16x3', lu_split6): x == hi + mid + lo; both residuals are exact in fp32.
+// (contract(off): when x is the product of a caller's multiply, hipcc would otherwise fuse it into these subtractions -- fma(a, b, -hi) --
+// and the pieces would sum to the UNROUNDED product instead of the fp32 value that was stored; found on the MI355X, not on the emulator)
 __device__ __host__ static inline void lu_split3(float x, float& hi, float& mid, float& lo) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     unsigned u = (unsigned)lu_f2bf(x) << 16;
     memcpy(&hi, &u, 4);
     const float r1 = x - hi;

@@ -679,10 +679,10 @@ class Engine:
     # ------------------------------------------------------------------ ConvLSTM layer, precision 'bf16x3'
     def _x3_route(self, k, F, cin, B, H, W, training=True):
         """precision 'bf16x3': does this ConvLSTM layer run on the split operands?  The domain of the fused bf16 step (F % 32 == 0,
-        F >= 64) and -- training -- of the bf16 kernel-row weight gradient (W % 32 == 0; inference frames, padded to any
-        width, have no weight gradient); other layers take the fp32 kernels."""
-        return (self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and (W % 32 == 0 or not training) and
-                ops.fused_step_applies(B, H, W, F, True))
+        F >= 64; any frame size); other layers take the fp32 kernels.  Where the bf16 kernel-row weight gradient does not apply
+        (W % 32 != 0: config-4's 496 / 248 / 124-pixel levels) the layer's weight gradients -- a third of its FLOPs -- are the
+        fp32 ones, formed from the fp32 tape that is there anyway; its convolutions still run split."""
+        return self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and ops.fused_step_applies(B, H, W, F, True)
 
     def _x3_weight(self, name, role, make, cp=None, order=1):
         """bf16 fragment image of the three-way split of a kernel (block order B; A for the kernels that meet dz, which is
@@ -819,12 +819,15 @@ class Engine:
         dz6_seq = dz6.view(T * B, H, W, 24 * F)
         hp6 = h6_all[:T].view(T * B, H, W, 6 * F)
         x6s = x6.view(T * B, H, W, -1)
-        with self._wgrad_side(dz_seq, dz6_seq, hp6, x6s, x_seq):
-            # (+ the bias gradient: the column sums of the hi, mid and lo blocks of dz6 add up to those of dz)
-            self._x3_wgrad(hp6, dz6_seq, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'])
+        with self._wgrad_side(dz_seq, dz6_seq, hp6, x6s, x_seq, h_all):
+            if ops.bf16_row_wgrad_ok(ops.split_piece(hp6, 'hi'), ops.split_piece(dz6_seq, 'hi'), k, 1):
+                # (+ the bias gradient: the column sums of the hi, mid and lo blocks of dz6 add up to those of dz)
+                self._x3_wgrad(hp6, dz6_seq, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'])
+            else:      # a width outside the bf16 kernel-row weight gradient: the fp32 one on the fp32 tape (_x3_route)
+                ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, dbias=self.G[pre + '.bias'])
             if 6 * Cin == x6s.shape[3] and ops.bf16_row_wgrad_ok(ops.split_piece(x6s, 'hi'), ops.split_piece(dz6_seq, 'hi'), k, 1):
                 self._x3_wgrad(x6s, dz6_seq, self.G[pre + '.kernel'])
-            else:      # thin image (or an odd channel count): the fp32 weight gradient, as in fp32 mode
+            else:      # thin image (or an odd channel count / width): the fp32 weight gradient, as in fp32 mode
                 ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
         dx = None
         if need_dx:
@@ -860,7 +863,8 @@ class Engine:
         rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k), order=0) if T > 1 else None
         kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0) if need_dx else None
         dx = torch.empty((T, B, H, W, Cin), device=dev, dtype=torch.float32) if need_dx else None
-        x_split = 6 * Cin == 6 * cp and ops.bf16_row_wgrad_ok(ops.split_piece(x6, 'hi'), ops.split_piece(dz6, 'hi'), k, 1)
+        h_split = ops.bf16_row_wgrad_ok(ops.split_piece(h6, 'hi'), ops.split_piece(dz6, 'hi'), k, 1)
+        x_split = Cin == cp and ops.bf16_row_wgrad_ok(ops.split_piece(x6, 'hi'), ops.split_piece(dz6, 'hi'), k, 1)
         first = True
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
@@ -874,16 +878,22 @@ class Engine:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
                 ops.conv_raw([(dz6, rt6)], B, H, W, H, W, k, 1, 1, p, p, F, None, dh_rec)
             beta0 = 0.0 if first else 1.0
-            ops.split6(h_all[t], out=h6)
-            self._x3_wgrad(h6, dz6, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'], beta0=beta0)
+            if h_split:
+                ops.split6(h_all[t], out=h6)
+                self._x3_wgrad(h6, dz6, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'], beta0=beta0)
             if x_split:
                 ops.split6(x5[t], cp, out=x6)
                 self._x3_wgrad(x6, dz6, self.G[pre + '.kernel'], beta0=beta0)
-            else:
-                ops.conv2d_wgrad(x5[t], dz[t], self.G[pre + '.kernel'], 1, beta=beta0)
             if need_dx:
                 ops.conv_raw([(dz6, kt6)], B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx[t])
             first = False
+        # weight gradients outside the bf16 kernel-row variant's domain (thin image, W % 32 != 0): the fp32 ones, hoisted over the
+        # window on the fp32 tape exactly as in fp32 mode
+        dz_seq = dz.view(T * B, H, W, 4 * F)
+        if not h_split:
+            ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, dbias=self.G[pre + '.bias'])
+        if not x_split:
+            ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
         rec['gates'] = rec['h_all'] = rec['c_all'] = rec['x'] = None
         return None if dx is None else dx.view(T * B, H, W, Cin)
 
