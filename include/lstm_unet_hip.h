@@ -154,6 +154,10 @@ int lu_pack_weights_f32(const float* w, int64_t w_tap_stride, int w_row_stride, 
 size_t lu_pack_weights_bf16_bytes(int k, int C, int N);
 int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
                          lu_stream_t stream);
+/* precision 'bf16x3' (ABI v11): the same image of the kernel's three-way bf16 split laid out along its row axis -- [tap][6][cp][N], block j = the
+ * piece lu_split6's `order` names (rows [C, cp) of a block zero) -- in one pass; lu_pack_weights_bf16_bytes(k, 6 * cp, N) bytes. */
+int lu_pack_weights_split6_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int cp, int N, int order,
+                                void* out, lu_stream_t stream);
 
 /* the same image for a rectangular k_h x k tap window given as a list of `taps` = k_h*k taps (size: taps instead of k*k) */
 int lu_pack_weights_taps_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int taps, int C, int N, void* out,

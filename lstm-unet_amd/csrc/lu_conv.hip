@@ -1218,6 +1218,40 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int64_t ta
                            (int64_t)gridDim.x * blockDim.x);
 }
 
+// precision 'bf16x3': the fragment image of the SPLIT kernel [tap][6][cp][N] (block j = piece `order` names of w, rows [C, cp) of a block
+// zero: lu_split6 of the weights + pack_weights_bf16_kernel in one pass -- 4 bytes read, 12 written per weight instead of 4 + 24 + 24 + 12)
+__global__ void pack_weights_split6_bf16_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C, int cp,
+                                                int N, unsigned order, unsigned short* __restrict__ out) {
+    const int C6 = 6 * cp;
+    const int nchunk = (C6 + CKB - 1) / CKB, nfr = (N + 31) / 32;
+    const int64_t total = (int64_t)kk * nchunk * nfr * 128;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ln = (int)(i & 63), j = (int)((i >> 6) & 1);
+        int64_t t = i >> 7;
+        const int fr = (int)(t % nfr);
+        t /= nfr;
+        const int chunk = (int)(t % nchunk);
+        const int tap = (int)(t / nchunk);
+        const int n = fr * 32 + (ln & 31);
+        const int c0 = chunk * CKB + 16 * j + 8 * (ln >> 5);
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ca = c0 + e, blk = ca / cp, c = ca - blk * cp;      // augmented channel -> (block, channel)
+            float hi = 0.f, mid = 0.f, lo = 0.f;
+            if (ca < C6 && c < C && n < N) lu_split3(w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n], hi, mid, lo);
+            const unsigned pc = (order >> (2 * (blk < 6 ? blk : 0))) & 3u;
+            v[e] = lu_f2bf(pc == 0 ? hi : (pc == 1 ? mid : lo));
+        }
+        lu_u4 pk;
+        pk.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+        pk.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+        pk.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+        pk.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+        *reinterpret_cast<lu_u4*>(out + (i << 3)) = pk;
+    }
+}
+
 // fp32 counterpart of pack_weights_bf16_kernel: [tap][16-channel chunk][column fragment][s][lane][4 floats] with
 // channel = 16 chunk + 8 s + 4 (lane >> 5) + e, column = 32 fragment + (lane & 31): the four floats of a lane are the B
 // operands of the four MFMAs fed by one ds_read_b128 of the halo.
@@ -3212,6 +3246,19 @@ extern "C" int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_
     const int64_t total = (int64_t)k * k * ((C + CKB - 1) / CKB) * ((N + 31) / 32) * 128;      // one thread per 8 elements
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N,
+              (unsigned short*)out);
+    return LU_CHECK_LAUNCH();
+}
+
+extern "C" int lu_pack_weights_split6_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int cp, int N,
+                                           int order, void* out, lu_stream_t stream) {
+    LU_REQUIRE(w && out && k > 0 && C > 0 && cp >= C && N > 0 && (order == 0 || order == 1), "lu_pack_weights_split6_bf16: bad arguments");
+    // piece (0 hi, 1 mid, 2 lo) of block j, two bits each: order 0 = A (lo, mid, hi, mid, hi, hi), 1 = B (hi, mid, lo, hi, mid, hi) -- lu_split6
+    const unsigned ord = order == 0 ? (2u | (1u << 2) | (0u << 4) | (1u << 6) | (0u << 8) | (0u << 10))
+                                    : (0u | (1u << 2) | (2u << 4) | (0u << 6) | (1u << 8) | (0u << 10));
+    const int64_t total = (int64_t)k * k * ((6 * cp + CKB - 1) / CKB) * ((N + 31) / 32) * 128;
+    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    LU_LAUNCH(pack_weights_split6_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, cp, N, ord,
               (unsigned short*)out);
     return LU_CHECK_LAUNCH();
 }

@@ -76,6 +76,7 @@ PROTOTYPES = {
     'lu_pack_weights_taps_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_pack_weights_bf16_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'lu_pack_weights_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
+    'lu_pack_weights_split6_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'lu_stride2_dgrad_weights': (C.c_int, [P, P] + [C.c_int] * 10 + [S]),
     'lu_weight_flip_transpose': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, S]),

@@ -687,7 +687,7 @@ class Engine:
     def _x3_weight(self, name, role, make, cp=None, order=1):
         """bf16 fragment image of the three-way split of a kernel (block order B; A for the kernels that meet dz, which is
         split in order B), once per weight change."""
-        return self._pack(name, role, lambda: ops.split6_weights(make(), cp, order))
+        return self._pack(name, role, make, packer=lambda w: ops.pack_split6_bf16(w, cp, order))
 
     def _lstm_forward_x3(self, bi, li, spec, x_seq, T, B, tape):
         """The ConvLSTM layer of precision 'bf16x3' (reference Networks.py:48-50,62-63; the fp32 form: _lstm_forward).  x_t and

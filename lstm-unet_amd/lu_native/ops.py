@@ -528,6 +528,19 @@ def split_piece(x6, piece):
     return x6[..., b * lp:(b + 1) * lp]
 
 
+def pack_split6_bf16(w, cp=None, order=1):
+    """fp32 kernel [k,k,C,N] (contiguous) -> the bf16 PackedW of its three-way split laid out six times along C ([k,k,6*cp,N], block
+    order B by default): pack_bf16(split6_weights(w, cp, order)) in one pass (lu_pack_weights_split6_bf16)."""
+    _chk(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
+    k, _, Cc, N = w.shape
+    cp = Cc if cp is None else cp
+    data = torch.empty(lib().lu_pack_weights_bf16_bytes(k, 6 * cp, N) // 2, device=w.device, dtype=torch.int16)
+    calls.check(lib(), lib().lu_pack_weights_split6_bf16(w.data_ptr(), w.stride(1), w.stride(2), k, Cc, cp, N, int(order), data.data_ptr(),
+                                                         _stream()), 'lu_pack_weights_split6_bf16')
+    return PackedW(data, (k, k, 6 * cp, N))
+
+
 def split6_weights(w, cp=None, order=1):
     """fp32 kernel [k,k,C,N] (contiguous) -> fp32 [k,k,6*cp,N] holding the pieces of its three-way bf16 split in block order B
     (hi, mid, lo, hi, mid, hi; rows [C, cp) of a block zero; order=0: A, for activations split in order B): every value is exactly

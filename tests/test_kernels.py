@@ -1239,3 +1239,20 @@ def test_gate_backward_with_the_split_image_of_dz(be):
         close(be.host(dcp2), be.host(dcp), 2e-6 * max(1.0, float(np.abs(be.host(dcp)).max())))
         ref6 = split6_ref(dz_got.reshape(-1, 4 * F), 4 * F, 1).reshape(fr, H, W, 24 * F)
         assert np.array_equal(KH.bf16_values(be.host(dz6)).view(np.uint32), ref6.view(np.uint32))
+
+
+def test_split6_weight_image_in_one_pass(be):
+    """lu_pack_weights_split6_bf16 == lu_pack_weights_bf16 of the lu_split6 (fp32) image of the kernel, bit for bit: both block
+    orders, a thin kernel with zero-padded blocks (C = 1 -> cp = 4), ragged channel / column counts."""
+    for (k, Cc, cp, N) in [(3, 16, 16, 40), (5, 1, 4, 64), (3, 20, 20, 33)]:
+        w = rnd(k, k, Cc, N, scale=0.3)
+        wd = be.dev(w)
+        for order in (0, 1):
+            w6 = split6_ref(w.reshape(k * k, Cc * N), Cc * N, order).reshape(k * k, 6, Cc, N)
+            w6p = np.zeros((k * k, 6, cp, N), np.float32)
+            w6p[:, :, :Cc] = w6
+            ref = be.host(KH.pack_bf16(be, be.dev(w6p.reshape(k, k, 6 * cp, N)), k, 6 * cp, N))
+            nbytes = be.lib.lu_pack_weights_bf16_bytes(k, 6 * cp, N)
+            out = be.empty((nbytes // 4 + 4,))
+            ck(be, be.lib.lu_pack_weights_split6_bf16(be.ptr(wd), Cc * N, N, k, Cc, cp, N, order, be.ptr(out), be.stream), 'pack split6')
+            assert np.array_equal(be.host(out)[:nbytes // 4].view(np.uint32), ref[:nbytes // 4].view(np.uint32)), (k, Cc, cp, N, order)
