@@ -119,8 +119,10 @@ class Engine:
         self.s2_fwd_bf16 = True      # stride-2 forward convs behind a ConvLSTM read its bf16 copy (A/B: bench.py --conv-flags 4096 turns it off)
         self._side_stream = None
         self._side_keep = []         # [(event behind the side-stream launches, the tensors they read)]
-        self.x3_lean_bytes = 24e9    # precision 'bf16x3': a layer whose split dz of the whole window would exceed this many bytes forms its
-                                     # weight / input gradients step by step from one step's split tensors instead (config-4: 162 GB at level 0)
+        self.x3_lean_bytes = None    # precision 'bf16x3': when the window-long split tensors of all layers together would exceed this many
+                                     # bytes (None: 30 % of the device's memory) every layer forms its weight / input gradients step by step
+                                     # from one step's split tensors instead (config-4: 273 GB of split dz; config-2: 22 GB, hoisted)
+        self._x3_lean = False
         self.x3_wgrad_launches = 2   # precision 'bf16x3': the six products of a weight gradient in two launches with the terms as frames (A/B: 6)
         self.x3_fused_split = True   # precision 'bf16x3': the gate epilogue writes the split image of h (A/B: False = a split6 pass per step)
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
@@ -738,7 +740,7 @@ class Engine:
         c_all = torch.empty((T + 1, B, H, W, F), device=dev, dtype=torch.float32)
         # lean: the split images live for one step only (two rolling slots of h6 here; backward re-splits h_t, x_t and forms dz6_t
         # per step) -- for layers whose window-long split dz would not fit beside the fp32 tape
-        lean = 2.0 * T * B * H * W * 24 * F > self.x3_lean_bytes
+        lean = self._x3_lean
         if not lean:
             x6 = ops.split6(x_seq, cp).view(T, B, H, W, 6 * cp)      # one pass per window; also the x operand of the kernel gradient
         else:         # (the window-long split of x is not kept either)
@@ -915,6 +917,17 @@ class Engine:
             x_in = ops.window_copy(x_tb, (H + sum(py), W + sum(px)), (py[0], px[0]), 1)
         else:
             x_in = x_tb
+        if self.precision == 'bf16x3' and training:
+            # window-long split tensors of every ConvLSTM layer (dz6 + the split hidden sequence), were they all kept
+            extra, hh, ww = 0.0, x_in.shape[1], x_in.shape[2]
+            for blk in plan['down']:
+                extra += sum(2.0 * T * B * hh * ww * 30 * l['f'] for l in blk['lstm'])
+                if blk['stride'] == 2:
+                    hh, ww = -(-hh // 2), -(-ww // 2)
+            limit = self.x3_lean_bytes
+            if limit is None:
+                limit = 0.3 * torch.cuda.get_device_properties(x_tb.device).total_memory if x_tb.device.type == 'cuda' else 1e18
+            self._x3_lean = extra > limit
         skips = []
         act = x_in
         for bi, blk in enumerate(plan['down']):
