@@ -6,6 +6,8 @@
 # in line so that the traced averages are the ones the bench's HIP events see), DP-over-gloo line, streaming repeatability
 tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
+# the whole GPU suite on the final tree first (its log is the round's test evidence)
+timeout 2400 python -m pytest tests -q -m gpu -s > gpurun_out/${tag}_gpu_tests.log 2>&1; tail -3 gpurun_out/${tag}_gpu_tests.log
 bash tools/gpu/pmc_traffic.sh $tag | tail -14
 # ... and (round 5) for the other workloads the bench lines below report: config-4, the config-5 per-GPU shape, the two net variants
 PMC_EXTRA="--hw 832 992 --batch 2 --unroll 16" PMC_SFX=_c4 PMC_MODES=fp32 bash tools/gpu/pmc_traffic.sh $tag | tail -4
@@ -27,6 +29,8 @@ python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --no-var
 # precision 'bf16x3' (fp32 arithmetic on the bf16 MFMA): its own line (with its streaming inference), its by-shape table, and the step next to the fp32 engine's
 python bench.py --precision bf16x3 --steps 8 --warmup 3 --no-cpu-baseline --no-variants --by-shape gpurun_out/${tag}_x3_by_shape.json > gpurun_out/${tag}_x3_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python tools/x3_compare.py > gpurun_out/${tag}_x3_compare_vs_fp32.json 2>> gpurun_out/${tag}_f32_bench.err
+python bench.py --precision bf16x3 --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-infer > gpurun_out/${tag}_x3_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
+python bench.py --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-infer --no-bf16 --no-x3 > gpurun_out/${tag}_f32_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --no-variants --no-infer --no-wgrad-overlap --by-shape gpurun_out/${tag}_bf16_by_shape.json > gpurun_out/${tag}_bf16_inline_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16 --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline --no-variants > gpurun_out/${tag}_bf16_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --hw 832 992 --batch 2 --unroll 16 --steps 3 --warmup 2 --no-bf16 --no-x3 --no-infer --no-cpu-baseline --no-variants > gpurun_out/${tag}_f32_c4_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
@@ -36,7 +40,7 @@ done; done
 LU_DP_BACKEND=gloo python bench.py --gpus 2 --check --sync-bn --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_dp2_gloo_bench_line.json 2> gpurun_out/${tag}_dp2_gloo.err; grep "check" gpurun_out/${tag}_dp2_gloo.err | tail -1
 python - <<PY
 import json
-for n in ('f32_bench_line','f32_long_bench_line','x3_bench_line','bf16_bench_line','bf16_inline_bench_line','bf16_c5shape_bench_line','f32_c4_bench_line',
+for n in ('f32_bench_line','f32_long_bench_line','x3_bench_line','x3_c5shape_bench_line','f32_c5shape_bench_line','bf16_bench_line','bf16_inline_bench_line','bf16_c5shape_bench_line','f32_c4_bench_line',
           'lstm3_fp32_bench_line','lstm3_bf16_bench_line','lstm3_bf16x3_bench_line','default5_fp32_bench_line','default5_bf16_bench_line','default5_bf16x3_bench_line','dp2_gloo_bench_line'):
     try:
         d=json.load(open('gpurun_out/${tag}_%s.json' % n))
