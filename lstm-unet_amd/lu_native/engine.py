@@ -123,6 +123,7 @@ class Engine:
                                      # bytes (None: 30 % of the device's memory) every layer forms its weight / input gradients step by step
                                      # from one step's split tensors instead (config-4: 273 GB of split dz; config-2: 22 GB, hoisted)
         self._x3_lean = False
+        self.x3_pad_wgrad = True     # precision 'bf16x3', W % 32 != 0: weight gradients on zero-padded copies of the split tensors (False: fp32 ones)
         self.x3_wgrad_launches = 2   # precision 'bf16x3': the six products of a weight gradient in two launches with the terms as frames (A/B: 6)
         self.x3_fused_split = True   # precision 'bf16x3': the gate epilogue writes the split image of h (A/B: False = a split6 pass per step)
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
@@ -681,9 +682,9 @@ class Engine:
     # ------------------------------------------------------------------ ConvLSTM layer, precision 'bf16x3'
     def _x3_route(self, k, F, cin, B, H, W, training=True):
         """precision 'bf16x3': does this ConvLSTM layer run on the split operands?  The domain of the fused bf16 step (F % 32 == 0,
-        F >= 64; any frame size); other layers take the fp32 kernels.  Where the bf16 kernel-row weight gradient does not apply
-        (W % 32 != 0: config-4's 496 / 248 / 124-pixel levels) the layer's weight gradients -- a third of its FLOPs -- are the
-        fp32 ones, formed from the fp32 tape that is there anyway; its convolutions still run split."""
+        F >= 64; any frame size); other layers take the fp32 kernels.  The bf16 kernel-row weight gradient wants W % 32 == 0:
+        on other widths (config-4's 496 / 248 / 124-pixel levels) it runs on zero-padded copies of the split tensors (_x3_pad_w;
+        x3_pad_wgrad = False: the fp32 weight gradients on the fp32 tape instead)."""
         return self.precision == 'bf16x3' and k in (3, 5) and F % 32 == 0 and F >= 64 and ops.fused_step_applies(B, H, W, F, True)
 
     def _x3_weight(self, name, role, make, cp=None, order=1):
@@ -768,6 +769,21 @@ class Engine:
         self._h16_seq = None
         return h_all[1:].view(T * B, H, W, F)
 
+    @staticmethod
+    def _x3_pad_w(t6, out=None):
+        """split6 tensor [frames,H,W,C6] -> the same rows zero-padded to a multiple of 32 pixels: the domain of the bf16 kernel-row weight
+        gradient.  Zero columns of dz add nothing to a weight gradient and zero columns of x are what SAME padding reads there anyway,
+        so the gradient of the padded problem IS the gradient (config-4's 496 / 248 / 124-pixel levels).  out: a buffer whose pad
+        columns are already zero (the step-by-step route reuses it)."""
+        fr, H, W, C6 = t6.shape
+        Wp = -(-W // 32) * 32
+        if Wp == W:
+            return t6
+        if out is None:
+            out = torch.zeros((fr, H, Wp, C6), device=t6.device, dtype=t6.dtype)
+        out[:, :, :W].copy_(t6)
+        return out
+
     def _x3_wgrad(self, x6, dy6, dw, dbias=None, beta0=0.0):
         """dw = x (*) dy on the split operands (x6 in order A, dy6 in order B: block t against block t is term t of
         ops.SPLIT_TERMS).  Two launches of the bf16 kernel-row weight gradient with the terms as extra frames
@@ -821,14 +837,17 @@ class Engine:
         dz6_seq = dz6.view(T * B, H, W, 24 * F)
         hp6 = h6_all[:T].view(T * B, H, W, 6 * F)
         x6s = x6.view(T * B, H, W, -1)
-        with self._wgrad_side(dz_seq, dz6_seq, hp6, x6s, x_seq, h_all):
-            if ops.bf16_row_wgrad_ok(ops.split_piece(hp6, 'hi'), ops.split_piece(dz6_seq, 'hi'), k, 1):
+        # W % 32 != 0: the weight gradients see zero-padded copies of the split tensors (_x3_pad_w)
+        dz6_w, hp6_w = (self._x3_pad_w(dz6_seq), self._x3_pad_w(hp6)) if self.x3_pad_wgrad else (dz6_seq, hp6)
+        x6s_w = self._x3_pad_w(x6s) if (self.x3_pad_wgrad and 6 * Cin == x6s.shape[3] and Cin >= 32) else x6s
+        with self._wgrad_side(dz_seq, dz6_seq, hp6, x6s, x_seq, h_all, dz6_w, hp6_w, x6s_w):
+            if ops.bf16_row_wgrad_ok(ops.split_piece(hp6_w, 'hi'), ops.split_piece(dz6_w, 'hi'), k, 1):
                 # (+ the bias gradient: the column sums of the hi, mid and lo blocks of dz6 add up to those of dz)
-                self._x3_wgrad(hp6, dz6_seq, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'])
-            else:      # a width outside the bf16 kernel-row weight gradient: the fp32 one on the fp32 tape (_x3_route)
+                self._x3_wgrad(hp6_w, dz6_w, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'])
+            else:      # outside the bf16 kernel-row weight gradient (x3_pad_wgrad = False): the fp32 one on the fp32 tape
                 ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, dbias=self.G[pre + '.bias'])
-            if 6 * Cin == x6s.shape[3] and ops.bf16_row_wgrad_ok(ops.split_piece(x6s, 'hi'), ops.split_piece(dz6_seq, 'hi'), k, 1):
-                self._x3_wgrad(x6s, dz6_seq, self.G[pre + '.kernel'])
+            if 6 * Cin == x6s.shape[3] and ops.bf16_row_wgrad_ok(ops.split_piece(x6s_w, 'hi'), ops.split_piece(dz6_w, 'hi'), k, 1):
+                self._x3_wgrad(x6s_w, dz6_w, self.G[pre + '.kernel'])
             else:      # thin image (or an odd channel count / width): the fp32 weight gradient, as in fp32 mode
                 ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
         dx = None
@@ -865,8 +884,14 @@ class Engine:
         rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k), order=0) if T > 1 else None
         kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0) if need_dx else None
         dx = torch.empty((T, B, H, W, Cin), device=dev, dtype=torch.float32) if need_dx else None
-        h_split = ops.bf16_row_wgrad_ok(ops.split_piece(h6, 'hi'), ops.split_piece(dz6, 'hi'), k, 1)
-        x_split = Cin == cp and ops.bf16_row_wgrad_ok(ops.split_piece(x6, 'hi'), ops.split_piece(dz6, 'hi'), k, 1)
+        # W % 32 != 0: the weight gradients see zero-padded copies (_x3_pad_w; the pad columns of the reused buffers stay zero)
+        Wp = -(-W // 32) * 32 if self.x3_pad_wgrad else W
+        pad = Wp != W
+        dz6_w = torch.zeros((B, H, Wp, 24 * F), device=dev, dtype=torch.bfloat16) if pad else dz6
+        h6_w = torch.zeros((B, H, Wp, 6 * F), device=dev, dtype=torch.bfloat16) if pad else h6
+        x6_w = torch.zeros((B, H, Wp, 6 * cp), device=dev, dtype=torch.bfloat16) if (pad and Cin == cp and Cin >= 32) else x6
+        h_split = ops.bf16_row_wgrad_ok(ops.split_piece(h6_w, 'hi'), ops.split_piece(dz6_w, 'hi'), k, 1)
+        x_split = Cin == cp and ops.bf16_row_wgrad_ok(ops.split_piece(x6_w, 'hi'), ops.split_piece(dz6_w, 'hi'), k, 1)
         first = True
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
@@ -880,12 +905,18 @@ class Engine:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
                 ops.conv_raw([(dz6, rt6)], B, H, W, H, W, k, 1, 1, p, p, F, None, dh_rec)
             beta0 = 0.0 if first else 1.0
+            if pad and (h_split or x_split):
+                self._x3_pad_w(dz6, out=dz6_w)
             if h_split:
                 ops.split6(h_all[t], out=h6)
-                self._x3_wgrad(h6, dz6, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'], beta0=beta0)
+                if pad:
+                    self._x3_pad_w(h6, out=h6_w)
+                self._x3_wgrad(h6_w, dz6_w, self.G[pre + '.recurrent_kernel'], dbias=self.G[pre + '.bias'], beta0=beta0)
             if x_split:
                 ops.split6(x5[t], cp, out=x6)
-                self._x3_wgrad(x6, dz6, self.G[pre + '.kernel'], beta0=beta0)
+                if pad:
+                    self._x3_pad_w(x6, out=x6_w)
+                self._x3_wgrad(x6_w, dz6_w, self.G[pre + '.kernel'], beta0=beta0)
             if need_dx:
                 ops.conv_raw([(dz6, kt6)], B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx[t])
             first = False

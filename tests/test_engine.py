@@ -704,7 +704,7 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch, W):
     ARITHMETIC, so the test is the fp32 engine's own: logits and every gradient tensor are compared with the fp64 oracle and
     must sit where the fp32 engine sits (<= 2x its error + 1e-6), and the two engines agree to 2e-5 / 2e-4 -- two hundred
     times closer than the bf16 mode's contract.  W = 24: a width outside the bf16 kernel-row weight gradient (W % 32 != 0, config-4's
-    coarse levels) -- the layer's convolutions still run split, its weight gradients are the fp32 ones on the fp32 tape."""
+    coarse levels) -- the convolutions run split as they are, the weight gradients on zero-padded copies of the split tensors."""
     from lu_native import calls, ops
     from lu_native.engine import Engine
     seen = []

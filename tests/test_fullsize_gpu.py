@@ -818,7 +818,7 @@ def test_config4_ragged_gradients_vs_oracle(full_engine, oracle_farm, precision)
     """A 208x248 crop of config-4's geometry: pixel rows of 248 / 124 / 62 / 31 -- the ragged-row (RG) kernel-row weight gradient
     at levels 0 / 1, the general kernel below, masked patch columns in every halo launch, odd-extent parity planes in the
     stride-2 input gradients (VERDICT round 4, next #1b)."""
-    if precision == 'bf16x3':      # split convolutions at every width; fp32 weight gradients where W % 32 != 0 (Engine._x3_route)
+    if precision == 'bf16x3':      # split convolutions at every width; weight gradients on zero-padded copies where W % 32 != 0 (Engine._x3_pad_w)
         _check_fp32_case(full_engine, oracle_farm, 'c4-ragged-208x248-T2-B1', precision='bf16x3')
     else:
         _check_fp32_case(full_engine, oracle_farm, 'c4-ragged-208x248-T2-B1', routes=(None, 'split'))
