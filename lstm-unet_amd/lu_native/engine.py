@@ -123,6 +123,7 @@ class Engine:
                                      # bytes (None: 30 % of the device's memory) every layer forms its weight / input gradients step by step
                                      # from one step's split tensors instead (config-4: 273 GB of split dz; config-2: 22 GB, hoisted)
         self._x3_lean = False
+        self.x3_conv_units = True    # precision 'bf16x3': the wide stride-1 3x3 / 5x5 Conv2D layers on split operands too (False: ConvLSTM layers only)
         self.x3_pad_wgrad = True     # precision 'bf16x3', W % 32 != 0: weight gradients on zero-padded copies of the split tensors (False: fp32 ones)
         self.x3_wgrad_launches = 2   # precision 'bf16x3': the six products of a weight gradient in two launches with the terms as frames (A/B: 6)
         self.x3_fused_split = True   # precision 'bf16x3': the gate epilogue writes the split image of h (A/B: False = a split6 pass per step)
@@ -355,6 +356,8 @@ class Engine:
         bf16 mode; sources may themselves arrive as bf16 tensors for the same reason)."""
         wname = f'{prefix}.conv.{ci}.kernel'
         w = self.P[wname]
+        if self._x3_unit(w.shape[0], spec['stride'], w.shape[3], srcs):
+            return self._conv_unit_x3(prefix, ci, spec, srcs, with_bn, training, tape)
         bf = self._bf16_unit(w.shape[0], spec['stride'], w.shape[3])
         any16 = any(x.dtype == torch.bfloat16 for (x, _, _) in srcs)
         if any16 and not (bf and all(x.dtype == torch.bfloat16 or x.shape[3] % 4 or x.shape[3] % 8 == 0 for (x, _, _) in srcs)):
@@ -435,6 +438,71 @@ class Engine:
         return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec,
                                 z16=z16 and tape is not None and self.precision == 'bf16' and self.act_bf16)
 
+    # ------------------------------------------------------------------ Conv2D unit, precision 'bf16x3'
+    def _x3_unit(self, k, stride, n_out, srcs):
+        """precision 'bf16x3': the wide stride-1 3x3 / 5x5 Conv2D layers (the bf16 halo kernel's domain: more than 64 output columns,
+        sources of at least 32 channels in 16-byte groups) run on split operands like the ConvLSTM convolutions; stride-2, 1x1 and the
+        narrow decoder tail stay on the fp32 kernels (HBM-bound layers: six times the MFMA work would not pay for the split passes)."""
+        return (self.precision == 'bf16x3' and self.x3_conv_units and stride == 1 and k in (3, 5) and n_out > 64 and n_out % 4 == 0 and
+                all(x.dtype == torch.float32 and cs >= 32 and cs % 8 == 0 and x.shape[3] == cs for (x, _, cs) in srcs))
+
+    def _conv_unit_x3(self, prefix, ci, spec, srcs, with_bn, training, tape):
+        """_conv_unit on split operands (Networks.py:69-72,146-151): every source as its split6 image (order A) against its slice of the
+        kernel split in order B -- the fp32 convolution to 2^-26 per product; bias, BatchNorm and LeakyReLU as in fp32 mode."""
+        wname = f'{prefix}.conv.{ci}.kernel'
+        w = self.P[wname]
+        bias = self.P[f'{prefix}.conv.{ci}.bias']
+        x6s = [ops.split6(x) for (x, _, _) in srcs]
+        pairs = [(x6, self._pack(wname, 'x3', lambda co=co, cs=cs: w[:, :, co:co + cs, :], co, cs,
+                                 packer=lambda v: ops.pack_split6_bf16(v, None, 1)))
+                 for x6, (_, co, cs) in zip(x6s, srcs)]
+        if with_bn and tape is None and not training:
+            scale, shift = self._bn_affine_infer(f'{prefix}.bn.{ci}')
+            return ops.conv2d(pairs, bias, 1, post=(scale, shift, LRELU_ALPHA))
+        y = ops.conv2d(pairs, bias, 1)
+        rec = None
+        if tape is not None:
+            rec = {'kind': 'conv', 'x3': True, 'prefix': prefix, 'ci': ci, 'spec': spec, 'srcs': srcs, 'x6s': x6s, 'bn': with_bn,
+                   'alt16': None}
+            tape.append(rec)
+        if not with_bn:
+            return y
+        if rec is not None:
+            rec['y'] = y
+        return self._bn_forward(f'{prefix}.bn.{ci}', y, training, rec)
+
+    def _conv_unit_backward_x3(self, rec, dy, need_dx):
+        """Input and weight gradients of a split Conv2D unit from dy (fp32, behind the BatchNorm backward): dy6 = split6(dy) in order B
+        once; per source the weight gradient with the terms as frames (the bias gradient rides on the first source's launch: its dy
+        blocks 0-2 are hi, mid, lo) and the input gradient as the convolution of dy6 with the flipped kernel slice split in order A."""
+        prefix, ci = rec['prefix'], rec['ci']
+        wname = f'{prefix}.conv.{ci}.kernel'
+        w, gw = self.P[wname], self.G[wname]
+        k = w.shape[0]
+        p = (k - 1) // 2
+        frames, H, W, N = dy.shape
+        dy6 = ops.split6(dy, order=1)
+        dy6_w = self._x3_pad_w(dy6) if self.x3_pad_wgrad else dy6
+        dxs = []
+        for si, ((x, co, cs), x6, need) in enumerate(zip(rec['srcs'], rec['x6s'], need_dx)):
+            x6_w = self._x3_pad_w(x6) if self.x3_pad_wgrad else x6
+            dbias = self.G[f'{prefix}.conv.{ci}.bias'] if si == 0 else None
+            with self._wgrad_side(x6, dy6, x6_w, dy6_w, x, dy):
+                if ops.bf16_row_wgrad_ok(ops.split_piece(x6_w, 'hi'), ops.split_piece(dy6_w, 'hi'), k, 1):
+                    self._x3_wgrad(x6_w, dy6_w, gw[:, :, co:co + cs, :], dbias=dbias)
+                else:
+                    ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], 1, dbias=dbias)
+            if need:
+                wt6 = self._pack(wname, 'x3t', lambda co=co, cs=cs: ops.flip_transpose(w, co, cs), co, cs,
+                                 packer=lambda v: ops.pack_split6_bf16(v, None, 0))
+                dx = torch.empty((frames, H, W, cs), device=dy.device, dtype=torch.float32)
+                ops.conv_raw([(dy6, wt6)], frames, H, W, H, W, k, 1, 1, p, p, cs, None, dx)
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+        rec['srcs'] = rec['x6s'] = None
+        return dxs
+
     def _dy16_ok(self, rec, dz, need_dx):
         """bf16 mode: may the gradient w.r.t. this unit's convolution output be STORED as bf16?  Yes when every reader rounds it
         to bf16 MFMA operands anyway: the weight gradient of every source on the bf16 kernel-row variant, every input gradient
@@ -479,6 +547,8 @@ class Engine:
             rec['y'] = None
         else:
             dy = dz
+        if rec.get('x3'):
+            return self._conv_unit_backward_x3(rec, dy, need_dx)
         dxs = []
         for si, ((x, co, cs), need) in enumerate(zip(rec['srcs'], need_dx)):
             # the bias gradient (column sums of dy) rides on the first source's weight-gradient launch

@@ -530,9 +530,9 @@ def split_piece(x6, piece):
 
 def pack_split6_bf16(w, cp=None, order=1):
     """fp32 kernel [k,k,C,N] (contiguous) -> the bf16 PackedW of its three-way split laid out six times along C ([k,k,6*cp,N], block
-    order B by default): pack_bf16(split6_weights(w, cp, order)) in one pass (lu_pack_weights_split6_bf16)."""
+    order B by default): pack_bf16(split6_weights(w, cp, order)) in one pass (lu_pack_weights_split6_bf16; channel-slice views allowed)."""
     _chk(w)
-    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
+    assert w.dtype == torch.float32 and w.dim() == 4 and w.stride(3) == 1 and w.stride(0) == w.shape[1] * w.stride(1)
     k, _, Cc, N = w.shape
     cp = Cc if cp is None else cp
     data = torch.empty(lib().lu_pack_weights_bf16_bytes(k, 6 * cp, N) // 2, device=w.device, dtype=torch.int16)

@@ -693,8 +693,10 @@ def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precisi
 
 # precision 'bf16x3': two stacked ConvLSTMs at W = 32 -- the first reads the thin image (fp32 kernel gradient, zero-padded
 # split blocks), the second a 64-channel input (split kernel gradient, split input gradient); level 1 (F = 8) stays fp32
-X3_NET = {'down_conv_kernels': [[(3, 16)], [(3, 8)]], 'lstm_kernels': [[(3, 64), (5, 64)], [(3, 8)]],
-          'up_conv_kernels': [[(3, 16)], [(3, 16), (1, 3)]]}
+# ... and two wide Conv2D units on split operands: down.0.conv.1 (32 -> 128, stride 1, behind the stride-2 fp32 layer) and up.0.conv.0 (two
+# sources: 32 + 128 channels -> 128)
+X3_NET = {'down_conv_kernels': [[(3, 32), (3, 128)], [(3, 32)]], 'lstm_kernels': [[(3, 64), (5, 64)], [(3, 8)]],
+          'up_conv_kernels': [[(3, 128)], [(3, 16), (1, 3)]]}
 
 
 @pytest.mark.parametrize('W', [32, 24])
@@ -794,7 +796,7 @@ def test_bf16x3_streaming_inference_on_ragged_frames(dev):
             e.build(cin, dev)
             e.load_params(p)
             outs[prec] = [e.forward(torch.from_numpy(f).to(dev), 1, 1, False).cpu().numpy().astype(np.float64) for f in frames]
-            assert (sum(seen) == 0) if prec == 'fp32' else (sum(seen) == 2 * len(frames)), (prec, sum(seen))      # two split ConvLSTM layers per frame
+            assert (sum(seen) == 0) if prec == 'fp32' else (sum(seen) == 4 * len(frames)), (prec, sum(seen))      # two split ConvLSTM layers + two split Conv2D units per frame
     finally:
         calls.conv2d = real
     for a, b in zip(outs['fp32'], outs['bf16x3']):
