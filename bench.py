@@ -459,6 +459,7 @@ def main():
                          "on the bf16 MFMA (ConvLSTM convolutions on the exact three-way bf16 split of their fp32 operands)")
     ap.add_argument('--no-x3', action='store_true', help='skip the secondary bf16x3-mode measurement of the same step')
     ap.add_argument('--ab-x3-split-pass', action='store_true', help='A/B, bf16x3: a split6 pass over h per step instead of the gate epilogue writing it')
+    ap.add_argument('--ab-x3-lstm-only', action='store_true', help='A/B, bf16x3: only the ConvLSTM layers on split operands (the Conv2D units on the fp32 kernels)')
     ap.add_argument('--ab-x3-wgrad6', action='store_true', help='A/B, bf16x3: one weight-gradient launch per product (six) instead of two launches with the terms as frames')
     ap.add_argument('--wgrad-overlap', action='store_true', help='A/B: weight gradients on the side stream (the default in bf16 mode only)')
     ap.add_argument('--net', choices=list(NETS), default='params',
@@ -525,6 +526,8 @@ def main():
         trainer.engine.x3_fused_split = False
     if args.ab_x3_wgrad6:
         trainer.engine.x3_wgrad_launches = 6
+    if args.ab_x3_lstm_only:
+        trainer.engine.x3_conv_units = False
     if args.ab_f32_act:
         trainer.engine.act_bf16 = False
         trainer.engine.grad_bf16 = False
