@@ -208,3 +208,47 @@ def test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files(tmp_path
     files = sorted(os.listdir(os.path.join(str(tmp_path), 'LSTMUNet', 't', ck[0], 'tf_ckpts')))
     for r in range(W):
         assert len([f for f in files if f.endswith('.rank%d.pt' % r)]) == 2, files
+
+
+@pytest.mark.gpu
+def test_bf16x3_train_loop_saved_model_and_streaming_inference(tmp_path, monkeypatch):
+    """--precision bf16x3 through the drivers: train2D.train (Params.precision) on a net whose ConvLSTM layers and wide Conv2D
+    units take the split route, the saved-model directory records the precision (model_params.pickle, next to the reference's
+    two keys, train2D.py:236-239), Inference2D.inference runs the streaming call pattern from it (Inference2D.py:27-62) in both
+    precisions."""
+    import Inference2D
+    import Params
+    import train2D
+    from PIL import Image
+    with engine_backend('hip'):
+        net = {'down_conv_kernels': [[(3, 32), (3, 128)], [(3, 32)]], 'lstm_kernels': [[(5, 64)], [(3, 64)]],
+               'up_conv_kernels': [[(3, 128)], [(3, 16), (1, 3)]]}
+        monkeypatch.setattr(Params.CTCParams, 'net_kernel_params', net)
+        params = Params.CTCParams(dict(experiment_name='x3', crop_size=(32, 64), batch_size=2, unroll_len=3, num_iterations=3,
+                                       validation_interval=2, print_to_console_interval=1, save_checkpoint_iteration=2,
+                                       save_checkpoint_dir=str(tmp_path), save_log_dir=str(tmp_path), data_format='NCHW',
+                                       learning_rate=1e-3, write_to_tb_interval=100, precision='bf16x3'))
+        trainer = train2D.train(params)
+        assert trainer.engine.precision == 'bf16x3' and trainer.step == 4
+        save_dir = params.experiment_save_dir
+        with open(os.path.join(save_dir, 'model_params.pickle'), 'rb') as f:
+            meta = pickle.load(f)
+        assert meta['precision'] == 'bf16x3' and meta['name'] == 'ULSTMnet2D'
+        seq_dir = tmp_path / 'seq'
+        seq_dir.mkdir()
+        rng = np.random.default_rng(0)
+        for t in range(3):
+            Image.fromarray((rng.random((37, 45)) * 255).astype(np.uint8)).save(seq_dir / ('t%03d.tif' % t))
+        outs = {}
+        for prec in ('bf16x3', 'fp32'):
+            out_dir = tmp_path / ('out_' + prec)
+            Inference2D.inference(Params.CTCInferenceParams(dict(
+                model_path=save_dir, sequence_path=str(seq_dir), output_path=str(out_dir), save_intermediate=False,
+                pre_sequence_frames=2, min_cell_size=1, max_cell_size=10 ** 6, data_format='NCHW', precision=prec)))
+            outs[prec] = [np.asarray(Image.open(out_dir / m)) for m in sorted(os.listdir(out_dir))]
+        for prec in outs:
+            assert len(outs[prec]) == 3 and outs[prec][0].shape == (37, 45) and outs[prec][0].dtype == np.uint16
+        # (three optimiser steps from a random init leave the softmax near its tie everywhere, so instance maps of two fp32-accurate
+        # engines need not agree pixel for pixel; the logits-level comparison is test_engine's and test_fullsize_gpu's)
+        diff = sum(int((a != b).sum()) for a, b in zip(outs['fp32'], outs['bf16x3']))
+        print('bf16x3 vs fp32 instance maps: %d of %d pixels differ' % (diff, 3 * 37 * 45))
