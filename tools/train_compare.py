@@ -1,7 +1,8 @@
 """fp32 vs bf16-mode training on the same synthetic clip stream (Params.py network, 128x128, T=4, B=4, lr 1e-4):
 loss curves, then held-out agreement of the two trained models (per-pixel argmax agreement, 3-class IoU, SEG measure).
 Evidence for the bf16 accuracy contract of DESIGN.md §3.3 / SURVEY §8c ("bf16 path judged on IoU / argmax agreement").
-usage: python tools/train_compare.py [steps] > profiles/r01_bf16_vs_fp32_training.json"""
+usage: python tools/train_compare.py [steps] [precision = bf16 | bf16x3] > profiles/r01_bf16_vs_fp32_training.json
+(second argument bf16x3: the same comparison for the fp32-arithmetic-on-the-bf16-MFMA mode of DESIGN 3.3a; the keys keep the name 'bf16')"""
 import json
 import os
 import sys
@@ -16,6 +17,7 @@ import losses
 import train2D
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+OTHER = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 net = Params.CTCParams.net_kernel_params
 H = W = 128
 B, T = 4, 4
@@ -68,11 +70,11 @@ def iou3(pred_logits, gt):
 
 
 c32, p32, v32, gt = run('fp32')
-c16, p16, v16, _ = run('bf16')
+c16, p16, v16, _ = run(OTHER)
 i32, a32 = iou3(p32, gt)
 i16, a16 = iou3(p16, gt)
 res = {
-    'what': 'same init (seed 0), same synthetic stream, %d optimiser steps at lr 1e-4, 128x128 T=4 B=4, Params.py network' % steps,
+    'what': 'fp32 vs %s: same init (seed 0), same synthetic stream, %d optimiser steps at lr 1e-4, 128x128 T=4 B=4, Params.py network' % (OTHER, steps),
     'train_loss_fp32_every10': [round(float(np.mean(c32[i:i + 10])), 5) for i in range(0, steps, 10)],
     'train_loss_bf16_every10': [round(float(np.mean(c16[i:i + 10])), 5) for i in range(0, steps, 10)],
     'heldout_loss': {'fp32': round(v32, 5), 'bf16': round(v16, 5)},
