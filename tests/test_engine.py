@@ -693,10 +693,10 @@ def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precisi
 
 # precision 'bf16x3': two stacked ConvLSTMs at W = 32 -- the first reads the thin image (fp32 kernel gradient, zero-padded
 # split blocks), the second a 64-channel input (split kernel gradient, split input gradient); level 1 (F = 8) stays fp32
-# ... and two wide Conv2D units on split operands: down.0.conv.1 (32 -> 128, stride 1, behind the stride-2 fp32 layer) and up.0.conv.0 (two
-# sources: 32 + 128 channels -> 128)
-X3_NET = {'down_conv_kernels': [[(3, 32), (3, 128)], [(3, 32)]], 'lstm_kernels': [[(3, 64), (5, 64)], [(3, 8)]],
-          'up_conv_kernels': [[(3, 128)], [(3, 16), (1, 3)]]}
+# ... and two wide Conv2D units on split operands: down.0.conv.1 (32 -> 96, stride 1, behind the stride-2 fp32 layer) and up.0.conv.0 (two
+# sources: 32 + 96 channels -> 96)
+X3_NET = {'down_conv_kernels': [[(3, 32), (3, 96)], [(3, 32)]], 'lstm_kernels': [[(3, 64), (5, 64)], [(3, 8)]],
+          'up_conv_kernels': [[(3, 96)], [(3, 16), (1, 3)]]}
 
 
 @pytest.mark.parametrize('W', [32, 24])
@@ -720,7 +720,8 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch, W):
     gt = rng.integers(-1, 3, size=(B, T, H, W)).astype(np.float32)
     cwt = torch.tensor([0.15, 0.25, 0.6], dtype=torch.float32, device=dev)
     res = {}
-    for prec in ('fp32', 'bf16x3', 'bf16x3-lean'):
+    split = 'bf16x3' if W == 32 else 'bf16x3-lean'      # (W = 24: the step-by-step route alone -- config-4's combination, and a third less emulator time)
+    for prec in (('fp32', 'bf16x3', 'bf16x3-lean') if W == 32 else ('fp32', 'bf16x3-lean')):
         del seen[:]
         e = Engine(net, pad_image=False, precision=prec.split('-')[0])
         if prec.endswith('lean'):
@@ -740,14 +741,14 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch, W):
         n_bf16 = sum(seen)
         # fused steps 2 layers x T x windows (+ T inference) + recurrent gradients 2 x (T - 1) x windows + one input gradient x windows
         assert (n_bf16 == 0) if prec == 'fp32' else (n_bf16 >= 2 * T * (n_win + 1) + (2 * (T - 1) + 1) * n_win), (prec, n_bf16)
-    for win in range(n_win):      # the step-by-step route: the same products, weight gradients summed over t in dw instead of inside the slabs
+    for win in range(n_win if W == 32 else 0):      # the step-by-step route: the same products, weight gradients summed over t in dw instead of inside the slabs
         (la, ga), (lb, gb) = res['bf16x3'][0][win], res['bf16x3-lean'][0][win]
         assert np.array_equal(la, lb)
         fl = grad_floor(ga)
         worst = max((float(np.abs(gb[k] - ga[k]).max() / max(np.abs(ga[k]).max(), fl)), k) for k in ga)
         assert worst[0] <= 2e-5, (win, worst)
     for win in range(n_win):
-        (l32, g32), (l3, g3) = res['fp32'][0][win], res['bf16x3'][0][win]
+        (l32, g32), (l3, g3) = res['fp32'][0][win], res[split][0][win]
         assert np.abs(l3 - l32).max() <= 2e-5 * np.abs(l32).max(), (win, np.abs(l3 - l32).max() / np.abs(l32).max())
         fl = grad_floor(g32)
         # (a conv bias in front of a BatchNorm has an exactly-zero true gradient: what either engine holds there is its own
@@ -756,11 +757,11 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch, W):
             return '.conv.' in k and k.endswith('.bias') and k.replace('.conv.', '.bn.').replace('.bias', '.gamma') in g32
         worst = max((float(np.linalg.norm(g3[k] - g32[k]) / max(np.linalg.norm(g32[k]), fl)), k) for k in g32 if not noise_only(k))
         assert worst[0] <= 2e-4, (win, worst)
-    assert np.abs(res['bf16x3'][1] - res['fp32'][1]).max() <= 2e-5 * np.abs(res['fp32'][1]).max()
+    assert np.abs(res[split][1] - res['fp32'][1]).max() <= 2e-5 * np.abs(res['fp32'][1]).max()
     # against the fp64 oracle (first window: zero state): both engines at fp32 rounding distance
     o = npo.model_forward(net, p, x, training=True, pad_image=False)['logits']
     e32 = np.abs(from_tb(res['fp32'][0][0][0], B, T) - o).max()
-    e3 = np.abs(from_tb(res['bf16x3'][0][0][0], B, T) - o).max()
+    e3 = np.abs(from_tb(res[split][0][0][0], B, T) - o).max()
     assert e3 <= 2.0 * e32 + 1e-6 * np.abs(o).max(), (e3, e32)
     # ... and every gradient tensor of the first window against fp64 autograd (oracle/torch_oracle.py): the split engine's worst
     # tensor within 2x the fp32 engine's worst (+ 1e-5 of the tensor scale)
@@ -769,7 +770,7 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch, W):
     gref = {k: v.numpy() for k, v in gref.items()}
     fl = grad_floor(gref)
     w32 = max(rel_err(res['fp32'][0][0][1][k], gref[k], fl) for k in gref)
-    w3 = max((rel_err(res['bf16x3'][0][0][1][k], gref[k], fl), k) for k in gref)
+    w3 = max((rel_err(res[split][0][0][1][k], gref[k], fl), k) for k in gref)
     print('bf16x3 vs fp64 oracle: logits %.3e (fp32 engine %.3e), worst gradient tensor %.3e %s (fp32 engine %.3e)' %
           (e3 / np.abs(o).max(), e32 / np.abs(o).max(), w3[0], w3[1], w32))
     assert w3[0] <= 2.0 * w32 + 1e-5, (w3, w32)
