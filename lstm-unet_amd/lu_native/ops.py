@@ -497,7 +497,7 @@ def to_f32(x, out=None):
 def split6(x, lp=None, out=None, order=0):
     """fp32 activations [frames,H,W,C] -> the bf16 tensor [frames,H,W,6*lp] of precision 'bf16x3' (lu_split6; order 0 = A: blocks lo,
     mid, hi, mid, hi, hi of the exact three-way bf16 split x = hi + mid + lo; order 1 = B: hi, mid, lo, hi, mid, hi; channels
-    [C, lp) of a block are zero).  Against weights laid out by split6_weights in the OTHER order a bf16 convolution over the
+    [C, lp) of a block are zero).  Against weights laid out by pack_split6_bf16 in the OTHER order a bf16 convolution over the
     6*lp channels IS the fp32 convolution to 2^-26 per product; block t of an order-A tensor against block t of an order-B tensor
     is term t of ops.SPLIT_TERMS (conv2d_wgrad(..., terms=...))."""
     _chk(x, out)
@@ -517,7 +517,7 @@ def split6(x, lp=None, out=None, order=0):
 
 SPLIT_A = {'lo': 0, 'mid': 1, 'hi': 2}      # first block of an order-A tensor that holds each piece (order B: hi 0, mid 1, lo 2)
 # the six products of precision 'bf16x3' as (piece of x, piece of dy), smallest first -- the order the channel blocks of a
-# split6 / split6_weights pair run through them
+# split6 / pack_split6_bf16 pair run through them
 SPLIT_TERMS = (('lo', 'hi'), ('mid', 'mid'), ('hi', 'lo'), ('mid', 'hi'), ('hi', 'mid'), ('hi', 'hi'))
 
 
@@ -530,7 +530,8 @@ def split_piece(x6, piece):
 
 def pack_split6_bf16(w, cp=None, order=1):
     """fp32 kernel [k,k,C,N] (contiguous) -> the bf16 PackedW of its three-way split laid out six times along C ([k,k,6*cp,N], block
-    order B by default): pack_bf16(split6_weights(w, cp, order)) in one pass (lu_pack_weights_split6_bf16; channel-slice views allowed)."""
+    order B by default; rows [C, cp) of a block zero): lu_split6 of the kernel along its row axis + lu_pack_weights_bf16 in one pass
+    (lu_pack_weights_split6_bf16; channel-slice views allowed)."""
     _chk(w)
     assert w.dtype == torch.float32 and w.dim() == 4 and w.stride(3) == 1 and w.stride(0) == w.shape[1] * w.stride(1)
     k, _, Cc, N = w.shape
@@ -539,20 +540,6 @@ def pack_split6_bf16(w, cp=None, order=1):
     calls.check(lib(), lib().lu_pack_weights_split6_bf16(w.data_ptr(), w.stride(1), w.stride(2), k, Cc, cp, N, int(order), data.data_ptr(),
                                                          _stream()), 'lu_pack_weights_split6_bf16')
     return PackedW(data, (k, k, 6 * cp, N))
-
-
-def split6_weights(w, cp=None, order=1):
-    """fp32 kernel [k,k,C,N] (contiguous) -> fp32 [k,k,6*cp,N] holding the pieces of its three-way bf16 split in block order B
-    (hi, mid, lo, hi, mid, hi; rows [C, cp) of a block zero; order=0: A, for activations split in order B): every value is exactly
-    representable in bf16, so pack_bf16 of the result is the weight image that goes with split6 activations."""
-    _chk(w)
-    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4
-    k0, k1, Cc, N = w.shape
-    cp = Cc if cp is None else cp
-    out = torch.empty((k0, k1, 6 * cp, N), device=w.device, dtype=torch.float32)
-    calls.check(lib(), lib().lu_split6(w.data_ptr(), k0 * k1, Cc * N, Cc * N, out.data_ptr(), 6 * cp * N, cp * N, int(order), cabi.LU_F32,
-                                       _stream()), 'lu_split6')
-    return out
 
 
 def im2col_bf16(x, k):
