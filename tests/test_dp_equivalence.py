@@ -98,7 +98,7 @@ dp = DataParallel(bucket_bytes=int(os.environ.get('LU_TEST_BUCKET_BYTES', 64 << 
 assert dp.world_size == int(os.environ['WORLD_SIZE']) and torch.cuda.is_available()
 assert list(dp.shard_slots(dp.world_size)) == [dp.rank] and list(dp.shard_slots(2 * dp.world_size)) == [2 * dp.rank, 2 * dp.rank + 1]
 d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
-net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+net = tiny_net(3, (64, 16, 16, 64), (16, 8, 8, 8)) if sys.argv[1] == 'bf16x3' else tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
 tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=True, seed=3,
                      precision=sys.argv[1])
 if os.environ.get('LU_TEST_NO_OVERLAP'):
@@ -118,13 +118,15 @@ dp.barrier()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision):
     """The N > 1 path on the REAL kernels: two ranks (gloo, sharing the one GPU of the test box -- RCCL needs one device
     per rank) x 1 slot with SyncBN == one process on the 2-slot batch.  What runs: rank-sharded slots, loss-sum all-reduce
     before the gradient, bucketed gradient all-reduce fired from the engine's backward, pooled BN statistics.
     precision='bf16': the engine then runs its weight gradients on the side stream, so every bucket hand-over has to join
-    it first (LU_TEST_NO_OVERLAP=1 runs the same comparison with the side stream off)."""
+    it first (LU_TEST_NO_OVERLAP=1 runs the same comparison with the side stream off).
+    precision='bf16x3' (on a net whose first and last ConvLSTM layers, F = 64, take the split route): fp32 arithmetic, so the fp32
+    limits apply -- gradients to summation-order noise."""
     import train2D
     import Networks
     rng = np.random.default_rng(0)
@@ -141,7 +143,7 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+    net = tiny_net(3, (64, 16, 16, 64), (16, 8, 8, 8)) if precision == 'bf16x3' else tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
     tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, seed=3, precision=precision)
     if os.environ.get('LU_TEST_NO_OVERLAP'):
         tr.engine.overlap_wgrad = False
@@ -156,7 +158,7 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     # (pooled-vs-whole-batch statistics differ in the last bits), stated 2e-3 of the largest gradient
     g_err = np.abs(got['grads1'] - ref_grads1).max() / np.abs(ref_grads1).max()
     print('dp2 vs single (%s), step-1 gradients: max err / max|g| = %.3e' % (precision, g_err))
-    assert g_err <= (2e-6 if precision == 'fp32' else 2e-3), g_err
+    assert g_err <= (2e-3 if precision == 'bf16' else 2e-6), g_err
     diff = np.abs(got['params'] - ref)
     print('dp2 vs single (%s): max %.3e, fraction > 1e-4: %.3e' % (precision, diff.max(), (diff > 1e-4).mean()))
     # bf16: the two wide ConvLSTM layers of this net (4F = 128 columns) do run on the bf16 MFMA kernels; pooled-vs-whole-batch
@@ -164,7 +166,7 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     # that into 1e-4-sized steps on ~0.5 % of the weights (measured 1.06e-3 / 5.2e-3, identical with the side stream off)
     # (round 3: the narrow decoder layers round to bf16 as well: 2.4e-2 of the weights; the pre-Adam gradients above are the
     # sharp check -- 8.7e-5 of the largest gradient)
-    frac = 2e-3 if precision == 'fp32' else 5e-2
+    frac = 5e-2 if precision == 'bf16' else 2e-3
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= frac, (diff.max(), (diff > 1e-4).mean())
 
 
