@@ -492,12 +492,14 @@ class Engine:
                     self._x3_wgrad(x6_w, dy6_w, gw[:, :, co:co + cs, :], dbias=dbias)
                 else:
                     ops.conv2d_wgrad(x, dy, gw[:, :, co:co + cs, :], 1, dbias=dbias)
-            if need:
+            if need and self._x3_dgrad_ok(cs):
                 wt6 = self._pack(wname, 'x3t', lambda co=co, cs=cs: ops.flip_transpose(w, co, cs), co, cs,
                                  packer=lambda v: ops.pack_split6_bf16(v, None, 0))
                 dx = torch.empty((frames, H, W, cs), device=dy.device, dtype=torch.float32)
                 ops.conv_raw([(dy6, wt6)], frames, H, W, H, W, k, 1, 1, p, p, cs, None, dx)
                 dxs.append(dx)
+            elif need:      # (a source of 40 / 48 ... channels: outside the halo kernel's column counts -- the fp32 input gradient)
+                dxs.append(ops.conv2d_dgrad(dy, w, (H, W), 1, co, cs, bank=self.bank if self.prep_batch else None))
             else:
                 dxs.append(None)
         rec['srcs'] = rec['x6s'] = None
@@ -840,6 +842,13 @@ class Engine:
         return h_all[1:].view(T * B, H, W, F)
 
     @staticmethod
+    def _x3_dgrad_ok(n_cols):
+        """An input gradient is a convolution with `n_cols` = the layer's INPUT channels as output columns: on split operands it needs
+        the bf16 halo kernel's column counts (more than 64, or its narrow blocks of 32 / 64); other layers (a 16-channel input) take the
+        fp32 input gradient on the fp32 dz."""
+        return n_cols % 4 == 0 and (n_cols > 64 or n_cols in (32, 64))
+
+    @staticmethod
     def _x3_pad_w(t6, out=None):
         """split6 tensor [frames,H,W,C6] -> the same rows zero-padded to a multiple of 32 pixels: the domain of the bf16 kernel-row weight
         gradient.  Zero columns of dz add nothing to a weight gradient and zero columns of x are what SAME padding reads there anyway,
@@ -921,10 +930,12 @@ class Engine:
             else:      # thin image (or an odd channel count / width): the fp32 weight gradient, as in fp32 mode
                 ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
         dx = None
-        if need_dx:
+        if need_dx and self._x3_dgrad_ok(Cin):
             kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0)
             dx = torch.empty((T * B, H, W, Cin), device=dev, dtype=torch.float32)
             ops.conv_raw([(dz6_seq, kt6)], T * B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx)
+        elif need_dx:
+            dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1, bank=self.bank if self.prep_batch else None)
         rec['h_all'] = rec['c_all'] = rec['x'] = rec['x6'] = rec['h6_all'] = None
         return dx
 
@@ -952,8 +963,9 @@ class Engine:
         dh_rec = None
         self._sync_weight_images()
         rt6 = self._x3_weight(pre + '.recurrent_kernel', 'x3t', lambda: ops.flip_transpose(rec_k), order=0) if T > 1 else None
-        kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0) if need_dx else None
-        dx = torch.empty((T, B, H, W, Cin), device=dev, dtype=torch.float32) if need_dx else None
+        dx_split = need_dx and self._x3_dgrad_ok(Cin)
+        kt6 = self._x3_weight(pre + '.kernel', 'x3t', lambda: ops.flip_transpose(kernel), order=0) if dx_split else None
+        dx = torch.empty((T, B, H, W, Cin), device=dev, dtype=torch.float32) if dx_split else None
         # W % 32 != 0: the weight gradients see zero-padded copies (_x3_pad_w; the pad columns of the reused buffers stay zero)
         Wp = -(-W // 32) * 32 if self.x3_pad_wgrad else W
         pad = Wp != W
@@ -987,7 +999,7 @@ class Engine:
                 if pad:
                     self._x3_pad_w(x6, out=x6_w)
                 self._x3_wgrad(x6_w, dz6_w, self.G[pre + '.kernel'], beta0=beta0)
-            if need_dx:
+            if dx_split:
                 ops.conv_raw([(dz6, kt6)], B, H, W, H, W, k, 1, 1, p, p, Cin, None, dx[t])
             first = False
         # weight gradients outside the bf16 kernel-row variant's domain (thin image, W % 32 != 0): the fp32 ones, hoisted over the
@@ -997,6 +1009,8 @@ class Engine:
             ops.conv2d_wgrad(h_all[:T].view(T * B, H, W, F), dz_seq, self.G[pre + '.recurrent_kernel'], 1, dbias=self.G[pre + '.bias'])
         if not x_split:
             ops.conv2d_wgrad(x_seq, dz_seq, self.G[pre + '.kernel'], 1)
+        if need_dx and not dx_split:      # (an input of few channels: the fp32 input gradient, hoisted as in fp32 mode)
+            dx = ops.conv2d_dgrad(dz_seq, kernel, (H, W), 1, bank=self.bank if self.prep_batch else None)
         rec['gates'] = rec['h_all'] = rec['c_all'] = rec['x'] = None
         return None if dx is None else dx.view(T * B, H, W, Cin)
 
