@@ -344,19 +344,21 @@ def test_reference_smoke_shape_contracts():
 
 
 @pytest.mark.gpu
-def test_hipgraph_replay_of_streaming_forward_is_bit_identical():
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_hipgraph_replay_of_streaming_forward_is_bit_identical(precision):
     """lu_native.graph.GraphedFrame: the per-frame launch sequence captured into a hipGraph reproduces the eager
     streaming forward bit for bit, including the in-place recurrent state (measured neutral for throughput: the frame is
-    bound by ~200 small kernels, not by the host launch path -- kept as an option)."""
+    bound by ~200 small kernels, not by the host launch path -- kept as an option).  bf16x3: on a net whose first
+    and last ConvLSTM layers take the split route (the split images of the state are captured launches like any other)."""
     import Networks
     from conftest import tiny_net
     from lu_native.graph import GraphedFrame
-    net = tiny_net(3, (32, 32, 32, 32), (16, 16, 16, 8))
+    net = tiny_net(3, (32, 32, 32, 32), (16, 16, 16, 8)) if precision == 'fp32' else tiny_net(3, (64, 32, 32, 64), (16, 16, 16, 8))
     torch.manual_seed(3)
     frames = [torch.randn(1, 1, 1, 40, 48) for _ in range(4)]
-    eager = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1)
+    eager = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1, precision=precision)
     want = [eager(f, training=False)[1].clone() for f in frames]
-    graphed = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1)
+    graphed = Networks.ULSTMnet2D(net, 'NCHW', True, seed=1, precision=precision)
     g = GraphedFrame(graphed, frames[0])
     g.reset_states()
     for f, w in zip(frames, want):
