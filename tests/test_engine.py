@@ -695,7 +695,7 @@ def test_training_windows_carry_state_lazily_without_changing_a_bit(dev, precisi
 # split blocks), the second a 64-channel input (split kernel gradient, split input gradient); level 1 (F = 8) stays fp32
 # ... and two wide Conv2D units on split operands: down.0.conv.1 (32 -> 96, stride 1, behind the stride-2 fp32 layer) and up.0.conv.0 (two
 # sources: 32 + 96 channels -> 96)
-X3_NET = {'down_conv_kernels': [[(3, 32), (3, 96)], [(3, 32)]], 'lstm_kernels': [[(3, 64), (5, 64)], [(3, 8)]],
+X3_NET = {'down_conv_kernels': [[(3, 32), (3, 96)], [(3, 32)]], 'lstm_kernels': [[(5, 64), (3, 64)], [(3, 8)]],
           'up_conv_kernels': [[(3, 96)], [(3, 16), (1, 3)]]}
 
 
