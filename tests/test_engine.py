@@ -709,6 +709,8 @@ def test_bf16x3_precision_mode_is_fp32_arithmetic(dev, monkeypatch, W):
     coarse levels) -- the convolutions run split as they are, the weight gradients on zero-padded copies of the split tensors."""
     from lu_native import calls, ops
     from lu_native.engine import Engine
+    if W == 24 and dev.type != 'cuda':
+        pytest.skip('the W % 32 != 0 case runs on the MI355X only (-m gpu): another minute of host emulation for the same host code')
     seen = []
     real = calls.conv2d
     monkeypatch.setattr(calls, 'conv2d', lambda *a, **k: (seen.append(k.get('precision', 0)), real(*a, **k))[1])
