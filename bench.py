@@ -388,7 +388,7 @@ def dp_report(dp, dev_index, engine, steps, launched, sync_bn):
     events, on scratch buffers of the real bucket sizes -- how long the gradient buckets and one SyncBN-sized all-reduce
     take when nothing overlaps them."""
     import torch.distributed as dist
-    if dp.world_size == 1:
+    if not dp.collectives:
         return {'backend': None, 'world_size': 1, 'devices': [{'rank': 0, 'device': dev_index,
                                                                'name': torch.cuda.get_device_name(dev_index)}]}
     mine = {'rank': dp.rank, 'local_rank': dp.local_rank, 'device': dev_index, 'name': torch.cuda.get_device_name(dev_index),
@@ -467,6 +467,9 @@ def main():
                          'lstm3 = 3x3 ConvLSTM (north_star wording)')
     ap.add_argument('--check', action='store_true',
                     help='N > 1: run the DP + SyncBN == single-process comparison inline first; refuse to print a line if it fails')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='N = 1: initialise the process group anyway (RCCL: backend nccl, one rank) and send the gradient buckets, the loss '
+                         'sums and -- with --sync-bn -- the BatchNorm statistics through real all-reduce calls (LU_DP_FORCE=1, lu_native/dp.py)')
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the `variants` block (lstm3 / default5 in fp32 and bf16, N = 1, headline net only)')
     ap.add_argument('--lib', default=None, metavar='SO',
@@ -502,8 +505,10 @@ def main():
 
     if args.lib:
         ops.LIB_PATH = lu_build.LIB = os.path.abspath(args.lib)      # (build_id on the line is then this file's)
+    if args.force_collectives:
+        os.environ['LU_DP_FORCE'] = '1'
     dp = DataParallel()
-    if dp.world_size > 1 and torch.distributed.get_world_size() != args.gpus:
+    if dp.collectives and torch.distributed.get_world_size() != args.gpus:
         _die('process group has %d ranks, --gpus %d' % (torch.distributed.get_world_size(), args.gpus))
     dev_index = dp.local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -571,7 +576,7 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if dp.world_size > 1:
+    if dp.collectives:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     ms1 = torch.cuda.memory_stats(dev)
@@ -581,7 +586,8 @@ def main():
     allocator['reserved_gb'] = round(ms1.get('reserved_bytes.all.current', 0) / 2 ** 30, 2)
     allocator['per'] = '%d timed steps' % args.steps
     dp_info = dp_report(dp, dev_index, trainer.engine, args.steps, dp.launched - launched0, args.sync_bn)
-    if dp.world_size > 1:
+    if dp.collectives:
+        dp_info['forced_world_of_one'] = dp.world_size == 1
         # proof of overlap: two more steps with per-bucket time stamps (outside the timed region: the stamps are device events,
         # but a traced step is not the step that is reported)
         dp.trace = []
@@ -863,7 +869,7 @@ def main():
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
-    if dp.world_size > 1:
+    if dp.collectives:
         torch.distributed.destroy_process_group()
 
 

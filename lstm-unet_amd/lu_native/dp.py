@@ -13,7 +13,11 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, backend=None, bucket_bytes=64 << 20):
+    def __init__(self, backend=None, bucket_bytes=64 << 20, force=None):
+        """force (or LU_DP_FORCE=1): a world of ONE still initialises the process group and sends every gradient bucket, the
+        loss sums and the SyncBN statistics through the backend's all-reduce (RCCL on a GPU): a 1-GPU box then exercises
+        everything of the multi-GPU step except the wire -- stream ordering between the compute stream, the weight-gradient
+        side stream and RCCL's stream, the async handles, the flat-buffer slicing."""
         self.rank = int(os.environ.get('RANK', '0'))
         self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -28,7 +32,10 @@ class DataParallel(object):
         # bucket is handed to the collective layer, when backward has ended (finish()) and when each all-reduce has been waited for
         self.trace = None
         self._trace_cur = []
-        if self.world_size > 1 and not dist.is_initialized():
+        if force is None:
+            force = os.environ.get('LU_DP_FORCE', '0') not in ('', '0')
+        self.collectives = self.world_size > 1 or bool(force)      # False: every call below is a no-op (a plain single-process step)
+        if self.collectives and not dist.is_initialized():
             if backend is None:
                 # LU_DP_BACKEND=gloo lets several ranks share ONE GPU (control-flow checks on a 1-GPU box)
                 backend = os.environ.get('LU_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -40,17 +47,17 @@ class DataParallel(object):
 
     # -- small synchronous-on-stream reductions ------------------------------------------
     def all_reduce_(self, t):
-        if self.world_size > 1:
+        if self.collectives:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
     def broadcast_(self, t, src=0):
-        if self.world_size > 1:
+        if self.collectives:
             dist.broadcast(t, src)
         return t
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.collectives:
             dist.barrier()
 
     # -- bucketed gradient all-reduce, overlapped with backward -----------------------------
@@ -59,7 +66,7 @@ class DataParallel(object):
 
     def bucket_ready(self, start, end):
         """Called by the engine as soon as flat[start:end] holds final local gradients."""
-        if self.world_size == 1:
+        if not self.collectives:
             return
         # adjacent ranges grow one bucket, whichever way the caller walks the flat buffer (the engine lays its parameters out
         # in backward-completion order, i.e. ascending): fewer, larger collectives -- 3 per step at Params.py widths
@@ -78,7 +85,7 @@ class DataParallel(object):
     def solo(cls):
         """A world of one inside a multi-rank process (bench.py --check: the single-process reference step): no collectives."""
         self = cls.__new__(cls)
-        self.rank, self.world_size, self.local_rank = 0, 1, 0
+        self.rank, self.world_size, self.local_rank, self.collectives = 0, 1, 0, False
         self.bucket_bytes, self._pending, self.launched, self._carry = 64 << 20, [], 0, None
         self.last_ranges, self._ranges, self.flat, self.trace, self._trace_cur = [], [], None, None, []
         return self

@@ -87,7 +87,7 @@ class Engine:
         self.pad_image = bool(pad_image)
         self.seed = seed
         self.dp = dp
-        self.sync_bn = bool(sync_bn) and dp is not None and dp.world_size > 1
+        self.sync_bn = bool(sync_bn) and dp is not None and bool(getattr(dp, 'collectives', dp.world_size > 1))      # (a forced world of one counts: dp.py)
         self.plan = None
         self.device = None
         self.P = {}       # name -> view into flat_params

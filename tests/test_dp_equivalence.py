@@ -276,3 +276,124 @@ def test_dpN_syncbn_over_rccl_equals_single_process(tmp_path, n_ranks):
     print('dp%d over RCCL vs single: loss err %.3e, step-1 gradient err / max|g| %.3e, all-reduce launches %d' %
           (n_ranks, np.abs(got['loss'] - np.array([float(l1), float(l2)])).max(), g_err, int(got['launched'][0])))
     assert np.abs(got['loss'] - np.array([float(l1), float(l2)])).max() <= 1e-5 and g_err <= 2e-6
+
+
+FORCED_WORKER = r"""
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from conftest import tiny_net
+import train2D, Networks
+from lu_native.dp import DataParallel
+forced = sys.argv[2] == 'forced'
+dp = DataParallel(backend='nccl', bucket_bytes=8 << 10, force=True) if forced else DataParallel.solo()
+if forced:
+    import torch.distributed as dist
+    assert dp.collectives and dp.world_size == 1 and dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
+net = tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8))
+tr = train2D.Trainer(Networks.ULSTMnet2D, net, 'NCHW', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=forced, seed=3, precision=sys.argv[1])
+assert tr.engine.sync_bn == forced
+if forced:
+    dp.trace = []
+_, _, loss = tr.train_step(d['x'], d['gt'])
+grads1 = tr.engine.flat_grads.cpu().numpy()
+tr.model.reset_states_per_batch(np.ones(d['x'].shape[0], np.float32))
+_, _, loss2 = tr.train_step(d['x'][:, ::-1].copy(), d['gt'][:, ::-1].copy())
+torch.cuda.synchronize()
+trace = dp.trace_report() if forced else []
+np.savez(os.path.join(%(tmp)r, 'dp1_%%s.npz' %% sys.argv[2]), params=tr.engine.flat_params.cpu().numpy(), loss=np.array([float(loss), float(loss2)]),
+         grads1=grads1, grads2=tr.engine.flat_grads.cpu().numpy(), launched=np.array([dp.launched]),
+         ranges=np.array(dp.last_ranges).reshape(-1, 2), n_flat=np.array([tr.engine.n_flat]),
+         librccl=np.array([int(any('librccl' in l for l in open('/proc/self/maps')))]),
+         issued=np.array([b['issued_ms_before_backward_end'] for b in (trace[-1] if trace else [])]))
+if forced:
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_dp1_rccl_forced_collectives_equals_plain_step(tmp_path, precision):
+    """RCCL with the hardware that exists: ONE rank.  DataParallel(force=True) (LU_DP_FORCE=1, bench.py --force-collectives)
+    initialises backend 'nccl' with WORLD_SIZE = 1 and sends every gradient bucket (async handles, waited for in finish()), the
+    loss sums and the SyncBN statistics through real ncclAllReduce calls on the one GPU -- the stream ordering between the compute
+    stream, the weight-gradient side stream (bf16) and RCCL's stream, the async-handle semantics gloo does not have and the
+    flat-buffer slicing; everything of SURVEY 8e's step except the wire.  A sum over one rank is the identity: two training
+    steps must give BIT-IDENTICAL losses, gradients and Adam-updated parameters to the plain single-process step."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 3, 1, 24, 32)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(2, 3, 1, 24, 32)).astype(np.float32)
+    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
+    script = tmp_path / 'worker_forced.py'
+    script.write_text(FORCED_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    port = 29600 + (os.getpid() + 13) % 1500
+    env = {k: v for k, v in os.environ.items() if k not in ('LU_DP_BACKEND', 'LU_DP_FORCE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    for mode in ('forced', 'plain'):
+        p = subprocess.run([sys.executable, str(script), precision, mode],
+                           env=dict(env, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0'),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+    a, b = np.load(tmp_path / 'dp1_forced.npz'), np.load(tmp_path / 'dp1_plain.npz')
+    ranges = a['ranges']
+    print('dp1 forced over RCCL [%s]: %d all-reduce launches in two steps, buckets of the last step %s, handed over %s ms before the end '
+          'of backward; librccl mapped: forced %d / plain %d' % (precision, int(a['launched'][0]), ranges.tolist(),
+                                                                 np.round(a['issued'], 3).tolist(), int(a['librccl'][0]), int(b['librccl'][0])))
+    assert int(a['librccl'][0]) == 1 and int(b['launched'][0]) == 0
+    # at least three buckets per step, contiguous, covering the flat gradient buffer front to back (backward-completion order)
+    assert int(a['launched'][0]) >= 6 and len(ranges) >= 3 and ranges[0][0] == 0 and ranges[-1][1] == int(a['n_flat'][0])
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1))
+    for k in ('loss', 'grads1', 'grads2', 'params'):
+        assert np.array_equal(a[k], b[k]), k
+
+
+FORCED_GLOO_WORKER = r"""
+import os, sys
+ROOT = %(root)r
+for p in (ROOT, os.path.join(ROOT, 'lstm-unet_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from engine_backend import engine_backend
+from conftest import tiny_net
+import train2D, Networks
+from lu_native.dp import DataParallel
+out = {}
+with engine_backend('emu'):
+    d = np.load(os.path.join(%(tmp)r, 'batch.npz'))
+    for mode in ('forced', 'plain'):
+        dp = DataParallel(backend='gloo', bucket_bytes=1 << 10, force=True) if mode == 'forced' else DataParallel.solo()
+        tr = train2D.Trainer(Networks.ULSTMnet2D, tiny_net(3), 'NHWC', [0.15, 0.25, 0.6], 1e-3, dp=dp, sync_bn=(mode == 'forced'), seed=3)
+        assert tr.engine.sync_bn == (mode == 'forced') and dp.collectives == (mode == 'forced')
+        _, _, loss = tr.train_step(d['x'], d['gt'])
+        out[mode + '_grads'] = tr.engine.flat_grads.numpy().copy()
+        out[mode + '_loss'] = np.array([float(loss)])
+        out[mode + '_launched'] = np.array([dp.launched])
+        out[mode + '_ranges'] = np.array(dp.last_ranges).reshape(-1, 2)
+        out['n_flat'] = np.array([tr.engine.n_flat])
+    assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1
+    np.savez(os.path.join(%(tmp)r, 'dp1_gloo.npz'), **out)
+    torch.distributed.destroy_process_group()
+"""
+
+
+def test_dp1_forced_collectives_over_gloo_equals_plain_step(tmp_path):
+    """The control flow of DataParallel(force=True) -- a world of ONE that still initialises the process group and routes the
+    gradient buckets, loss sums and SyncBN statistics through all-reduce calls -- on the host-emulated kernels over gloo
+    (the RCCL leg: test_dp1_rccl_forced_collectives_equals_plain_step, -m gpu).  Identity sums: bit-identical to the plain step."""
+    rng = np.random.default_rng(5)
+    np.savez(tmp_path / 'batch.npz', x=rng.standard_normal((2, 2, 16, 16, 1)).astype(np.float32),
+             gt=rng.integers(-1, 3, size=(2, 2, 16, 16, 1)).astype(np.float32))
+    script = tmp_path / 'worker_forced_gloo.py'
+    script.write_text(FORCED_GLOO_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    env = {k: v for k, v in os.environ.items() if k not in ('LU_DP_BACKEND', 'LU_DP_FORCE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, str(script)], env=dict(env, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + (os.getpid() + 29) % 1500)),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    d = np.load(tmp_path / 'dp1_gloo.npz')
+    r = d['forced_ranges']
+    assert int(d['plain_launched'][0]) == 0 and int(d['forced_launched'][0]) == len(r) >= 3
+    assert r[0][0] == 0 and r[-1][1] == int(d['n_flat'][0]) and all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))
+    assert np.array_equal(d['forced_grads'], d['plain_grads']) and np.array_equal(d['forced_loss'], d['plain_loss'])
