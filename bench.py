@@ -106,7 +106,15 @@ def annotate_x3(rows):
         if 'bf16' in r_['kernel']:
             r_['executed_over_algorithmic'] = 6
             r_['algorithmic_fp32_tflops'] = round(r_['achieved'] / 6.0, 2)
-            r_['algorithmic_over_fp32_mfma_peak'] = round(r_['achieved'] / 6.0 / PEAK_FP32_MFMA_TFLOPS, 4)
+
+
+def x3_summary(rows, sec, flops, frames):
+    """precision 'bf16x3', whole step, priced against the pipe that executes it: the bf16 MFMA FLOPs actually issued (6 x the
+    algorithmic FLOPs of the layers on split operands = sum over the bf16 kernel classes of rate x time) over the step time, against the
+    bf16 peak.  No fraction of the fp32 peak is reported: the mode does not run on that pipe (round-5 verdict, weak #6)."""
+    ex = sum(r_['achieved'] * r_['ms_per_step'] for r_ in rows if 'bf16' in r_['kernel']) / (1e3 * sec)      # TFLOP/s
+    return {'executed_bf16_tflops': round(ex, 1), 'frac_of_bf16_peak': round(ex / PEAK_BF16_MFMA_TFLOPS, 4), 'bf16_peak': PEAK_BF16_MFMA_TFLOPS,
+            'algorithmic_fp32_tflops': round(flops / 1e12 / sec, 2), 'fp32_equivalent_frames_per_s': round(frames / sec, 3)}
 
 
 def measure_variant(net, precision, batches, B, T, H, W, dp, steps, warmup):
@@ -142,11 +150,17 @@ def measure_variant(net, precision, batches, B, T, H, W, dp, steps, warmup):
     peak = PEAK_BF16_MFMA_TFLOPS if precision == 'bf16' else PEAK_FP32_MFMA_TFLOPS
     del tr
     torch.cuda.empty_cache()
-    return {'ms_per_step': round(1e3 * sec, 3), 'frames_per_s': round(B * T / sec, 3),
-            'train_gflop_per_frame': round(flops / (B * T) / 1e9, 1), 'step_tflops_achieved': round(flops / 1e12 / sec, 2),
-            'frac_of_peak': round(flops / 1e12 / sec / peak, 4), 'peak': peak, 'steps': steps,
-            'mfma_kernels': [{k_: r_[k_] for k_ in ('kernel', 'achieved', 'frac', 'launches_per_step', 'ms_per_step', 'algorithmic_fp32_tflops')
-                              if k_ in r_} for r_ in rows]}
+    out = {'ms_per_step': round(1e3 * sec, 3), 'frames_per_s': round(B * T / sec, 3),
+           'train_gflop_per_frame': round(flops / (B * T) / 1e9, 1), 'step_tflops_achieved': round(flops / 1e12 / sec, 2),
+           'frac_of_peak': round(flops / 1e12 / sec / peak, 4), 'peak': peak, 'steps': steps,
+           'mfma_kernels': [{k_: r_[k_] for k_ in ('kernel', 'achieved', 'frac', 'launches_per_step', 'ms_per_step', 'algorithmic_fp32_tflops')
+                             if k_ in r_} for r_ in rows]}
+    if precision == 'bf16x3':      # priced against the pipe it runs on: executed bf16 FLOPs over the bf16 peak, never a fraction of the fp32 peak
+        for k_ in ('frac_of_peak', 'peak', 'step_tflops_achieved'):
+            out.pop(k_)
+        out.update(x3_summary(rows, sec, flops, B * T))
+        out['dtype'] = 'f32 results via 3 x bf16 split'
+    return out
 
 
 def synthetic_batches(n, B, T, H, W, rank, device):
@@ -323,7 +337,7 @@ def dry_run_plan(args):
     order = ['up.%d' % i for i in reversed(range(len(plan['up'])))] + ['down.%d' % i for i in reversed(range(len(plan['down'])))]
     launched = []
     sim = DataParallel.solo()
-    sim.world_size = max(n, 2)      # (the merging rule only runs for N > 1; nothing here issues a collective)
+    sim.world_size, sim.collectives = max(n, 2), True      # (the merging rule only runs with collectives on; nothing here issues one)
     sim._launch = lambda s_, e_: launched.append((s_, e_))
     for blk in order:
         sim.bucket_ready(*members[blk])
@@ -811,11 +825,9 @@ def main():
                           "on v_mfma_f32_32x32x16_bf16 "
                           "over the exact three-way bf16 split of their fp32 operands -- x = hi + mid + lo, six bf16 products per fp32 product, "
                           "each exact in the fp32 accumulator, the dropped ones below 2^-26 -- everything else on the fp32 kernels; nothing "
-                          "is stored rounded.  'step_tflops_achieved' / 'frac_of_fp32_mfma_peak' count the ALGORITHMIC fp32 FLOPs of the step "
-                          "(the MFMA pipe executes 6x that on the split layers: see mfma_kernels, priced against the bf16 peak)")
-        split3['frac_of_fp32_mfma_peak'] = round(split3['step_tflops_achieved'] / PEAK_FP32_MFMA_TFLOPS, 4)
-        split3.pop('frac_of_peak', None)
-        split3.pop('peak', None)
+                          "is stored rounded.  'executed_bf16_tflops' / 'frac_of_bf16_peak': the bf16 MFMA FLOPs the pipe executes (6x the algorithmic "
+                          "FLOPs on the split layers) against the 2.5 PFLOP/s bf16 peak; 'algorithmic_fp32_tflops' / 'fp32_equivalent_frames_per_s': "
+                          "the step's fp32 FLOPs and frames over the same time")
     # ---- the kernel-size variants SURVEY D1 asks to report beside the headline net (N = 1, default headline run only) ----
     variants = None
     if dp.world_size == 1 and args.net == 'params' and not args.no_variants:
@@ -844,7 +856,7 @@ def main():
             'metric': 'training frames/sec (seq_len*batch) at %dx%d' % (H, W),
             'value': round(frames_per_s, 3), 'unit': 'frames/s', 'n_gpus': dp.world_size, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 as 3 x bf16 (exact split, 6 MFMA products, fp32 accumulate)'}[args.precision],
+            'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'f32 results via 3 x bf16 split'}[args.precision],
             'data': 'synthetic',
             'config': {'workload': ('BASELINE config-2 per GPU: ' if (H, W, T, B, args.net) == (256, 256, 8, 4, 'params') else
                                     ('BASELINE config-4: ' if (H, W, T, B) == (832, 992, 16, 2) else '')) +
@@ -863,6 +875,7 @@ def main():
             'inference': infer,
             'bf16_mode': mixed,
             'bf16x3_mode': split3,
+            'bf16x3_summary': x3_summary(rows, ms_per_step * 1e-3, total_flops, B * T) if args.precision == 'bf16x3' else None,
             'variants': variants,
             'roofline': roofline, 'cpu_baseline': cpu,
         }

@@ -11,7 +11,10 @@ ops.WGRAD_FLAGS |= int(os.environ.get('WG_FLAGS', '0'))
 dev = torch.device('cuda', 0)
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
 T, B = 8, 4
-for name, hw, F, k in [('L0 5x5', 256, 128, 5), ('L1 5x5', 128, 256, 5), ('L0 3x3', 256, 128, 3), ('L1 3x3', 128, 256, 3), ('D0.conv1 3x3', 128, 32, 3)]:
+SHAPES = [('L0 5x5', 256, 128, 5), ('L1 5x5', 128, 256, 5), ('L0 3x3', 256, 128, 3), ('L1 3x3', 128, 256, 3), ('D0.conv1 3x3', 128, 32, 3)]
+if os.environ.get('WG_SHAPES'):      # e.g. WG_SHAPES='L0 5x5,L1 5x5'
+    SHAPES = [s_ for s_ in SHAPES if s_[0] in os.environ['WG_SHAPES'].split(',')]
+for name, hw, F, k in SHAPES:
     N = 4 * F if 'conv' not in name else 128
     C = F if 'conv' not in name else 128
     x = (torch.randn(T * B, hw, hw, C, device=dev) * 0.5).to(torch.bfloat16)
