@@ -216,6 +216,20 @@ __device__ __host__ static inline void lu_split3(float x, float& hi, float& mid,
 #pragma clang fp contract(off)
 #endif
     unsigned u = (unsigned)lu_f2bf(x) << 16;
+    if ((u & 0x7F800000u) == 0x7F800000u) {      // the rounded hi is not finite (round 6)
+        unsigned xb;
+        memcpy(&xb, &x, 4);
+        if ((xb & 0x7F800000u) != 0x7F800000u) {
+            u = (xb & 0x80000000u) | 0x7F7F0000u;      // finite x within 2^-9 of FLT_MAX: hi = the largest finite bf16, the residuals stay exact
+        } else {                                       // inf / NaN travel in hi alone (inf - inf would make the other pieces NaN)
+            u = xb & 0xFFFF0000u;
+            if ((xb & 0x007FFFFFu) && !(u & 0x007F0000u)) u |= 0x00400000u;      // a NaN whose payload sits in the low half stays a NaN
+            memcpy(&hi, &u, 4);
+            mid = 0.f;
+            lo = 0.f;
+            return;
+        }
+    }
     memcpy(&hi, &u, 4);
     const float r1 = x - hi;
     u = (unsigned)lu_f2bf(r1) << 16;

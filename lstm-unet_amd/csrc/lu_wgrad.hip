@@ -708,6 +708,25 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
     }
     const int64_t x_gap = a.x_fs - (int64_t)a.HWo * a.x_ps, y_gap = a.dy_fs - (int64_t)a.HWo * a.dy_ps;      // (S == 1: Hin * Win == HWo)
     const lu_u4* const zpa = zp;
+    // Stage cursor -> next stage (stride 1; W % 32 == 0: a run never straddles two rows).  BRANCH-FREE (round 6): written as nested ifs
+    // this was three scalar branches in the middle of the stage -- basic-block boundaries that fenced the stage's LDS stores and global
+    // loads off from the MFMAs of k-steps 1 .. 3, so that the sched_group_barrier interleave below had nothing to interleave: the ~140
+    // staging instructions of a stage ran as ONE lump between k-step 0 and k-step 1 with the MFMA pipe idle (ISA of round 5).
+    auto advance_cursor = [&]() {
+        ++ls;
+        ox0 += PRB;
+        const bool row_end = ox0 >= a.Wout;
+        ox0 = row_end ? 0 : ox0;
+        oy += row_end ? 1 : 0;
+        const bool frame_end = oy == a.Hout;            // (only ever true together with row_end)
+        oy = frame_end ? 0 : oy;
+        pf += frame_end ? 1 : 0;
+        tleft -= frame_end ? 1 : 0;
+        const bool term_end = tleft == 0;               // terms: the next frame belongs to the next term
+        tleft = term_end ? a.tf : tleft;
+        xcur += PRB * a.x_ps + (frame_end ? x_gap : (int64_t)0) + (term_end ? a.x_tj : (int64_t)0);
+        ycur += PRB * a.dy_ps + (frame_end ? y_gap : (int64_t)0) + (term_end ? a.y_tj : (int64_t)0);
+    };
     auto load_stage = [&](lu_u4 (&rx)[XPASS], lu_u4 (&ry)[YPASS]) {
         if constexpr (S == 1) {
             const unsigned live = ls < n_it ? 1u : 0u;
@@ -731,24 +750,7 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
                 const lu_u4* pp = YB ? reinterpret_cast<const lu_u4*>(yb + ycur + yvo[i]) : reinterpret_cast<const lu_u4*>(a.dy + ycur + yvo[i]);
                 ry[i] = *((ok & 1u) ? pp : zpa);
             }
-            ++ls;
-            ox0 += PRB;
-            xcur += PRB * a.x_ps;
-            ycur += PRB * a.dy_ps;
-            if (ox0 >= a.Wout) {          // W % 32 == 0: a run never straddles two rows
-                ox0 = 0;
-                if (++oy == a.Hout) {
-                    oy = 0;
-                    ++pf;
-                    xcur += x_gap;
-                    ycur += y_gap;
-                    if (--tleft == 0) {      // (terms: the next frame belongs to the next term)
-                        tleft = a.tf;
-                        xcur += a.x_tj;
-                        ycur += a.y_tj;
-                    }
-                }
-            }
+            advance_cursor();
             return;
         }
         const bool live = ls < n_it;
@@ -967,24 +969,7 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
                 lu_glds16(reinterpret_cast<const float*>((ok & 1u) ? sp : zs), reinterpret_cast<float*>((isx ? Xd : Yd) + dlds[k2]));
             }
         }
-        ++ls;
-        ox0 += PRB;
-        xcur += PRB * a.x_ps;
-        ycur += PRB * a.dy_ps;
-        if (ox0 >= a.Wout) {
-            ox0 = 0;
-            if (++oy == a.Hout) {
-                oy = 0;
-                ++pf;
-                xcur += x_gap;
-                ycur += y_gap;
-                if (--tleft == 0) {
-                    tleft = a.tf;
-                    xcur += a.x_tj;
-                    ycur += a.y_tj;
-                }
-            }
-        }
+        advance_cursor();
     };
     // bias gradient of a DMA'd stage: column sums of its dy tile read back from LDS, by the same (row, piece) -> thread map and in
     // the same stage order as the register-staged form sums its pieces (bit-identical partial sums)

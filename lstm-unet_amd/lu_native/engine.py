@@ -443,8 +443,13 @@ class Engine:
         """precision 'bf16x3': the wide stride-1 3x3 / 5x5 Conv2D layers (the bf16 halo kernel's domain: more than 64 output columns,
         sources of at least 32 channels in 16-byte groups) run on split operands like the ConvLSTM convolutions; stride-2, 1x1 and the
         narrow decoder tail stay on the fp32 kernels (HBM-bound layers: six times the MFMA work would not pay for the split passes)."""
+        return (self._x3_conv_route(k, stride, n_out, [cs for (_, _, cs) in srcs]) and
+                all(x.dtype == torch.float32 and x.shape[3] == cs for (x, _, cs) in srcs))
+
+    def _x3_conv_route(self, k, stride, n_out, src_channels):
+        """The shape half of _x3_unit (what forward()'s memory estimate can know before any tensor exists)."""
         return (self.precision == 'bf16x3' and self.x3_conv_units and stride == 1 and k in (3, 5) and n_out > 64 and n_out % 4 == 0 and
-                all(x.dtype == torch.float32 and cs >= 32 and cs % 8 == 0 and x.shape[3] == cs for (x, _, cs) in srcs))
+                all(cs >= 32 and cs % 8 == 0 for cs in src_channels))
 
     def _conv_unit_x3(self, prefix, ci, spec, srcs, with_bn, training, tape):
         """_conv_unit on split operands (Networks.py:69-72,146-151): every source as its split6 image (order A) against its slice of the
@@ -1034,11 +1039,23 @@ class Engine:
             x_in = x_tb
         if self.precision == 'bf16x3' and training:
             # window-long split tensors of every ConvLSTM layer (dz6 + the split hidden sequence), were they all kept
+            # (bytes per pixel and frame: dz6 48 F + h6 12 F, the layer input's x6 12 cin, the split copy every Conv2D unit on split
+            # operands keeps on the tape 12 cin; levels whose width is not a multiple of 32 also hold zero-padded full-window copies
+            # of all of them for the kernel-row weight gradient, _x3_pad_w: about twice the bytes)
             extra, hh, ww = 0.0, x_in.shape[1], x_in.shape[2]
+            px = lambda h_, w_: float(T * B * h_ * w_) * (2.0 if w_ % 32 else 1.0)      # noqa: E731
             for blk in plan['down']:
-                extra += sum(2.0 * T * B * hh * ww * 30 * l['f'] for l in blk['lstm'])
-                if blk['stride'] == 2:
-                    hh, ww = -(-hh // 2), -(-ww // 2)
+                extra += sum(px(hh, ww) * (60.0 * l['f'] + 12.0 * (-(-l['cin'] // 8) * 8)) for l in blk['lstm'])
+                for l in blk['conv']:
+                    ho, wo = -(-hh // l['stride']), -(-ww // l['stride'])
+                    if self._x3_conv_route(l['k'], l['stride'], l['cout'], [l['cin']]):
+                        extra += px(ho, wo) * 12.0 * l['cin']
+                    hh, ww = ho, wo
+            for blk in plan['up']:
+                hh, ww = hh * blk['up_factor'], ww * blk['up_factor']
+                for ci, l in enumerate(blk['conv']):
+                    if self._x3_conv_route(l['k'], 1, l['cout'], [blk['c_up'], blk['c_skip']] if ci == 0 else [l['cin']]):
+                        extra += px(hh, ww) * 12.0 * l['cin']
             limit = self.x3_lean_bytes
             if limit is None:
                 limit = 0.3 * torch.cuda.get_device_properties(x_tb.device).total_memory if x_tb.device.type == 'cuda' else 1e18

@@ -338,6 +338,8 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     if terms is not None:
         first, n_terms = terms
         assert x.dtype == dy.dtype == torch.bfloat16 and x.shape[3] % 6 == 0 and dy.shape[3] % 6 == 0 and first + n_terms <= 6
+        # the bias gradient is the column sum of dy = hi + mid + lo: blocks 0..2 of order B, each exactly once
+        assert dbias is None or (first, n_terms) == (0, 3), 'dbias rides on terms (0, 3) only'
         xts, yts = x.shape[3] // 6, dy.shape[3] // 6
         x, dy = x[..., first * xts:(first + 1) * xts], dy[..., first * yts:(first + 1) * yts]
     frames, Hin, Win, Cin = x.shape

@@ -380,11 +380,16 @@ def train(params):
         # agree_on_failure raised on every rank at once; anything else (SIGINT to one pid, an error inside a step) may be
         # this rank's alone -- no collectives from here on in that case
         in_step_with_peers = dp.world_size == 1 or agreed
+        # a single process has nobody to agree with: the reader's own exception (type and text) is what the caller and the log see,
+        # as before AgreedFailure existed; with peers, AgreedFailure carries it as __cause__ on the rank that failed
+        own = err.__cause__ if (agreed and dp.world_size == 1 and err.__cause__ is not None) else None
         if not params.dry_run:
-            log_print('Saving Model Before closing due to error: {}'.format(str(err)))
+            log_print('Saving Model Before closing due to error: {}'.format(str(own if own is not None else err)))
             # all ranks in step: the resumable checkpoint gets the rank-averaged BatchNorm statistics like a regular one
             save_ckpt(collective=in_step_with_peers and dp.world_size > 1)
         if not handled:
+            if own is not None:
+                raise own from None
             raise
     finally:
         if not params.dry_run and trainer.engine.plan is not None and in_step_with_peers and bn_synced_at[0] != trainer.step:

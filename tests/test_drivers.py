@@ -92,6 +92,40 @@ def test_train_loop_checkpoint_and_inference_roundtrip(dev, tmp_path, monkeypatc
     assert m.shape == (size + 3, size + 5) and m.dtype == np.uint16
 
 
+def test_single_process_reader_error_is_checkpointed_and_reraised_as_itself(dev, tmp_path, monkeypatch):
+    """A reader failure the reference does not handle (the worker threads' RuntimeError), ONE process: the loop checkpoints and
+    then re-raises the reader's own exception -- not the AgreedFailure wrapper the multi-rank agreement uses (callers
+    that catch the concrete type must keep working); a ValueError still ends the loop the reference's way (save, return)."""
+    import Params
+    import train2D
+    big = dev.type == 'cuda'
+    size = 32 if big else 16
+    monkeypatch.setattr(Params.CTCParams, 'net_kernel_params', tiny_net(3, (32, 16, 16, 32), (16, 8, 8, 8)) if big else tiny_net(3))
+    for kind in (RuntimeError, ValueError):
+        args = dict(experiment_name='t', crop_size=(size, size), batch_size=1, unroll_len=2, num_iterations=6, validation_interval=100,
+                    print_to_console_interval=1, save_checkpoint_iteration=100, save_checkpoint_dir=str(tmp_path / kind.__name__),
+                    save_log_dir=str(tmp_path / kind.__name__), data_format='NCHW', learning_rate=1e-3, write_to_tb_interval=100)
+        params = Params.CTCParams(args)
+        real, calls = params.train_data_provider.get_batch, [0]
+
+        def flaky():
+            calls[0] += 1
+            if calls[0] == 3:
+                raise kind('non-finite: the reader workers stopped')
+            return real()
+        params.train_data_provider.get_batch = flaky
+        logged = []
+        monkeypatch.setattr(train2D, 'log_print', lambda *a: logged.append(' '.join(map(str, a))))
+        if kind is RuntimeError:
+            with pytest.raises(RuntimeError, match='reader workers stopped') as ei:
+                train2D.train(params)
+            assert type(ei.value) is RuntimeError
+        else:
+            assert train2D.train(params).step == 3
+        assert any(m.startswith('Saving Model Before closing due to error: non-finite') for m in logged), logged
+        assert os.path.exists(os.path.join(params.experiment_save_dir, 'model.ckpt.index'))
+
+
 DP_LOOP_WORKER = r'''
 import os, sys
 ROOT = %(root)r
@@ -239,13 +273,27 @@ def test_bf16x3_train_loop_saved_model_and_streaming_inference(tmp_path, monkeyp
         rng = np.random.default_rng(0)
         for t in range(3):
             Image.fromarray((rng.random((37, 45)) * 255).astype(np.uint8)).save(seq_dir / ('t%03d.tif' % t))
-        outs = {}
+        outs, sms, seen = {}, {}, []
+        real_stream = Inference2D.stream_softmax
+
+        def spy(model, frames, *a, **k):      # which engine does the driver hand the frames to, and what comes out of it
+            seen.append(model.engine.precision)
+            for t, sm in real_stream(model, frames, *a, **k):
+                sms.setdefault(seen[-1], []).append(sm.detach().cpu().numpy().copy())
+                yield t, sm
+        monkeypatch.setattr(Inference2D, 'stream_softmax', spy)
         for prec in ('bf16x3', 'fp32'):
             out_dir = tmp_path / ('out_' + prec)
             Inference2D.inference(Params.CTCInferenceParams(dict(
                 model_path=save_dir, sequence_path=str(seq_dir), output_path=str(out_dir), save_intermediate=False,
                 pre_sequence_frames=2, min_cell_size=1, max_cell_size=10 ** 6, data_format='NCHW', precision=prec)))
             outs[prec] = [np.asarray(Image.open(out_dir / m)) for m in sorted(os.listdir(out_dir))]
+        # the driver routed each request to an engine of that precision, and the two engines agree on the softmax of the saved model
+        # at the fp32 tolerance test_engine uses for the mode (this test used to print a pixel count and assert nothing)
+        assert seen == ['bf16x3', 'fp32'] and len(sms['bf16x3']) == len(sms['fp32']) == 3
+        sm_err = max(float(np.abs(a - b).max()) for a, b in zip(sms['bf16x3'], sms['fp32']))
+        print('bf16x3 vs fp32 softmax from the saved model: max |diff| %.3e' % sm_err)
+        assert sm_err <= 2e-5
         for prec in outs:
             assert len(outs[prec]) == 3 and outs[prec][0].shape == (37, 45) and outs[prec][0].dtype == np.uint16
         # (three optimiser steps from a random init leave the softmax near its tie everywhere, so instance maps of two fp32-accurate

@@ -1133,8 +1133,12 @@ def test_conv3_bf16_sources_tall_patch_equals_the_8_row_kernel(be):
 def np_split3(x):
     """numpy restatement of the three-way bf16 split (lu_split6): x == hi + mid + lo exactly."""
     x = f32(x)
-    hi = KH.bf16_round(x)
-    r1 = (x - hi).astype(np.float32)
+    with np.errstate(over='ignore', invalid='ignore'):
+        hi = KH.bf16_round(x)
+        # a finite x within 2^-9 of FLT_MAX would round to inf: hi = the largest finite bf16, the residuals stay exact;  +-inf travel
+        # in hi alone (lu_device.h lu_split3, round 6)
+        hi = np.where(np.isinf(hi) & np.isfinite(x), np.copysign(np.float32(3.3895313892515355e38), x), hi).astype(np.float32)
+        r1 = np.where(np.isfinite(x), x - hi, 0.0).astype(np.float32)
     mid = KH.bf16_round(r1)
     lo = KH.bf16_round((r1 - mid).astype(np.float32))
     return hi, mid, lo
@@ -1159,6 +1163,8 @@ def test_split6_pieces_are_exact_and_in_block_order(be):
     xs = f32(mags)
     xs[0, :4] = [0.0, -0.0, 1.0, np.float32(1.0) + np.float32(2.0 ** -23)]
     xs[1, :4] = [3.0e38, -3.0e38, 1.17549435e-38 * 4096, 65504.0]
+    # values fp32 carries and a naive split turns into NaN: FLT_MAX, the first float that rounds to a bf16 inf, +-inf
+    xs[2, :6] = [np.finfo(np.float32).max, -np.finfo(np.float32).max, np.float32(3.3961775292304601e38), np.float32(3.39e38), np.inf, -np.inf]
     for (L, lp, xstride, ypad) in [(16, 16, 16, 0), (12, 12, 16, 8), (5, 8, 16, 0), (1, 4, 16, 4)]:
         x2d = np.ascontiguousarray(xs[:, :L])
         hi, mid, lo = np_split3(x2d)
