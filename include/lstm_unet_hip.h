@@ -245,7 +245,12 @@ typedef struct lu_wgrad_desc {
                                * term t reads x at x + t * x_term_stride + f * x_frame_stride and dy at dy + t * dy_term_stride + f *
                                * dy_frame_stride (strides in elements).  With the channel blocks of two lu_split6 tensors as the terms (x in
                                * order 0, dy in order 1, term stride = one block) ONE launch sums the six bf16 products of the exact three-way
-                               * split: the fp32 weight gradient on the bf16 MFMA, accumulated inside the blocks instead of across launches. */
+                               * split: the fp32 weight gradient on the bf16 MFMA, accumulated inside the blocks instead of across launches.
+                               * terms == 6 with LU_WGRAD_F_PIECES3 (ABI v12): the PIECE-AWARE form of the same sum -- x and dy are lu_split6 tensors whose first
+                               * three channel blocks (block stride x_term_stride / dy_term_stride) are the three pieces of the operand (x, order
+                               * 0: lo, mid, hi; dy, order 1: hi, mid, lo); one pass over `frames` frames stages each piece once and issues the
+                               * six products from registers (half the staged bytes and LDS fragment reads per MFMA of the terms-as-frames form).
+                               * Stride-1 3x3 / 5x5, C % 128 == 0, W % 32 == 0; dbias = column sums of hi + mid + lo = dy is allowed. */
     int64_t x_term_stride, dy_term_stride;
 } lu_wgrad_desc;
 
@@ -272,6 +277,8 @@ enum {
     LU_WGRAD_F_KP16 = 16384,     /* fp32 kernel-row variant: 16-pixel stages where 32-pixel ones would be taken (A/B, tests) */
     LU_WGRAD_F_HALF_BLOCK = 65536, /* precision 1, bf16 operands, stride-1 5x5: 4-wave blocks of 64 channels x 128 columns (two independent blocks
                                   * per CU) instead of 8-wave blocks of 128 channels -- round 5 A/B; bit-identical dw, dbias to fp32 re-association */
+    LU_WGRAD_F_PIECES3 = 131072, /* terms == 6 (ABI v12, precision 'bf16x3'): the piece-aware kernel -- each of the three pieces of x and dy staged once per
+                                  * 32-pixel run, the six products issued from registers (wgrad_row_x3_kernel); C % 128 == 0, stride-1 3x3 / 5x5 */
     LU_WGRAD_F_XREALIGN = 32768  /* precision 1, bf16 operands, stride-1 5x5, 128-channel tiles: every tap fetches its own re-aligned x rows
                                   * with transposing LDS reads instead of cutting them out of one fetch with funnel shifts / register
                                   * moves (round 5 A/B; bit-identical) */

@@ -708,25 +708,6 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
     }
     const int64_t x_gap = a.x_fs - (int64_t)a.HWo * a.x_ps, y_gap = a.dy_fs - (int64_t)a.HWo * a.dy_ps;      // (S == 1: Hin * Win == HWo)
     const lu_u4* const zpa = zp;
-    // Stage cursor -> next stage (stride 1; W % 32 == 0: a run never straddles two rows).  BRANCH-FREE (round 6): written as nested ifs
-    // this was three scalar branches in the middle of the stage -- basic-block boundaries that fenced the stage's LDS stores and global
-    // loads off from the MFMAs of k-steps 1 .. 3, so that the sched_group_barrier interleave below had nothing to interleave: the ~140
-    // staging instructions of a stage ran as ONE lump between k-step 0 and k-step 1 with the MFMA pipe idle (ISA of round 5).
-    auto advance_cursor = [&]() {
-        ++ls;
-        ox0 += PRB;
-        const bool row_end = ox0 >= a.Wout;
-        ox0 = row_end ? 0 : ox0;
-        oy += row_end ? 1 : 0;
-        const bool frame_end = oy == a.Hout;            // (only ever true together with row_end)
-        oy = frame_end ? 0 : oy;
-        pf += frame_end ? 1 : 0;
-        tleft -= frame_end ? 1 : 0;
-        const bool term_end = tleft == 0;               // terms: the next frame belongs to the next term
-        tleft = term_end ? a.tf : tleft;
-        xcur += PRB * a.x_ps + (frame_end ? x_gap : (int64_t)0) + (term_end ? a.x_tj : (int64_t)0);
-        ycur += PRB * a.dy_ps + (frame_end ? y_gap : (int64_t)0) + (term_end ? a.y_tj : (int64_t)0);
-    };
     auto load_stage = [&](lu_u4 (&rx)[XPASS], lu_u4 (&ry)[YPASS]) {
         if constexpr (S == 1) {
             const unsigned live = ls < n_it ? 1u : 0u;
@@ -750,7 +731,24 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
                 const lu_u4* pp = YB ? reinterpret_cast<const lu_u4*>(yb + ycur + yvo[i]) : reinterpret_cast<const lu_u4*>(a.dy + ycur + yvo[i]);
                 ry[i] = *((ok & 1u) ? pp : zpa);
             }
-            advance_cursor();
+            ++ls;
+            ox0 += PRB;
+            xcur += PRB * a.x_ps;
+            ycur += PRB * a.dy_ps;
+            if (ox0 >= a.Wout) {          // W % 32 == 0: a run never straddles two rows
+                ox0 = 0;
+                if (++oy == a.Hout) {
+                    oy = 0;
+                    ++pf;
+                    xcur += x_gap;
+                    ycur += y_gap;
+                    if (--tleft == 0) {      // (terms: the next frame belongs to the next term)
+                        tleft = a.tf;
+                        xcur += a.x_tj;
+                        ycur += a.y_tj;
+                    }
+                }
+            }
             return;
         }
         const bool live = ls < n_it;
@@ -969,7 +967,24 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
                 lu_glds16(reinterpret_cast<const float*>((ok & 1u) ? sp : zs), reinterpret_cast<float*>((isx ? Xd : Yd) + dlds[k2]));
             }
         }
-        advance_cursor();
+        ++ls;
+        ox0 += PRB;
+        xcur += PRB * a.x_ps;
+        ycur += PRB * a.dy_ps;
+        if (ox0 >= a.Wout) {
+            ox0 = 0;
+            if (++oy == a.Hout) {
+                oy = 0;
+                ++pf;
+                xcur += x_gap;
+                ycur += y_gap;
+                if (--tleft == 0) {
+                    tleft = a.tf;
+                    xcur += a.x_tj;
+                    ycur += a.y_tj;
+                }
+            }
+        }
     };
     // bias gradient of a DMA'd stage: column sums of its dy tile read back from LDS, by the same (row, piece) -> thread map and in
     // the same stage order as the register-staged form sums its pieces (bit-identical partial sums)
@@ -1180,6 +1195,296 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
             if (n0 + tid < a.N) a.bias_ws[((int64_t)z * brc + bslot) * a.N + n0 + tid] = s;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Piece-aware kernel-row weight gradient of precision 'bf16x3' (round 6; lu_wgrad_desc.terms == 6).
+// x and dy are lu_split6 tensors; their first three channel blocks are the three bf16 pieces of the fp32 operand -- x (order A):
+// lo, mid, hi; dy (order B): hi, mid, lo.  The six products of the mode (lo hi + mid mid + hi lo + mid hi + hi mid + hi hi) were, in
+// round 5, six times the FRAMES of wgrad_row_bf16_kernel (terms as frames): every piece of x and dy was staged and its fragments
+// were read from LDS once per product it takes part in -- 12 bytes per element, 0.7 transposing LDS reads per MFMA, on a kernel the
+// round-6 ablations (profiles/r06_wgrad_bf16_ablation.txt) show paying for exactly those two streams: MFMAs alone 94 % busy at
+// 2.30 GHz, + fragment reads 81 % at 1.88 GHz, + staging 67 % at 1.76 GHz.  Here a stage holds the THREE pieces of a 32-pixel run
+// of both operands (6 bytes per element), a piece's fragments are read once per k-step and feed every product the piece occurs in
+// from registers: 21 reads per 60 MFMAs (0.35 per MFMA), half the staged bytes per MFMA, 120 MFMAs per wave and stage barrier
+// instead of 40.  Block = 128 channels x 128 columns x one kernel row, 8 waves (4 x 2) of 32c x 64n x K taps as in the bf16 kernel.
+// Staging is LDS-DMA (global_load_lds_dwordx4, no staging registers -- the 42 fragment registers of a k-step need the room): dense
+// 256-byte rows, the 64-byte segment s of row r stored at s ^ (r & 3) by swizzling the SOURCE address; two stage buffers, the
+// transfers of stage it + 1 run under the 120 MFMAs of stage it (~4 us: longer than a loaded memory round trip).
+// Order of the products inside a k-step: the five small ones first, hi x hi last; per fp32 accumulator that is one rounding per
+// MFMA of 16 pixels, 6 per 16 products -- fewer than the fp32 MFMA kernel's one per 2.
+// The bias gradient (column sums of dy = hi + mid + lo) is read back from the staged dy tiles by the block whose turn it is.
+// ---------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(512, 2) void wgrad_row_x3_kernel(WgradArgs a) {
+    constexpr int PRB = 32, BM = 128, BN = 128, XP = PRB + K - 1, NWV = 8, NFW = 2, NT = 512;
+    constexpr int XPA = (XP + 3) / 4 * 4;              // x rows allocated per piece: whole wave instructions of 4 rows
+    constexpr int XI1 = XPA / 4, YI1 = PRB / 4;        // wave instructions per piece tile
+    constexpr int XI = 3 * XI1, YI = 3 * YI1;
+    constexpr int XB1 = 3 * XPA * BM, YB1 = 3 * PRB * BN;      // bf16 elements per stage buffer
+    constexpr int NR = (8 + K - 1 + 3) / 4;
+    LU_DYN_LDS(unsigned short, smem);      // Xs[2][3][XPA][128] | Ys[2][3][32][128] | Bred[8 * 128] floats (wgrad_row_x3_lds)
+    unsigned short* const Xs = smem;
+    unsigned short* const Ys = smem + 2 * XB1;
+    float* const Bred = reinterpret_cast<float*>(Ys + 2 * YB1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % 4, wn = wave / 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;      // XCD-aware numbering, as wgrad_row_bf16_kernel
+    const int z = (jb / a.inner) * 8 + xcd;
+    if (z >= a.splits) return;
+    int tl = jb % a.inner;
+    const int rc = a.inner / a.n_tiles;          // K * c_tiles
+    const int n0 = (tl / rc) * BN;
+    tl -= (tl / rc) * rc;
+    const int kh = tl / a.c_tiles;
+    const int c0 = (tl - kh * a.c_tiles) * BM;
+    const int64_t p_begin = (int64_t)z * a.chunk;
+    int64_t p_end = p_begin + a.chunk;
+    if (p_end > a.M) p_end = a.M;
+    const int n_it = p_end > p_begin ? (int)((p_end - p_begin + PRB - 1) / PRB) : 0;
+
+    int64_t pf = 0;
+    int oy = 0, ox0 = 0, ls = 0;
+    {
+        const int64_t p = p_begin < a.M ? p_begin : 0;
+        pf = p / a.HWo;
+        const int r = (int)(p - pf * a.HWo);
+        oy = r / a.Wout;
+        ox0 = r - oy * a.Wout;
+    }
+    int64_t xcur = pf * a.x_fs + ((int64_t)(oy + kh - a.pad_t) * a.Win + (ox0 - a.pad_l)) * a.x_ps + c0;
+    int64_t ycur = pf * a.dy_fs + ((int64_t)oy * a.Wout + ox0) * a.dy_ps + n0;
+    const int64_t x_gap = a.x_fs - (int64_t)a.HWo * a.x_ps, y_gap = a.dy_fs - (int64_t)a.HWo * a.dy_ps;
+    const bool want_bias = a.bias_ws != nullptr;
+    const int brc = rc, bslot = kh * a.c_tiles + c0 / BM;
+    int bphase = 0;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+    // DMA: wave instruction ii = wave + 8 k2 of a stage (x pieces first, then dy pieces) copies 4 tile rows x 256 bytes.  A lane's part
+    // of the source address -- row (lane >> 4) of the four, swizzled 16-byte piece -- is the same for every instruction (all of them
+    // start on a multiple of 4 rows): ONE offset register per operand; which instruction it is lives in scalar registers.
+    const int uw = LU_UNIFORM(wave);
+    const int l4 = lane >> 4;
+    const int pc = (lane & 15) ^ (4 * l4);            // source piece: the swizzle is applied on the way in
+    // (fields selected by a run-time condition below are copied to locals first: a select between two MEMBERS of the by-value argument
+    // struct becomes a select between their addresses, and the whole struct moves to scratch memory -- 424 bytes per lane in the first build)
+    const int x_ps = a.x_ps, dy_ps = a.dy_ps;
+    const int64_t x_pj = a.x_tj, y_pj = a.y_tj;
+    const int lx = l4 * x_ps + 8 * pc, ly = l4 * dy_ps + 8 * pc;
+    // per-lane validity as 0 / 1 words and bit arithmetic (lane-varying bools with && / || become exec-masked branches around each transfer)
+    const unsigned x_ok = c0 + 8 * pc < a.C ? 1u : 0u, y_ok = n0 + 8 * pc < a.N ? 1u : 0u;
+    const unsigned x_lo = l4 < a.pad_l ? 1u : 0u;                                    // first row group: rows left of the run
+    const unsigned x_hi = 4 * (XI1 - 1) + l4 >= PRB + a.pad_l ? 1u : 0u;             // last row group: rows right of it ...
+    const unsigned x_out = 4 * (XI1 - 1) + l4 < XP ? 0u : 1u;                        // ... and rows past the tile (allocation only)
+    auto dma_stage = [&](unsigned short* Xd, unsigned short* Yd) {
+        const unsigned live = ls < n_it ? 1u : 0u;
+        const unsigned rowok = (unsigned)(oy + kh - a.pad_t) < (unsigned)a.Hin ? live : 0u;
+        const unsigned e_lo = ox0 == 0 ? 1u : 0u, e_hi = ox0 + PRB >= a.Wout ? 1u : 0u;
+        const unsigned short* const xb = reinterpret_cast<const unsigned short*>(a.x) + xcur;
+        const unsigned short* const yb = reinterpret_cast<const unsigned short*>(a.dy) + ycur;
+        const unsigned short* const zs = reinterpret_cast<const unsigned short*>(a.zero16 ? a.zero16 : (const void*)lu_zero16);
+        // x instructions uw, uw + 8, ... < XI, then dy instructions uw, uw + 8, ... < YI: which operand a slot belongs to is a compile-time
+        // property (a run-time select between the two base pointers in front of the valid ? source : zeros select sent the argument struct
+        // to scratch memory in the first build); only the last x slot is partial (wave-uniform test)
+#pragma unroll
+        for (int k2 = 0; k2 < (XI + NWV - 1) / NWV; ++k2) {
+            const int ii = uw + NWV * k2;
+            if (NWV * (k2 + 1) <= XI || ii < XI) {
+                const int p = ii / XI1, g = ii - p * XI1;      // piece, row group
+                const unsigned bad = (g == 0 ? (e_lo & x_lo) : 0u) | (g == XI1 - 1 ? ((e_hi & x_hi) | x_out) : 0u);      // (g: wave-uniform)
+                const unsigned ok = rowok & x_ok & (bad ^ 1u);
+                const unsigned short* sp = xb + ((int64_t)4 * g * x_ps + p * x_pj) + lx;
+                lu_glds16(reinterpret_cast<const float*>((ok & 1u) ? sp : zs), reinterpret_cast<float*>(Xd + (p * XPA + 4 * g) * BM));
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < (YI + NWV - 1) / NWV; ++k2) {
+            const int ii = uw + NWV * k2;
+            if (NWV * (k2 + 1) <= YI || ii < YI) {
+                const int q = ii / YI1, g = ii - q * YI1;
+                const unsigned ok = live & y_ok;
+                const unsigned short* sp = yb + ((int64_t)4 * g * dy_ps + q * y_pj) + ly;
+                lu_glds16(reinterpret_cast<const float*>((ok & 1u) ? sp : zs), reinterpret_cast<float*>(Yd + (q * PRB + 4 * g) * BN));
+            }
+        }
+        ++ls;
+        ox0 += PRB;
+        xcur += PRB * x_ps;
+        ycur += PRB * dy_ps;
+        if (ox0 >= a.Wout) {          // W % 32 == 0: a run never straddles two rows
+            ox0 = 0;
+            if (++oy == a.Hout) {
+                oy = 0;
+                xcur += x_gap;
+                ycur += y_gap;
+            }
+        }
+    };
+
+    f32x16 acc[K][NFW];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nf][r] = 0.f;
+
+    // this lane inside a 4-row x 32-column transposed fetch (wgrad_row_bf16_kernel); every row a lane reads is (a multiple of 4) +
+    // frow, so the swizzle term of its 64-byte segment is a per-lane constant
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int xoff = frow * BM + ((wm ^ (frow & 3)) * 32) + fcol;
+    int yoff[NFW];
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) yoff[nf] = frow * BN + (((wn * NFW + nf) ^ (frow & 3)) * 32) + fcol;
+
+    auto bias_stage_lds = [&](const unsigned short* Yr) {
+        const bool mine = want_bias && bphase == bslot;      // (uniform)
+        bphase = bphase + 1 == brc ? 0 : bphase + 1;
+        if (mine) {      // thread -> (row tid / 16, 16-byte piece tid % 16) of each of the three dy piece tiles: dy = hi + mid + lo
+            const int yr = tid >> 4, q16 = tid & 15;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const lu_u4 v = *reinterpret_cast<const lu_u4*>(&Yr[(q * PRB + yr) * BN + 8 * (q16 ^ (4 * (yr & 3)))]);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += lu_bits2f(w4[e] << 16);
+                    bsum[2 * e + 1] += lu_bits2f(w4[e] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    // fragment helpers (kernel scope, not nested in the stage function: nested closures kept their captures -- and with them the whole
+    // argument struct -- in scratch memory in the first build)
+    auto yfr = [&](const unsigned short* __restrict__ Yr, int q, int j, lu_bf16x8 (&bv)[NFW]) {
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) {
+            const unsigned short* base = &Yr[(q * PRB + 16 * j) * BN + yoff[nf]];
+            const lu_bf16x4 lo = lu_lds_tr16(base), hi = lu_lds_tr16(base + 4 * BN);
+            bv[nf][0] = lo[0]; bv[nf][1] = lo[1]; bv[nf][2] = lo[2]; bv[nf][3] = lo[3];
+            bv[nf][4] = hi[0]; bv[nf][5] = hi[1]; bv[nf][6] = hi[2]; bv[nf][7] = hi[3];
+        }
+    };
+    auto xrows = [&](const unsigned short* __restrict__ Xr, int p, int j, short (&xw)[4 * NR]) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const lu_bf16x4 q4 = lu_lds_tr16(&Xr[(p * XPA + 16 * j + 4 * r) * BM + xoff]);
+            xw[4 * r] = q4[0]; xw[4 * r + 1] = q4[1]; xw[4 * r + 2] = q4[2]; xw[4 * r + 3] = q4[3];
+        }
+    };
+    auto group = [&](const short (&xw)[4 * NR], const lu_bf16x8 (&bv)[NFW]) {      // the K taps of one product
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            lu_bf16x8 av;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = xw[t + e];
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf) acc[t][nf] = lu_mfma_bf16(av, bv[nf], acc[t][nf]);
+        }
+    };
+    // One stage.  As __restrict__ PARAMETERS of an inlined function the buffer being filled and the buffer being read carry
+    // scoped-noalias metadata: hipcc would otherwise drain the DMA counter (vmcnt(0)) in front of every transposing LDS read that
+    // MAY alias a transfer in flight (see wgrad_row_bf16_kernel's DMA loop).
+    auto stage = [&](unsigned short* __restrict__ Xd, unsigned short* __restrict__ Yd, const unsigned short* __restrict__ Xr,
+                     const unsigned short* __restrict__ Yr) {
+        dma_stage(Xd, Yd);
+#ifndef LU_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        bias_stage_lds(Yr);
+#pragma unroll
+        for (int j = 0; j < PRB / 16; ++j) {
+            // x pieces 0 / 1 / 2 = lo / mid / hi, dy pieces 0 / 1 / 2 = hi / mid / lo
+            lu_bf16x8 y_hi[NFW], y_q[NFW];
+            short xa[4 * NR], xb_[4 * NR];
+            yfr(Yr, 0, j, y_hi);
+            xrows(Xr, 0, j, xa);
+            group(xa, y_hi);      // lo  x hi
+            xrows(Xr, 1, j, xb_);
+            yfr(Yr, 1, j, y_q);
+            group(xb_, y_q);      // mid x mid
+            xrows(Xr, 2, j, xa);
+            group(xb_, y_hi);     // mid x hi
+            group(xa, y_q);       // hi  x mid
+            yfr(Yr, 2, j, y_q);
+            group(xa, y_q);       // hi  x lo
+            group(xa, y_hi);      // hi  x hi
+        }
+    };
+
+    auto stage_sync = [&]() {
+#ifdef LU_EMU
+        __syncthreads();
+#else
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): this wave's transfers of the next stage have landed
+        __builtin_amdgcn_s_barrier();
+#endif
+    };
+    dma_stage(Xs, Ys);      // stage 0
+    stage_sync();
+    for (int it = 0; it < n_it; ++it) {
+        const int b = it & 1;
+        stage(Xs + (b ^ 1) * XB1, Ys + (b ^ 1) * YB1, Xs + b * XB1, Ys + b * YB1);
+        stage_sync();
+    }
+
+    const int l31 = lane & 31;
+    float* slab = a.ws + (int64_t)z * a.slab;
+    {
+        // 16-byte slab stores: each wave turns its fragments round in a private slice of the (dead) operand LDS (see wgrad_row_bf16_kernel)
+        float* const Exw = reinterpret_cast<float*>(smem) + wave * (16 * 36);      // [16 rows][32 columns + 4]
+        const int cq = lane & 7;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int tap = kh * K + t;
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+                        Exw[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 36 + l31] = acc[t][nf][8 * half + rr];
+                    LU_WAVE_SYNC();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int lp = (lane >> 3) + 8 * q;
+                        const int c = c0 + wm * 32 + 16 * half + lp;
+                        const int n = n0 + wn * 32 * NFW + 32 * nf + 4 * cq;
+                        const float4 v = *reinterpret_cast<const float4*>(&Exw[lp * 36 + 4 * cq]);
+                        if (c < a.C && n < a.N) *reinterpret_cast<float4*>(&slab[((int64_t)tap * a.C + c) * a.N + n]) = v;
+                    }
+                    LU_WAVE_SYNC();
+                }
+        }
+    }
+    if (want_bias) {          // rows of a piece column live in different lanes / waves: shuffle, then 8 wave partials (fixed order)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+            v += lu_shfl_xor(v, 32);
+            v += lu_shfl_xor(v, 16);
+            bsum[e] = v;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Bred[wave * BN + 8 * lane + e] = bsum[e];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) s += Bred[w * BN + tid];
+            if (n0 + tid < a.N) a.bias_ws[((int64_t)z * brc + bslot) * a.N + n0 + tid] = s;
+        }
+    }
+}
+
+size_t wgrad_row_x3_lds(int K) {
+    const int XPA = (32 + K - 1 + 3) / 4 * 4;
+    return (size_t)(2 * 3 * XPA * 128 + 2 * 3 * 32 * 128) * sizeof(unsigned short) + 8 * 128 * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1473,12 +1778,19 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     a.dy_ps = d->dy_pix_stride;
     a.C = d->C;
     a.N = d->N;
-    const int terms = d->terms > 1 ? d->terms : 1;
+    // terms == 6 + LU_WGRAD_F_PIECES3 (ABI v12): the piece-aware kernel of precision 'bf16x3' -- all six products from the first three channel blocks of the
+    // two split6 tensors in ONE pass over the frames (wgrad_row_x3_kernel); 2 .. 5: that many products with the terms as frames
+    const bool pieces3 = d->terms == 6 && (d->flags & LU_WGRAD_F_PIECES3);
+    const int terms = (d->terms > 1 && !pieces3) ? d->terms : 1;
     a.M = (int64_t)d->frames * terms * d->Hout * d->Wout;
     if (terms > 1) {
         a.tf = d->frames;
         a.x_tj = d->x_term_stride - (int64_t)d->frames * d->x_frame_stride;
         a.y_tj = d->dy_term_stride - (int64_t)d->frames * d->dy_frame_stride;
+    }
+    if (pieces3) {      // (the kernel reads the fields as the piece strides)
+        a.x_tj = d->x_term_stride;
+        a.y_tj = d->dy_term_stride;
     }
     a.chunk = ((a.M + splits - 1) / splits + 63) / 64 * 64;     // multiple of every kernel's pixel run (16 / 32 / 64)
     a.HWo = d->Hout * d->Wout;
@@ -1533,6 +1845,9 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
                "C %% 8 == 0, N %% 8 == 0, W %% 32 == 0, 16-byte aligned)");
     LU_REQUIRE(terms == 1 || (row_bf16 && row_variant && xb && yb && d->x_term_stride % 8 == 0 && d->dy_term_stride % 8 == 0),
                "lu_conv2d_wgrad: terms > 1 belongs to the bf16 kernel-row variant on bf16 operands (stride-1 3x3 / 5x5, C >= 64, W %% 32 == 0)");
+    LU_REQUIRE(!pieces3 || (row_bf16 && row_variant && xb && yb && d->C % 128 == 0 && d->x_term_stride % 8 == 0 && d->dy_term_stride % 8 == 0 &&
+                            3 * (int64_t)d->x_term_stride <= d->x_pix_stride && 3 * (int64_t)d->dy_term_stride <= d->dy_pix_stride),
+               "lu_conv2d_wgrad: LU_WGRAD_F_PIECES3 (piece-aware 'bf16x3' weight gradient) needs bf16 split6 operands, stride-1 3x3 / 5x5, C %% 128 == 0, W %% 32 == 0");
     LU_REQUIRE(!d->dbias || row_variant || small3 || (row_s2 && row_bf16),
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
@@ -1550,7 +1865,8 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
     // LU_WGRAD_F_NO_TAPS9 keeps the kernel-row form (A/B, tests), LU_WGRAD_F_TAPS9 selects the fat waves.
     const bool taps9 = row_bf16 && row_variant && d->k == 3 && d->stride == 1 && d->C >= 64 && !(d->flags & LU_WGRAD_F_NO_TAPS9) &&
                        !(d->flags & (LU_WGRAD_F_CT64 | LU_WGRAD_F_CT128));
-    const int bias_rows_per_split = small3 ? 1 : taps9 ? (d->C + 63) / 64
+    const bool taps9_ = taps9 && !pieces3;
+    const int bias_rows_per_split = small3 ? 1 : pieces3 ? d->k * (d->C / 128) : taps9_ ? (d->C + 63) / 64
                                                 : row_bf16 ? d->k * ((d->C + ct_bf16 - 1) / ct_bf16)
                                                 : row_variant ? d->k * ((d->C + 63) / 64) : 1;      // (blocks sharing a dy tile)
     if (d->phase == 2) {
@@ -1561,7 +1877,15 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         if (tiles <= 16) LU_LAUNCH((wgrad_small3_kernel<2>), grid, dim3(512), stream, a);
         else if (tiles <= 24) LU_LAUNCH((wgrad_small3_kernel<3>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_small3_kernel<5>), grid, dim3(512), stream, a);
-    } else if (taps9) {
+    } else if (pieces3) {
+        a.c_tiles = d->C / 128;
+        a.n_tiles = (d->N + 127) / 128;
+        a.inner = a.n_tiles * d->k * a.c_tiles;
+        a.splits = splits;
+        dim3 grid((unsigned)(8 * a.inner * ((splits + 7) / 8)));      // XCD-aware numbering: see the kernel
+        if (d->k == 5) LU_LAUNCH_DYN((wgrad_row_x3_kernel<5>), grid, dim3(512), wgrad_row_x3_lds(5), stream, a);
+        else LU_LAUNCH_DYN((wgrad_row_x3_kernel<3>), grid, dim3(512), wgrad_row_x3_lds(3), stream, a);
+    } else if (taps9_) {
         a.c_tiles = (d->C + 63) / 64;
         a.n_tiles = (d->N + 127) / 128;
         a.inner = a.n_tiles * a.c_tiles;

@@ -2,7 +2,7 @@
 no policy, no fallbacks.  `bind(path)` loads ONE shared object and attaches the prototypes."""
 import ctypes as C
 
-ABI_VERSION = 11         # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
+ABI_VERSION = 12         # lu_abi_version() of include/lstm_unet_hip.h this binding was written for
 c_f32p = C.c_void_p      # raw device pointers travel as integers
 i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -30,6 +30,7 @@ LU_WGRAD_F_DMA = 4096
 LU_WGRAD_F_NO_DMA = 8192
 LU_WGRAD_F_XREALIGN = 32768
 LU_WGRAD_F_HALF_BLOCK = 65536
+LU_WGRAD_F_PIECES3 = 131072
 
 
 class ConvSrc(C.Structure):

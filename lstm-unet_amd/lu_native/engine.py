@@ -864,8 +864,14 @@ class Engine:
         if Wp == W:
             return t6
         if out is None:
-            out = torch.zeros((fr, H, Wp, C6), device=t6.device, dtype=t6.dtype)
-        out[:, :, :W].copy_(t6)
+            out = torch.empty((fr, H, Wp, C6), device=t6.device, dtype=t6.dtype)
+        if C6 % 8 == 0 and t6.is_contiguous() and out.is_contiguous():
+            # the library's window copy (zero fill outside) on the rows seen as fp32: 16-byte transactions, one launch -- as a torch
+            # strided copy of 2-byte elements this was 74 ms of a config-4 step
+            ops.window_copy(t6.view(torch.float32), (H, Wp), (0, 0), 0, out=out.view(torch.float32))
+        else:
+            out[:, :, W:].zero_()
+            out[:, :, :W].copy_(t6)
         return out
 
     def _x3_wgrad(self, x6, dy6, dw, dbias=None, beta0=0.0):
@@ -879,6 +885,9 @@ class Engine:
             for t in range(6):
                 ops.conv2d_wgrad(x6[..., t * lp:(t + 1) * lp], dy6[..., t * ln:(t + 1) * ln], dw, 1, beta=beta0 if t == 0 else 1.0,
                                  bf16=True, dbias=dbias if t < 3 else None, dbias_beta=beta0 if t == 0 else 1.0)
+            return
+        if ops.x3_pieces_ok(x6, dy6, dw.shape[0]):      # round 6: each piece staged once, the six products from registers -- one launch
+            ops.conv2d_wgrad(x6, dy6, dw, 1, beta=beta0, bf16=True, dbias=dbias, dbias_beta=beta0, terms=(0, 6), pieces=True)
             return
         ops.conv2d_wgrad(x6, dy6, dw, 1, beta=beta0, bf16=True, dbias=dbias, dbias_beta=beta0, terms=(0, 3))
         ops.conv2d_wgrad(x6, dy6, dw, 1, beta=1.0, bf16=True, terms=(3, 3))

@@ -325,22 +325,36 @@ def bf16_row_wgrad_ok(x, dy, k, stride):
             Hout == Hin and Wout == Win and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
 
 
-def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta=0.0, terms=None):
+X3_PIECES = os.environ.get('LU_X3_PIECES', '1') != '0'      # precision 'bf16x3': the piece-aware weight-gradient kernel where it applies (LU_X3_PIECES=0: terms as frames, the round-5 form; A/B)
+
+
+def x3_pieces_ok(x6, dy6, k):
+    """lu_wgrad_desc.terms == 6 applies: split6 tensors on the device, stride-1 3x3 / 5x5, 128-channel tiles, 32-pixel runs inside a row."""
+    return (X3_PIECES and x6.dtype == dy6.dtype == torch.bfloat16 and k in (3, 5) and x6.shape[3] % 6 == 0 and dy6.shape[3] % 6 == 0 and
+            (x6.shape[3] // 6) % 128 == 0 and (dy6.shape[3] // 6) % 8 == 0 and x6.shape[2] % 32 == 0 and x6.shape[1:3] == dy6.shape[1:3] and
+            x6.stride(2) % 8 == 0 and dy6.stride(2) % 8 == 0 and x6.stride(0) % 8 == 0 and dy6.stride(0) % 8 == 0 and
+            x6.data_ptr() % 16 == 0 and dy6.data_ptr() % 16 == 0 and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
+
+
+def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta=0.0, terms=None, pieces=False):
     """dw ([k,k,C,N], may be a channel-slice view of a wider kernel gradient) = x (*) dy.
     dbias (optional [N]): the layer's bias gradient = column sums of dy -- summed on the side by the kernel-row wgrad
     kernels where they apply, by a separate lu_colsum pass elsewhere.
     x / dy may be bf16 tensors (the bf16 BPTT tape) when the bf16 kernel-row variant applies (bf16_row_wgrad_ok).
     terms = (first block, count) with x / dy split6 tensors (x in order A, dy in order B; precision 'bf16x3'): ONE launch sums
     block t of x against block t of dy for the `count` blocks from `first` on -- lu_wgrad_desc.terms; dbias then is the column sum
-    of those dy blocks (the first three of order B are hi, mid, lo: exactly dy)."""
+    of those dy blocks (the first three of order B are hi, mid, lo: exactly dy).  terms = (0, 6) with pieces=True: all six products
+    in one pass of the piece-aware kernel (x3_pieces_ok, LU_WGRAD_F_PIECES3; round 6)."""
     _chk(x, dy, dw, dbias)
     n_terms, xts, yts = 0, 0, 0
     if terms is not None:
         first, n_terms = terms
         assert x.dtype == dy.dtype == torch.bfloat16 and x.shape[3] % 6 == 0 and dy.shape[3] % 6 == 0 and first + n_terms <= 6
         # the bias gradient is the column sum of dy = hi + mid + lo: blocks 0..2 of order B, each exactly once
-        assert dbias is None or (first, n_terms) == (0, 3), 'dbias rides on terms (0, 3) only'
+        assert dbias is None or (first, n_terms) == (0, 3) or (pieces and (first, n_terms) == (0, 6)), \
+            'dbias rides on terms (0, 3) or the piece-aware (0, 6) only'
         xts, yts = x.shape[3] // 6, dy.shape[3] // 6
+        assert not pieces or ((first, n_terms) == (0, 6) and x3_pieces_ok(x, dy, dw.shape[0])), 'pieces: terms (0, 6) where x3_pieces_ok'
         x, dy = x[..., first * xts:(first + 1) * xts], dy[..., first * yts:(first + 1) * yts]
     frames, Hin, Win, Cin = x.shape
     _, Hout, Wout, N = dy.shape
@@ -370,6 +384,8 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
             (128 if (Cin % 128 == 0 or Cin > 256) else 64)
         all_taps = (k == 3 and stride == 1 and Cin >= 64 and      # mirrors lu_conv2d_wgrad: the all-taps form of the 3x3 layers
                     not (WGRAD_FLAGS & (cabi.LU_WGRAD_F_NO_TAPS9 | cabi.LU_WGRAD_F_CT64 | cabi.LU_WGRAD_F_CT128)))
+        if pieces:      # piece-aware kernel: 128-channel kernel-row tiles; a pixel carries six products
+            ct, all_taps = 128, False
         splits = calls.wgrad_splits_bf16_row(frames * max(1, n_terms) * Hout * Wout, k, Cin, N, ct, all_taps=all_taps)
     else:
         splits = calls.wgrad_splits(frames * Hout * Wout, k, Cin, N, row_variant=row_variant, small3=small3,
@@ -379,7 +395,7 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
                          splits, beta, precision=1 if bf16 else 0,
                          dbias=dbias.data_ptr() if (dbias is not None and (row_variant or small3)) else None,
                          dbias_beta=dbias_beta, x_dtype=cabi.LU_BF16 if xb else cabi.LU_F32,
-                         dy_dtype=cabi.LU_BF16 if yb else cabi.LU_F32, flags=WGRAD_FLAGS, terms=n_terms, x_term_stride=xts,
+                         dy_dtype=cabi.LU_BF16 if yb else cabi.LU_F32, flags=WGRAD_FLAGS | (cabi.LU_WGRAD_F_PIECES3 if pieces else 0), terms=n_terms, x_term_stride=xts,
                          dy_term_stride=yts)
     assert n_terms == 0 or (bf16_row and stride == 1 and k in (3, 5)), 'terms: the bf16 kernel-row weight gradient, stride 1'
     if dbias is not None and not (row_variant or small3):
@@ -392,6 +408,8 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
          'wgrad_kernel (strided / thin / narrow layers)')
     if bf16_row:
         kind = 'wgrad_row_bf16_kernel<%d> (bf16-MFMA weight gradients hoisted over T)' % k
+    if pieces:
+        kind = 'wgrad_row_x3_kernel<%d> (bf16-MFMA weight gradients on the three pieces of the split operands, hoisted over T)' % k
     if EVENT_LOG is not None:      # bench.py's roofline pass: time the MFMA kernel alone, the slab reduce outside the bracket
         d.phase = 1
         with _timed(kind, 2.0 * k * k * Cin * N * frames * max(1, n_terms) * Hout * Wout):

@@ -918,6 +918,18 @@ def test_window_copy_reflect_crop_embed(be):
     exp = np.ones((2, 10, 11, 2), np.float32)
     exp[:, 2:7, 1:7] += x
     assert np.array_equal(be.host(emb), exp)
+    # the 16-byte form (C and the pixel stride in groups of four floats): reflect pad, crop out of a channel slice of a wider
+    # tensor, and the zero-padded width extension precision 'bf16x3' feeds the kernel-row weight gradient (engine._x3_pad_w)
+    x8 = rnd(2, 5, 6, 12)
+    x8d = be.dev(x8)
+    y8 = be.empty((2, 10, 11, 8))
+    ck(be, be.lib.lu_window_copy(be.ptr(x8d, 4), 12, be.ptr(y8), 2, 5, 6, 10, 11, 8, 2, 1, 1, 0.0, be.stream), 'reflect vec4')
+    assert np.array_equal(be.host(y8), npo.reflect_pad_hw(x8[..., 4:], (2, 3), (1, 4)).astype(np.float32))
+    wide = be.dev(np.full((2, 5, 32, 12), 7.0))
+    ck(be, be.lib.lu_window_copy(be.ptr(x8d), 12, be.ptr(wide), 2, 5, 6, 5, 32, 12, 0, 0, 0, 0.0, be.stream), 'pad to W % 32 == 0')
+    exp8 = np.zeros((2, 5, 32, 12), np.float32)
+    exp8[:, :, :6] = x8
+    assert np.array_equal(be.host(wide), exp8)
 
 
 def test_softmax_wce(be):
@@ -1220,6 +1232,30 @@ def test_split6_weight_gradient_with_the_terms_as_frames_is_fp32_arithmetic(be, 
     assert e6 <= 2.0 * e32 + 2e-6 * np.abs(ref).max() and e16 >= 30.0 * e6
     close(one, dw, 5e-5 * max(1.0, np.abs(ref).max()))
     close(db, dy.reshape(-1, N).astype(np.float64).sum(0), 2e-4)
+
+
+@pytest.mark.parametrize('case', [(5, 2, 3, 64, 128, 128, 3), (3, 1, 4, 32, 128, 200, 2), (5, 1, 2, 32, 256, 128, 1)])
+def test_split6_weight_gradient_piece_aware_kernel_is_fp32_arithmetic(be, case):
+    """LU_WGRAD_F_PIECES3 (round 6, wgrad_row_x3_kernel): ONE pass over the frames stages the three pieces of a 32-pixel run of x and dy
+    once and issues the six products of the split from registers.  Against the fp64 oracle the result sits where the exact-fp32 MFMA
+    kernel sits (and where the terms-as-frames form of round 5 sits), far below the plain bf16 kernel; the bias gradient is the column sum
+    of hi + mid + lo = dy; beta accumulates; ragged column counts (N = 200), two channel tiles (C = 256), slabs that start mid-frame."""
+    k, fr, H, W, Cc, N, splits = case
+    x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N, scale=0.3)
+    _, ref = _torch_conv_grads(x, np.zeros((k, k, Cc, N), np.float32), dy, 1)
+    x6 = split6_ref(x.reshape(-1, Cc), Cc, 0).reshape(fr, H, W, 6 * Cc)
+    dy6 = split6_ref(dy.reshape(-1, N), N, 1).reshape(fr, H, W, 6 * N)
+    dw, db = KH.conv2d_wgrad(be, x6, dy6, k, 1, splits=splits, terms=(0, 6), flags=cabi.LU_WGRAD_F_PIECES3, dbias0=np.full(N, 7.0, np.float32))
+    frames_form = KH.conv2d_wgrad(be, x6, dy6, k, 1, splits=splits, terms=(0, 6))      # round 5: the six products as six times the frames
+    e32 = np.abs(KH.conv2d_wgrad(be, x, dy, k, 1, splits=splits) - ref).max()
+    e6, e6f = np.abs(dw - ref).max(), np.abs(frames_form - ref).max()
+    e16 = np.abs(KH.conv2d_wgrad(be, x, dy, k, 1, splits=splits, precision=1) - ref).max()
+    print('split6 wgrad, piece-aware k=%d C=%d N=%d: |err| vs fp64  fp32 MFMA %.3e   pieces %.3e   terms-as-frames %.3e   bf16 %.3e' % (k, Cc, N, e32, e6, e6f, e16))
+    assert e6 <= 2.0 * e32 + 2e-6 * np.abs(ref).max() and e16 >= 30.0 * e6
+    close(dw, frames_form, 5e-5 * max(1.0, np.abs(ref).max()))
+    close(db, dy.reshape(-1, N).astype(np.float64).sum(0), 2e-4)
+    acc = KH.conv2d_wgrad(be, x6, dy6, k, 1, splits=splits, terms=(0, 6), flags=cabi.LU_WGRAD_F_PIECES3, dw0=np.full_like(dw, 0.5), beta=1.0)
+    close(acc, dw + 0.5, 1e-6 * max(1.0, np.abs(ref).max()))
 
 
 def test_gate_backward_with_the_split_image_of_dz(be):
