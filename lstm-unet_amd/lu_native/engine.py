@@ -1052,19 +1052,19 @@ class Engine:
             # operands keeps on the tape 12 cin; levels whose width is not a multiple of 32 also hold zero-padded full-window copies
             # of all of them for the kernel-row weight gradient, _x3_pad_w: about twice the bytes)
             extra, hh, ww = 0.0, x_in.shape[1], x_in.shape[2]
-            px = lambda h_, w_: float(T * B * h_ * w_) * (2.0 if w_ % 32 else 1.0)      # noqa: E731
+            n_px = lambda h_, w_: float(T * B * h_ * w_) * (2.0 if w_ % 32 else 1.0)      # noqa: E731
             for blk in plan['down']:
-                extra += sum(px(hh, ww) * (60.0 * l['f'] + 12.0 * (-(-l['cin'] // 8) * 8)) for l in blk['lstm'])
+                extra += sum(n_px(hh, ww) * (60.0 * l['f'] + 12.0 * (-(-l['cin'] // 8) * 8)) for l in blk['lstm'])
                 for l in blk['conv']:
                     ho, wo = -(-hh // l['stride']), -(-ww // l['stride'])
                     if self._x3_conv_route(l['k'], l['stride'], l['cout'], [l['cin']]):
-                        extra += px(ho, wo) * 12.0 * l['cin']
+                        extra += n_px(ho, wo) * 12.0 * l['cin']
                     hh, ww = ho, wo
             for blk in plan['up']:
                 hh, ww = hh * blk['up_factor'], ww * blk['up_factor']
                 for ci, l in enumerate(blk['conv']):
                     if self._x3_conv_route(l['k'], 1, l['cout'], [blk['c_up'], blk['c_skip']] if ci == 0 else [l['cin']]):
-                        extra += px(hh, ww) * 12.0 * l['cin']
+                        extra += n_px(hh, ww) * 12.0 * l['cin']
             limit = self.x3_lean_bytes
             if limit is None:
                 limit = 0.3 * torch.cuda.get_device_properties(x_tb.device).total_memory if x_tb.device.type == 'cuda' else 1e18
