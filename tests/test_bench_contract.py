@@ -36,18 +36,25 @@ def test_algorithmic_flops_match_survey():
     assert b.net_by_name('params') is Params.CTCParams.net_kernel_params
 
 
-def _run_bench(extra, env_extra, timeout=900):
-    import json
+def _start_bench(extra, env_extra):
     import subprocess
     import sys
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     env.update(env_extra)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=timeout)
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
-    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()[-3000:]
+    return subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py')] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def _finish_bench(p, timeout=900):
+    import json
+    out, err = p.communicate(timeout=timeout)
+    lines = [l for l in out.decode().splitlines() if l.startswith('{')]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), err.decode()[-3000:]
+
+
+def _run_bench(extra, env_extra, timeout=900):
+    return _finish_bench(_start_bench(extra, env_extra), timeout)
 
 
 def test_bench_refuses_mismatched_launches():
@@ -62,6 +69,10 @@ SMALL = ['--steps', '2', '--warmup', '1', '--size', '64', '--batch', '1', '--unr
          '--no-bf16']
 
 
+EARLY_JOBS = {'test_bench_self_launches_n_ranks[gloo]':
+              lambda tmp: {'procs': [_start_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': 'gloo'})]}}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('backend', ['gloo', 'nccl'])
 def test_bench_self_launches_n_ranks(backend):
@@ -73,7 +84,8 @@ def test_bench_self_launches_n_ranks(backend):
         rc, line, err = _run_bench(['--gpus', '2'] + SMALL, {'LU_DP_BACKEND': 'nccl'})
         assert rc == 2 and line is None and 'needs 2 visible GPUs' in err      # refuses instead of measuring one GPU
         pytest.skip('RCCL needs one device per rank: %d visible' % torch.cuda.device_count())
-    rc, line, err = _run_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': backend})
+    h = globals().get('_EARLY_HANDLES', {}).pop('test_bench_self_launches_n_ranks[%s]' % backend, None)      # (conftest.py: started in front of the first test)
+    rc, line, err = _finish_bench(h['procs'][0]) if h else _run_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': backend})
     assert rc == 0 and line is not None, err
     # --check: the DP == single-process comparison ran inline before the timing, and the overlap proof is on the line
     assert 'vs single process' in err and line['dp']['self_check']['ok'] and line['dp']['self_check']['grad_err_over_max'] <= 2e-6

@@ -170,14 +170,7 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     assert diff.max() <= 2.5e-3 and (diff > 1e-4).mean() <= frac, (diff.max(), (diff > 1e-4).mean())
 
 
-@pytest.mark.gpu
-def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp_path):
-    """EIGHT ranks x 1 slot on the real kernels (gloo, all on the one GPU of the test box; VERDICT round 4, item 6): shard_slots
-    with W = 8, SyncBN with 8 contributors, the gradient all-reduce in THREE OR MORE buckets (a small bucket size: the tiny
-    net's 0.1 MB of gradients would otherwise leave as one), loss sums over 8 ranks -- loss and pre-Adam gradients must equal
-    the single-process step on the 8-slot batch.  What an 8-GPU box adds to this is RCCL itself and one device per rank."""
-    import train2D
-    import Networks
+def _launch_dp8_syncbn(tmp_path):
     W = 8
     rng = np.random.default_rng(8)
     x = rng.standard_normal((W, 3, 1, 24, 32)).astype(np.float32)
@@ -190,6 +183,24 @@ def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(W), LOCAL_RANK='0', LU_DP_BACKEND='gloo',
                                        LU_TEST_BUCKET_BYTES='65536', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(W)]
+    return {'tmp': tmp_path, 'procs': procs, 'x': x, 'gt': gt}
+
+
+EARLY_JOBS = {'test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process': _launch_dp8_syncbn}
+
+
+@pytest.mark.gpu
+def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp_path):
+    """EIGHT ranks x 1 slot on the real kernels (gloo, all on the one GPU of the test box; VERDICT round 4, item 6): shard_slots
+    with W = 8, SyncBN with 8 contributors, the gradient all-reduce in THREE OR MORE buckets (a small bucket size: the tiny
+    net's 0.1 MB of gradients would otherwise leave as one), loss sums over 8 ranks -- loss and pre-Adam gradients must equal
+    the single-process step on the 8-slot batch.  What an 8-GPU box adds to this is RCCL itself and one device per rank."""
+    import train2D
+    import Networks
+    W = 8
+    h = globals().get('_EARLY_HANDLES', {}).pop('test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process', None) or \
+        _launch_dp8_syncbn(tmp_path)      # (conftest.py starts the eight ranks in front of the first test of a -m gpu session)
+    tmp_path, procs, x, gt = h['tmp'], h['procs'], h['x'], h['gt']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
