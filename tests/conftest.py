@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests whose ranks are launched in front of the first test (a module's EARLY_JOBS, see _multi_process_jobs_from_the_first_test)
+    run LAST: their processes then have the whole session to start up, rendezvous and finish beside the other tests, and the test
+    itself only collects the result.  (Run first, the bench self-launch waited 336 s for its two ranks while the oracle farm and
+    sixteen other ranks were starting: round 6, profiles/README.)  Same test ids, same assertions."""
+    def early(it):
+        jobs = getattr(it.module, 'EARLY_JOBS', None) or {}
+        return it.name in jobs or it.name.split('[')[0] in jobs
+    items[:] = [it for it in items if not early(it)] + [it for it in items if early(it)]
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

@@ -117,6 +117,21 @@ dp.barrier()
 '''
 
 
+def _launch_dp2(tmp_path, precision):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 1, 24, 32)).astype(np.float32)
+    gt = rng.integers(-1, 3, size=(2, 3, 1, 24, 32)).astype(np.float32)
+    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
+    script = tmp_path / 'worker_gpu.py'
+    script.write_text(GPU_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
+    port = 29600 + (os.getpid() + 11 * ['fp32', 'bf16', 'bf16x3'].index(precision)) % 1500      # (the three may be in flight at once)
+    procs = [subprocess.Popen([sys.executable, str(script), precision],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', LU_DP_BACKEND='gloo',
+                                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    return {'tmp': tmp_path, 'procs': procs, 'x': x, 'gt': gt}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision):
@@ -129,17 +144,9 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     limits apply -- gradients to summation-order noise."""
     import train2D
     import Networks
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((2, 3, 1, 24, 32)).astype(np.float32)
-    gt = rng.integers(-1, 3, size=(2, 3, 1, 24, 32)).astype(np.float32)
-    np.savez(tmp_path / 'batch.npz', x=x, gt=gt)
-    script = tmp_path / 'worker_gpu.py'
-    script.write_text(GPU_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
-    port = 29600 + os.getpid() % 1500
-    procs = [subprocess.Popen([sys.executable, str(script), precision],
-                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', LU_DP_BACKEND='gloo',
-                                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    h = globals().get('_EARLY_HANDLES', {}).pop('test_dp2_syncbn_on_the_hip_kernels_equals_single_process[%s]' % precision, None) or \
+        _launch_dp2(tmp_path, precision)      # (conftest.py starts the ranks in front of the first test of a -m gpu session)
+    tmp_path, procs, x, gt = h['tmp'], h['procs'], h['x'], h['gt']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
@@ -187,6 +194,9 @@ def _launch_dp8_syncbn(tmp_path):
 
 
 EARLY_JOBS = {'test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process': _launch_dp8_syncbn}
+if not os.environ.get('LU_TEST_NO_OVERLAP'):
+    EARLY_JOBS.update({'test_dp2_syncbn_on_the_hip_kernels_equals_single_process[%s]' % p_: (lambda tmp, p_=p_: _launch_dp2(tmp, p_))
+                       for p_ in ('fp32', 'bf16', 'bf16x3')})
 
 
 @pytest.mark.gpu

@@ -708,13 +708,15 @@ def start_oracle_farm():
     for (p_, B, T, H, W, tr, seed, lab) in sorted(FWD_CASES, key=lambda c: -c[1] * c[2] * c[3] * c[4]):
         farm.submit(_fwd_key(p_, B, T, H, W, tr, seed),
                     dict(kind='forward', H=H, W=W, T=T, B=B, seed=seed, training=tr, labels=lab, dtype='float64',
-                         bf16_operands=(p_ == 'bf16'), threads=12))
+                         bf16_operands=(p_ == 'bf16'), threads=6))      # (half-minute passes with four minutes to spare: few threads each,
+                                                                         # so that the farm leaves host cores to the multi-rank tests' start-up)
     # longest jobs first
     order = sorted(GRAD_CASES.items(), key=lambda kv: -kv[1]['H'] * kv[1]['W'] * kv[1]['T'] * kv[1]['B'])
     for ar in ('f64', 'r64', 'f32'):
         for name, c in order:
             if ar in c['arith']:
-                spec = dict(H=c['H'], W=c['W'], T=c['T'], B=c['B'], seed=c['seed'], carried=c['carried'], threads=16, **_ARITH[ar])
+                big = c['H'] * c['W'] * c['T'] * c['B'] >= 256 * 256 * 2 and ar != 'f32'      # the critical path: fp64 autograd at 256 x 256
+                spec = dict(H=c['H'], W=c['W'], T=c['T'], B=c['B'], seed=c['seed'], carried=c['carried'], threads=16 if big else 8, **_ARITH[ar])
                 farm.submit('%s.%s' % (name, ar), spec)
     _SESSION['farm'] = farm
     return farm
