@@ -638,7 +638,7 @@ def main():
         try:     # L2-fabric bytes per launch from the committed rocprofv3 --pmc passes: a STATIC table
             if wl_sfx is not None:      # collected by tools/gpu/pmc_traffic.sh, not measured in this run
                 sfx = ('' if args.precision == 'fp32' else '_' + args.precision) + wl_sfx
-                rounds = ('r05', 'r04', 'r03', 'r02', 'r01') if wl_sfx == '' else ('r05',)
+                rounds = ('r06', 'r05', 'r04', 'r03', 'r02', 'r01') if wl_sfx == '' else ('r06', 'r05')
                 name = next(n for n in ['%s_pmc_traffic%s.json' % (r_, sfx) for r_ in rounds]
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
@@ -679,7 +679,7 @@ def main():
         util_db, util_src, util_build = {}, None, None
         try:
             if wl_sfx is not None:
-                rounds = ('r05', 'r04', 'r03', 'r02') if wl_sfx == '' else ('r05',)
+                rounds = ('r06', 'r05', 'r04', 'r03', 'r02') if wl_sfx == '' else ('r06', 'r05')
                 name = next(n for n in ['%s_pmc_mfma_util%s.json' % (r_, wl_sfx) for r_ in rounds]
                             if os.path.exists(os.path.join(ROOT, 'profiles', n)))
                 with open(os.path.join(ROOT, 'profiles', name)) as fh:
