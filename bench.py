@@ -461,20 +461,10 @@ def main():
     ap.add_argument('--no-wgrad-overlap', action='store_true', help='A/B: weight gradients in line instead of on the side stream')
     ap.add_argument('--wgrad-flags', type=int, default=0, help='A/B: LU_WGRAD_F_* bits OR-ed into every weight-gradient descriptor')
     ap.add_argument('--conv-flags', type=int, default=0, help='A/B: LU_CONV_F_* bits OR-ed into every convolution descriptor')
-    ap.add_argument('--ab-f32-act', action='store_true', help='A/B: bf16 mode with every activation stored as fp32 (round 2 / early round 3)')
-    ap.add_argument('--wgrad-rounds', type=int, default=0, help='A/B: rounds of blocks the bf16 kernel-row weight gradient is split into (default 5)')
-    ap.add_argument('--ab-f32-grad', action='store_true', help='A/B: bf16 mode with the BatchNorm-backward gradients stored as fp32')
-    ap.add_argument('--ab-no-prep', action='store_true',
-                    help='A/B: derived weight images one launch at a time per step, recurrent state copied / masked eagerly (before round 3)')
-    ap.add_argument('--ab-old-tail', action='store_true',
-                    help='A/B: bf16 mode with the decoder tail on the kernels of round 2 (gather / fp32 tiles, fp32 all-taps weight gradients)')
     ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
                     help="bf16: BASELINE config-5 mixed precision (bf16 MFMA operands, fp32 everything else); bf16x3: fp32 arithmetic "
                          "on the bf16 MFMA (ConvLSTM convolutions on the exact three-way bf16 split of their fp32 operands)")
     ap.add_argument('--no-x3', action='store_true', help='skip the secondary bf16x3-mode measurement of the same step')
-    ap.add_argument('--ab-x3-split-pass', action='store_true', help='A/B, bf16x3: a split6 pass over h per step instead of the gate epilogue writing it')
-    ap.add_argument('--ab-x3-lstm-only', action='store_true', help='A/B, bf16x3: only the ConvLSTM layers on split operands (the Conv2D units on the fp32 kernels)')
-    ap.add_argument('--ab-x3-wgrad6', action='store_true', help='A/B, bf16x3: one weight-gradient launch per product (six) instead of two launches with the terms as frames')
     ap.add_argument('--wgrad-overlap', action='store_true', help='A/B: weight gradients on the side stream (the default in bf16 mode only)')
     ap.add_argument('--net', choices=list(NETS), default='params',
                     help='kernel-size variant (SURVEY D1): params = train2D.py default = the headline; default5 = 5x5 everywhere; '
@@ -541,37 +531,8 @@ def main():
         trainer.engine.overlap_wgrad = False
     if args.wgrad_overlap:
         trainer.engine.overlap_wgrad = True
-    if args.ab_x3_split_pass:
-        trainer.engine.x3_fused_split = False
-    if args.ab_x3_wgrad6:
-        trainer.engine.x3_wgrad_launches = 6
-    if args.ab_x3_lstm_only:
-        trainer.engine.x3_conv_units = False
-    if args.ab_f32_act:
-        trainer.engine.act_bf16 = False
-        trainer.engine.grad_bf16 = False
-    if args.ab_no_prep:
-        trainer.engine.prep_batch = False
-    if args.wgrad_rounds:
-        from lu_native import calls as _calls
-        _calls.BF16_ROW_ROUNDS = args.wgrad_rounds
-    if args.ab_f32_grad:
-        trainer.engine.grad_bf16 = False
     ops.WGRAD_FLAGS |= args.wgrad_flags
     ops.CONV_FLAGS |= args.conv_flags
-    if args.conv_flags & 4096:      # (LU_CONV_F_NO_NARROW doubles as the A/B switch of the round-3 stride-2 kernels; the gather kernel
-        trainer.engine.s2_fwd_bf16 = False      # it sends the N = 32 / 64 layers to reads fp32 tensors only)
-        trainer.engine.narrow_bf16 = False
-        trainer.engine.act_bf16 = False
-        trainer.engine.grad_bf16 = False
-    if args.ab_old_tail:
-        from lu_native import cabi
-        trainer.engine.narrow_bf16 = False
-        trainer.engine.s2_fwd_bf16 = False
-        trainer.engine.act_bf16 = False
-        trainer.engine.grad_bf16 = False
-        ops.CONV_FLAGS |= cabi.LU_CONV_F_NO_NARROW
-        ops.WGRAD_FLAGS |= cabi.LU_WGRAD_F_NO_NARROW_BF16
 
     def one_step(i):
         img, seg, keep = batches[i % len(batches)]

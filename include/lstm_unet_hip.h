@@ -63,11 +63,7 @@ enum {
     LU_CONV_F_PATCH16 = 2,       /* ... force 16 x 32-pixel patches (5x5 only) */
     LU_CONV_F_NO_HALO = 4,       /* fp32: take the general gather kernel where the halo kernel would apply */
     LU_CONV_F_XCD_BY_N = 8,      /* halo kernel: give every XCD its own column tiles */
-    LU_CONV_F_LDS_DMA = 16,      /* general fp32 kernel: global_load_lds staging (measured slower) */
-    LU_CONV_F_MF2 = 32,          /* general fp32 kernel: 4-wave variant of the wide tiles */
     LU_CONV_F_GENERAL = 64,      /* general fp32 kernel: the fully general (dilation-capable) instantiation */
-    LU_CONV_F_LOOP_GEN1 = 128,   /* bf16 halo kernel: the first loop generation (run-time tap state machine) instead of the
-                                  * compile-time unrolled tap sequence -- A/B and regression tests */
     LU_CONV_F_GATES_BF16 = 256,  /* LU_EPI_LSTM, precision 1: gates_out is a bf16 tensor (the bf16 BPTT tape) */
     LU_CONV_F_SRC1_CENTER = 512, /* precision 1 halo kernel, two sources: src[1] contributes its CENTRE tap only (k*k = 1):
                                   * the im2col image of a thin input (lu_im2col_bf16) as one 32-channel chunk, weights
@@ -80,16 +76,10 @@ enum {
                                   * blocks of the halo kernel (A/B runs and tests: the two must agree) */
     LU_CONV_F_HALF_BLOCK = 8192, /* precision 1 halo kernel, N > 64 (5x5; 3x3 on bf16 sources): 4-wave blocks on 8 x 32 patches, two
                                   * independent blocks per CU, instead of one 8-wave block on a 16 x 32 patch (bit-identical) */
-    LU_CONV_F_LOOP_GEN2 = 32768, /* bf16 halo kernel: the second loop generation (taps of a chunk kernel row by kernel row, one LDS fragment
-                                  * read per MFMA) where the third (ABI v10: kernel column by kernel column, a halo row's fragment feeds up
-                                  * to k MFMAs; another fp32 summation order, results agree to rounding) would be taken -- A/B, tests */
-    LU_CONV_F_H16_SPLIT = 65536, /* LU_EPI_LSTM, precision 1 (ABI v11): h16_out receives the lu_split6 image of h -- [pixel][6][F] bf16, channel blocks
+    LU_CONV_F_H16_SPLIT = 65536  /* LU_EPI_LSTM, precision 1 (ABI v11): h16_out receives the lu_split6 image of h -- [pixel][6][F] bf16, channel blocks
                                   * lo, mid, hi, mid, hi, hi of the exact three-way bf16 split -- instead of its rounded bf16 copy: the recurrent
                                   * operand of the next step of precision 'bf16x3' (fp32 arithmetic on the bf16 MFMA) */
-    LU_CONV_F_SPLIT_TAPS = 16384 /* precision 0 halo kernel with splits > 1: slices of ceil(k*k*chunks / splits) pipeline stages that may
-                                  * begin on any tap of a chunk (the run-time counted loop of ABI <= v9) instead of whole 16-channel
-                                  * chunks per slice on the compile-time tap sequence (the default since ABI v10 whenever every slice
-                                  * gets a chunk; another summation split: results differ by fp32 re-association) -- A/B, tests */
+                                 /* (bits 128, 16384, 32768 -- LOOP_GEN1, SPLIT_TAPS, LOOP_GEN2 -- selected A/B forms of rounds 2-5 that ABI v12 no longer ships) */
 };
 
 typedef struct lu_conv_desc {
@@ -120,8 +110,7 @@ typedef struct lu_conv_desc {
                                      * staged; every src[i].w must then point to weights packed by lu_pack_weights_bf16
                                      * (w_tap_stride / w_row_stride ignored).  Stride-1 3x3 / 5x5, N > 64, 16-byte aligned sources
                                      * with C % 4 == 0 only (pad a thin input with zero channels: the packed image is zero there).
-                                     * 2: fp32 MFMA with weights packed by lu_pack_weights_f32 (stride-1 3x3 / 5x5, N > 64, aligned
-                                     * sources; same arithmetic as 0). */
+                                     * (2 -- fp32 MFMA on fragment-packed weights, measured neutral -- left with ABI v12.) */
     void* workspace;
     int64_t out_row_stride;         /* elements between output rows; 0 = dense (Wout * out_pix_stride).  Lets a launch
                                      * write one parity plane of a stride-2 input gradient in place. */
@@ -146,11 +135,6 @@ typedef struct lu_conv_desc {
 
 /* bf16 weight image for precision == 1: [tap][ceil(C/32)][N][32] bf16 (zero-filled beyond C), built from a
  * [k*k][C][N] fp32 matrix addressed as w + tap*w_tap_stride + c*w_row_stride + n. */
-/* precision == 2: the same fragment-order image in fp32 ([tap][ceil(C/16)][ceil(N/32)][2][64 lanes][4 floats]): exact fp32 MFMA
- * arithmetic (bit-identical to precision 0 without a K split), weights streamed from L2 instead of staged through LDS. */
-size_t lu_pack_weights_f32_bytes(int k, int C, int N);
-int lu_pack_weights_f32(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
-                        lu_stream_t stream);
 size_t lu_pack_weights_bf16_bytes(int k, int C, int N);
 int lu_pack_weights_bf16(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
                          lu_stream_t stream);
@@ -262,26 +246,15 @@ enum {
     LU_WGRAD_F_SMALL_TILE = 16,  /* general kernel: 128 x 128 instead of 128 x 256 tiles */
     LU_WGRAD_F_PRB32 = 32,       /* bf16 kernel-row variant: 32-pixel stages where 64-pixel ones would be taken (A/B, tests) */
     LU_WGRAD_F_NO_RAGGED = 64,   /* fp32 kernel-row variant: only for W % 16 == 0 (other widths: the one-tap-per-block kernel) -- A/B */
-    LU_WGRAD_F_NO_SLIDE = 512,   /* fp32 kernel-row variant: every k-pair re-reads its K x rows from LDS (the instance of rounds 1-2; A/B) */
-    LU_WGRAD_F_KP32 = 256,       /* fp32 kernel-row variant, W % 32 == 0: 32-pixel stages -- the library's own choice since ABI v9 (the
-                                    bit is accepted and changes nothing) */
     LU_WGRAD_F_NO_NARROW_BF16 = 128, /* precision 1: keep the narrow layers (C < 64) on the fp32 all-taps / general kernels -- A/B */
-    LU_WGRAD_F_TAPS9 = 1024,     /* precision 1, stride-1 3x3, C >= 64 (the all-taps form: one block = nine taps of a 64-channel x
-                                  * 128-column tile, the library's own choice on 8 waves): 4 fat waves instead, one per SIMD,
-                                  * accumulators in AGPRs (bf16 operands; measured slower -- A/B, tests) */
-    LU_WGRAD_F_NO_TAPS9 = 2048,  /* ... keep the kernel-row form (one block = three taps of a kernel row) -- A/B, tests */
-    LU_WGRAD_F_DMA = 4096,       /* precision 1, bf16 operands, stride 1: tiles by global_load_lds straight into swizzled LDS rows (three stage
-                                  * buffers, counted vmcnt waits) instead of staging registers + ds_write -- bit-identical; the library's own
-                                  * choice for the all-taps 3x3 form (+3.5 %), opt-in for the 5x5 kernel-row form (measured -3 %) */
-    LU_WGRAD_F_NO_DMA = 8192,    /* ... never (A/B, tests) */
-    LU_WGRAD_F_KP16 = 16384,     /* fp32 kernel-row variant: 16-pixel stages where 32-pixel ones would be taken (A/B, tests) */
-    LU_WGRAD_F_HALF_BLOCK = 65536, /* precision 1, bf16 operands, stride-1 5x5: 4-wave blocks of 64 channels x 128 columns (two independent blocks
-                                  * per CU) instead of 8-wave blocks of 128 channels -- round 5 A/B; bit-identical dw, dbias to fp32 re-association */
-    LU_WGRAD_F_PIECES3 = 131072, /* terms == 6 (ABI v12, precision 'bf16x3'): the piece-aware kernel -- each of the three pieces of x and dy staged once per
-                                  * 32-pixel run, the six products issued from registers (wgrad_row_x3_kernel); C % 128 == 0, stride-1 3x3 / 5x5 */
-    LU_WGRAD_F_XREALIGN = 32768  /* precision 1, bf16 operands, stride-1 5x5, 128-channel tiles: every tap fetches its own re-aligned x rows
-                                  * with transposing LDS reads instead of cutting them out of one fetch with funnel shifts / register
-                                  * moves (round 5 A/B; bit-identical) */
+    LU_WGRAD_F_NO_TAPS9 = 2048,  /* precision 1, stride-1 3x3, C >= 64: keep the kernel-row form (one block = three taps of a kernel row) instead of
+                                  * the all-taps form (one block = nine taps of a 64-channel x 128-column tile, 8 waves) -- the previous form; tests */
+    LU_WGRAD_F_NO_DMA = 8192,    /* all-taps 3x3 form on bf16 operands: staging registers + ds_write instead of global_load_lds into swizzled LDS rows
+                                  * (the library's own choice there, +3.5 %; bit-identical) -- the previous form; tests */
+    LU_WGRAD_F_PIECES3 = 131072  /* terms == 6 (ABI v12, precision 'bf16x3'): the piece-aware kernel -- each of the three pieces of x and dy staged once per
+                                  * 32-pixel run, the six products issued from registers (wgrad_row_x3_kernel); C % 128 == 0, stride-1 3x3 / 5x5.
+                                  * (Bits 256, 512, 1024, 4096, 16384, 32768, 65536 -- KP32, NO_SLIDE, TAPS9, DMA, KP16, XREALIGN, HALF_BLOCK -- selected
+                                  * A/B instances of rounds 3-5 that ABI v12 no longer ships; their measurements are in DESIGN 9a.) */
 };
 
 size_t lu_conv2d_wgrad_workspace_bytes(const lu_wgrad_desc* d);

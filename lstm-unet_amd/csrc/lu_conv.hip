@@ -3,8 +3,8 @@
 // Kernels in this file (host dispatch: lu_conv2d_fwd at the bottom):
 //   conv_fwd_kernel         general fp32 path: any k <= 7, stride 1/2, input dilation 2, thin sources, narrow outputs
 //   conv_halo_kernel        fp32, stride-1 3x3 / 5x5 with > 64 output columns: 8 x 32 patch, halo staged once per chunk
-//   conv_halo_frag_kernel   the halo kernel with fragment-order weights streamed from L2 (bf16 MFMA = precision 1; the fp32
-//                           instantiation = precision 2 is a measured-neutral option)
+//   conv_halo_frag_kernel / conv_halo_frag3_kernel   the halo kernel with fragment-order bf16 weights streamed from L2 (precision 1):
+//                           first loop generation (3x3 on fp32 sources / 8-row patches, narrow N = 32 / 64 blocks) / third (everything else)
 //   conv_gather_bf16_kernel bf16 MFMA for everything outside the halo kernel's domain (stride 2, parity planes, 1x1, 7x7)
 //   ksplit_reduce / flip_transpose / s2_dgrad_weights / pack_weights_*   helpers around them
 // The description below is the common scheme, written for conv_fwd_kernel.
@@ -1252,29 +1252,6 @@ __global__ void pack_weights_split6_bf16_kernel(const float* __restrict__ w, int
     }
 }
 
-// fp32 counterpart of pack_weights_bf16_kernel: [tap][16-channel chunk][column fragment][s][lane][4 floats] with
-// channel = 16 chunk + 8 s + 4 (lane >> 5) + e, column = 32 fragment + (lane & 31): the four floats of a lane are the B
-// operands of the four MFMAs fed by one ds_read_b128 of the halo.
-__global__ void pack_weights_f32_kernel(const float* __restrict__ w, int64_t tap_stride, int row_stride, int kk, int C, int N,
-                                        float* __restrict__ out) {
-    const int nchunk = (C + CK - 1) / CK, nfr = (N + 31) / 32;
-    const int64_t total = (int64_t)kk * nchunk * nfr * 512;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), sh = (int)((i >> 8) & 1);
-        int64_t t = i >> 9;
-        const int fr = (int)(t % nfr);
-        t /= nfr;
-        const int chunk = (int)(t % nchunk);
-        const int tap = (int)(t / nchunk);
-        const int n = fr * 32 + (ln & 31);
-        const int c = chunk * CK + 8 * sh + 4 * (ln >> 5) + e;
-        out[i] = (c < C && n < N) ? w[(int64_t)tap * tap_stride + (int64_t)c * row_stride + n] : 0.f;
-    }
-}
-
-// F32 = false: bf16 operands, 32-channel chunks.  F32 = true: the same structure on the exact fp32 MFMA
-// (v_mfma_f32_32x32x2_f32), 16-channel chunks, weights packed by pack_weights_f32_kernel -- both halo images have an
-// 80-byte pixel pitch and both weight images 2 KB per (tap, chunk, column fragment), so only the MFMA block differs.
 // Epilogue of the fragment kernels (both loop generations): bias / K-split stores, or the fused ConvLSTM gate block with
 // its exchange of the four gate fragments through the (dead) halo LDS.
 template <int EPI, int RW, int NFR = 4>
@@ -1451,14 +1428,13 @@ __device__ __forceinline__ void frag_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 // NFR = column fragments (of 32) per block: 4 (128 columns, 2 row groups of waves) for the wide layers; 2 / 1 for the narrow
 // decoder tail (N = 64 / 32: 4 / 8 row groups of RW = 2 / 1 rows, i.e. the same 8 x 32 patch) -- those layers are bound by
 // HBM, not by the matrix pipe, and all they need is the halo staged once and every wave busy on its own rows.
-template <int K, int EPI, int RW, bool F32, bool B16, int NFR = 4>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
-__global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_frag_kernel(ConvArgs a) {
+template <int K, int EPI, int RW, bool B16, int NFR = 4>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
+__global__ __launch_bounds__(512, 2) void conv_halo_frag_kernel(ConvArgs a) {
     const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
-    static_assert(!(F32 && B16), "bf16 tensors feed the bf16 MFMA only");
     static_assert(NFR == 4 || (EPI == LU_EPI_BIAS && (NFR == 1 || NFR == 2)), "narrow blocks: bias epilogue only");
     constexpr int BN = 32 * NFR, NT = 512, TH = (8 / NFR) * RW, TW = 32;
     constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
-    constexpr int CKS = F32 ? CK : CKB;                // channels per stage
+    constexpr int CKS = CKB;                           // channels per stage
     constexpr int PC = B16 ? 8 : 4;                    // channels per 16-byte piece
     constexpr int G = CKS / PC;                        // 16-byte global channel groups per halo pixel
     constexpr int ESZ = B16 ? 2 : 4;                   // bytes per source element
@@ -1495,7 +1471,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     const int ps_s0 = a.src[0].pix_stride, ps_s1 = a.src[1].pix_stride;
     const int C_s0 = a.src[0].C, C_s1 = a.src[1].C;
     const int nch_s0 = a.src[0].nchunk, nch_s1 = a.src[1].nchunk;
-    const bool ctr1 = !F32 && a.src1_center != 0;      // source 1 = one chunk, centre tap only (it is the LAST stage)
+    const bool ctr1 = a.src1_center != 0;      // source 1 = one chunk, centre tap only (it is the LAST stage)
     const int kk = K * K;
     auto tap_advance = [&](IterState& st) {          // iter_advance without the kernarg look-ups
         ++st.tap;
@@ -1533,7 +1509,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
     auto piece_store = [&](int p, int hb, const lu_u4& r) {
         const int hp = (tid + NT * p) / G;
         if (hp < HP) {
-            if (F32 || B16) {      // raw copy: 4 floats / 8 bf16
+            if (B16) {      // raw copy: 8 bf16
                 *reinterpret_cast<lu_u4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
             } else {
                 lu_u2 v;
@@ -1564,46 +1540,14 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         const int arow = (RW * wm + st.kh) * HWD + (lane & 31) + st.kw;
         const unsigned char* ab = &Ah[hb * AH_BYTES + arow * PITCH + khalf16];
 #ifdef LU_ABL_MFMA_ONLY      // ablation build (tools only): the MFMA stream without LDS reads -- practical MFMA ceiling
-        if (F32) {
-            for (int rep = 0; rep < 8; ++rep)
+    const lu_bf16x8 u0 = __builtin_bit_cast(lu_bf16x8, b0), u1 = __builtin_bit_cast(lu_bf16x8, b1);
 #pragma unroll
-                for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(b0.x, b1.y, acc[i]);
-        } else {
-            const lu_bf16x8 u0 = __builtin_bit_cast(lu_bf16x8, b0), u1 = __builtin_bit_cast(lu_bf16x8, b1);
+        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(u1, u0, acc[i]);
 #pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(u1, u0, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(u0, u1, acc[i]);
-        }
+        for (int i = 0; i < RW; ++i) acc[i] = lu_mfma_bf16(u0, u1, acc[i]);
         (void)ab;
         return;
 #endif
-        if (F32) {
-            // lanes 0-31 hold k = 8 s + j, lanes 32-63 k = 8 s + 4 + j (j = 0..3) of pixel row `arow`: one ds_read_b128 feeds
-            // four MFMAs; b0 / b1 carry the matching weight rows for s = 0 / 1.  MFMA order = (s, j) as in conv_halo_kernel.
-            float4 a0[RW], a1[RW];
-#pragma unroll
-            for (int i = 0; i < RW; ++i) a0[i] = *reinterpret_cast<const float4*>(ab + i * HWD * PITCH);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) a1[i] = *reinterpret_cast<const float4*>(ab + i * HWD * PITCH + 32);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].x, b0.x, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].y, b0.y, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].z, b0.z, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a0[i].w, b0.w, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].x, b1.x, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].y, b1.y, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].z, b1.z, acc[i]);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) acc[i] = lu_mfma(a1[i].w, b1.w, acc[i]);
-            return;
-        }
         const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
         if (LU_DBG(a, 2)) {      // ablation: no A-fragment LDS reads
 #pragma unroll
@@ -1653,7 +1597,7 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
         }
         // Register ring of B fragments, D stages deep: slot s holds stage it0 + s (mod D) and is refilled for the stage D
         // further on as soon as its MFMAs are issued -- the distance has to cover the L2 latency under load.
-        constexpr int D = (RW == 8 && !F32) ? 4 : 2;
+        constexpr int D = RW == 8 ? 4 : 2;
         float4 rb0[D], rb1[D];
         IterState sS[D];
         sS[0] = st;
@@ -1733,16 +1677,13 @@ __global__ __launch_bounds__(512, ((F32 && RW == 4) ? 4 : 2)) void conv_halo_fra
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Second loop generation of the bf16 fragment kernel (what precision = 1 launches).  Same tile, same LDS images, same
-// fragment streams and the same epilogue as conv_halo_frag_kernel -- what changes is WHO does the bookkeeping.  The first
-// generation advanced a run-time (source, chunk, tap) state machine per pipeline stage: ~200 scalar / vector instructions
-// between two groups of 16 MFMAs, i.e. as many issue cycles as the MFMAs themselves take at bf16 rates (an in-order wave
-// cannot hide its own bookkeeping behind its own MFMAs; the compile-time ablations of tools/gpu/r02_ablate.sh put the
-// MFMA-only loop at 1.5 PFLOP/s against 0.96-1.13 for the real one).  Here the K*K taps of a channel chunk are a
-// compile-time unrolled sequence: tap offsets into the halo, the ring slot of every weight fragment, the tap at which
-// each piece of the next halo is requested and stored are all constants of the instruction stream, and only the chunk
-// (source pointer, weight base) is run-time state, updated once per K*K stages.  The weight-fragment ring is K deep so
-// that slot = tap % K stays static across chunks (K*K % K == 0).
+// The bf16 fragment kernel the product launches for the wide layers is conv_halo_frag3_kernel below (third loop generation, round 5).
+// Generation 1 (conv_halo_frag_kernel above) advances a run-time (source, chunk, tap) state machine per pipeline stage -- ~200 scalar /
+// vector instructions between two groups of 16 MFMAs -- and is kept for the shapes it still serves: 3x3 layers on fp32 sources /
+// 8-row patches and the narrow N = 32 / 64 blocks.  Generation 2 (round 2-4: the K*K taps of a chunk as a compile-time unrolled
+// sequence, kernel row by kernel row, one LDS fragment read per MFMA) was the step between them; it left the library in round 6 with its
+// measurements in DESIGN 3.3 / profiles/HISTORY.md.  What generation 3 inherits from it: only the chunk (source pointer, weight base) is
+// run-time state, updated once per K*K stages.
 // ---------------------------------------------------------------------------------------------------------
 struct ChunkDesc {
     const unsigned char* x;      // source activations of this block's frame (byte pointer)
@@ -1758,199 +1699,9 @@ struct ChunkDesc {
 // 1 ("half blocks", round 4): 4 waves = ONE row group x 4 column fragments, an RW x 32 patch, 256 threads -- the same RW MFMAs
 // per weight fragment and the same registers per wave, but TWO INDEPENDENT blocks per CU (2 x 2 halo images of 8 + K - 1 rows:
 // 138 KB at K = 5): one block's prologue / epilogue / barrier wait runs under the other block's MFMAs.
-template <int K, int EPI, int RW, bool B16, int WM = 2>      // RW = patch rows per wave: 4 (8 x 32 patch) or 8 (16 x 32 patch)
-__global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a) {
-    const float* const lu_z16 = a.zero16 ? a.zero16 : lu_zero16;
-    constexpr int BN = 128, NT = 256 * WM, TH = WM * RW, TW = 32, KK = K * K;
-    constexpr int HWD = TW + K - 1, HHT = TH + K - 1, HP = HHT * HWD;
-    constexpr int CKS = CKB;                            // channels per stage
-    constexpr int PC = B16 ? 8 : 4;                     // channels per 16-byte piece
-    constexpr int G = CKS / PC;                         // 16-byte global channel groups per halo pixel
-    constexpr int ESZ = B16 ? 2 : 4;                    // bytes per source element
-    constexpr int HPASS = (HP * G + NT - 1) / NT;       // halo pieces per thread and chunk
-    constexpr int PAD = (K - 1) / 2;
-    constexpr int EX_LD = BN + 4;
-    constexpr int PITCH = 80;                           // bytes per halo pixel: (32 + 8) bf16
-    constexpr int AH_BYTES = HP * PITCH;
-    constexpr int D = K;                                // weight-fragment ring depth (stages)
-    static_assert(HPASS + 2 <= KK, "the next halo is fetched one piece per tap and stored two taps later");
-    static_assert(WM == 1 || WM == 2, "one or two row groups of waves");
-    static_assert(EPI != LU_EPI_LSTM || WM * TW * EX_LD * 4 <= 2 * AH_BYTES, "gate exchange aliases the two halo images");
-    static_assert(4 * WM * 16 * 36 * 4 <= 2 * AH_BYTES, "bias-epilogue exchange (a 16 x 36 slice per wave) aliases the two halo images");
-    LU_DYN_LDS(unsigned char, Ah);                      // [2][AH_BYTES]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    int tile, nt, ks;
-    if (!lu_block_tile(a, tile, nt, ks)) return;
-    const int f = tile / a.tiles_pf;
-    const int t2 = tile - f * a.tiles_pf;
-    const int y0 = (t2 / a.tiles_x) * TH, x0 = (t2 % a.tiles_x) * TW;
-    const int n0 = nt * BN;
-    const lu_u4* const zp = reinterpret_cast<const lu_u4*>(lu_z16);
-    const int q = tid % G;
-    const int nfr = (a.N + 31) >> 5;
-    const int frag = (EPI == LU_EPI_LSTM) ? (wn * a.F + nt * 32) >> 5 : nt * 4 + wn;
-    const bool frag_ok = frag < nfr;
-    const int wl = frag * 2048 + lane * 16;             // this lane's bytes inside a (tap, chunk) block of the packed weights
-
-    // chunks with K*K taps: source 0, then source 1 unless that one is the centre-tap image (handled after the loop)
-    const int nch0 = a.src[0].nchunk, nch1 = a.n_src > 1 ? a.src[1].nchunk : 0;
-    const bool ctr1 = a.src1_center != 0;
-    const int n_full = nch0 + (ctr1 ? 0 : nch1);
-    auto describe = [&](int ci) {
-        ChunkDesc d;
-        const int s = (ci >= nch0) ? 1 : 0;                  // (ci == n_full with ctr1: the centre chunk = source 1, chunk 0)
-        const int ch = ci - (s ? nch0 : 0);
-        const int nch = s ? a.src[1].nchunk : nch0;
-        d.x = reinterpret_cast<const unsigned char*>(a.src[s].x) + (int64_t)f * a.src[s].frame_stride * ESZ;
-        d.w = reinterpret_cast<const unsigned char*>(a.src[s].w) + (int64_t)ch * nfr * 2048 + wl;
-        d.wts = (int64_t)nch * nfr * 2048;
-        d.ps = a.src[s].pix_stride;
-        d.C = a.src[s].C;
-        d.c0 = ch * CKS;
-        d.single = (s && ctr1) ? 1 : 0;
-        return d;
-    };
-    // K split: whole chunks per slice
-    int cb = 0, ce = n_full;
-    if (a.ksplit > 1) {
-        const int per = (n_full + a.ksplit - 1) / a.ksplit;
-        cb = ks * per < n_full ? ks * per : n_full;
-        ce = cb + per < n_full ? cb + per : n_full;
-    }
-
-    auto piece_load = [&](int p, const ChunkDesc& d, lu_u4& r, bool want) {
-        const int hp = (tid + NT * p) / G;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int iy = y0 + hy - PAD, ix = x0 + hx - PAD;
-        const bool ok = want && hp < HP && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const int c = d.c0 + PC * q;
-        const int64_t off = ((int64_t)(iy * a.Win + ix) * d.ps + c) * ESZ;
-        r = *((ok && c < d.C) ? reinterpret_cast<const lu_u4*>(d.x + off) : zp);
-    };
-    auto piece_store = [&](int p, int hb, const lu_u4& r) {
-        const int hp = (tid + NT * p) / G;
-        if (hp < HP) {
-            if (B16) {
-                *reinterpret_cast<lu_u4*>(&Ah[hb * AH_BYTES + hp * PITCH + 16 * q]) = r;
-            } else {
-                lu_u2 v;
-                v.x = lu_pack2bf(lu_bits2f(r.x), lu_bits2f(r.y));
-                v.y = lu_pack2bf(lu_bits2f(r.z), lu_bits2f(r.w));
-                *reinterpret_cast<lu_u2*>(&Ah[hb * AH_BYTES + hp * PITCH + 8 * q]) = v;
-            }
-        }
-    };
-    auto load_b = [&](const ChunkDesc& d, int tap, float4& b0, float4& b1) {
-        const unsigned char* wp = d.w + (d.single ? 0 : tap) * d.wts;
-        b0 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp) : lu_z16);
-        b1 = *reinterpret_cast<const float4*>(frag_ok ? reinterpret_cast<const float*>(wp + 1024) : lu_z16);
-    };
-
-    f32x16 acc[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    // this lane's A-fragment address for (row 0 of its row group, tap (0, 0)); a tap adds a compile-time constant
-    const int abase = (RW * wm * HWD + (lane & 31)) * PITCH + 16 * (lane >> 5);
-    // One tap = RW MFMAs on the first 16 channels of the chunk (A fragments a0), RW on the second (a1).  The fragment reads run a
-    // whole MFMA group ahead: a1[i] is requested behind the MFMA on a0[i], and -- round 4 -- the NEXT tap's a0[i] behind the MFMA
-    // on a1[i] (same halo image, offset known at compile time), so a tap no longer opens with RW reads and an LDS round trip in
-    // front of its first MFMA (16 MFMAs of 32 cycles per tap: ~150 of ~660 cycles; only the first tap behind a chunk barrier still
-    // does -- the next halo image is complete only there).  No extra registers: a0 is dead while a1 is consumed.
-    // NAH of the RW fragments travel ahead: all of them where the registers allow (K = 3: a three-deep weight ring), half at K = 5
-    // with 8-row waves (a five-deep ring = 40 registers: with all eight ahead the fragments stay live across the bookkeeping
-    // between two taps and the kernel spills) -- the first NAH MFMAs of a tap then cover the reads of the others.
-    constexpr int NAH = (K == 5 && RW == 8) ? (B16 ? 4 : 0) : RW;      // (fp32 sources at K = 5: 247-252 registers already, none)
-    lu_bf16x8 a0[RW];
-    auto mma_stage = [&](int hb, int tapoff, const float4& b0, const float4& b1, bool first, bool ahead, int tapoff_next) {
-        const unsigned char* ab = &Ah[hb * AH_BYTES + abase + tapoff];
-        const unsigned char* an = &Ah[hb * AH_BYTES + abase + tapoff_next];
-        const lu_bf16x8 bv0 = __builtin_bit_cast(lu_bf16x8, b0), bv1 = __builtin_bit_cast(lu_bf16x8, b1);
-        lu_bf16x8 a1[RW];
-#pragma unroll
-        for (int i = first ? 0 : NAH; i < RW; ++i) a0[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            acc[i] = lu_mfma_bf16(a0[i], bv0, acc[i]);
-            a1[i] = *reinterpret_cast<const lu_bf16x8*>(ab + i * HWD * PITCH + 32);
-        }
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            acc[i] = lu_mfma_bf16(a1[i], bv1, acc[i]);
-            if (ahead && i < NAH) a0[i] = *reinterpret_cast<const lu_bf16x8*>(an + i * HWD * PITCH);
-        }
-        if (first) LU_SCHED_GROUP(0x100, RW);
-        else if (NAH < RW) LU_SCHED_GROUP(0x100, RW - NAH);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            LU_SCHED_GROUP(0x008, 1);
-            LU_SCHED_GROUP(0x100, 1);
-        }
-        if (ahead) {
-#pragma unroll
-            for (int i = 0; i < NAH; ++i) {
-                LU_SCHED_GROUP(0x008, 1);
-                LU_SCHED_GROUP(0x100, 1);
-            }
-            if (NAH < RW) LU_SCHED_GROUP(0x008, RW - NAH);
-        } else {
-            LU_SCHED_GROUP(0x008, RW);
-        }
-    };
-
-    const bool have_center = ctr1 && ce == n_full;           // this slice ends with the centre-tap stage
-    if (ce > cb || have_center) {
-        ChunkDesc cur = describe(cb < ce ? cb : n_full);
-        float4 rb0[D], rb1[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) load_b(cur, j, rb0[j], rb1[j]);
-        {
-            lu_u4 rh[HPASS];                     // first halo: all pieces at once
-#pragma unroll
-            for (int p = 0; p < HPASS; ++p) piece_load(p, cur, rh[p], true);
-#pragma unroll
-            for (int p = 0; p < HPASS; ++p) piece_store(p, 0, rh[p]);
-        }
-        __syncthreads();
-        int hb = 0;
-        lu_u4 rp0 = lu_u4{0u, 0u, 0u, 0u}, rp1 = lu_u4{0u, 0u, 0u, 0u};
-        for (int ci = cb; ci < ce; ++ci) {
-            const bool has_next = ci + 1 < ce || have_center;
-            const ChunkDesc nxt = describe(has_next ? ci + 1 : ci);      // (no next chunk: harmless re-reads of this one)
-            lu_static_for<KK>([&](auto tc) {
-                constexpr int tap = decltype(tc)::value;
-                constexpr int sl = tap % D;
-                LU_SCHED_FENCE();
-                constexpr int tn = tap + 1 < KK ? tap + 1 : tap;
-                mma_stage(hb, ((tap / K) * HWD + (tap % K)) * PITCH, rb0[sl], rb1[sl], tap == 0, tap + 1 < KK,
-                          ((tn / K) * HWD + (tn % K)) * PITCH);
-                LU_SCHED_FENCE();
-                // the piece requested two taps ago is older than the fragments the MFMAs above waited for: it has landed
-                if (tap >= 2 && tap - 2 < HPASS) piece_store(tap - 2, hb ^ 1, ((tap - 2) & 1) ? rp1 : rp0);
-                if (tap < HPASS) piece_load(tap, nxt, (tap & 1) ? rp1 : rp0, has_next);
-                if (tap + D < KK) load_b(cur, tap + D, rb0[sl], rb1[sl]);
-                else load_b(nxt, tap + D - KK, rb0[sl], rb1[sl]);
-            });
-            __syncthreads();                     // the next halo is complete and every wave is done with the old one
-            hb ^= 1;
-            cur = nxt;
-        }
-        if (have_center) {                       // one more stage: the centre tap of the im2col chunk (ring slot 0 holds its fragments)
-            LU_SCHED_FENCE();
-            mma_stage(hb, (PAD * HWD + PAD) * PITCH, rb0[0], rb1[0], true, false, 0);
-            LU_SCHED_FENCE();
-        }
-    }
-    frag_epilogue<EPI, RW>(a, acc, Ah, f, y0, x0, nt, n0, ks);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Third loop generation of the bf16 fragment kernel (round 5): same tile, same LDS images, same weight-fragment stream, same
-// epilogue as conv_halo_frag2_kernel -- another ORDER of the K*K taps of a chunk, chosen for the bytes it moves per MFMA.
+// epilogue as the second generation -- another ORDER of the K*K taps of a chunk, chosen for the bytes it moves per MFMA.
 // Generations 1-2 walk the taps kernel row by kernel row and read, per tap, one A fragment (ds_read_b128, 1 KB per wave) per
 // patch row and channel half: ONE LDS read per MFMA -- at the bf16 rate that is half of the LDS pipe's 256 B/clk at full MFMA
 // speed, and on these power-limited kernels (1.6-1.9 GHz under load) LDS bytes are watts.  But tap (kh, kw) on
@@ -1962,7 +1713,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag2_kernel(ConvArgs a
 // RW + K - 1 + K steps of lead); the next chunk's halo pieces are requested / stored at sub-stage boundaries (a sub-stage = one
 // kernel column x one channel half).  Everything is a compile-time sequence as in generation 2; only the chunk is run-time state.
 // Each accumulator sums its taps column-major instead of row-major: another fp32 summation order -- results agree with
-// generations 1-2 to rounding (tests compare with the oracle and with generation 2 at 5e-5), not bit for bit.
+// generation 1 to rounding (tests compare with the oracle at 5e-5), not bit for bit.
 // ---------------------------------------------------------------------------------------------------------
 template <int K, int EPI, int RW, bool B16, int WM = 2>
 __global__ __launch_bounds__(256 * WM, 2) void conv_halo_frag3_kernel(ConvArgs a) {
@@ -2893,7 +2644,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         bool all16 = d->n_src > 0;
         for (int i = 0; i < d->n_src; ++i) all16 = all16 && d->src[i].dtype == LU_BF16;
         const int force = (d->flags & LU_CONV_F_PATCH16) ? 16 : (d->flags & LU_CONV_F_PATCH8) ? 8 : 0;
-        if (d->precision == 1 && d->k == 3 && !narrow_n && d->epilogue == LU_EPI_BIAS && all16 && !(d->flags & LU_CONV_F_LOOP_GEN1) &&
+        if (d->precision == 1 && d->k == 3 && !narrow_n && d->epilogue == LU_EPI_BIAS && all16 &&
             d->splits <= 1 &&
             (force ? force == 16 : (int64_t)d->frames * ((d->Hout + 15) / 16) * tiles_x * ((d->N + 127) / 128) >= 256))
             th = 16;
@@ -2910,7 +2661,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
                                 (d->epilogue == LU_EPI_LSTM ? d->N / 128 : (d->N + 127) / 128) * (d->epilogue == LU_EPI_LSTM || d->splits < 1 ? 1 : d->splits);
         const bool forced = (d->flags & (LU_CONV_F_PATCH8 | LU_CONV_F_PATCH16)) != 0;
         const bool own_choice = !forced && blocks8 >= 512 && (d->epilogue == LU_EPI_LSTM || d->k == 3);
-        half_blk = d->precision == 1 && !narrow_n && !(d->flags & LU_CONV_F_LOOP_GEN1) && (d->k == 5 || (d->k == 3 && all16)) &&
+        half_blk = d->precision == 1 && !narrow_n && (d->k == 5 || (d->k == 3 && all16)) &&
                    ((d->flags & LU_CONV_F_HALF_BLOCK) || own_choice);
         if (half_blk) th = 8;
     }
@@ -2927,14 +2678,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         m_tiles = (int64_t)d->frames * tiles_y * tiles_x;
     }
     const bool want_xcd_n = (d->flags & LU_CONV_F_XCD_BY_N) != 0;
-    const bool gen1 = (d->flags & LU_CONV_F_LOOP_GEN1) != 0;      // A/B: the first loop generation of the bf16 fragment kernel
-    const bool gen2 = (d->flags & LU_CONV_F_LOOP_GEN2) != 0;      // A/B: the second (row-major taps) where the third (column-major, round 5) is taken
 #define LU_ARGS(...) __VA_ARGS__
-#define LU_LAUNCH_FRAG23(targs, grid_, blk_, lds_)                                                          \
-    do {                                                                                                     \
-        if (gen2) LU_LAUNCH_DYN((conv_halo_frag2_kernel<targs>), grid_, blk_, lds_, stream, a);              \
-        else LU_LAUNCH_DYN((conv_halo_frag3_kernel<targs>), grid_, blk_, lds_, stream, a);                   \
-    } while (0)
+#define LU_LAUNCH_FRAG23(targs, grid_, blk_, lds_) LU_LAUNCH_DYN((conv_halo_frag3_kernel<targs>), grid_, blk_, lds_, stream, a)
     bool src16 = false;      // all sources bf16 tensors (a property of the launch: mixed element types are rejected)
     for (int s2 = 0; s2 < a.n_src; ++s2) {
         LU_REQUIRE(!a.src[s2].bf16 || (halo && d->precision == 1),
@@ -2945,13 +2690,10 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         src16 = a.src[s2].bf16 != 0;
     }
     LU_REQUIRE(!a.src1_center || (halo && a.n_src == 2), "lu_conv2d_fwd: LU_CONV_F_SRC1_CENTER needs the halo kernel and two sources");
-    LU_REQUIRE(d->precision >= 0 && d->precision <= 2, "lu_conv2d_fwd: unknown precision %d", d->precision);
+    LU_REQUIRE(d->precision == 0 || d->precision == 1, "lu_conv2d_fwd: unknown precision %d", d->precision);
     if (d->precision == 1)
         LU_REQUIRE(d->dil == 1 && (halo || d->epilogue == LU_EPI_BIAS),
                    "lu_conv2d_fwd: bf16 mode has no input dilation, and the ConvLSTM epilogue needs a stride-1 3x3 / 5x5 layer");
-    if (d->precision == 2)
-        LU_REQUIRE(halo, "lu_conv2d_fwd: fragment-packed fp32 weights (precision 2) cover stride-1 3x3 / 5x5 layers with "
-                         "more than 64 output columns only");
     a.m_tiles = (int32_t)m_tiles;
     const int64_t m_tiles8 = (m_tiles + 7) / 8 * 8;     // XCD-aware order pads the m-tile count to 8
     a.ksplit = 1;
@@ -2969,10 +2711,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         return dim3((unsigned)((a.xcd_by_n ? m_tiles : m_tiles8) * a.n_tiles), (unsigned)a.ksplit);
     };
     dim3 block(256);
-    // LDS-DMA tile staging measured 4-5 % SLOWER than VGPR staging here (123.5 vs 129.9 TFLOP/s on the recurrent
-    // dgrads): opt-in only, kept as a measured negative result.
-    const bool dma = (d->flags & LU_CONV_F_LDS_DMA) != 0;
-    const bool mf1 = !(d->flags & LU_CONV_F_MF2);   // 8-wave / 4-waves-per-SIMD variant for the wide (NF = 4) tiles
+    // (LDS-DMA tile staging of the general fp32 kernel measured 4-5 % slower than VGPR staging, its 4-wave form of the wide tiles neutral:
+    // both opt-in instances left with ABI v12)
     if (d->epilogue == LU_EPI_LSTM) {
         LU_REQUIRE(d->N % 4 == 0 && (d->N / 4) % 32 == 0, "lu_conv2d_fwd: LSTM epilogue needs F %% 32 == 0 (N=%d)", d->N);
         LU_REQUIRE(bvec, "lu_conv2d_fwd: LSTM epilogue needs 16-byte aligned weights");
@@ -3009,24 +2749,15 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         if (half_blk && src16 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, true, 1), grid, dim3(256), halo_bf16_lds(5, 4));
         else if (half_blk && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, false, 1), grid, dim3(256), halo_bf16_lds(5, 4));
         else if (half_blk) LU_LAUNCH_FRAG23(LU_ARGS(3, LU_EPI_LSTM, 8, true, 1), grid, dim3(256), halo_bf16_lds(3, 4));
-        else if (d->precision == 1 && !gen1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, true), grid, dim3(512), halo_bf16_lds(5, 8));
-        else if (d->precision == 1 && !gen1 && src16 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 4, true), grid, dim3(512), halo_bf16_lds(5, 4));
-        else if (d->precision == 1 && !gen1 && d->k == 5 && th == 16) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, false), grid, dim3(512), halo_bf16_lds(5, 8));
-        else if (d->precision == 1 && !gen1 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 4, false), grid, dim3(512), halo_bf16_lds(5, 4));
-        else if (d->precision == 1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, true>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 1 && src16 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 1 && src16) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
-        else if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, false, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, false, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
-        else if (d->precision == 2 && d->k == 5 && th == 16) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 8, true, false>), grid, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->precision == 2 && d->k == 5) LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_LSTM, 4, true, false>), grid, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (d->precision == 2) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, true, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (d->precision == 1 && src16 && d->k == 5 && th == 16) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, true), grid, dim3(512), halo_bf16_lds(5, 8));
+        else if (d->precision == 1 && src16 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 4, true), grid, dim3(512), halo_bf16_lds(5, 4));
+        else if (d->precision == 1 && d->k == 5 && th == 16) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 8, false), grid, dim3(512), halo_bf16_lds(5, 8));
+        else if (d->precision == 1 && d->k == 5) LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_LSTM, 4, false), grid, dim3(512), halo_bf16_lds(5, 4));
+        else if (d->precision == 1 && src16) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, true>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
+        else if (d->precision == 1) LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_LSTM, 4, false>), grid, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_LSTM, true>), grid, dim3(512), stream, a);      // (the gate epilogue takes no K split)
         else if (halo) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_LSTM, true>), grid, dim3(512), stream, a);
-        else if (mf1 && dma) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, true>), grid, dim3(512), stream, a);
-        else if (mf1) LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, false>), grid, dim3(512), stream, a);
-        else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 2, false>), grid, block, stream, a);
+        else LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_LSTM, false, 1, false>), grid, dim3(512), stream, a);
         return LU_CHECK_LAUNCH();
     }
     LU_REQUIRE(d->epilogue == LU_EPI_BIAS, "lu_conv2d_fwd: unknown epilogue %d", d->epilogue);
@@ -3039,72 +2770,46 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         a.ws = (float*)d->workspace;
     }
     LU_REQUIRE(!slabs_only || a.ksplit > 1, "lu_conv2d_fwd: LU_CONV_F_SLABS_ONLY with more splits than half the k-steps (%d)", a.n_it);
-    if (d->precision == 2) {     // fp32 MFMA, fragment-packed weights (halo shapes only, checked above)
-        a.n_tiles = (d->N + 127) / 128;
-        const dim3 gridb = tile_grid();
-        if (d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, true, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, true, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, true, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
-        int rcb = LU_CHECK_LAUNCH();
-        if (rcb || slabs_only) return rcb;
-        if (a.ksplit == 1) return post_pass();
-        const int64_t totb = a.M * a.N;
-        const unsigned rgb = (unsigned)((totb + 255) / 256 < 8192 ? (totb + 255) / 256 : 8192);
-        LU_LAUNCH(ksplit_reduce_kernel, dim3(rgb), dim3(256), stream, (const float*)a.ws, a.ksplit, a.M, a.N, a.HWo, a.bias,
-                  a.out, a.out_frame_stride, a.out_pix_stride, a.Wout, a.out_row_stride, a.post_scale, a.post_shift, a.post_alpha);
-        return LU_CHECK_LAUNCH();
-    }
     if (d->precision == 1) {     // bf16 MFMA operands: halo kernel where it applies, the gather kernel everywhere else
         a.n_tiles = (d->N + 127) / 128;
         const bool narrow = halo && d->N <= 64;      // N = 32 / 64: one block covers every column (NFR = 1 / 2)
         const dim3 gridb = tile_grid();
         if (narrow && d->N == 32 && d->k == 5 && src16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 1, false, true, 1>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 1, true, 1>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (narrow && d->N == 32 && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 1, false, false, 1>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 1, false, 1>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (narrow && d->N == 32 && src16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 1, false, true, 1>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 1, true, 1>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (narrow && d->N == 32)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 1, false, false, 1>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 1, false, 1>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (narrow && d->k == 5 && src16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 2, false, true, 2>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 2, true, 2>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (narrow && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 2, false, false, 2>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 2, false, 2>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
         else if (narrow && src16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, true, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, true, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (narrow)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, false, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 2, false, 2>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo && half_blk && src16 && d->k == 5)
             LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, true, 1), gridb, dim3(256), halo_bf16_lds(5, 4));
         else if (halo && half_blk && d->k == 5)
             LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, false, 1), gridb, dim3(256), halo_bf16_lds(5, 4));
         else if (halo && half_blk)
             LU_LAUNCH_FRAG23(LU_ARGS(3, LU_EPI_BIAS, 8, true, 1), gridb, dim3(256), halo_bf16_lds(3, 4));
-        else if (halo && !gen1 && src16 && d->k == 5 && th == 16)
-            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, true), gridb, dim3(512), halo_bf16_lds(5, 8));
-        else if (halo && !gen1 && src16 && d->k == 5)
-            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 4, true), gridb, dim3(512), halo_bf16_lds(5, 4));
-        else if (halo && !gen1 && d->k == 5 && th == 16)
-            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, false), gridb, dim3(512), halo_bf16_lds(5, 8));
-        else if (halo && !gen1 && d->k == 5)
-            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 4, false), gridb, dim3(512), halo_bf16_lds(5, 4));
         else if (halo && src16 && d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, true>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, true), gridb, dim3(512), halo_bf16_lds(5, 8));
         else if (halo && src16 && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
-        else if (halo && !gen1 && src16 && d->k == 3 && th == 16)
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 4, true), gridb, dim3(512), halo_bf16_lds(5, 4));
+        else if (halo && d->k == 5 && th == 16)
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 8, false), gridb, dim3(512), halo_bf16_lds(5, 8));
+        else if (halo && d->k == 5)
+            LU_LAUNCH_FRAG23(LU_ARGS(5, LU_EPI_BIAS, 4, false), gridb, dim3(512), halo_bf16_lds(5, 4));
+        else if (halo && src16 && d->k == 3 && th == 16)
             LU_LAUNCH_FRAG23(LU_ARGS(3, LU_EPI_BIAS, 8, true), gridb, dim3(512), halo_bf16_lds(3, 8));
         else if (halo && src16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
-        else if (halo && d->k == 5 && th == 16)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 8, false, false>), gridb, dim3(512), halo_bf16_lds(5, 8), stream, a);
-        else if (halo && d->k == 5)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<5, LU_EPI_BIAS, 4, false, false>), gridb, dim3(512), halo_bf16_lds(5, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, true>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else if (halo)
-            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
+            LU_LAUNCH_DYN((conv_halo_frag_kernel<3, LU_EPI_BIAS, 4, false>), gridb, dim3(512), halo_bf16_lds(3, 4), stream, a);
         else
             LU_LAUNCH(conv_gather_bf16_kernel, gridb, dim3(512), stream, a);
         int rcb = LU_CHECK_LAUNCH();
@@ -3117,8 +2822,8 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         return LU_CHECK_LAUNCH();
     }
     // fp32 halo kernel with a K split: whole chunks per slice (the compile-time tap sequence, round 5) whenever every slice gets
-    // at least one chunk; LU_CONV_F_SPLIT_TAPS keeps the counted loop (slices of ceil(n_it / splits) stages from any tap on)
-    a.split_chunks = (halo && nf == 4 && a.ksplit > 1 && !(d->flags & LU_CONV_F_SPLIT_TAPS) &&
+    // at least one chunk; otherwise the counted loop (slices of ceil(n_it / splits) stages from any tap on)
+    a.split_chunks = (halo && nf == 4 && a.ksplit > 1 &&
                       lu_conv_chunk_splits(a.n_it / a.kk, a.ksplit) == a.ksplit) ? 1 : 0;
     const dim3 grid = tile_grid();
     const bool gen = d->dil != 1 || (d->flags & LU_CONV_F_GENERAL) != 0;   // A/B knob for tools/kbench.py
@@ -3129,9 +2834,7 @@ extern "C" int lu_conv2d_fwd(const lu_conv_desc* d, lu_stream_t stream) {
         else if (halo && NF_ == 4 && d->k == 5) LU_LAUNCH((conv_halo_kernel<5, LU_EPI_BIAS>), grid, dim3(512), stream, a); \
         else if (halo && NF_ == 4) LU_LAUNCH((conv_halo_kernel<3, LU_EPI_BIAS>), grid, dim3(512), stream, a);   \
         else if (gen) LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, true, 2, false>), grid, block, stream, a); \
-        else if (NF_ == 4 && BV_ && mf1 && dma)                                                                 \
-            LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1, true>), grid, dim3(512), stream, a);     \
-        else if (NF_ == 4 && BV_ && mf1)                                                                        \
+        else if (NF_ == 4 && BV_)                                                                               \
             LU_LAUNCH((conv_fwd_kernel<4, true, LU_EPI_BIAS, false, 1, false>), grid, dim3(512), stream, a);    \
         else LU_LAUNCH((conv_fwd_kernel<NF_, BV_, LU_EPI_BIAS, false, 2, false>), grid, block, stream, a);      \
         int rc_ = LU_CHECK_LAUNCH();                                                            \
@@ -3270,19 +2973,6 @@ extern "C" int lu_pack_weights_taps_bf16(const float* w, int64_t w_tap_stride, i
     const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     LU_LAUNCH(pack_weights_bf16_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, taps, C, N,
               (unsigned short*)out);
-    return LU_CHECK_LAUNCH();
-}
-
-extern "C" size_t lu_pack_weights_f32_bytes(int k, int C, int N) {
-    return (size_t)k * k * ((C + CK - 1) / CK) * (size_t)((N + 31) / 32) * 512 * sizeof(float);
-}
-
-extern "C" int lu_pack_weights_f32(const float* w, int64_t w_tap_stride, int w_row_stride, int k, int C, int N, void* out,
-                                   lu_stream_t stream) {
-    LU_REQUIRE(w && out && k > 0 && C > 0 && N > 0, "lu_pack_weights_f32: bad arguments");
-    const int64_t total = (int64_t)k * k * ((C + CK - 1) / CK) * ((N + 31) / 32) * 512;
-    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    LU_LAUNCH(pack_weights_f32_kernel, dim3(g), dim3(256), stream, w, w_tap_stride, w_row_stride, k * k, C, N, (float*)out);
     return LU_CHECK_LAUNCH();
 }
 

@@ -264,13 +264,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // same run widened by K-1 pixels ([16+K-1][64]); tap kw simply reads it shifted by kw rows.  Load bytes per FLOP
 // drop 2.3x versus one-tap-per-block; 8 waves (2 x 4), K accumulators each -> 4 waves/SIMD.
 // ---------------------------------------------------------------------------------------------------------
-// KPT = pixels per stage: 16, or -- LU_WGRAD_F_KP32, W % 32 == 0 -- 32 (half as many block-wide barriers per MFMA, two loader
-// passes per stage, LDS 59 KB).  Measured SLOWER on MI355X (config-2: 0.800 vs 0.834 of the fp32 MFMA peak on this kernel,
-// 574.4 vs 567.3 ms per step, same box, alternating runs): kept as an opt-in instance and a recorded negative result.
-// SLIDE: the K x-rows a k-pair reads (rows kk2 + khalf + t) overlap the next pair's (kk2 + 2 + ...) in K - 2 rows: keep them
-// in registers and fetch only two new values per pair -- 3 instead of 6 LDS reads per 5 MFMAs (the LDS pipe of a CU with 16
-// resident waves was ~60 % busy on those reads).  Same values, same MFMA order: bit-identical results.
-template <int K, bool RG, int KPT = 16, bool SLIDE = true>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
+// KPT = pixels per stage: 32 wherever W % 32 == 0 (half as many block-wide barriers per MFMA, two loader passes per stage, LDS 59 KB;
+// the library's own choice since round 4's lean stage loads), 16 on the other widths (W % 16 == 0, and the ragged rows of RG).
+// The K x-rows a k-pair reads (rows kk2 + khalf + t) overlap the next pair's (kk2 + 2 + ...) in K - 2 rows: they slide through
+// registers and a pair fetches only two new values -- 3 instead of 6 LDS reads per 5 MFMAs (the LDS pipe of a CU with 16 resident waves
+// was ~60 % busy on those reads).  (The form that re-read all K rows per pair, bit-identical, was kept as an A/B instance until round 6.)
+template <int K, bool RG, int KPT = 16>      // RG: ragged widths (W % 16 != 0), a compile-time property so that the aligned instance pays nothing
 __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     constexpr int KP = KPT;      // (shadows the file-level stage length inside this kernel)
     static_assert(KPT == 16 || (KPT == 32 && !RG), "32-pixel stages: aligned widths only");
@@ -445,20 +444,11 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     }
     __syncthreads();
     const int khalf = lane >> 5, l31 = lane & 31;
-    float av[K];
-    auto mma_pair = [&](int buf, int kk2) {      // !SLIDE: every k-pair reads its K x rows and its dy value right where it needs them
-        const float bv = Ys[buf][(kk2 + khalf) * BNw + wn * 32 + l31];
-#pragma unroll
-        for (int t = 0; t < K; ++t) av[t] = Xs[buf][(kk2 + khalf + t) * BMw + wm * 32 + l31];
-#pragma unroll
-        for (int t = 0; t < K; ++t) acc[t] = lu_mfma(av[t], bv, acc[t]);
-    };
-    // SLIDE (the product form, round 4): the LDS reads run AHEAD of the MFMAs.  A lane reads x rows m = 0 .. KP + K - 3 (+ khalf) and
+    // The LDS reads run AHEAD of the MFMAs (round 4).  A lane reads x rows m = 0 .. KP + K - 3 (+ khalf) and
     // KP / 2 dy values per stage; k-pair p multiplies rows 2p .. 2p + K - 1 by dy value p, i.e. it adds two new rows and one dy value
     // to what pair p - 1 held.  Pair p + 1's three values are requested before pair p's MFMAs are issued, through ONE base register
     // per operand and immediate offsets, so the waits the compiler places are counted and a wave never sits on an LDS round trip
     // with an empty MFMA queue (rounds 1-3: read -> s_waitcnt lgkmcnt(0) -> 2-3 MFMAs, covered only by the other resident waves).
-    // Same values, same MFMA order per accumulator: bit-identical to the !SLIDE form.
     constexpr int NP = KP / 2, NX = KP + K - 2;
     constexpr int PD = 2;      // pairs of look-ahead (5x5 with 32-pixel stages: two loop-invariant registers spill for it and it is still 0.9 % faster than one)
     const float* const xrd = &Xs[0][khalf * BMw + wm * 32 + l31];
@@ -475,36 +465,26 @@ __global__ __launch_bounds__(512, 4) void wgrad_row_kernel(WgradArgs a) {
     };
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
-        if (SLIDE) {
-            rd_pair(buf, 0);
-            rd_pair(buf, 1);
-            if (PD > 1) rd_pair(buf, 2);
-            mma_p(0);
-        } else {
-            mma_pair(buf, 0);
-        }
+        rd_pair(buf, 0);
+        rd_pair(buf, 1);
+        if (PD > 1) rd_pair(buf, 2);
+        mma_p(0);
         LU_SCHED_FENCE();
         if (it + 1 < n_it) advance();
         load_stage(it + 1 < n_it ? it + 1 : it);
         LU_SCHED_FENCE();
-        if (SLIDE) {
 #pragma unroll
-            for (int p = 1; p < NP - 1; ++p) {
-                if (p + PD < NP) rd_pair(buf, p + PD);
-                mma_p(p);
-                LU_SCHED_FENCE();
-            }
-        } else {
-#pragma unroll
-            for (int kk2 = 2; kk2 < KP - 2; kk2 += 2) mma_pair(buf, kk2);
+        for (int p = 1; p < NP - 1; ++p) {
+            if (p + PD < NP) rd_pair(buf, p + PD);
+            mma_p(p);
+            LU_SCHED_FENCE();
         }
         LU_SCHED_FENCE();
         store_stage(buf ^ 1);
         if (want_bias && it + 1 < n_it && bphase == bme) bias_acc();      // (the last iteration re-fetched its own run: not counted twice)
         bphase = bphase + 1 == brc ? 0 : bphase + 1;
         LU_SCHED_FENCE();
-        if (SLIDE) mma_p(NP - 1);
-        else mma_pair(buf, KP - 2);
+        mma_p(NP - 1);
         __syncthreads();
     }
 
@@ -585,12 +565,10 @@ constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 //   R = K ("all taps", round 4; 3x3 only): the block owns ALL K x K taps of its (c, n) tile -- the x tile holds the K input rows
 //   under the 32-pixel run, the dy tile is shared by K * K taps instead of K: 1.5x the MFMAs per staged byte and per stage
 //   barrier, x and dy fetched once instead of K times per 128 columns.  The K * K * NFW accumulator tiles do not fit beside a
-//   second wave on the SIMD, so the block is 64 channels x 128 columns on either
-//     NWV = 8 waves (2 x 4, 32c x 32n x 9 taps = 144 accumulator registers each, two waves per SIMD), or
-//     NWV = 4 "fat" waves (2 x 2, 32c x 64n x 9 taps = 288 accumulator registers -- the accumulators live in AGPRs, ONE wave per
-//     SIMD with the whole 512-entry register file): every x fragment feeds two column fragments, i.e. half the LDS fragment
-//     reads, funnel shifts and per-stage bookkeeping instructions per MFMA of the 8-wave form.
-//   DMA (round 4; bf16 operands, stride 1; opt-in, measured SLOWER -- see the loop): the tiles go from global memory STRAIGHT into LDS (global_load_lds_dwordx4: a wave
+//   second wave on the SIMD, so the block is 64 channels x 128 columns on 8 waves (2 x 4, 32c x 32n x 9 taps = 144 accumulator
+//   registers each, two waves per SIMD).  (Four "fat" waves -- 288 accumulators in AGPRs, one wave per SIMD -- measured slower: removed.)
+//   DMA (round 4; bf16 operands, stride 1; the all-taps 3x3 form's default, +3.5 %; -3 % / -1.5 % on the 5x5 kernel-row form, whose DMA
+//   instances were removed in round 6): the tiles go from global memory STRAIGHT into LDS (global_load_lds_dwordx4: a wave
 //   instruction copies 64 x 16 bytes to 1 KB of consecutive LDS) -- no staging registers, no ds_write_b128 (13 issue cycles
 //   each, 5 per thread and 64-pixel stage), no load -> store dependency inside the stage.  Compile-time ablations of the
 //   register-staged loop (tools/gpu/r04_wg_ablate.sh, L1 5x5: 5.34 ms): without the global loads 4.06, without the LDS stores
@@ -598,14 +576,11 @@ constexpr int PRB = 32;      // pixels per stage of the bf16 kernel
 //   (the 1 KB of an instruction is contiguous), so bank conflicts of the transposing fragment reads are avoided by a swizzle
 //   applied to the SOURCE address instead: the 64-byte column segment s of row r is stored at segment s ^ (r & 3) (256-byte
 //   rows: four rows of a fragment read land on four different bank quarters) resp. s ^ ((r >> 1) & 1) (128-byte rows).
-//   XRD (round 5): how a tap's x fragment is formed.  0: the 8 + K - 1 rows of a k-step are fetched once and the K fragments cut out of
-//   the registers -- a 16-bit funnel shift per register for odd taps, and (what the instruction stream showed) four v_mov per tap
-//   whose first register is odd: an MFMA operand is an EVEN-aligned register tuple, so "pure renaming" only works for taps 0 and 4.
-//   1.4-1.8 VALU instructions per MFMA in the loop body (profiles/r04_pmc_sq.json: 2.5 over the whole kernel).  2: every tap reads its
-//   own rows t .. t + 7 with two transposing reads (row offsets keep the 8-byte alignment): 2 K + 2 NFW reads per k-step instead of
-//   NR + 2 NFW (K = 5: 14 instead of 7; the LDS pipe is ~35 % busy with that), no VALU instruction left in the loop body.
-template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8, bool DMA = false, int XRD = 0>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
-__global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad_row_bf16_kernel(WgradArgs a) {
+//   The 8 + K - 1 x rows of a k-step are fetched once and the K tap fragments cut out of the registers -- a 16-bit funnel shift per register for odd
+//   taps, four v_mov per tap whose first register is odd (an MFMA operand is an EVEN-aligned register tuple).  Round 5 measured the alternative --
+//   every tap reading its own re-aligned rows, no VALU work left in the loop body, twice the LDS reads -- at -0.5 %: removed in round 6.
+template <int K, int CT, bool XB, bool YB, int S = 1, int PRBT = PRB, int R = 1, int NWV = 8, bool DMA = false>      // CT = channel tile: 64 (waves 2 x 4, 32c x 32n each) or 128 (waves 4 x 2, 32c x 64n each)
+__global__ __launch_bounds__(64 * NWV, 2) void wgrad_row_bf16_kernel(WgradArgs a) {
     constexpr int PRB = PRBT;      // (shadows the file-level default inside this kernel)
     constexpr int BMw = CT, BNw = 128, XP = S * (PRB - 1) + K, NT = 64 * NWV;
     constexpr int WMC = CT / 32, WNN = NWV / WMC, NFW = BNw / (32 * WNN);
@@ -876,17 +851,7 @@ __global__ __launch_bounds__(64 * NWV, ((NWV == 4 && R > 1) ? 1 : 2)) void wgrad
         lu_bf16x8 bv[NFW];
 #pragma unroll
         for (int nf = 0; nf < NFW; ++nf) bv[nf] = frag(&Ys[buf * (PRB * YLD) + yoff + 16 * j * YLD + 32 * nf + yseg[nf]], YLD);
-        if constexpr (S == 1 && XRD == 2) {
-#pragma unroll
-            for (int kr = 0; kr < R; ++kr) {
-#pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    const lu_bf16x8 av = frag(&Xs[buf * (XPA * XLD) + xoff + xseg[kr] + (kr * XP + 16 * j + t) * XLD], XLD);
-#pragma unroll
-                    for (int nf = 0; nf < NFW; ++nf) acc[kr * K + t][nf] = lu_mfma_bf16(av, bv[nf], acc[kr * K + t][nf]);
-                }
-            }
-        } else if constexpr (S == 1) {
+        if constexpr (S == 1) {
 #pragma unroll
             for (int kr = 0; kr < R; ++kr) {      // the R input rows of the tile (all-taps form) -- one for the kernel-row form
                 short xw[4 * NR];
@@ -1852,17 +1817,12 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
                "lu_conv2d_wgrad: dbias is produced by the kernel-row / all-taps variants only (stride-1 3x3 / 5x5, W %% 16 == 0, "
                "aligned operands, C >= 64 or a narrow 3x3 layer); use lu_colsum for this layer");
     // bf16 kernel-row variant: channel tile, and the bias rows per split that go with it (also needed by a phase-2 call)
-    // LU_WGRAD_F_HALF_BLOCK (round 5 A/B): 4-wave blocks of 64 channels x 128 columns -- the same 32c x 64n x K wave tile as the 128-channel /
-    // 8-wave block, TWO independent blocks per CU (66 KB of LDS each) so that one block's stage barrier / staging phase runs under the
-    // other's MFMAs, at 1.5x the staged bytes per MFMA (the dy tile is fetched by twice as many blocks)
-    const bool half_wg = (d->flags & LU_WGRAD_F_HALF_BLOCK) && d->k == 5 && d->stride == 1 && d->x_dtype == LU_BF16 && d->dy_dtype == LU_BF16;
-    const int ct_bf16 = (d->k == 1 || (d->stride == 2 && d->k == 5) || half_wg) ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
+    const int ct_bf16 = (d->k == 1 || (d->stride == 2 && d->k == 5)) ? 64 : (d->flags & LU_WGRAD_F_CT64) ? 64 : (d->flags & LU_WGRAD_F_CT128) ? 128
                                                                                           : (d->C % 128 == 0 || d->C > 256 ? 128 : 64);
-    // all-taps form of the 3x3 layers (one block = all nine taps of a 64-channel x 128-column tile): 4 fat waves, or 8 thin ones
-    // Measured (round 4, same-box A/B, config-2 shapes): 8 waves 0.196 -> 0.215 of peak on the Params-net 3x3 layers, 0.295 -> 0.345 on
-    // the 3x3 ConvLSTM kernels (64-pixel stages where W % 64 == 0: +1 %); 4 fat waves 0.155 / 0.218 -- one wave per SIMD leaves the
-    // compiler-scheduled stage nothing to hide its LDS / global latencies behind.  The library's own choice is the 8-wave form;
-    // LU_WGRAD_F_NO_TAPS9 keeps the kernel-row form (A/B, tests), LU_WGRAD_F_TAPS9 selects the fat waves.
+    // all-taps form of the 3x3 layers (one block = all nine taps of a 64-channel x 128-column tile, 8 waves)
+    // Measured (round 4, same-box A/B, config-2 shapes): 0.196 -> 0.215 of peak on the Params-net 3x3 layers, 0.295 -> 0.345 on the 3x3
+    // ConvLSTM kernels (64-pixel stages where W % 64 == 0: +1 %).  (A 4-fat-wave instance -- 288 accumulators in AGPRs, one wave per
+    // SIMD -- measured 0.155 / 0.218 and was removed in round 6.)  LU_WGRAD_F_NO_TAPS9 keeps the kernel-row form (the previous form; tests).
     const bool taps9 = row_bf16 && row_variant && d->k == 3 && d->stride == 1 && d->C >= 64 && !(d->flags & LU_WGRAD_F_NO_TAPS9) &&
                        !(d->flags & (LU_WGRAD_F_CT64 | LU_WGRAD_F_CT128));
     const bool taps9_ = taps9 && !pieces3;
@@ -1898,19 +1858,17 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, false, 1, 32, 3, NWV_>), grid, dim3(64 * NWV_), wgrad_row_bf16_lds(3, 64, 1, 32, true, 3, 64 * NWV_), stream, a);    \
         else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, false, false, 1, 32, 3, NWV_>), grid, dim3(64 * NWV_), wgrad_row_bf16_lds(3, 64, 1, 32, false, 3, 64 * NWV_), stream, a);           \
     } while (0)
-        // (fat waves: bf16 operands only -- an fp32 operand's conversion registers do not fit beside 288 accumulators)
         const bool p64 = d->Wout % 64 == 0 && xb && yb && !(d->flags & LU_WGRAD_F_PRB32);      // 64-pixel stages (bf16 operands)
-        // LDS-DMA staging (bf16 operands): measured +3.5 % on the all-taps 3x3 form (three stage buffers, counted waits), -3 % on the 5x5
-        // kernel-row form, which keeps its staging registers unless LU_WGRAD_F_DMA asks
-        const bool dma9 = xb && yb && !(d->flags & (LU_WGRAD_F_NO_DMA | LU_WGRAD_F_TAPS9));
+        // LDS-DMA staging (bf16 operands): measured +3.5 % on the all-taps 3x3 form (three stage buffers, counted waits); -3 % (round 4) / -1.5 %
+        // (round 6) on the 5x5 kernel-row form, whose instances were removed in round 6 (LU_WGRAD_F_NO_DMA keeps the register-staged all-taps form)
+        const bool dma9 = xb && yb && !(d->flags & LU_WGRAD_F_NO_DMA);
         if (p64 && dma9)
             LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 64, 3, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 64, true, 3, 512, true), stream, a);
         else if (dma9)
             LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 32, 3, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 32, true, 3, 512, true), stream, a);
-        else if (p64 && !(d->flags & LU_WGRAD_F_TAPS9))
+        else if (p64)
             LU_LAUNCH_DYN((wgrad_row_bf16_kernel<3, 64, true, true, 1, 64, 3, 8>), grid, dim3(512), wgrad_row_bf16_lds(3, 64, 1, 64, true, 3, 512), stream, a);
-        else if (!(d->flags & LU_WGRAD_F_TAPS9) || !(xb && yb)) LU_WG9(8);
-        else LU_WG9(4);
+        else LU_WG9(8);
 #undef LU_WG9
     } else if (row_bf16) {
         const int ct = ct_bf16;
@@ -1940,25 +1898,10 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         else if (xb) LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, true, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 2, 32, true), stream, a);          \
         else LU_LAUNCH_DYN((wgrad_row_bf16_kernel<K_, CT_, false, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(K_, CT_, 2, 32, false), stream, a);                 \
     } while (0)
-        const bool dma = xb && yb && d->stride == 1 && (d->flags & LU_WGRAD_F_DMA);      // LDS-DMA staging (bf16 operands; opt-in: measured slower)
-        if (dma && d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32))
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 64, 1, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 64, true, 1, 512, true), stream, a);
-        else if (dma && d->k == 5 && ct == 128)
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 32, 1, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 32, true, 1, 512, true), stream, a);
-        else if (dma && d->k == 5)
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 64, true, true, 1, 32, 1, 8, true>), grid, dim3(512), wgrad_row_bf16_lds(5, 64, 1, 32, true, 1, 512, true), stream, a);
-        else if (d->stride == 2 && d->k == 5) LU_WGB2(5, 64);
+        if (d->stride == 2 && d->k == 5) LU_WGB2(5, 64);
         else if (d->stride == 2 && ct == 128) LU_WGB2(3, 128);
         else if (d->stride == 2) LU_WGB2(3, 64);
         else if (d->k == 1) LU_WGB(1, 64);
-        else if (half_wg && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32))
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 64, true, true, 1, 64, 1, 4>), grid, dim3(256), wgrad_row_bf16_lds(5, 64, 1, 64, true, 1, 256), stream, a);
-        else if (half_wg)
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 64, true, true, 1, 32, 1, 4>), grid, dim3(256), wgrad_row_bf16_lds(5, 64, 1, 32, true, 1, 256), stream, a);
-        else if (xb && yb && d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32) && (d->flags & LU_WGRAD_F_XREALIGN))
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 64, 1, 8, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 64, true), stream, a);
-        else if (xb && yb && d->k == 5 && ct == 128 && (d->flags & LU_WGRAD_F_XREALIGN))
-            LU_LAUNCH_DYN((wgrad_row_bf16_kernel<5, 128, true, true, 1, 32, 1, 8, false, 2>), grid, dim3(512), wgrad_row_bf16_lds(5, 128, 1, 32, true), stream, a);
         else if (d->k == 5 && ct == 128 && d->Wout % 64 == 0 && !(d->flags & LU_WGRAD_F_PRB32)) LU_WGB64(5);
         else if (d->k == 5 && ct == 128) LU_WGB(5, 128);
         else if (d->k == 5) LU_WGB(5, 64);
@@ -1981,14 +1924,12 @@ extern "C" int lu_conv2d_wgrad(const lu_wgrad_desc* d, lu_stream_t stream) {
         dim3 grid((unsigned)(nxt * a.xfold), (unsigned)(d->k * a.c_tiles), (unsigned)((splits + a.xfold - 1) / a.xfold));
         // 32-pixel stages wherever a run of 32 stays inside an image row (half the block-wide barriers per MFMA; with the lean stage
         // loads of round 4 faster than 16: 5x5 0.899 -> 0.914, 3x3 0.716 -> 0.732 of peak; rounds 1-3 had measured them slower)
-        const bool kp32 = !a.ragged && d->Wout % 32 == 0 && !(d->flags & (LU_WGRAD_F_KP16 | LU_WGRAD_F_NO_SLIDE));
+        const bool kp32 = !a.ragged && d->Wout % 32 == 0;
         if (d->k == 5 && a.ragged) LU_LAUNCH((wgrad_row_kernel<5, true>), grid, dim3(512), stream, a);
         else if (d->k == 5 && kp32) LU_LAUNCH((wgrad_row_kernel<5, false, 32>), grid, dim3(512), stream, a);
-        else if (d->k == 5 && (d->flags & LU_WGRAD_F_NO_SLIDE)) LU_LAUNCH((wgrad_row_kernel<5, false, 16, false>), grid, dim3(512), stream, a);
         else if (d->k == 5) LU_LAUNCH((wgrad_row_kernel<5, false>), grid, dim3(512), stream, a);
         else if (a.ragged) LU_LAUNCH((wgrad_row_kernel<3, true>), grid, dim3(512), stream, a);
         else if (kp32) LU_LAUNCH((wgrad_row_kernel<3, false, 32>), grid, dim3(512), stream, a);
-        else if (d->flags & LU_WGRAD_F_NO_SLIDE) LU_LAUNCH((wgrad_row_kernel<3, false, 16, false>), grid, dim3(512), stream, a);
         else LU_LAUNCH((wgrad_row_kernel<3, false>), grid, dim3(512), stream, a);
     } else if (!xvec) {
         const int gy = (a.kk * d->C + 31) / 32;

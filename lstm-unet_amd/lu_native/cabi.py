@@ -10,26 +10,17 @@ LU_EPI_BIAS, LU_EPI_LSTM = 0, 1
 LU_F32, LU_BF16 = 0, 1
 # lu_conv_desc.flags / lu_wgrad_desc.flags (include/lstm_unet_hip.h)
 LU_CONV_F_PATCH8, LU_CONV_F_PATCH16, LU_CONV_F_NO_HALO, LU_CONV_F_XCD_BY_N = 1, 2, 4, 8
-LU_CONV_F_LDS_DMA, LU_CONV_F_MF2, LU_CONV_F_GENERAL = 16, 32, 64
-LU_CONV_F_LOOP_GEN1, LU_CONV_F_GATES_BF16, LU_CONV_F_SRC1_CENTER, LU_CONV_F_NO_BALANCE = 128, 256, 512, 1024
+LU_CONV_F_GENERAL = 64
+LU_CONV_F_GATES_BF16, LU_CONV_F_SRC1_CENTER, LU_CONV_F_NO_BALANCE = 256, 512, 1024
 LU_CONV_F_SLABS_ONLY = 2048
 LU_CONV_F_NO_NARROW = 4096
 LU_CONV_F_HALF_BLOCK = 8192
-LU_CONV_F_SPLIT_TAPS = 16384
-LU_CONV_F_LOOP_GEN2 = 32768
 LU_CONV_F_H16_SPLIT = 65536
 LU_WGRAD_F_NO_ROW, LU_WGRAD_F_NO_SMALL3, LU_WGRAD_F_CT64, LU_WGRAD_F_CT128, LU_WGRAD_F_SMALL_TILE, LU_WGRAD_F_PRB32 = 1, 2, 4, 8, 16, 32
 LU_WGRAD_F_NO_RAGGED = 64
 LU_WGRAD_F_NO_NARROW_BF16 = 128
-LU_WGRAD_F_KP32 = 256
-LU_WGRAD_F_KP16 = 16384
-LU_WGRAD_F_NO_SLIDE = 512
-LU_WGRAD_F_TAPS9 = 1024
 LU_WGRAD_F_NO_TAPS9 = 2048
-LU_WGRAD_F_DMA = 4096
 LU_WGRAD_F_NO_DMA = 8192
-LU_WGRAD_F_XREALIGN = 32768
-LU_WGRAD_F_HALF_BLOCK = 65536
 LU_WGRAD_F_PIECES3 = 131072
 
 
@@ -72,8 +63,6 @@ PROTOTYPES = {
     'lu_last_error': (C.c_char_p, []),
     'lu_abi_version': (C.c_int, []),
     'lu_conv2d_fwd': (C.c_int, [C.POINTER(ConvDesc), S]),
-    'lu_pack_weights_f32_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    'lu_pack_weights_f32': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_pack_weights_taps_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),
     'lu_pack_weights_bf16_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'lu_pack_weights_bf16': (C.c_int, [P, i64, C.c_int, C.c_int, C.c_int, C.c_int, P, S]),

@@ -125,8 +125,6 @@ class Engine:
         self._x3_lean = False
         self.x3_conv_units = True    # precision 'bf16x3': the wide stride-1 3x3 / 5x5 Conv2D layers on split operands too (False: ConvLSTM layers only)
         self.x3_pad_wgrad = True     # precision 'bf16x3', W % 32 != 0: weight gradients on zero-padded copies of the split tensors (False: fp32 ones)
-        self.x3_wgrad_launches = 2   # precision 'bf16x3': the six products of a weight gradient in two launches with the terms as frames (A/B: 6)
-        self.x3_fused_split = True   # precision 'bf16x3': the gate epilogue writes the split image of h (A/B: False = a split6 pass per step)
         self._persistent_states = False  # True (lu_native.graph): inference copies the new state INTO the existing state
                                          # tensors instead of adopting the step's output tensors as the state
 
@@ -798,10 +796,10 @@ class Engine:
             hit = self._state16.get((bi, li))
             h6 = hit[1] if (hit is not None and hit[0] is h_prev) else ops.split6(h_prev)
             for t in range(T):
-                h6_next = torch.empty((B, H, W, 6 * F), device=dev, dtype=torch.bfloat16) if self.x3_fused_split else None
+                h6_next = torch.empty((B, H, W, 6 * F), device=dev, dtype=torch.bfloat16)      # (written by the gate epilogue: LU_CONV_F_H16_SPLIT)
                 ops.convlstm_step(x6[t], h6, c_prev, k6, r6, bias, h_seq[t], c_seq[t], None, h6_out=h6_next)
                 h_prev, c_prev = h_seq[t], c_seq[t]
-                h6 = h6_next if h6_next is not None else ops.split6(h_prev)
+                h6 = h6_next
             if self.persistent_states and st is not None:
                 st[0].copy_(h_prev)
                 st[1].copy_(c_prev)
@@ -831,13 +829,10 @@ class Engine:
         ops.split6(h_all[0], out=h6_all[0])
         gates = torch.empty((T, B, H, W, 4 * F), device=dev, dtype=torch.float32)
         for t in range(T):
-            # (the gate epilogue writes the split image of h_t next to h_t: LU_CONV_F_H16_SPLIT; A/B: x3_fused_split = False)
-            fused = self.x3_fused_split and t + 1 < T
+            # (the gate epilogue writes the split image of h_t next to h_t: LU_CONV_F_H16_SPLIT)
             src, dst = (h6_all[t & 1], h6_all[(t + 1) & 1]) if lean else (h6_all[t], h6_all[t + 1])
             ops.convlstm_step(ops.split6(x5f[t], cp, out=x6_t) if lean else x6[t], src, c_all[t], k6, r6, bias, h_all[t + 1],
-                              c_all[t + 1], gates[t], h6_out=dst if fused else None)
-            if t + 1 < T and not fused:
-                ops.split6(h_all[t + 1], out=dst)
+                              c_all[t + 1], gates[t], h6_out=dst if t + 1 < T else None)
         self._states[bi][li] = [h_all[T], c_all[T]]
         self._alias.add((bi, li))
         self._state16.pop((bi, li), None)
@@ -878,14 +873,7 @@ class Engine:
         """dw = x (*) dy on the split operands (x6 in order A, dy6 in order B: block t against block t is term t of
         ops.SPLIT_TERMS).  Two launches of the bf16 kernel-row weight gradient with the terms as extra frames
         (lu_wgrad_desc.terms): the three small products -- whose dy blocks are hi, mid, lo, i.e. dy itself, so the bias gradient
-        rides on this launch as the column sums of the three pieces -- then the three large ones on top (beta = 1).
-        x3_wgrad_launches = 6: one launch per product on channel-slice views (the first form, A/B)."""
-        if self.x3_wgrad_launches == 6:
-            lp, ln = x6.shape[3] // 6, dy6.shape[3] // 6
-            for t in range(6):
-                ops.conv2d_wgrad(x6[..., t * lp:(t + 1) * lp], dy6[..., t * ln:(t + 1) * ln], dw, 1, beta=beta0 if t == 0 else 1.0,
-                                 bf16=True, dbias=dbias if t < 3 else None, dbias_beta=beta0 if t == 0 else 1.0)
-            return
+        rides on this launch as the column sums of the three pieces -- then the three large ones on top (beta = 1)."""
         if ops.x3_pieces_ok(x6, dy6, dw.shape[0]):      # round 6: each piece staged once, the six products from registers -- one launch
             ops.conv2d_wgrad(x6, dy6, dw, 1, beta=beta0, bf16=True, dbias=dbias, dbias_beta=beta0, terms=(0, 6), pieces=True)
             return
@@ -916,11 +904,7 @@ class Engine:
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
             # dz6 in order B: block t of dz6 meets block t of the order-A x6 / h6 in the weight gradients
-            if self.x3_fused_split and F % 4 == 0:
-                ops.lstm_gates_bwd_split(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz6[t], dc[t & 1])
-            else:
-                ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
-                ops.split6(dz[t], out=dz6[t], order=1)
+            ops.lstm_gates_bwd_split(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz6[t], dc[t & 1])
             if t > 0:
                 if dh_rec is None:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)
@@ -991,11 +975,7 @@ class Engine:
         first = True
         for t in reversed(range(T)):
             dc_in = dc[(t + 1) & 1] if t < T - 1 else None
-            if self.x3_fused_split and F % 4 == 0:
-                ops.lstm_gates_bwd_split(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz6, dc[t & 1])
-            else:
-                ops.lstm_gates_bwd(gates[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz[t], dc[t & 1])
-                ops.split6(dz[t], out=dz6, order=1)
+            ops.lstm_gates_bwd_split(dz[t], c_all[t], c_all[t + 1], dh5[t], dh_rec, dc_in, dz6, dc[t & 1])
             if t > 0:
                 if dh_rec is None:
                     dh_rec = torch.empty((B, H, W, F), device=dev, dtype=torch.float32)

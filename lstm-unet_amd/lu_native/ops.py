@@ -83,8 +83,8 @@ def _p(t):
 
 
 class PackedW(object):
-    """MFMA-fragment-order image of a [k,k,C,N] kernel: precision 1 = bf16 (lu_pack_weights_bf16), 2 = fp32
-    (lu_pack_weights_f32); the value of lu_conv_desc.precision that goes with it."""
+    """MFMA-fragment-order bf16 image of a [k,k,C,N] kernel (lu_pack_weights_bf16) and the value of lu_conv_desc.precision that goes
+    with it (1)."""
     __slots__ = ('data', 'shape', 'precision')
 
     def __init__(self, data, shape, precision=1):
@@ -100,18 +100,6 @@ def pack_bf16(w):
     calls.check(lib(), lib().lu_pack_weights_bf16(w.data_ptr(), w.stride(1), w.stride(2), k, Cc, N, data.data_ptr(),
                                                   _stream()), 'lu_pack_weights_bf16')
     return PackedW(data, w.shape)
-
-
-def pack_f32(w):
-    """fp32 [k,k,C,N] kernel (channel-slice views allowed) -> fragment-order fp32 PackedW (same arithmetic as the plain
-    layout; the convolution then streams its weights from L2 instead of staging them through LDS)."""
-    _chk(w)
-    assert w.dim() == 4 and w.stride(3) == 1 and w.stride(0) == w.shape[1] * w.stride(1)
-    k, _, Cc, N = w.shape
-    data = torch.empty(lib().lu_pack_weights_f32_bytes(k, Cc, N) // 4, device=w.device, dtype=torch.float32)
-    calls.check(lib(), lib().lu_pack_weights_f32(w.data_ptr(), w.stride(1), w.stride(2), k, Cc, N, data.data_ptr(),
-                                                 _stream()), 'lu_pack_weights_f32')
-    return PackedW(data, w.shape, 2)
 
 
 def pack_taps_bf16(w):
@@ -379,8 +367,7 @@ def conv2d_wgrad(x, dy, dw, stride, beta=0.0, bf16=False, dbias=None, dbias_beta
     if bf16_row and stride == 2:
         row_variant = True           # (the bias gradient rides on this launch as well)
     if bf16_row:
-        half_wg = bool(WGRAD_FLAGS & cabi.LU_WGRAD_F_HALF_BLOCK) and k == 5 and stride == 1 and xb and yb      # (mirrors lu_conv2d_wgrad)
-        ct = 64 if (k == 1 or (stride == 2 and k == 5) or half_wg or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
+        ct = 64 if (k == 1 or (stride == 2 and k == 5) or WGRAD_FLAGS & cabi.LU_WGRAD_F_CT64) else 128 if (WGRAD_FLAGS & cabi.LU_WGRAD_F_CT128) else \
             (128 if (Cin % 128 == 0 or Cin > 256) else 64)
         all_taps = (k == 3 and stride == 1 and Cin >= 64 and      # mirrors lu_conv2d_wgrad: the all-taps form of the 3x3 layers
                     not (WGRAD_FLAGS & (cabi.LU_WGRAD_F_NO_TAPS9 | cabi.LU_WGRAD_F_CT64 | cabi.LU_WGRAD_F_CT128)))

@@ -16,17 +16,6 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
 
 
-def pytest_collection_modifyitems(config, items):
-    """Tests whose ranks are launched in front of the first test (a module's EARLY_JOBS, see _multi_process_jobs_from_the_first_test)
-    run LAST: their processes then have the whole session to start up, rendezvous and finish beside the other tests, and the test
-    itself only collects the result.  (Run first, the bench self-launch waited 336 s for its two ranks while the oracle farm and
-    sixteen other ranks were starting: round 6, profiles/README.)  Same test ids, same assertions."""
-    def early(it):
-        jobs = getattr(it.module, 'EARLY_JOBS', None) or {}
-        return it.name in jobs or it.name.split('[')[0] in jobs
-    items[:] = [it for it in items if not early(it)] + [it for it in items if early(it)]
-
-
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
@@ -47,37 +36,6 @@ def _oracle_farm_from_the_first_test(request):
     yield
     if mod is not None and getattr(mod, '_SESSION', {}).get('farm') is not None:
         mod._SESSION.pop('farm').close()
-
-
-@pytest.fixture(scope='session', autouse=True)
-def _multi_process_jobs_from_the_first_test(request, tmp_path_factory):
-    """The multi-rank GPU tests (eight gloo ranks on the one GPU: DP8 + SyncBN, the train2D loop with a failing rank; bench.py's
-    self-launch) spend a minute each in process start-up -- 8 x `import torch` + library load + rendezvous -- while the GPU idles
-    (222 of the suite's 703 s, round 6).  A test module lists them as EARLY_JOBS = {test name: launcher(tmp dir) -> handle}; the
-    ones whose test is selected are launched here, in front of the first test, and the test picks its handle up (or launches
-    itself when run alone / not registered).  Only in sessions that contain such tests and see a GPU."""
-    started = []
-    try:
-        import torch
-        have_gpu = torch.cuda.is_available()
-    except Exception:
-        have_gpu = False
-    if have_gpu and not os.environ.get('LU_TEST_NO_EARLY_JOBS'):
-        for it in request.session.items:
-            jobs = getattr(it.module, 'EARLY_JOBS', None)
-            base = it.name.split('[')[0]
-            if jobs and it.name in jobs or jobs and base in jobs:
-                key = it.name if it.name in jobs else base
-                store = it.module.__dict__.setdefault('_EARLY_HANDLES', {})
-                if key not in store:
-                    store[key] = jobs[key](tmp_path_factory.mktemp('early_' + base[:40]))
-                    started.append((store, key))
-    yield
-    for store, key in started:      # a test that never ran (deselected by -x, failed collection): do not leave its ranks behind
-        h = store.pop(key, None)
-        for p_ in (h or {}).get('procs', []):
-            if p_.poll() is None:
-                p_.kill()
 
 
 # small nets used across tests ---------------------------------------------------------

@@ -102,13 +102,6 @@ def pack_bf16(be, wd, k, Cin, N):
     return out
 
 
-def pack_f32(be, wd, k, Cin, N):
-    nbytes = be.lib.lu_pack_weights_f32_bytes(k, Cin, N)
-    out = be.empty((nbytes // 4 + 4,))
-    calls.check(be.lib, be.lib.lu_pack_weights_f32(be.ptr(wd), Cin * N, N, k, Cin, N, be.ptr(out), be.stream), 'pack32')
-    return out
-
-
 def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None, splits=1, precision=0, flags=0,
            bf16_src=(), post=None, slabs=False):
     """srcs: [frames,H,W,C] numpy arrays; ws: [k,k,C,N] numpy arrays. Returns numpy.
@@ -131,7 +124,7 @@ def conv2d(be, srcs, ws, bias, k, stride=1, dil=1, pad=None, out_hw=None, N=None
         xd, wd = (be.dev(bf16_bits(x), np.int16) if b16 else be.dev(x)), be.dev(w)
         keep += [xd, wd]
         if precision:
-            wd = (pack_bf16 if precision == 1 else pack_f32)(be, wd, k, Cin, N)
+            wd = pack_bf16(be, wd, k, Cin, N)
             keep.append(wd)
         cs.append(calls.conv_src(be.ptr(xd), Hin * Win * Cin, Cin, Cin, be.ptr(wd), Cin * N, N,
                                  dtype=cabi.LU_BF16 if b16 else cabi.LU_F32))
@@ -331,7 +324,7 @@ def convlstm_step_fused(be, x_t, h, c, kernel, rec, bias, precision=0, flags=0):
     srcs = [calls.conv_src(be.ptr(xd), H * W * Cin, Cin, Cin, be.ptr(kd), Cin * 4 * F, 4 * F),
             calls.conv_src(be.ptr(hd), H * W * F, F, F, be.ptr(rd), F * 4 * F, 4 * F)]
     if precision:
-        pk = pack_bf16 if precision == 1 else pack_f32
+        pk = pack_bf16
         kp, rp = pk(be, kd, k, Cin, 4 * F), pk(be, rd, k, F, 4 * F)
         srcs = [calls.conv_src(be.ptr(xd), H * W * Cin, Cin, Cin, be.ptr(kp), 0, 0),
                 calls.conv_src(be.ptr(hd), H * W * F, F, F, be.ptr(rp), 0, 0)]

@@ -69,10 +69,6 @@ SMALL = ['--steps', '2', '--warmup', '1', '--size', '64', '--batch', '1', '--unr
          '--no-bf16']
 
 
-EARLY_JOBS = {'test_bench_self_launches_n_ranks[gloo]':
-              lambda tmp: {'procs': [_start_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': 'gloo'})]}}
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize('backend', ['gloo', 'nccl'])
 def test_bench_self_launches_n_ranks(backend):
@@ -84,8 +80,7 @@ def test_bench_self_launches_n_ranks(backend):
         rc, line, err = _run_bench(['--gpus', '2'] + SMALL, {'LU_DP_BACKEND': 'nccl'})
         assert rc == 2 and line is None and 'needs 2 visible GPUs' in err      # refuses instead of measuring one GPU
         pytest.skip('RCCL needs one device per rank: %d visible' % torch.cuda.device_count())
-    h = globals().get('_EARLY_HANDLES', {}).pop('test_bench_self_launches_n_ranks[%s]' % backend, None)      # (conftest.py: started in front of the first test)
-    rc, line, err = _finish_bench(h['procs'][0]) if h else _run_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': backend})
+    rc, line, err = _run_bench(['--gpus', '2', '--sync-bn', '--check'] + SMALL, {'LU_DP_BACKEND': backend})
     assert rc == 0 and line is not None, err
     # --check: the DP == single-process comparison ran inline before the timing, and the overlap proof is on the line
     assert 'vs single process' in err and line['dp']['self_check']['ok'] and line['dp']['self_check']['grad_err_over_max'] <= 2e-6

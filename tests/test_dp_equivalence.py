@@ -144,8 +144,7 @@ def test_dp2_syncbn_on_the_hip_kernels_equals_single_process(tmp_path, precision
     limits apply -- gradients to summation-order noise."""
     import train2D
     import Networks
-    h = globals().get('_EARLY_HANDLES', {}).pop('test_dp2_syncbn_on_the_hip_kernels_equals_single_process[%s]' % precision, None) or \
-        _launch_dp2(tmp_path, precision)      # (conftest.py starts the ranks in front of the first test of a -m gpu session)
+    h = _launch_dp2(tmp_path, precision)
     tmp_path, procs, x, gt = h['tmp'], h['procs'], h['x'], h['gt']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
@@ -193,12 +192,6 @@ def _launch_dp8_syncbn(tmp_path):
     return {'tmp': tmp_path, 'procs': procs, 'x': x, 'gt': gt}
 
 
-EARLY_JOBS = {'test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process': _launch_dp8_syncbn}
-if not os.environ.get('LU_TEST_NO_OVERLAP'):
-    EARLY_JOBS.update({'test_dp2_syncbn_on_the_hip_kernels_equals_single_process[%s]' % p_: (lambda tmp, p_=p_: _launch_dp2(tmp, p_))
-                       for p_ in ('fp32', 'bf16', 'bf16x3')})
-
-
 @pytest.mark.gpu
 def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp_path):
     """EIGHT ranks x 1 slot on the real kernels (gloo, all on the one GPU of the test box): shard_slots
@@ -208,8 +201,7 @@ def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp
     import train2D
     import Networks
     W = 8
-    h = globals().get('_EARLY_HANDLES', {}).pop('test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process', None) or \
-        _launch_dp8_syncbn(tmp_path)      # (conftest.py starts the eight ranks in front of the first test of a -m gpu session)
+    h = _launch_dp8_syncbn(tmp_path)
     tmp_path, procs, x, gt = h['tmp'], h['procs'], h['x'], h['gt']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):

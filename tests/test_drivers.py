@@ -228,9 +228,6 @@ def _launch_dp8_loop(tmp_path):
     return {'tmp': tmp_path, 'procs': procs}
 
 
-EARLY_JOBS = {'test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files': _launch_dp8_loop}
-
-
 @pytest.mark.gpu
 def test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files(tmp_path):
     """EIGHT ranks over gloo on the one GPU of the test box, HIP kernels underneath (make the first
@@ -238,8 +235,7 @@ def test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files(tmp_path
     error on the LAST rank at iteration 5 that every rank must leave the loop with at the same step, the collective error-path
     checkpoint (BatchNorm statistics averaged over 8 ranks), one run directory, eight rotating per-rank state files."""
     W = 8
-    h = globals().get('_EARLY_HANDLES', {}).pop('test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files', None) or \
-        _launch_dp8_loop(tmp_path)      # (conftest.py starts the eight ranks in front of the first test of a -m gpu session)
+    h = _launch_dp8_loop(tmp_path)
     tmp_path, procs = h['tmp'], h['procs']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):

@@ -79,11 +79,9 @@ def test_conv_halo_ksplit_ranges_start_anywhere_in_a_chunk(be):
         xa, xb = rnd(2, 9, 35, 16), rnd(2, 9, 35, 32)            # 9 x 35: ragged patches (8 x 32 tiles hang over)
         wa, wb, b = rnd(k, k, 16, 128, scale=0.1), rnd(k, k, 32, 128, scale=0.1), rnd(128)
         ref = npo.conv2d_same(xa, wa, b, 1) + npo.conv2d_same(xb, wb, None, 1)
-        ST = cabi.LU_CONV_F_SPLIT_TAPS      # (the default since ABI v10 deals out whole chunks where every slice gets one: next test)
         for sp in splits:                                          # 5x5: 75 stages -> slices of 38 / 25 / 13 / 11; 3x3: 27 -> 14 / 7 / 6 / 4
-            close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp, flags=ST), ref, 5e-5)
             close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp), ref, 5e-5)      # 3 chunks: sp = 2, 3 chunk-aligned, the others counted
-        close(KH.conv2d(be, [xb], [wb], None, k, 1, splits=7 if k == 5 else 3, flags=ST), npo.conv2d_same(xb, wb, None, 1), 5e-5)
+        close(KH.conv2d(be, [xb], [wb], None, k, 1, splits=7 if k == 5 else 3), npo.conv2d_same(xb, wb, None, 1), 5e-5)      # 2 chunks, more slices: counted
 
 
 def test_conv_halo_ksplit_whole_chunks_on_the_compile_time_tap_sequence(be):
@@ -91,17 +89,14 @@ def test_conv_halo_ksplit_whole_chunks_on_the_compile_time_tap_sequence(be):
     so that K-split launches run the compile-time tap sequence of the unsplit ones (conv_halo_kernel<K, BIAS, ST = true>).  Chunk
     counts that do not divide (7 chunks over 2 / 3 / 4 / 7 slices: 4+3, 3+3+1, 2+2+2+1, 1 x 7), slices that cross from the first
     source into the second, ragged patches, a ragged last chunk (C = 40: 16 + 16 + 8) -- against the oracle; 5 slices of 7 chunks would
-    leave one empty, so the library keeps the counted loop there (same result as LU_CONV_F_SPLIT_TAPS, bit for bit)."""
-    ST = cabi.LU_CONV_F_SPLIT_TAPS
+    leave one empty, so the library keeps the counted loop there."""
     for k in (5, 3):
         xa, xb = rnd(2, 9, 35, 40), rnd(2, 9, 35, 64)
         wa, wb, b = rnd(k, k, 40, 128, scale=0.1), rnd(k, k, 64, 128, scale=0.1), rnd(128)
         ref = npo.conv2d_same(xa, wa, b, 1) + npo.conv2d_same(xb, wb, None, 1)      # 3 + 4 = 7 chunks
         for sp in (2, 3, 4, 7):
             close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=sp), ref, 5e-5)
-        a5 = KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=5)
-        close(a5, ref, 5e-5)
-        assert np.array_equal(a5, KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=5, flags=ST))
+        close(KH.conv2d(be, [xa, xb], [wa, wb], b, k, 1, splits=5), ref, 5e-5)
     # the slab form (LU_CONV_F_SLABS_ONLY + lu_lstm_gates_fwd_slabs) rides on the same launch: covered by
     # test_conv_post_affine_lrelu_and_slab_gates, whose K-split launches take whole chunks as well
 
@@ -193,22 +188,18 @@ def test_conv_halo_variant(be):
     close(gates[..., F:2 * F], npo.hard_sigmoid(z[..., F:2 * F]), 2e-5)
 
 
-@pytest.mark.parametrize('patch', ['8', '16', 'half', '8-gen2', '16-gen2', 'half-gen2'])
+@pytest.mark.parametrize('patch', ['8', '16', 'half'])
 def test_conv_bf16_mfma_variant(be, patch):
     # 8 x 32 / 16 x 32 pixel patches (the latter: 5x5, >= 256 blocks) forced through lu_conv_desc.flags; 'half': 4-wave blocks
-    # on 8 x 32 patches (WM = 1, two independent blocks per CU).  Default = the third loop generation (round 5, ABI v10:
-    # conv_halo_frag3_kernel, kernel-column-major taps) wherever the second would run; '-gen2' = LU_CONV_F_LOOP_GEN2
-    if be.name == 'emu' and patch in ('16-gen2', 'half-gen2'):
-        pytest.skip('host emulator: one second-generation variant keeps the CPU suite within minutes')
-    base = {'16': cabi.LU_CONV_F_PATCH16, '8': cabi.LU_CONV_F_PATCH8, 'half': cabi.LU_CONV_F_HALF_BLOCK}[patch.split('-')[0]]
-    _conv_bf16_cases(be, base | (cabi.LU_CONV_F_LOOP_GEN2 if patch.endswith('gen2') else 0))
+    # on 8 x 32 patches (WM = 1, two independent blocks per CU).  The wide layers run the third loop generation (round 5:
+    # conv_halo_frag3_kernel, kernel-column-major taps); 3x3 on fp32 sources / 8-row patches and the narrow blocks the first.
+    _conv_bf16_cases(be, {'16': cabi.LU_CONV_F_PATCH16, '8': cabi.LU_CONV_F_PATCH8, 'half': cabi.LU_CONV_F_HALF_BLOCK}[patch])
 
 
 def test_conv_bf16_half_blocks_are_bitwise_equal_to_the_full_blocks(be):
     """LU_CONV_F_HALF_BLOCK only changes which waves own which patch rows: same taps, same channel order, same fp32 accumulation
     per output -- bias layers (3x3 / 5x5 on bf16 sources, two sources, ragged extents, a partial column tile, a K split) and the
-    fused ConvLSTM step on the bf16 tape (5x5, and 3x3 -- which half blocks move from the first loop generation to the second)
-    must give the same bits as the library's default kernels."""
+    fused ConvLSTM step on the bf16 tape must give the same bits as the library's default kernels."""
     emu = be.name == 'emu'          # (the host emulator runs a subset: the CPU suite has to stay within minutes)
     # Third generation (the default): every block shape of the 5x5 kernel and the two 3x3 shapes that run it sum in the same order
     x5, w5, b5 = KH.bf16_round(rnd(2 - emu, 19, 33, 72)), rnd(5, 5, 72, 160, scale=0.1), rnd(160)
@@ -223,41 +214,24 @@ def test_conv_bf16_half_blocks_are_bitwise_equal_to_the_full_blocks(be):
         assert np.array_equal(o3[0], o3[1])                       # half blocks / 16-row patches: the third generation
         close(o3[0], o3[2], 5e-5)                                 # 8-row patches: the first generation's kernel (row-major taps)
         close(o3[0], npo.conv2d_same(x3, KH.bf16_round(w3), b3, 1), 5e-5)
-    # Second generation (LU_CONV_F_LOOP_GEN2) and first: the statement of round 4, bit for bit
-    HB = cabi.LU_CONV_F_HALF_BLOCK | cabi.LU_CONV_F_LOOP_GEN2
-    G2 = cabi.LU_CONV_F_LOOP_GEN2
-    for (fr, H, W, Cc, N, k, sp) in [(2, 20, 40, 40, 136, 3, 1), (1, 16, 32, 64, 128, 3, 1), (2, 19, 33, 72, 160, 5, 1),
-                                     (1, 9, 33, 96, 72, 5, 2)][:4 if not emu else 1] + ([(1, 9, 33, 40, 72, 5, 2)] if emu else []):
-        x = KH.bf16_round(rnd(fr, H, W, Cc))
-        w, b = rnd(k, k, Cc, N, scale=0.1), rnd(N)
-        for f0 in (cabi.LU_CONV_F_PATCH8 | G2, cabi.LU_CONV_F_PATCH16 | G2)[:2 if not emu else 1]:
-            want = KH.conv2d(be, [x], [w], b, k, splits=sp, precision=1, flags=f0, bf16_src=(0,))
-            assert np.array_equal(KH.conv2d(be, [x], [w], b, k, splits=sp, precision=1, flags=HB, bf16_src=(0,)), want)
-    xa, xb = KH.bf16_round(rnd(1, 17, 32, 40)), KH.bf16_round(rnd(1, 17, 32, 24))
-    wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
-    assert np.array_equal(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=HB, bf16_src=(0, 1)),
-                          KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=G2, bf16_src=(0, 1)))
     x5 = rnd(1, 16, 34, 36)                                      # fp32 sources: 5x5 only (the 3x3 halo needs bf16 pieces)
     w5, b5 = rnd(5, 5, 36, 128, scale=0.1), rnd(128)
-    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=HB), KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=G2))
-    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=cabi.LU_CONV_F_HALF_BLOCK),      # ... and the third, fp32 sources
+    assert np.array_equal(KH.conv2d(be, [x5], [w5], b5, 5, precision=1, flags=cabi.LU_CONV_F_HALF_BLOCK),
                           KH.conv2d(be, [x5], [w5], b5, 5, precision=1))
     F = 32
-    for (k, cin, center) in [(5, 8, False), (3, 8, False), (3, 1, True), (5, 1, True)][:4 if not emu else 3]:
-        x, h, c = rnd(2 - emu, 18, 40, cin), rnd(2 - emu, 18, 40, F, scale=0.5), rnd(2 - emu, 18, 40, F)
-        ker, rec, b = rnd(k, k, cin, 4 * F, scale=0.3), rnd(k, k, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
-        want = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=G2)
-        got = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=HB)
-        for a_, b_ in zip(got, want):
-            assert np.array_equal(a_, b_), (k, cin, center)
     x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)      # fp32 sources, fp32 gates out
     ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
-    for a_, b_ in zip(KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=HB),
-                      KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=G2)):
-        assert np.array_equal(a_, b_)
-    for a_, b_ in zip(KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=cabi.LU_CONV_F_HALF_BLOCK),      # third generation
+    for a_, b_ in zip(KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=cabi.LU_CONV_F_HALF_BLOCK),
                       KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1)):
         assert np.array_equal(a_, b_)
+    if not emu:      # the fused step on the bf16 tape, 5x5 with and without the centre-tap image chunk: half blocks == 16-row patches
+        for (k, cin, center) in [(5, 8, False), (5, 1, True)]:
+            x, h, c = rnd(2, 18, 40, cin), rnd(2, 18, 40, F, scale=0.5), rnd(2, 18, 40, F)
+            ker, rec, b = rnd(k, k, cin, 4 * F, scale=0.3), rnd(k, k, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
+            want = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=cabi.LU_CONV_F_PATCH16)
+            got = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, center=center, flags=cabi.LU_CONV_F_HALF_BLOCK)
+            for a_, b_ in zip(got, want):
+                assert np.array_equal(a_, b_), (k, cin, center)
 
 
 def _conv_bf16_cases(be, flags=0):
@@ -265,17 +239,11 @@ def _conv_bf16_cases(be, flags=0):
     on the SAME bf16-rounded operands only the summation order differs (tolerance as for the fp32 kernels); against
     the unrounded oracle the error is the bf16 operand rounding (2^-9 relative per operand)."""
     R = KH.bf16_round
-    gen2 = bool(flags & cabi.LU_CONV_F_LOOP_GEN2)
     for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
                                      (1, 8, 33, 100, 96, 3, 2)]:
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
         got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags)
         close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
-        g1 = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags | cabi.LU_CONV_F_LOOP_GEN1)
-        if gen2:      # the first two loop generations walk the same (chunk, tap) order: bit-identical
-            assert np.array_equal(got, g1)
-        else:         # the third sums a chunk's taps kernel column by kernel column: the same products, another fp32 order
-            close(got, g1, 5e-5)
         full = npo.conv2d_same(x, w, b, 1)
         assert np.abs(got - full).max() <= 2.0 ** -7 * np.abs(full).max()
     xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources (UpBlock concat)
@@ -302,7 +270,7 @@ def _conv_bf16_cases(be, flags=0):
         x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
         got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=1, flags=flags, bf16_src=(0,))
         close(got, npo.conv2d_same(R(x), R(w), b, 1), 5e-5)
-        if sp == 1 and (gen2 or k == 5):      # (3x3, third generation: fp32 sources stay on the first generation's kernel, another order)
+        if sp == 1 and k == 5:      # (3x3: fp32 sources stay on the first generation's kernel, another summation order)
             assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1, precision=1, flags=flags))
     close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=1, flags=flags, bf16_src=(0, 1)),
           npo.conv2d_same(R(xa), R(wa)) + npo.conv2d_same(R(xb), R(wb)), 5e-5)
@@ -314,12 +282,6 @@ def _conv_bf16_cases(be, flags=0):
     h0, c0, g0 = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=1, flags=flags)
     hg, cg, g16, h16 = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags)
     assert np.array_equal(hg, h0) and np.array_equal(cg, c0)
-    hg1, cg1, g161, _ = KH.convlstm_step_tape16(be, x, h, c, ker, rec, b, flags=flags | cabi.LU_CONV_F_LOOP_GEN1)
-    if gen2:
-        assert np.array_equal(hg1, hg) and np.array_equal(cg1, cg) and np.array_equal(g161, g16)
-    else:
-        close(hg1, hg, 3e-5)
-        close(cg1, cg, 3e-5)
     assert np.array_equal(g16, R(g0)) and np.array_equal(h16, R(h0))
     for (k, cin) in [(5, 1), (3, 3)]:
         x, h, c = rnd(2, 16, 32, cin), rnd(2, 16, 32, F, scale=0.5), rnd(2, 16, 32, F)
@@ -331,34 +293,6 @@ def _conv_bf16_cases(be, flags=0):
         assert np.array_equal(h16, R(hg))
         z = npo.conv2d_same(R(x), R(ker), b) + npo.conv2d_same(R(h), R(rec))
         assert np.abs(g16[..., 2 * F:3 * F] - np.tanh(z[..., 2 * F:3 * F])).max() <= 2.0 ** -8
-
-
-@pytest.mark.parametrize('patch', ['8', '16'])
-def test_conv_f32_fragment_weights_variant(be, patch):
-    """precision = 2: the fragment-order halo kernel on the exact fp32 MFMA (weights packed by lu_pack_weights_f32 and
-    streamed from L2).  Same tap / channel order as the LDS-staged kernel, so without a K split the two agree bit for bit."""
-    flags = cabi.LU_CONV_F_PATCH16 if patch == '16' else cabi.LU_CONV_F_PATCH8
-    for (fr, H, W, Cc, N, k, sp) in [(1, 16, 32, 20, 136, 3, 1), (2, 16, 30, 36, 128, 5, 1), (1, 17, 40, 64, 72, 5, 3),
-                                     (1, 8, 60, 100, 96, 3, 2)]:
-        x, w, b = rnd(fr, H, W, Cc), rnd(k, k, Cc, N, scale=0.2), rnd(N)
-        got = KH.conv2d(be, [x], [w], b, k, 1, splits=sp, precision=2, flags=flags)
-        close(got, npo.conv2d_same(x, w, b, 1), 5e-5)
-        if sp == 1:
-            assert np.array_equal(got, KH.conv2d(be, [x], [w], b, k, 1))
-    xa, xb = rnd(1, 16, 32, 40), rnd(1, 16, 32, 24)               # two sources
-    wa, wb = rnd(3, 3, 40, 72, scale=0.1), rnd(3, 3, 24, 72, scale=0.1)
-    close(KH.conv2d(be, [xa, xb], [wa, wb], None, 3, 1, precision=2, flags=flags), npo.conv2d_same(xa, wa) + npo.conv2d_same(xb, wb), 5e-5)
-    F = 32                                                         # fused ConvLSTM step (gates exchanged through LDS)
-    x, h, c = rnd(1, 16, 32, 8), rnd(1, 16, 32, F, scale=0.5), rnd(1, 16, 32, F)
-    ker, rec, b = rnd(5, 5, 8, 4 * F, scale=0.3), rnd(5, 5, F, 4 * F, scale=0.1), rnd(4 * F, scale=0.5)
-    h1, c1 = npo.convlstm_step(x, h, c, ker, rec, b)
-    hg, cg, gates = KH.convlstm_step_fused(be, x, h, c, ker, rec, b, precision=2, flags=flags)
-    close(hg, h1, 2e-5)
-    close(cg, c1, 2e-5)
-    h0, c0, g0 = KH.convlstm_step_fused(be, x, h, c, ker, rec, b)
-    assert np.array_equal(hg, h0) and np.array_equal(cg, c0) and np.array_equal(gates, g0)
-    with pytest.raises(RuntimeError):
-        KH.conv2d(be, [rnd(1, 8, 8, 8)], [rnd(3, 3, 8, 72)], None, 3, 2, precision=2, flags=flags)
 
 
 def test_conv_bf16_narrow_blocks(be):
@@ -487,8 +421,8 @@ def test_randomized_conv_shapes(be):
         Cc = int(rng.choice([1, 3, 4, 8, 20, 33, 64, 72]))
         N = int(rng.choice([2, 3, 8, 24, 33, 70, 96, 136]))
         sp = int(rng.choice([1, 1, 2, 3]))
-        prec = int(rng.choice([0, 0, 1, 2]))
-        if Cc % 4 != 0 or (prec == 2 and not (s_ == 1 and k in (3, 5) and N > 64 and N % 4 == 0)):
+        prec = int(rng.choice([0, 0, 1, 1]))
+        if Cc % 4 != 0:
             prec = 0
         x = f32(rng.standard_normal((fr, H, W, Cc)))
         w = f32(rng.standard_normal((k, k, Cc, N)) * 0.2)
@@ -562,9 +496,9 @@ def test_wgrad_kernel_row_ragged_widths(be):
 
 def test_wgrad_kernel_row_32_pixel_stages(be):
     """fp32 kernel-row weight gradient with 32-pixel stages (W % 32 == 0: two loader passes per stage, half the block-wide barriers
-    per MFMA -- the library's own choice since round 4, LU_WGRAD_F_KP16 restores 16-pixel stages).  The MFMA k order over the
-    pixels is unchanged, so dw is bit-identical to the 16-pixel instance; the bias sums fold two rows into one slot
-    (summation order only)."""
+    per MFMA -- the library's own choice since round 4) against the oracle: 5x5 and 3x3, pixel splits, a masked channel tail, the bias
+    gradient with beta.  (Until round 6 the 16-pixel and the re-reading instances were kept for bit-identity A/Bs; the 16-pixel
+    instance still runs every width with W % 32 != 0: test_wgrad_fused_bias_gradient, test_wgrad_kernel_row_ragged_widths.)"""
     cases = [(2, 5, 32, 72, 136, 3), (1, 4, 64, 64, 128, 2), (1, 3, 96, 132, 72, 1), (3, 2, 32, 64, 520, 4)]
     if be.name == 'emu':          # (the host emulator runs a subset: the CPU suite has to stay within minutes)
         cases = cases[:1] + cases[2:3]
@@ -575,20 +509,12 @@ def test_wgrad_kernel_row_32_pixel_stages(be):
         dw, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0)
         close(dw, ref, 2e-4)
         close(db, dy.reshape(-1, N).astype(np.float64).sum(0) + db0, 2e-4)
-        assert np.array_equal(dw, KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, flags=cabi.LU_WGRAD_F_KP32))      # (accepted, no effect)
-        dw16, db16 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, dbias0=db0, dbias_beta=1.0, flags=cabi.LU_WGRAD_F_KP16)
-        assert np.array_equal(dw, dw16)
-        close(db, db16, 1e-5)
-        # ... and to the instance that re-reads all K x rows per k-pair instead of sliding them through registers
-        assert np.array_equal(dw16, KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, flags=cabi.LU_WGRAD_F_NO_SLIDE))
         n3 = min(N, 128)
         x3, dy3 = np.ascontiguousarray(x[..., :64]), np.ascontiguousarray(dy[..., :n3])
         _, ref3 = _torch_conv_grads(x3, rnd(3, 3, 64, n3), dy3, 1)
         dw3, db3 = KH.conv2d_wgrad(be, x3, dy3, 3, 1, splits=sp, dbias0=db0[:n3], dbias_beta=1.0)
         close(dw3, ref3, 2e-4)
         close(db3, dy3.reshape(-1, n3).astype(np.float64).sum(0) + db0[:n3], 2e-4)
-        assert np.array_equal(dw3, KH.conv2d_wgrad(be, x3, dy3, 3, 1, splits=sp, flags=cabi.LU_WGRAD_F_KP16))
-        assert np.array_equal(dw3, KH.conv2d_wgrad(be, x3, dy3, 3, 1, splits=sp, flags=cabi.LU_WGRAD_F_NO_SLIDE))
 
 
 def test_wgrad_all_taps_narrow_layers(be):
@@ -683,60 +609,32 @@ def _wgrad_bf16_cases(be, flags=0):
 
 
 def test_wgrad_bf16_lds_dma_equals_register_staging(be):
-    """bf16 operands reach LDS by global_load_lds (dense rows, 64-byte column segments XOR-swizzled by the row; three stage buffers,
-    counted vmcnt waits) instead of through staging registers and ds_write: same tiles, same fragments, same MFMA order --
-    bit-identical weight AND bias gradients.  The library's own choice for the all-taps 3x3 form (measured +3.5 %), opt-in
-    (LU_WGRAD_F_DMA) for the 5x5 kernel-row form (measured -3 %); LU_WGRAD_F_NO_DMA keeps the registers everywhere.  5x5 on 128- /
-    64-channel tiles with 64- / 32-pixel stages, the all-taps 3x3 form (198- / 102-row x tiles: the swizzle term changes with the
-    kernel row), masked channel / column tails, image borders, odd slab counts."""
-    cases = [(1, 5, 64, 128, 136, 5, 2), (2, 4, 32, 128, 128, 5, 3), (1, 6, 64, 72, 264, 5, 1),
-             (2, 5, 64, 136, 72, 3, 3), (1, 7, 32, 64, 128, 3, 1), (3, 3, 96, 200, 136, 5, 2)]
+    """The all-taps 3x3 form on bf16 operands reaches LDS by global_load_lds (dense rows, 64-byte column segments XOR-swizzled by the
+    row; three stage buffers, counted vmcnt waits) instead of through staging registers and ds_write (LU_WGRAD_F_NO_DMA, the
+    previous form): same tiles, same fragments, same MFMA order -- bit-identical weight AND bias gradients, and both against the
+    oracle.  198- / 102-row x tiles (the swizzle term changes with the kernel row), 64- / 32-pixel stages, masked channel / column
+    tails, image borders, odd slab counts.  (The 5x5 kernel-row form's DMA instances measured -3 % / -1.5 % and left in round 6.)"""
+    cases = [(2, 5, 64, 136, 72, 3, 3), (1, 7, 32, 64, 128, 3, 1), (1, 4, 64, 72, 264, 3, 2)]
     if be.name == 'emu':          # (the host emulator runs a subset: the CPU suite has to stay within minutes)
-        cases = [(1, 3, 64, 128, 136, 5, 2), (1, 4, 32, 72, 128, 5, 1), (2, 3, 64, 72, 72, 3, 3), (1, 4, 32, 64, 128, 3, 1)]
+        cases = [(2, 3, 64, 72, 72, 3, 3), (1, 4, 32, 64, 128, 3, 1)]
     for (fr, H, W, Cc, N, k, sp) in cases:
         x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
         want, db0 = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True,
                                     dbias0=np.zeros(N, np.float32), flags=cabi.LU_WGRAD_F_NO_DMA)
-        got, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
-                                  flags=cabi.LU_WGRAD_F_DMA)
+        got, db = KH.conv2d_wgrad(be, x, dy, k, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32))
         assert np.array_equal(got, want), (Cc, N, k, sp)
         assert np.array_equal(db, db0), (Cc, N, k, sp)
         _, gw = _torch_conv_grads(KH.bf16_round(x), rnd(k, k, Cc, N), KH.bf16_round(dy), 1)
         close(got, gw, 2e-4)
 
 
-def test_wgrad_bf16_realigned_x_reads_equal_the_funnel_shift_form(be):
-    """LU_WGRAD_F_XREALIGN (round 5): every tap of the 5x5 kernel-row form fetches its own re-aligned x rows (two transposing LDS
-    reads per tap) instead of cutting the K fragments out of one fetch with funnel shifts and register moves: the same fragments in
-    the same MFMA order -- bit-identical weight and bias gradients.  128-channel tiles, 64- and 32-pixel stages, image borders,
-    a masked channel tail (C = 200), odd slab counts."""
-    cases = [(1, 5, 64, 128, 136, 2), (2, 4, 32, 128, 128, 3), (3, 3, 96, 200, 136, 2), (1, 6, 128, 256, 128, 1)]
-    if be.name == 'emu':
-        cases = [(1, 3, 64, 128, 136, 2), (1, 4, 32, 128, 128, 1)]
-    for (fr, H, W, Cc, N, sp) in cases:
-        x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N)
-        want, db0 = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32))
-        got, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
-                                  flags=cabi.LU_WGRAD_F_XREALIGN)
-        assert np.array_equal(got, want) and np.array_equal(db, db0), (Cc, N, sp)
-        # LU_WGRAD_F_HALF_BLOCK: 4-wave blocks of 64 channels (two independent blocks per CU), the same wave tile and pixel order: the
-        # weight gradient is bit-identical; the bias gradient's stages are shared out over twice as many blocks (K * c_tiles), i.e.
-        # its fp32 partial sums associate differently
-        got, db = KH.conv2d_wgrad(be, x, dy, 5, 1, splits=sp, precision=1, x_bf16=True, dy_bf16=True, dbias0=np.zeros(N, np.float32),
-                                  flags=cabi.LU_WGRAD_F_HALF_BLOCK)
-        assert np.array_equal(got, want), ('half', Cc, N, sp)
-        close(db, db0, 1e-5 * max(1.0, float(np.abs(db0).max())))
-        _, gw = _torch_conv_grads(KH.bf16_round(x), rnd(5, 5, Cc, N), KH.bf16_round(dy), 1)
-        close(got, gw, 2e-4)
-
-
-@pytest.mark.parametrize('form', ['fat4', 'w8'])
+@pytest.mark.parametrize('form', ['w8'])
 def test_wgrad_bf16_all_taps_form_equals_the_kernel_row_form(be, form):
-    """The all-taps form of the 3x3 layers (round 4; LU_WGRAD_F_TAPS9: its fat-wave instance): one block accumulates all nine taps of a 64-channel x 128-column tile (x tile = three
-    input rows, dy tile shared by nine taps) on 4 fat waves (accumulators in AGPRs) or 8 waves.  Every (tap, c, n) sum still
+    """The all-taps form of the 3x3 layers (round 4): one block accumulates all nine taps of a 64-channel x 128-column tile (x tile = three
+    input rows, dy tile shared by nine taps) on 8 waves.  Every (tap, c, n) sum still
     walks the pixels of its slab in the same 16-pixel MFMA steps: bit-identical to the kernel-row form, bias gradient included;
     operand types, ragged channel / column counts, top / bottom image rows, odd stage and slab counts."""
-    fl = cabi.LU_WGRAD_F_TAPS9 if form == 'fat4' else 0      # (0: the library's own choice = the 8-wave all-taps form)
+    fl = 0      # (the library's own choice = the 8-wave all-taps form; LU_WGRAD_F_CT64 below = the kernel-row form)
     R = KH.bf16_round
     for (fr, H, W, Cc, N, sp, xb, yb) in [(2, 5, 32, 72, 136, 3, True, True), (1, 4, 64, 64, 128, 1, True, True),
                                           (3, 3, 32, 128, 64, 9, True, True), (1, 6, 32, 136, 264, 2, True, False),
@@ -1125,21 +1023,21 @@ def test_bn_lrelu_bwd_apply_bf16_result_and_state_begin(be):
                 assert np.array_equal(be.host(d16), KH.bf16_bits(f32(want)))
 
 
-def test_conv3_bf16_sources_tall_patch_equals_the_8_row_kernel(be):
-    """3x3 bf16 layers on bf16 sources run the second loop generation on 16-row patches (conv_halo_frag2_kernel<3, BIAS, 8, true>)
-    when the launch has enough tiles; forced either way (LU_CONV_F_PATCH16 / PATCH8) the two kernels must give the same bits
-    (same taps, same channel order, same fp32 accumulation), ragged extents and a partial column tile included."""
+def test_conv3_bf16_sources_tall_patch_and_the_8_row_kernel(be):
+    """3x3 bf16 layers on bf16 sources run the third loop generation on 16-row patches (conv_halo_frag3_kernel<3, BIAS, 8, true>) when
+    the launch has enough tiles, the first generation on 8-row patches otherwise; forced either way (LU_CONV_F_PATCH16 / PATCH8) both
+    against the oracle on the same bf16-rounded operands, and against each other to fp32 summation order (kernel-column-major vs
+    kernel-row-major taps); ragged extents and a partial column tile included."""
     for (H, W, Cc, N) in [(20, 40, 40, 136), (16, 32, 64, 128)]:
         x = KH.bf16_round(rnd(2, H, W, Cc))
         w, b = rnd(3, 3, Cc, N, scale=0.1), rnd(N)
-        G2 = cabi.LU_CONV_F_LOOP_GEN2      # (the tall patch of the third generation sums column-major: to rounding, below)
-        o8 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH8 | G2, bf16_src=(0,))
-        o16 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16 | G2, bf16_src=(0,))
-        assert np.array_equal(o8, o16)
+        o8 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH8, bf16_src=(0,))
+        o16 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16, bf16_src=(0,))
         ref = npo.conv2d_same(x.astype(np.float64), KH.bf16_round(w).astype(np.float64), b.astype(np.float64), 1)
-        close(o16, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))
-        o16g3 = KH.conv2d(be, [x], [w], b, 3, precision=1, flags=cabi.LU_CONV_F_PATCH16, bf16_src=(0,))
-        close(o16g3, ref, 5e-5 * max(1.0, float(np.abs(ref).max())))
+        tol = 5e-5 * max(1.0, float(np.abs(ref).max()))
+        close(o16, ref, tol)
+        close(o8, ref, tol)
+        close(o8, o16, tol)
 
 
 def np_split3(x):
@@ -1241,6 +1139,8 @@ def test_split6_weight_gradient_piece_aware_kernel_is_fp32_arithmetic(be, case):
     kernel sits (and where the terms-as-frames form of round 5 sits), far below the plain bf16 kernel; the bias gradient is the column sum
     of hi + mid + lo = dy; beta accumulates; ragged column counts (N = 200), two channel tiles (C = 256), slabs that start mid-frame."""
     k, fr, H, W, Cc, N, splits = case
+    if be.name == 'emu':      # (the host emulator runs one frame per case: the CPU suite has to stay within minutes)
+        fr, H, splits = 1, min(H, 3), min(splits, 2)
     x, dy = rnd(fr, H, W, Cc), rnd(fr, H, W, N, scale=0.3)
     _, ref = _torch_conv_grads(x, np.zeros((k, k, Cc, N), np.float32), dy, 1)
     x6 = split6_ref(x.reshape(-1, Cc), Cc, 0).reshape(fr, H, W, 6 * Cc)

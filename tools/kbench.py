@@ -38,12 +38,6 @@ for name, hw, cin, F in levels:
         ho, co, g = torch.empty_like(h), torch.empty_like(c), torch.empty(B, hw, hw, 4 * F, device=dev)
         fl = 2.0 * k * k * (cin + F) * 4 * F * hw * hw * B
         timeit(lambda: ops.convlstm_step(x, h, c, kx, kh, b, ho, co, g), fl, 'lstm_step_fused ' + name)
-        if 'frag' in which:
-            xp = x if cin % 4 == 0 else torch.cat([x, torch.zeros(B, hw, hw, 4 - cin % 4, device=dev)], -1)
-            fk, fh = ops.pack_f32(kx), ops.pack_f32(kh)
-            ho3, co3 = torch.empty_like(h), torch.empty_like(c)
-            timeit(lambda: ops.convlstm_step(xp, h, c, fk, fh, b, ho3, co3, g), fl, 'lstm_step_fused_frag ' + name)
-            print('   bit-identical to the LDS-staged kernel:', bool((ho3 == ho).all() and (co3 == co).all()))
         if 'bf16' in which:
             pk, ph = ops.pack_bf16(kx), ops.pack_bf16(kh)
             ho2, co2 = torch.empty_like(h), torch.empty_like(c)
@@ -58,9 +52,6 @@ for name, hw, cin, F in levels:
         p = (k - 1) // 2
         fl = 2.0 * k * k * F * 4 * F * hw * hw * B
         timeit(lambda: ops.conv_raw([(dz, wt)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad ' + name)
-        if 'frag' in which:
-            fw = ops.pack_f32(wt)
-            timeit(lambda: ops.conv_raw([(dz, fw)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad_frag ' + name)
         if 'bf16' in which:
             pw = ops.pack_bf16(wt)
             timeit(lambda: ops.conv_raw([(dz, pw)], B, hw, hw, hw, hw, k, 1, 1, p, p, F, None, out), fl, 'rec_dgrad_bf16 ' + name)
