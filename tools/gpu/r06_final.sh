@@ -6,8 +6,9 @@
 # in line so that the traced averages are the ones the bench's HIP events see), DP-over-gloo line, streaming repeatability
 tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${tag}_smoke.log
 # the whole GPU suite on the final tree first (its log is the round's test evidence)
-timeout 2400 python -m pytest tests -q -m gpu -s --durations=20 > gpurun_out/${tag}_gpu_tests.log 2>&1; tail -3 gpurun_out/${tag}_gpu_tests.log
+[ -n "$RUN_SUITE" ] && { timeout 2400 python -m pytest tests -q -m gpu -s --durations=20 > gpurun_out/${tag}_gpu_tests.log 2>&1; tail -3 gpurun_out/${tag}_gpu_tests.log; }
 bash tools/gpu/pmc_traffic.sh $tag | tail -14
 # ... and (round 6) for the other workloads the bench lines below report: config-4, the config-5 per-GPU shape, the two net variants
 PMC_EXTRA="--hw 832 992 --batch 2 --unroll 16" PMC_SFX=_c4 PMC_MODES=fp32 bash tools/gpu/pmc_traffic.sh $tag | tail -4
@@ -28,6 +29,9 @@ python bench.py --steps 8 --warmup 3 --no-variants --no-cpu-baseline --by-shape 
 python bench.py --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --no-variants > gpurun_out/${tag}_bf16_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 # precision 'bf16x3' (fp32 arithmetic on the bf16 MFMA): its own line (with its streaming inference), its by-shape table, and the step next to the fp32 engine's
 python bench.py --precision bf16x3 --steps 8 --warmup 3 --no-cpu-baseline --no-variants --by-shape gpurun_out/${tag}_x3_by_shape.json > gpurun_out/${tag}_x3_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
+for fl in 0 8; do python bench.py --precision bf16x3 --conv-flags $fl --steps 8 --warmup 3 --no-cpu-baseline --no-variants --no-infer 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16x3 step, conv flags $fl (8 = LU_CONV_F_XCD_BY_N):', d['ms_per_step'])" | tee -a gpurun_out/${tag}_x3_xcd_by_n_ab.log; done
 python tools/x3_compare.py > gpurun_out/${tag}_x3_compare_vs_fp32.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --precision bf16x3 --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-infer > gpurun_out/${tag}_x3_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
 python bench.py --size 512 --batch 2 --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-infer --no-bf16 --no-x3 > gpurun_out/${tag}_f32_c5shape_bench_line.json 2>> gpurun_out/${tag}_f32_bench.err
