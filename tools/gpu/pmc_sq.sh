@@ -4,7 +4,7 @@ tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 args=""
-for mode in fp32 bf16; do
+for mode in fp32 bf16 bf16x3; do
   dirs=""
   i=0
   for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
