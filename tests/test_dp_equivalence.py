@@ -397,8 +397,8 @@ def test_dp1_forced_collectives_over_gloo_equals_plain_step(tmp_path):
     gradient buckets, loss sums and SyncBN statistics through all-reduce calls -- on the host-emulated kernels over gloo
     (the RCCL leg: test_dp1_rccl_forced_collectives_equals_plain_step, -m gpu).  Identity sums: bit-identical to the plain step."""
     rng = np.random.default_rng(5)
-    np.savez(tmp_path / 'batch.npz', x=rng.standard_normal((2, 2, 16, 16, 1)).astype(np.float32),
-             gt=rng.integers(-1, 3, size=(2, 2, 16, 16, 1)).astype(np.float32))
+    np.savez(tmp_path / 'batch.npz', x=rng.standard_normal((1, 2, 16, 16, 1)).astype(np.float32),      # (one slot: the emulator is slow)
+             gt=rng.integers(-1, 3, size=(1, 2, 16, 16, 1)).astype(np.float32))
     script = tmp_path / 'worker_forced_gloo.py'
     script.write_text(FORCED_GLOO_WORKER % {'root': ROOT, 'tmp': str(tmp_path)})
     env = {k: v for k, v in os.environ.items() if k not in ('LU_DP_BACKEND', 'LU_DP_FORCE', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
