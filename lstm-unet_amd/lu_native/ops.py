@@ -313,7 +313,8 @@ def bf16_row_wgrad_ok(x, dy, k, stride):
             Hout == Hin and Wout == Win and not (WGRAD_FLAGS & cabi.LU_WGRAD_F_NO_ROW))
 
 
-X3_PIECES = os.environ.get('LU_X3_PIECES', '1') != '0'      # precision 'bf16x3': the piece-aware weight-gradient kernel where it applies (LU_X3_PIECES=0: terms as frames, the round-5 form; A/B)
+X3_PIECES = True      # precision 'bf16x3': the piece-aware weight-gradient kernel where it applies (False: two launches with the terms as frames, the round-5 form --
+                      # what layers outside x3_pieces_ok still run; tools/wgbench_x3.py and the round's A/B set it from outside)
 
 
 def x3_pieces_ok(x6, dy6, k):

@@ -1,3 +1,4 @@
+# (HISTORICAL: see r06d_call.sh)
 # round 6, third GPU call: the piece-aware 'bf16x3' weight gradient (wgrad_row_x3_kernel) against the terms-as-frames form -- micro-benchmark, the
 # kernel tests, the bf16x3 step both ways --, the forced one-rank RCCL bench line (with a fault handler: the first attempt printed no line), then the
 # whole GPU suite with per-test durations

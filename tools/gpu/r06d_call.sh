@@ -1,3 +1,4 @@
+# (HISTORICAL: ran on binary 345e144325b810a5, when ops.X3_PIECES still read LU_X3_PIECES from the environment; the switch is a module attribute now)
 # round 6, fourth GPU call: the bf16x3 step with the piece-aware weight gradient against the terms-as-frames form (LU_X3_PIECES=0), same box, alternating;
 # config-4 and the 512x512 shape in the mode; then the whole GPU suite (oracle farm + multi-rank jobs started in front of the first test) with durations
 tag=${1:-r06d}
