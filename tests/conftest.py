@@ -38,9 +38,6 @@ def _oracle_farm_from_the_first_test(request):
         mod._SESSION.pop('farm').close()
 
 
-SHARED_JOBS = {}      # rank processes one multi-rank GPU test starts on behalf of the next one (see test_dp_equivalence's eight-rank test)
-
-
 # small nets used across tests ---------------------------------------------------------
 def tiny_net(k_lstm=3, widths=(8, 8, 12, 16), up=(12, 8, 8, 8)):
     return {

@@ -193,7 +193,7 @@ def _launch_dp8_syncbn(tmp_path):
 
 
 @pytest.mark.gpu
-def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp_path, request, tmp_path_factory):
+def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp_path):
     """EIGHT ranks x 1 slot on the real kernels (gloo, all on the one GPU of the test box): shard_slots
     with W = 8, SyncBN with 8 contributors, the gradient all-reduce in THREE OR MORE buckets (a small bucket size: the tiny
     net's 0.1 MB of gradients would otherwise leave as one), loss sums over 8 ranks -- loss and pre-Adam gradients must equal
@@ -202,13 +202,6 @@ def test_dp8_syncbn_three_buckets_over_gloo_on_one_gpu_equals_single_process(tmp
     import Networks
     W = 8
     h = _launch_dp8_syncbn(tmp_path)
-    # The eight ranks of tests/test_drivers.py's train-loop test start now as well, if that test is part of this session: both tests
-    # are a minute of process start-up each (8 x interpreter + library load + rendezvous) that can overlap (the GPU suite's time limit)
-    import conftest
-    want = 'test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files'
-    if any(it.name == want for it in request.session.items) and want not in conftest.SHARED_JOBS:
-        import test_drivers
-        conftest.SHARED_JOBS[want] = test_drivers._launch_dp8_loop(tmp_path_factory.mktemp('dp8_loop'))
     tmp_path, procs, x, gt = h['tmp'], h['procs'], h['x'], h['gt']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):

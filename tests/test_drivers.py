@@ -235,8 +235,7 @@ def test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files(tmp_path
     error on the LAST rank at iteration 5 that every rank must leave the loop with at the same step, the collective error-path
     checkpoint (BatchNorm statistics averaged over 8 ranks), one run directory, eight rotating per-rank state files."""
     W = 8
-    import conftest
-    h = conftest.SHARED_JOBS.pop('test_dp8_loop_on_one_gpu_failure_agreement_and_per_rank_state_files', None) or _launch_dp8_loop(tmp_path)
+    h = _launch_dp8_loop(tmp_path)
     tmp_path, procs = h['tmp'], h['procs']
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
