@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'lstm-unet_amd'))
 import torch
 from lu_native import ops
+if os.environ.get('WG_ROUNDS'):      # rounds of blocks the pixel axis is cut into (calls.BF16_ROW_ROUNDS; default 5)
+    from lu_native import calls as _calls
+    _calls.BF16_ROW_ROUNDS = int(os.environ['WG_ROUNDS'])
 if os.environ.get('KB_LIB'):
     ops.LIB_PATH = os.path.abspath(os.environ['KB_LIB'])
 dev = torch.device('cuda', 0)
